@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Headline benchmark: interpolated frames/s of the EVFIAutoEx training step (forward + Lap/census
+loss + backward + flat RCCL gradient all-reduce + Adam) at B=8 per GPU, 256x256, synthetic data.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU; weak scaling (B=8 per rank).  Rank 0 prints ONE JSON line.  Besides the
+contract fields the line carries
+  roofline      the dominant hand-written kernel of the step (by device time inside the timed
+                region, measured with hipEvent pairs the library records on the launch stream):
+                algorithmic bytes per launch / average launch duration vs the 8 TB/s HBM peak
+  kernels       the same figures for every hand-written kernel that ran in the timed region
+  cpu_baseline  the CPU oracle (oracle/model_ref.py + loss_ref.py, a port of the reference path)
+                timed on this box's host cores on a bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "ebfi-be_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+B_PER_GPU, H, W, TB, C_FEAT, K_FAC = 8, 256, 256, 16, 64, 5
+
+
+def algorithmic_bytes(B):
+    """Bytes one launch must move; P = B*h*w feature pixels at h=H/2, w=W/2."""
+    P = B * (H // 2) * (W // 2)
+    e = 4
+    return {
+        "fac_fwd_tile_f32": e * P * C_FEAT * (1 + K_FAC ** 2 + 1),
+        "fac_bwd_rows_f32": e * P * C_FEAT * (K_FAC ** 2 + 1 + 1 + 1 + K_FAC ** 2),
+        "frame2lap": e * B * H * W * (3 + 1),
+    }
+
+
+def cpu_baseline(model_args, seconds_hint=20.0):
+    """Oracle fwd+bwd on the host cores: B=1 256x256, same architecture, bounded iterations."""
+    from oracle import loss_ref, model_ref
+    from ebfi_amd.engine import synthetic_batch
+    from ebfi_amd.model import EVFIAutoEx
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+    torch.manual_seed(123)
+    sd = {k: v.clone().requires_grad_(v.is_floating_point())
+          for k, v in EVFIAutoEx(**model_args).state_dict().items()}
+    # same branch as the GPU run (RGBLap exposure decision); Frame2Lap via the oracle's numpy restatement
+    frame, event, t, gtex, target = synthetic_batch(1, H, W, TB, device="cpu")
+
+    def one():
+        s, f = model_ref.evfi_forward(sd, model_args, frame, event, t, gtex)
+        loss_ref.train_loss(s, f, target).backward()
+
+    t0 = time.perf_counter()
+    one()                                   # warm-up (cold caches, thread pool)
+    first = time.perf_counter() - t0
+    iters = max(1, min(4, int(seconds_hint / max(first, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        one()
+    dt = time.perf_counter() - t0
+    return {"value": round(iters / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d timed iterations (after 1 warm-up) of B=1 256x256 fwd+bwd of the same model "
+                      "through oracle/model_ref.py + oracle/loss_ref.py on CPU" % iters}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from ebfi_amd import _native as N
+    from ebfi_amd.engine import DEFAULT_MODEL_ARGS, Engine, synthetic_batch
+
+    eng = Engine(DEFAULT_MODEL_ARGS, device=device, precision=args.precision, lr=1e-4, seed=123)
+    batch = synthetic_batch(B_PER_GPU, H, W, TB, device=device, seed=123, rank=rank)   # resident in HBM
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        eng.train_step(*batch)
+    sync()
+    N.prof_reset()
+    N.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = eng.train_step(*batch)
+    sync()
+    elapsed = time.perf_counter() - t0
+    N.prof_enable(False)
+    kernels = N.prof_collect()
+
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    elapsed = t_max.item()
+
+    if rank == 0:
+        alg = algorithmic_bytes(B_PER_GPU)
+        per_kernel = {}
+        for name, (launches, total_ms) in kernels.items():
+            if name.startswith("__") or launches == 0:
+                continue
+            avg_ms = total_ms / launches
+            entry = {"launches": launches, "avg_ms": round(avg_ms, 5)}
+            if name in alg:
+                entry["algorithmic_bytes"] = alg[name]
+                entry["achieved_GBps"] = round(alg[name] / (avg_ms * 1e-3) / 1e9, 1)
+                entry["frac_of_hbm_peak"] = round(entry["achieved_GBps"] / HBM_PEAK_GBS, 4)
+            per_kernel[name] = entry
+        ranked = sorted((k for k in per_kernel if "achieved_GBps" in per_kernel[k]),
+                        key=lambda k: -per_kernel[k]["avg_ms"] * per_kernel[k]["launches"])
+        roofline = None
+        if ranked:
+            d = per_kernel[ranked[0]]
+            roofline = {"kernel": ranked[0], "bound": "hbm", "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": d["frac_of_hbm_peak"], "traffic": None,
+                        "avg_launch_ms": d["avg_ms"], "algorithmic_bytes_per_launch": d["algorithmic_bytes"]}
+        out = {
+            "metric": "interpolated frames/sec (train fwd+bwd) at B=8 256x256",
+            "value": round(world * B_PER_GPU * args.steps / elapsed, 3),
+            "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
+            "config": {"workload": "EVFIAutoEx (config/train_ours.yml defaults, 5.69 M params) train step: fwd + "
+                                   "Lap/census loss + bwd + flat grad all-reduce + Adam; B=%d per GPU, %dx%d frames, "
+                                   "TB=%d event bins, Poisson(0.35) event counts" % (B_PER_GPU, H, W, TB),
+                       "global_batch": world * B_PER_GPU, "parallelism": "dp%d" % world,
+                       "loss": float(loss.item())},
+            "roofline": roofline,
+            "kernels": per_kernel,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dict(DEFAULT_MODEL_ARGS))
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Builds libebfi_hip.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="$HERE/../lib"
+mkdir -p "$OUT" "$HERE/obj"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -munsafe-fp-atomics ${EBFI_EXTRA_FLAGS:-}"
+objs=()
+pids=()
+for src in "$HERE"/*.hip; do
+    obj="$HERE/obj/$(basename "${src%.hip}").o"
+    objs+=("$obj")
+    if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/common.hpp" -nt "$obj" ] || [ "$HERE/../../include/ebfi_hip.h" -nt "$obj" ]; then
+        $HIPCC $FLAGS -c "$src" -o "$obj" &
+        pids+=($!)
+    fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libebfi_hip.so" "${objs[@]}"
+echo "built $OUT/libebfi_hip.so"

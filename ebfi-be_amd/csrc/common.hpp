@@ -1,0 +1,40 @@
+// Shared host-side helpers of libebfi_hip.so (error reporting, launch checks, event profiler).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/ebfi_hip.h"
+
+namespace ebfi {
+
+// thread-local last-error text; returns `code` so call sites can `return fail(...)`.
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// hipGetLastError() after a launch -> EBFI_OK / EBFI_ERR_LAUNCH (with message)
+int check_launch(const char *what);
+
+// RAII hipEvent bracket around one kernel launch (no-op unless ebfi_prof_enable(1)).
+class ProfScope {
+  public:
+    ProfScope(const char *kernel_name, hipStream_t stream);
+    ~ProfScope();
+    ProfScope(const ProfScope &) = delete;
+    ProfScope &operator=(const ProfScope &) = delete;
+
+  private:
+    int slot_;
+    hipStream_t stream_;
+};
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+struct Dims4 {
+    int64_t v[4];
+};
+static inline Dims4 dims4(const int64_t *p) { return Dims4{{p[0], p[1], p[2], p[3]}}; }
+
+}  // namespace ebfi

@@ -1,0 +1,496 @@
+// Modulated deformable convolution v2 (DCNv2) for gfx950, fp32.
+//
+// Semantics: reference models/DCNv2/src/cuda/dcn_v2_cuda.cu:20-216 (wrappers) and
+// src/cuda/dcn_v2_im2col_cuda.cu:25-402 (kernels); entry points replace `_ext.dcn_v2_forward` /
+// `_ext.dcn_v2_backward` (src/dcn_v2.h:9-92).
+//
+// The reference materialises a [B, C*kh*kw, Ho*Wo] column tensor in HBM (302 MB at B=8, 64ch,
+// 128x128), runs one big matmul, and in backward loops over samples launching 3 kernels + 3
+// matmuls each.  Here the column tensor never leaves the CU:
+//
+//   forward   workgroup = 64 output pixels x 64 output channels.  The K = C*kh*kw contraction is
+//             walked in chunks of one deformable group's channels (<= 72 rows): the 4 waves sample
+//             the chunk's columns (offset/mask read coalesced along pixels, 4-corner gathers from
+//             the L2-resident input planes, x mask) straight into LDS next to the matching weight
+//             slice, then each wave drives one 32x32 tile with exact-fp32 MFMA
+//             (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain, so parity with the fp32 reference
+//             holds to rounding order).  bias is added last like the reference.
+//   backward  (1) data kernel: per pixel tile, colgrad = W^T . grad_out for one chunk via 16x16x4
+//             fp32 MFMA into LDS, then the same sampling walk produces grad_offset / grad_mask
+//             (deterministic, one writer each) and scatters grad_input with fp32 atomics -- the
+//             reference does the same with atomicAdd (dcn_v2_im2col_cuda.cu:249);
+//             (2) weight kernel: re-samples the columns per tile and contracts them against
+//             grad_out over PIXELS with MFMA, each workgroup accumulating its share of tiles in
+//             registers and writing one partial [Co, C*kk] slab; (3) a tiny reduction kernel sums
+//             the slabs (and the bias partials) in a fixed order => grad_weight / grad_bias are
+//             bit-reproducible.
+#include "common.hpp"
+
+using namespace ebfi;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int NP = 64;     // pixels per workgroup tile
+constexpr int KC = 72;     // max contraction rows per chunk (one group's channels x taps)
+constexpr int KCP = 80;    // KC rounded up to a multiple of 16 (MFMA m/n tiles in backward)
+constexpr int WSTR = 65;   // forward: weight-slice row stride (co fastest, odd => conflict-free transposing store)
+constexpr int S80 = 80;    // backward data: row stride of the [k][m] operand images (2 rows -> disjoint banks)
+constexpr int S81 = 81;    // backward weight: row stride of transposed images written column-wise
+
+struct Geom {
+    int B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, dg;
+    int Ho, Wo, HWo, kk, cpg, CB, nsub, nchunks, tiles_per_img, Kd;
+};
+
+struct Tap {
+    float w1, w2, w3, w4;   // bilinear weights of (low,low) (low,high) (high,low) (high,high)
+    int o1, o2, o3, o4;     // plane offsets of the four corners, -1 when outside the image
+    float lh, lw;           // fractional parts (for the coordinate gradient)
+    bool valid;             // -1 < h < H and -1 < w < W   (dcn_v2_im2col_cuda.cu:180)
+};
+
+__device__ __forceinline__ Tap make_tap(float h, float w, int H, int W) {
+    Tap t;
+    t.valid = (h > -1.f) && (w > -1.f) && (h < (float)H) && (w < (float)W);
+    t.w1 = t.w2 = t.w3 = t.w4 = 0.f;
+    t.o1 = t.o2 = t.o3 = t.o4 = -1;
+    t.lh = t.lw = 0.f;
+    if (t.valid) {
+        const int h0 = (int)floorf(h), w0 = (int)floorf(w);
+        const int h1 = h0 + 1, w1 = w0 + 1;
+        const float lh = h - (float)h0, lw = w - (float)w0;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        t.lh = lh; t.lw = lw;
+        t.w1 = hh * hw; t.w2 = hh * lw; t.w3 = lh * hw; t.w4 = lh * lw;
+        if (h0 >= 0 && w0 >= 0) t.o1 = h0 * W + w0;
+        if (h0 >= 0 && w1 <= W - 1) t.o2 = h0 * W + w1;
+        if (h1 <= H - 1 && w0 >= 0) t.o3 = h1 * W + w0;
+        if (h1 <= H - 1 && w1 <= W - 1) t.o4 = h1 * W + w1;
+    }
+    return t;
+}
+
+__device__ __forceinline__ void corners(const float *__restrict__ plane, const Tap &t, float &v1, float &v2,
+                                        float &v3, float &v4) {
+    v1 = t.o1 >= 0 ? plane[t.o1] : 0.f;
+    v2 = t.o2 >= 0 ? plane[t.o2] : 0.f;
+    v3 = t.o3 >= 0 ? plane[t.o3] : 0.f;
+    v4 = t.o4 >= 0 ? plane[t.o4] : 0.f;
+}
+
+struct Chunk {
+    int grp, cbase, cb, KL;   // deformable group, first global channel, channels, rows = cb*kk
+};
+__device__ __forceinline__ Chunk get_chunk(const Geom &g, int chunk) {
+    Chunk c;
+    c.grp = chunk / g.nsub;
+    const int c0 = (chunk - c.grp * g.nsub) * g.CB;
+    c.cb = min(g.CB, g.cpg - c0);
+    c.cbase = c.grp * g.cpg + c0;
+    c.KL = c.cb * g.kk;
+    return c;
+}
+
+// sample position of (pixel p, tap) of group grp; pad_w_eff lets the caller apply the reference's
+// pad_h-for-pad_w quirk of col2im.
+struct TapPos {
+    float h, w, mask;
+};
+__device__ __forceinline__ TapPos tap_pos(const Geom &g, const float *__restrict__ off, const float *__restrict__ msk,
+                                          int b, int grp, int tap, int p, int pad_w_eff) {
+    const int ho = p / g.Wo, wo = p - ho * g.Wo;
+    const int i = tap / g.kw, j = tap - i * g.kw;
+    const int64_t ob = ((int64_t)(b * g.dg + grp) * 2 * g.kk + 2 * tap) * g.HWo + p;
+    const float dy = off[ob], dx = off[ob + g.HWo];
+    TapPos r;
+    r.mask = msk[((int64_t)(b * g.dg + grp) * g.kk + tap) * g.HWo + p];
+    r.h = (float)(ho * g.sh - g.ph + i * g.dh) + dy;
+    r.w = (float)(wo * g.sw - pad_w_eff + j * g.dw) + dx;
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256) void dcn_fwd_f32(const float *__restrict__ x, const float *__restrict__ wgt,
+                                                   const float *__restrict__ bias, const float *__restrict__ off,
+                                                   const float *__restrict__ msk, float *__restrict__ out, Geom g) {
+    __shared__ float sW[(KC + 2) * WSTR];   // [kl][co]
+    __shared__ float sCol[(KC + 2) * NP];   // [kl][px]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / g.tiles_per_img;
+    const int p0 = (blockIdx.x - b * g.tiles_per_img) * NP;
+    const int co_base = blockIdx.y * 64;
+    const int mt = wave >> 1, nt = wave & 1;
+    const bool tile_live = co_base + mt * 32 < g.Co;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    for (int chunk = 0; chunk < g.nchunks; ++chunk) {
+        const Chunk ck = get_chunk(g, chunk);
+        const int KLp = (ck.KL + 1) & ~1;
+        __syncthreads();   // previous chunk's MFMA reads are done
+        for (int i = tid; i < 64 * KLp; i += 256) {
+            const int co = i / KLp, kl = i - co * KLp;
+            float v = 0.f;
+            if (kl < ck.KL && co_base + co < g.Co)
+                v = wgt[(int64_t)(co_base + co) * g.Kd + (int64_t)ck.cbase * g.kk + kl];
+            sW[kl * WSTR + co] = v;
+        }
+        for (int it = tid; it < g.kk * NP; it += 256) {
+            const int px = it & (NP - 1), tap = it / NP;
+            const int p = p0 + px;
+            if (p < g.HWo) {
+                const TapPos tp = tap_pos(g, off, msk, b, ck.grp, tap, p, g.pw);
+                const Tap t = make_tap(tp.h, tp.w, g.H, g.W);
+                const float *plane = x + (int64_t)(b * g.C + ck.cbase) * g.H * g.W;
+                for (int cl = 0; cl < ck.cb; ++cl, plane += (int64_t)g.H * g.W) {
+                    float v1, v2, v3, v4;
+                    corners(plane, t, v1, v2, v3, v4);
+                    const float val = (t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4);
+                    sCol[(cl * g.kk + tap) * NP + px] = val * tp.mask;
+                }
+            } else {
+                for (int cl = 0; cl < ck.cb; ++cl) sCol[(cl * g.kk + tap) * NP + px] = 0.f;
+            }
+        }
+        if (KLp != ck.KL && tid < NP) sCol[ck.KL * NP + tid] = 0.f;
+        __syncthreads();
+        if (tile_live) {
+            const float *ap = sW + (lane >> 5) * WSTR + mt * 32 + (lane & 31);
+            const float *bp = sCol + (lane >> 5) * NP + nt * 32 + (lane & 31);
+            for (int ks = 0; ks < KLp; ks += 2)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[ks * WSTR], bp[ks * NP], acc, 0, 0, 0);
+        }
+    }
+    if (tile_live) {
+        const int p = p0 + nt * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (co < g.Co && p < g.HWo) out[(int64_t)(b * g.Co + co) * g.HWo + p] = acc[r] + bias[co];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: data
+// grad_offset, grad_mask (plain stores, one owner per element) and grad_input (fp32 atomics).
+__global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict__ x, const float *__restrict__ wgt,
+                                                        const float *__restrict__ off, const float *__restrict__ msk,
+                                                        const float *__restrict__ gout, float *__restrict__ gx,
+                                                        float *__restrict__ goff, float *__restrict__ gmsk, Geom g) {
+    __shared__ float sG[64 * S80];     // grad_out block  [co][px]
+    __shared__ float sWt[64 * S80];    // weight slice    [co][kl]
+    __shared__ float sCG[KCP * NP];    // column gradient [kl][px]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / g.tiles_per_img;
+    const int p0 = (blockIdx.x - b * g.tiles_per_img) * NP;
+    const int nco = (g.Co + 63) / 64;
+    const int pad_w_quirk = g.ph;      // col2im is launched with (pad_h, pad_h): dcn_v2_im2col_cuda.cu:368
+
+    for (int chunk = 0; chunk < g.nchunks; ++chunk) {
+        const Chunk ck = get_chunk(g, chunk);
+        const int mtiles = (ck.KL + 15) >> 4;
+        f32x4 acc[KCP / 16];
+#pragma unroll
+        for (int m = 0; m < KCP / 16; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        for (int cob = 0; cob < nco; ++cob) {
+            __syncthreads();   // previous readers of sG / sWt / sCG are done
+            if (chunk == 0 || nco > 1) {
+                for (int i = tid; i < 64 * NP; i += 256) {
+                    const int co = i / NP, px = i - co * NP;
+                    float v = 0.f;
+                    if (cob * 64 + co < g.Co && p0 + px < g.HWo)
+                        v = gout[(int64_t)(b * g.Co + cob * 64 + co) * g.HWo + p0 + px];
+                    sG[co * S80 + px] = v;
+                }
+            }
+            for (int i = tid; i < 64 * KCP; i += 256) {
+                const int co = i / KCP, kl = i - co * KCP;
+                float v = 0.f;
+                if (kl < ck.KL && cob * 64 + co < g.Co)
+                    v = wgt[(int64_t)(cob * 64 + co) * g.Kd + (int64_t)ck.cbase * g.kk + kl];
+                sWt[co * S80 + kl] = v;
+            }
+            __syncthreads();
+            // colgrad[kl][px] += sum_co W[co][kl] * gout[co][px];  wave owns pixel n-tile `wave`
+            const float *ap = sWt + (lane >> 4) * S80 + (lane & 15);
+            const float *bp = sG + (lane >> 4) * S80 + wave * 16 + (lane & 15);
+            for (int ks = 0; ks < 64; ks += 4) {
+                const float bv = bp[ks * S80];
+#pragma unroll
+                for (int m = 0; m < KCP / 16; ++m)
+                    if (m < mtiles)
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[ks * S80 + m * 16], bv, acc[m], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < KCP / 16; ++m)
+            if (m < mtiles) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    sCG[(m * 16 + (lane >> 4) * 4 + r) * NP + wave * 16 + (lane & 15)] = acc[m][r];
+            }
+        __syncthreads();
+
+        const bool first_sub = (chunk % g.nsub) == 0;   // first channel sub-block of this group
+        for (int it = tid; it < g.kk * NP; it += 256) {
+            const int px = it & (NP - 1), tap = it / NP;
+            const int p = p0 + px;
+            if (p >= g.HWo) continue;
+            const TapPos tp = tap_pos(g, off, msk, b, ck.grp, tap, p, g.pw);
+            const Tap t = make_tap(tp.h, tp.w, g.H, g.W);
+            // grad_input positions follow the quirk; identical to `t` whenever pad_h == pad_w
+            Tap tq = t;
+            if (pad_w_quirk != g.pw) {
+                const TapPos tpq = tap_pos(g, off, msk, b, ck.grp, tap, p, pad_w_quirk);
+                tq = make_tap(tpq.h, tpq.w, g.H, g.W);
+            }
+            float val_h = 0.f, val_w = 0.f, mval = 0.f;
+            const float *plane = x + (int64_t)(b * g.C + ck.cbase) * g.H * g.W;
+            float *gplane = gx + (int64_t)(b * g.C + ck.cbase) * g.H * g.W;
+            for (int cl = 0; cl < ck.cb; ++cl, plane += (int64_t)g.H * g.W, gplane += (int64_t)g.H * g.W) {
+                const float cg = sCG[(cl * g.kk + tap) * NP + px];
+                if (t.valid) {
+                    float v1, v2, v3, v4;
+                    corners(plane, t, v1, v2, v3, v4);
+                    mval += cg * (t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4);
+                    // d(sample)/dh and d(sample)/dw  (dmcn_get_coordinate_weight_cuda, :82-123)
+                    const float wh = -(1.f - t.lw) * v1 - t.lw * v2 + (1.f - t.lw) * v3 + t.lw * v4;
+                    const float ww = -(1.f - t.lh) * v1 + (1.f - t.lh) * v2 - t.lh * v3 + t.lh * v4;
+                    val_h += wh * cg * tp.mask;
+                    val_w += ww * cg * tp.mask;
+                }
+                if (tq.valid) {
+                    const float top = cg * tp.mask;
+                    if (tq.o1 >= 0) atomicAdd(gplane + tq.o1, tq.w1 * top);
+                    if (tq.o2 >= 0) atomicAdd(gplane + tq.o2, tq.w2 * top);
+                    if (tq.o3 >= 0) atomicAdd(gplane + tq.o3, tq.w3 * top);
+                    if (tq.o4 >= 0) atomicAdd(gplane + tq.o4, tq.w4 * top);
+                }
+            }
+            const int64_t ob = ((int64_t)(b * g.dg + ck.grp) * 2 * g.kk + 2 * tap) * g.HWo + p;
+            const int64_t mb = ((int64_t)(b * g.dg + ck.grp) * g.kk + tap) * g.HWo + p;
+            if (first_sub) {
+                goff[ob] = val_h;
+                goff[ob + g.HWo] = val_w;
+                gmsk[mb] = mval;
+            } else {   // same thread owns this element in every sub-block: plain read-modify-write
+                goff[ob] += val_h;
+                goff[ob + g.HWo] += val_w;
+                gmsk[mb] += mval;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: weight
+// slab[wg][co*Kd + k] = sum over this workgroup's pixel tiles of gout[co][p] * col[k][p];
+// slab[wg][Co*Kd + co] = sum of gout[co][p].
+__global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restrict__ x, const float *__restrict__ off,
+                                                          const float *__restrict__ msk,
+                                                          const float *__restrict__ gout, float *__restrict__ slab,
+                                                          Geom g, int total_tiles) {
+    __shared__ float sGt[NP * S81];    // grad_out tile transposed [px][co]
+    __shared__ float sCt[NP * S81];    // columns transposed       [px][kl]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co_base = blockIdx.y * 64;
+    const int64_t slab_stride = (int64_t)g.Co * g.Kd + g.Co;
+    float *my = slab + (int64_t)blockIdx.x * slab_stride;
+    float bsum = 0.f;
+
+    for (int chunk = 0; chunk < g.nchunks; ++chunk) {
+        const Chunk ck = get_chunk(g, chunk);
+        const int ntiles = (ck.KL + 15) >> 4;
+        f32x4 acc[KCP / 16];
+#pragma unroll
+        for (int n = 0; n < KCP / 16; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+            const int b = tile / g.tiles_per_img;
+            const int p0 = (tile - b * g.tiles_per_img) * NP;
+            __syncthreads();
+            for (int i = tid; i < 64 * NP; i += 256) {
+                const int co = i / NP, px = i - co * NP;
+                float v = 0.f;
+                if (co_base + co < g.Co && p0 + px < g.HWo)
+                    v = gout[(int64_t)(b * g.Co + co_base + co) * g.HWo + p0 + px];
+                sGt[px * S81 + co] = v;
+            }
+            // zero the kl padding columns [KL, ntiles*16) once per tile (cheap) so MFMA reads zeros
+            for (int i = tid; i < NP * 16; i += 256) {
+                const int px = i >> 4, kl = (ntiles - 1) * 16 + (i & 15);
+                if (kl >= ck.KL) sCt[px * S81 + kl] = 0.f;
+            }
+            for (int it = tid; it < g.kk * NP; it += 256) {
+                const int px = it & (NP - 1), tap = it / NP;
+                const int p = p0 + px;
+                if (p < g.HWo) {
+                    const TapPos tp = tap_pos(g, off, msk, b, ck.grp, tap, p, g.pw);
+                    const Tap t = make_tap(tp.h, tp.w, g.H, g.W);
+                    const float *plane = x + (int64_t)(b * g.C + ck.cbase) * g.H * g.W;
+                    for (int cl = 0; cl < ck.cb; ++cl, plane += (int64_t)g.H * g.W) {
+                        float v1, v2, v3, v4;
+                        corners(plane, t, v1, v2, v3, v4);
+                        const float val = (t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4);
+                        sCt[px * S81 + cl * g.kk + tap] = val * tp.mask;
+                    }
+                } else {
+                    for (int cl = 0; cl < ck.cb; ++cl) sCt[px * S81 + cl * g.kk + tap] = 0.f;
+                }
+            }
+            __syncthreads();
+            if (chunk == 0 && tid < 64) {
+                float s = 0.f;
+                for (int px = 0; px < NP; ++px) s += sGt[px * S81 + tid];
+                bsum += s;
+            }
+            // acc[co][kl] += sum_px gout[co][px] * col[kl][px];  wave owns co m-tile `wave`
+            const float *ap = sGt + (lane >> 4) * S81 + wave * 16 + (lane & 15);
+            const float *bp = sCt + (lane >> 4) * S81 + (lane & 15);
+            for (int ks = 0; ks < NP; ks += 4) {
+                const float av = ap[ks * S81];
+#pragma unroll
+                for (int n = 0; n < KCP / 16; ++n)
+                    if (n < ntiles)
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[ks * S81 + n * 16], acc[n], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < KCP / 16; ++n)
+            if (n < ntiles) {
+                const int kl = n * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co_base + wave * 16 + (lane >> 4) * 4 + r;
+                    if (kl < ck.KL && co < g.Co) my[(int64_t)co * g.Kd + (int64_t)ck.cbase * g.kk + kl] = acc[n][r];
+                }
+            }
+    }
+    if (tid < 64 && co_base + tid < g.Co) my[(int64_t)g.Co * g.Kd + co_base + tid] = bsum;
+}
+
+__global__ void dcn_bwd_reduce_f32(const float *__restrict__ slab, int nslabs, int64_t n_weight, int64_t n_total,
+                                   float *__restrict__ gw, float *__restrict__ gb) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_total) return;
+    float s = 0.f;
+    for (int k = 0; k < nslabs; ++k) s += slab[(int64_t)k * n_total + j];
+    if (j < n_weight) gw[j] = s;
+    else gb[j - n_weight] = s;
+}
+
+int make_geom(Geom &g, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
+              int dw, int dg) {
+    if (B < 0 || C <= 0 || H <= 0 || W <= 0 || Co <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || ph < 0 || pw < 0 ||
+        dh <= 0 || dw <= 0 || dg <= 0)
+        return fail(EBFI_ERR_ARG, "dcn: non-positive dimension");
+    if (C % dg != 0) return fail(EBFI_ERR_ARG, "dcn: channels %d not divisible by deformable_group %d", C, dg);
+    if (kh * kw > KC) return fail(EBFI_ERR_UNSUPPORTED, "dcn: kernel %dx%d has more than %d taps", kh, kw, KC);
+    g = Geom{B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, dg, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    g.Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1;
+    g.Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;
+    if (g.Ho <= 0 || g.Wo <= 0) return fail(EBFI_ERR_ARG, "dcn: empty output %dx%d", g.Ho, g.Wo);
+    g.HWo = g.Ho * g.Wo;
+    g.kk = kh * kw;
+    g.cpg = C / dg;
+    g.CB = KC / g.kk;
+    if (g.CB > g.cpg) g.CB = g.cpg;
+    g.nsub = (g.cpg + g.CB - 1) / g.CB;
+    g.nchunks = dg * g.nsub;
+    g.tiles_per_img = (g.HWo + NP - 1) / NP;
+    g.Kd = C * g.kk;
+    if ((int64_t)B * C * H * W > (1LL << 31) - 1 || (int64_t)B * g.tiles_per_img > (1LL << 31) - 1)
+        return fail(EBFI_ERR_ARG, "dcn: tensor too large for 32-bit plane indexing");
+    return EBFI_OK;
+}
+
+int weight_grid(const Geom &g) {
+    const int64_t tiles = (int64_t)g.B * g.tiles_per_img;
+    return (int)(tiles < 512 ? tiles : 512);
+}
+
+}  // namespace
+
+extern "C" int ebfi_dcn_forward(const void *input, const void *weight, const void *bias, const void *offset,
+                                const void *mask, void *output, int B, int C, int H, int W, int Co, int kh, int kw,
+                                int sh, int sw, int ph, int pw, int dh, int dw, int deformable_group, int dtype,
+                                void *stream) {
+    if (!input || !weight || !bias || !offset || !mask || !output) return fail(EBFI_ERR_ARG, "dcn_forward: null argument");
+    if (dtype != EBFI_F32) return fail(EBFI_ERR_UNSUPPORTED, "dcn_forward: dtype %d not implemented (fp32 only)", dtype);
+    Geom g;
+    if (int rc = make_geom(g, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, deformable_group)) return rc;
+    if (B == 0) return EBFI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)(B * g.tiles_per_img), (unsigned)((Co + 63) / 64));
+    {
+        ProfScope ps("dcn_fwd_f32", st);
+        hipLaunchKernelGGL(dcn_fwd_f32, grid, dim3(256), 0, st, static_cast<const float *>(input),
+                           static_cast<const float *>(weight), static_cast<const float *>(bias),
+                           static_cast<const float *>(offset), static_cast<const float *>(mask),
+                           static_cast<float *>(output), g);
+    }
+    return check_launch("dcn_fwd_f32");
+}
+
+extern "C" size_t ebfi_dcn_backward_workspace(int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw,
+                                              int ph, int pw, int dh, int dw, int deformable_group, int dtype) {
+    (void)dtype;
+    Geom g;
+    if (make_geom(g, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, deformable_group) != EBFI_OK) return 0;
+    return (size_t)weight_grid(g) * ((size_t)g.Co * g.Kd + g.Co) * sizeof(float);
+}
+
+extern "C" int ebfi_dcn_backward(const void *input, const void *weight, const void *bias, const void *offset,
+                                 const void *mask, const void *grad_output, void *grad_input, void *grad_offset,
+                                 void *grad_mask, void *grad_weight, void *grad_bias, int B, int C, int H, int W,
+                                 int Co, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                                 int deformable_group, void *workspace, size_t workspace_bytes, int dtype,
+                                 void *stream) {
+    (void)bias;
+    if (!input || !weight || !offset || !mask || !grad_output || !grad_input || !grad_offset || !grad_mask ||
+        !grad_weight || !grad_bias)
+        return fail(EBFI_ERR_ARG, "dcn_backward: null argument");
+    if (dtype != EBFI_F32) return fail(EBFI_ERR_UNSUPPORTED, "dcn_backward: dtype %d not implemented (fp32 only)", dtype);
+    Geom g;
+    if (int rc = make_geom(g, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, deformable_group)) return rc;
+    const size_t need = ebfi_dcn_backward_workspace(B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, deformable_group, dtype);
+    if (!workspace || workspace_bytes < need)
+        return fail(EBFI_ERR_WORKSPACE, "dcn_backward: workspace %zu bytes < required %zu", workspace_bytes, need);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float *x = static_cast<const float *>(input), *wgt = static_cast<const float *>(weight);
+    const float *off = static_cast<const float *>(offset), *msk = static_cast<const float *>(mask);
+    const float *go = static_cast<const float *>(grad_output);
+    if (hipMemsetAsync(grad_input, 0, (size_t)B * C * H * W * sizeof(float), st) != hipSuccess)
+        return fail(EBFI_ERR_LAUNCH, "dcn_backward: memset of grad_input failed");
+    if (B == 0) {
+        (void)hipMemsetAsync(grad_weight, 0, (size_t)Co * g.Kd * sizeof(float), st);
+        (void)hipMemsetAsync(grad_bias, 0, (size_t)Co * sizeof(float), st);
+        return EBFI_OK;
+    }
+    {
+        ProfScope ps("dcn_bwd_data_f32", st);
+        hipLaunchKernelGGL(dcn_bwd_data_f32, dim3((unsigned)(B * g.tiles_per_img)), dim3(256), 0, st, x, wgt, off, msk,
+                           go, static_cast<float *>(grad_input), static_cast<float *>(grad_offset),
+                           static_cast<float *>(grad_mask), g);
+    }
+    if (int rc = check_launch("dcn_bwd_data_f32")) return rc;
+    const int nwg = weight_grid(g);
+    {
+        ProfScope ps("dcn_bwd_weight_f32", st);
+        hipLaunchKernelGGL(dcn_bwd_weight_f32, dim3((unsigned)nwg, (unsigned)((Co + 63) / 64)), dim3(256), 0, st, x, off,
+                           msk, go, static_cast<float *>(workspace), g, B * g.tiles_per_img);
+    }
+    if (int rc = check_launch("dcn_bwd_weight_f32")) return rc;
+    const int64_t n_weight = (int64_t)Co * g.Kd, n_total = n_weight + Co;
+    {
+        ProfScope ps("dcn_bwd_reduce_f32", st);
+        hipLaunchKernelGGL(dcn_bwd_reduce_f32, dim3((unsigned)ceil_div(n_total, 256)), dim3(256), 0, st,
+                           static_cast<const float *>(workspace), nwg, n_weight, n_total,
+                           static_cast<float *>(grad_weight), static_cast<float *>(grad_bias));
+    }
+    return check_launch("dcn_bwd_reduce_f32");
+}

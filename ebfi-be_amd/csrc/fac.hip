@@ -1,0 +1,391 @@
+// Filter-Adaptive Convolution (FAC) for gfx950.
+//
+// Semantics: reference models/FAC/kernelconv2d/KernelConv2D_kernel.cu:25-53 (forward),
+// :91-125 (grad_input), :128-150 (grad_kernel); entry points replace KernelConv2D_cuda.cpp:10-61.
+//
+// The op is pure HBM streaming (AI ~0.46 FLOP/B): per (b, c) plane it reads K*K filter planes once,
+// an input plane K*K times (on-chip reuse) and writes one plane.  Design:
+//   forward   one 256-thread workgroup per TH x TW output tile of a (b,c) plane; the (TH+K-1) x
+//             (TW+K-1) input halo tile is staged once in LDS; every thread owns 4 consecutive x and
+//             issues K*K independent 16-byte coalesced loads of the filter planes (all in flight
+//             together), fp32 FMA in the reference's (ky,kx) order, one 16-byte store.
+//   backward  ONE fused kernel for both gradients so the filter planes and grad_output are read
+//             once: a thread owns 4 consecutive x of one row Y of the PADDED grid, walks the K rows
+//             y = Y - ky that feed it, writes grad_kernel = in * gout (16-byte streaming stores) and
+//             keeps 4+K-1 private partial sums of grad_input; the K-1 partials that belong to the
+//             next thread's columns move one lane up with a wave shuffle (carried across x-chunks),
+//             so grad_input needs no atomics, no LDS and no zero-fill.
+//   generic   per-element kernels (any stride, any K, 64-bit indexing) for everything the fast
+//             paths do not cover; still HIP -- there is no CPU fallback.
+#include "common.hpp"
+
+using namespace ebfi;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// streamed-once data: non-temporal 16-byte accesses
+__device__ __forceinline__ f32x4 ld_stream4(const float *p) {
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+}
+__device__ __forceinline__ void st_stream4(float *p, f32x4 v) {
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p));
+}
+
+struct Str4 {
+    int64_t s0, s1, s2, s3;
+};
+static inline Str4 str4(const int64_t *p) { return Str4{p[0], p[1], p[2], p[3]}; }
+
+// ------------------------------------------------------------------------------------------------
+// forward, vectorised tile kernel.  Requirements (checked by the launcher): innermost stride 1 for
+// all three tensors, Wo % 4 == 0, filter/output rows 16-byte aligned.
+template <int K, int TH, int TW>
+__global__ __launch_bounds__(256) void fac_fwd_tile_f32(const float *__restrict__ in, Str4 is,
+                                                        const float *__restrict__ kern, Str4 ks,
+                                                        float *__restrict__ out, Str4 os, int C, int Ho,
+                                                        int Wo) {
+    static_assert(TH * (TW / 4) == 256, "tile must map onto 256 threads");
+    constexpr int IH = TH + K - 1;
+    constexpr int IW = TW + K - 1;
+    constexpr int NV = (4 + K - 1 + 3) / 4;   // float4 reads per thread per tile row
+    constexpr int IWP = TW - 4 + 4 * NV;      // padded LDS row: every thread's NV reads stay inside
+    static_assert(IWP >= IW, "LDS row too short");
+    __shared__ __attribute__((aligned(16))) float tile[IH * IWP];
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z / C, c = blockIdx.z % C;
+    const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+    const int Hi = Ho + K - 1, Wi = Wo + K - 1;
+
+    const float *inp = in + (int64_t)b * is.s0 + (int64_t)c * is.s1;
+    for (int i = tid; i < IH * IWP; i += 256) {
+        const int r = i / IWP, col = i - r * IWP;
+        const int yy = y0 + r, xx = x0 + col;
+        float v = 0.f;
+        if (col < IW && yy < Hi && xx < Wi) v = inp[(int64_t)yy * is.s2 + xx];
+        tile[i] = v;
+    }
+    __syncthreads();
+
+    const int ty = tid / (TW / 4), tx = tid % (TW / 4);
+    const int y = y0 + ty, x = x0 + 4 * tx;
+    if (y >= Ho || x >= Wo) return;
+
+    const float *kp = kern + (int64_t)b * ks.s0 + (int64_t)c * K * K * ks.s1 + (int64_t)y * ks.s2 + x;
+    f32x4 kv[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) kv[t] = ld_stream4(kp + (int64_t)t * ks.s1);
+
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+        float r[4 * NV];
+        const float4 *row = reinterpret_cast<const float4 *>(&tile[(ty + ky) * IWP + 4 * tx]);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const float4 q = row[v];
+            r[4 * v + 0] = q.x; r[4 * v + 1] = q.y; r[4 * v + 2] = q.z; r[4 * v + 3] = q.w;
+        }
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            const f32x4 w = kv[ky * K + kx];
+            a0 = fmaf(r[kx + 0], w.x, a0);
+            a1 = fmaf(r[kx + 1], w.y, a1);
+            a2 = fmaf(r[kx + 2], w.z, a2);
+            a3 = fmaf(r[kx + 3], w.w, a3);
+        }
+    }
+    float *op = out + (int64_t)b * os.s0 + (int64_t)c * os.s1 + (int64_t)y * os.s2 + x;
+    f32x4 res = {a0, a1, a2, a3};
+    *reinterpret_cast<f32x4 *>(op) = res;
+}
+
+// forward, generic: one thread per output element, any strides / K.
+__global__ void fac_fwd_generic_f32(const float *__restrict__ in, Str4 is, const float *__restrict__ kern,
+                                    Str4 ks, float *__restrict__ out, Str4 os, int64_t total, int C, int Ho,
+                                    int Wo, int K) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % Wo);
+    const int y = (int)((idx / Wo) % Ho);
+    const int c = (int)((idx / ((int64_t)Wo * Ho)) % C);
+    const int64_t b = idx / ((int64_t)Wo * Ho * C);
+    const float *ip = in + b * is.s0 + (int64_t)c * is.s1;
+    const float *kp = kern + b * ks.s0 + (int64_t)c * K * K * ks.s1 + (int64_t)y * ks.s2 + (int64_t)x * ks.s3;
+    float acc = 0.f;
+    for (int ky = 0; ky < K; ++ky)
+        for (int kx = 0; kx < K; ++kx)
+            acc = fmaf(ip[(int64_t)(y + ky) * is.s2 + (int64_t)(x + kx) * is.s3],
+                       kp[(int64_t)(ky * K + kx) * ks.s1], acc);
+    out[b * os.s0 + (int64_t)c * os.s1 + (int64_t)y * os.s2 + (int64_t)x * os.s3] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, fused row kernel (see file header).  K in {1,3,5}; innermost strides 1; Wo % 4 == 0;
+// filter / grad_kernel / grad_output rows 16-byte aligned.  TPR = lanes per row (power of two <= 64).
+template <int K, int TPR>
+__global__ __launch_bounds__(256) void fac_bwd_rows_f32(const float *__restrict__ in, Str4 is,
+                                                        const float *__restrict__ kern, Str4 ks,
+                                                        const float *__restrict__ gout, Str4 gs,
+                                                        float *__restrict__ gin, Str4 gis,
+                                                        float *__restrict__ gkern, Str4 gks, int C, int Ho,
+                                                        int Wo) {
+    static_assert(K == 1 || K == 3 || K == 5, "carry scheme needs K-1 <= 4");
+    constexpr int RPW = 64 / TPR;          // rows per wave
+    constexpr int ROWS = 4 * RPW;          // rows per 256-thread workgroup
+    constexpr int NS = 4 + K - 1;          // private partial sums / input values per thread
+    constexpr int NU = K - 1;              // partials owned by the next lane
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane / TPR, tx = lane % TPR;
+    const int Y = blockIdx.x * ROWS + wave * RPW + r;   // row of the padded grid
+    const int b = blockIdx.y / C, c = blockIdx.y % C;
+    const int Hi = Ho + K - 1, Wi = Wo + K - 1;
+    const int nx4 = Wo >> 2;
+    const bool rowok = Y < Hi;
+    const int nchunks = nx4 / TPR + 1;     // the lane right after the last loading lane writes the tail
+
+    const float *inrow = in + (int64_t)b * is.s0 + (int64_t)c * is.s1 + (int64_t)Y * is.s2;
+    const float *kbase = kern + (int64_t)b * ks.s0 + (int64_t)c * K * K * ks.s1;
+    const float *gbase = gout + (int64_t)b * gs.s0 + (int64_t)c * gs.s1;
+    float *gkbase = gkern ? gkern + (int64_t)b * gks.s0 + (int64_t)c * K * K * gks.s1 : nullptr;
+    float *ginrow = gin ? gin + (int64_t)b * gis.s0 + (int64_t)c * gis.s1 + (int64_t)Y * gis.s2 : nullptr;
+
+    float carry[NU > 0 ? NU : 1];
+#pragma unroll
+    for (int m = 0; m < NU; ++m) carry[m] = 0.f;
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int x4 = chunk * TPR + tx;
+        const int x = x4 << 2;
+        const bool active = rowok && x4 < nx4;
+        float s[NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) s[j] = 0.f;
+        if (active) {
+            float inr[NS];
+            if (gkbase != nullptr) {
+#pragma unroll
+                for (int j = 0; j < NS; ++j) inr[j] = inrow[x + j];   // x + j <= Wo - 4 + 3 + K - 1 < Wi
+            }
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                const int y = Y - ky;
+                if (y < 0 || y >= Ho) continue;
+                const float4 g = *reinterpret_cast<const float4 *>(gbase + (int64_t)y * gs.s2 + x);
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const int t = ky * K + kx;
+                    const f32x4 w = ld_stream4(kbase + (int64_t)t * ks.s1 + (int64_t)y * ks.s2 + x);
+                    if (gkbase != nullptr) {
+                        const f32x4 p = {inr[kx + 0] * g.x, inr[kx + 1] * g.y, inr[kx + 2] * g.z, inr[kx + 3] * g.w};
+                        st_stream4(gkbase + (int64_t)t * gks.s1 + (int64_t)y * gks.s2 + x, p);
+                    }
+                    s[kx + 0] = fmaf(w.x, g.x, s[kx + 0]);
+                    s[kx + 1] = fmaf(w.y, g.y, s[kx + 1]);
+                    s[kx + 2] = fmaf(w.z, g.z, s[kx + 2]);
+                    s[kx + 3] = fmaf(w.w, g.w, s[kx + 3]);
+                }
+            }
+        }
+        // hand the K-1 upper partials to the lane that owns those columns (all lanes take part)
+        float o[4] = {s[0], s[1], s[2], s[3]};
+        if constexpr (NU > 0) {
+#pragma unroll
+            for (int m = 0; m < NU; ++m) {
+                float left = __shfl_up(s[4 + m], 1, TPR);
+                if (tx == 0) left = carry[m];
+                const float last = __shfl(s[4 + m], TPR - 1, TPR);
+                o[m] += left;
+                carry[m] = last;
+            }
+        }
+        if (ginrow != nullptr && rowok) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                if (x + m < Wi) ginrow[x + m] = o[m];
+        }
+    }
+}
+
+__global__ void fac_bwd_input_generic_f32(const float *__restrict__ kern, Str4 ks,
+                                          const float *__restrict__ gout, Str4 gs, float *__restrict__ gin,
+                                          Str4 gis, int64_t total, int C, int Ho, int Wo, int K) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int Hi = Ho + K - 1, Wi = Wo + K - 1;
+    const int X = (int)(idx % Wi);
+    const int Y = (int)((idx / Wi) % Hi);
+    const int c = (int)((idx / ((int64_t)Wi * Hi)) % C);
+    const int64_t b = idx / ((int64_t)Wi * Hi * C);
+    float acc = 0.f;
+    for (int ky = 0; ky < K; ++ky)
+        for (int kx = 0; kx < K; ++kx) {
+            const int y = Y - ky, x = X - kx;
+            if (y < 0 || y > Ho - 1 || x < 0 || x > Wo - 1) continue;
+            const float w = kern[b * ks.s0 + ((int64_t)c * K * K + ky * K + kx) * ks.s1 + (int64_t)y * ks.s2 +
+                                 (int64_t)x * ks.s3];
+            acc = fmaf(w, gout[b * gs.s0 + (int64_t)c * gs.s1 + (int64_t)y * gs.s2 + (int64_t)x * gs.s3], acc);
+        }
+    gin[b * gis.s0 + (int64_t)c * gis.s1 + (int64_t)Y * gis.s2 + (int64_t)X * gis.s3] = acc;
+}
+
+__global__ void fac_bwd_kernel_generic_f32(const float *__restrict__ in, Str4 is,
+                                           const float *__restrict__ gout, Str4 gs, float *__restrict__ gkern,
+                                           Str4 gks, int64_t total, int C, int Ho, int Wo, int K) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % Wo);
+    const int y = (int)((idx / Wo) % Ho);
+    const int kx = (int)((idx / ((int64_t)Wo * Ho)) % K);
+    const int ky = (int)((idx / ((int64_t)Wo * Ho * K)) % K);
+    const int c = (int)((idx / ((int64_t)Wo * Ho * K * K)) % C);
+    const int64_t b = idx / ((int64_t)Wo * Ho * K * K * C);
+    const float v = in[b * is.s0 + (int64_t)c * is.s1 + (int64_t)(y + ky) * is.s2 + (int64_t)(x + kx) * is.s3] *
+                    gout[b * gs.s0 + (int64_t)c * gs.s1 + (int64_t)y * gs.s2 + (int64_t)x * gs.s3];
+    gkern[b * gks.s0 + ((int64_t)c * K * K + ky * K + kx) * gks.s1 + (int64_t)y * gks.s2 + (int64_t)x * gks.s3] = v;
+}
+
+// rows of `p` start 16-byte aligned and the three outer strides keep that alignment
+static bool vec4_ok(const void *p, const Str4 &s) {
+    return p != nullptr && aligned16(p) && s.s3 == 1 && (s.s0 % 4 == 0) && (s.s1 % 4 == 0) && (s.s2 % 4 == 0);
+}
+
+int check_shapes(const int64_t *ish, const int64_t *ksh, int K, int64_t *B, int64_t *C, int64_t *Ho, int64_t *Wo) {
+    if (K < 1) return fail(EBFI_ERR_ARG, "fac: kernel_size %d < 1", K);
+    *B = ish[0]; *C = ish[1]; *Ho = ksh[2]; *Wo = ksh[3];
+    if (ksh[0] != *B) return fail(EBFI_ERR_ARG, "fac: batch mismatch input %lld vs kernel %lld", (long long)ish[0], (long long)ksh[0]);
+    if (ksh[1] != *C * K * K)
+        return fail(EBFI_ERR_ARG, "fac: kernel has %lld channels, expected C*K*K = %lld", (long long)ksh[1], (long long)(*C * K * K));
+    if (ish[2] - K != *Ho - 1 || ish[3] - K != *Wo - 1)
+        return fail(EBFI_ERR_ARG, "fac: input %lldx%lld is not output %lldx%lld + K-1 (K=%d)", (long long)ish[2],
+                    (long long)ish[3], (long long)*Ho, (long long)*Wo, K);
+    if (*B < 0 || *C < 0 || *Ho < 0 || *Wo < 0 || *Ho > (1 << 24) || *Wo > (1 << 24) || *B * *C > (1LL << 31) - 1)
+        return fail(EBFI_ERR_ARG, "fac: tensor extent out of range");
+    return EBFI_OK;
+}
+
+template <int K>
+void launch_fwd_tile(hipStream_t st, const float *in, Str4 is, const float *kern, Str4 ks, float *out, Str4 os,
+                     int B, int C, int Ho, int Wo) {
+    if (Wo <= 64) {
+        dim3 grid((unsigned)ceil_div(Wo, 64), (unsigned)ceil_div(Ho, 16), (unsigned)(B * C));
+        ProfScope ps("fac_fwd_tile_f32", st);
+        hipLaunchKernelGGL((fac_fwd_tile_f32<K, 16, 64>), grid, dim3(256), 0, st, in, is, kern, ks, out, os, C, Ho, Wo);
+    } else {
+        dim3 grid((unsigned)ceil_div(Wo, 128), (unsigned)ceil_div(Ho, 8), (unsigned)(B * C));
+        ProfScope ps("fac_fwd_tile_f32", st);
+        hipLaunchKernelGGL((fac_fwd_tile_f32<K, 8, 128>), grid, dim3(256), 0, st, in, is, kern, ks, out, os, C, Ho, Wo);
+    }
+}
+
+template <int K, int TPR>
+void launch_bwd_rows_t(hipStream_t st, const float *in, Str4 is, const float *kern, Str4 ks, const float *go,
+                       Str4 gs, float *gin, Str4 gis, float *gk, Str4 gks, int B, int C, int Ho, int Wo) {
+    constexpr int ROWS = 4 * (64 / TPR);
+    dim3 grid((unsigned)ceil_div(Ho + K - 1, ROWS), (unsigned)(B * C));
+    ProfScope ps("fac_bwd_rows_f32", st);
+    hipLaunchKernelGGL((fac_bwd_rows_f32<K, TPR>), grid, dim3(256), 0, st, in, is, kern, ks, go, gs, gin, gis, gk, gks,
+                       C, Ho, Wo);
+}
+
+template <int K>
+void launch_bwd_rows(hipStream_t st, const float *in, Str4 is, const float *kern, Str4 ks, const float *go, Str4 gs,
+                     float *gin, Str4 gis, float *gk, Str4 gks, int B, int C, int Ho, int Wo) {
+    const int nx4 = Wo / 4;
+    if (nx4 <= 8) launch_bwd_rows_t<K, 8>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo);
+    else if (nx4 <= 16) launch_bwd_rows_t<K, 16>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo);
+    else if (nx4 <= 32) launch_bwd_rows_t<K, 32>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo);
+    else launch_bwd_rows_t<K, 64>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo);
+}
+
+}  // namespace
+
+extern "C" int ebfi_fac_forward(const void *input, const int64_t input_shape[4], const int64_t input_stride[4],
+                                const void *kernel, const int64_t kernel_shape[4], const int64_t kernel_stride[4],
+                                int kernel_size, void *output, const int64_t output_shape[4],
+                                const int64_t output_stride[4], int dtype, void *stream) {
+    if (!input || !kernel || !output || !input_shape || !input_stride || !kernel_shape || !kernel_stride ||
+        !output_shape || !output_stride)
+        return fail(EBFI_ERR_ARG, "fac_forward: null argument");
+    if (dtype != EBFI_F32) return fail(EBFI_ERR_UNSUPPORTED, "fac_forward: dtype %d not implemented (fp32 only)", dtype);
+    int64_t B, C, Ho, Wo;
+    const int K = kernel_size;
+    if (int rc = check_shapes(input_shape, kernel_shape, K, &B, &C, &Ho, &Wo)) return rc;
+    if (output_shape[0] != B || output_shape[1] != C || output_shape[2] != Ho || output_shape[3] != Wo)
+        return fail(EBFI_ERR_ARG, "fac_forward: output shape mismatch");
+    if (B * C * Ho * Wo == 0) return EBFI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float *in = static_cast<const float *>(input);
+    const float *kern = static_cast<const float *>(kernel);
+    float *out = static_cast<float *>(output);
+    const Str4 is = str4(input_stride), ks = str4(kernel_stride), os = str4(output_stride);
+
+    // gridDim.z carries the (b, c) plane index: at most 65535 planes on the tiled path
+    const bool fast = (K == 1 || K == 3 || K == 5) && is.s3 == 1 && (Wo % 4 == 0) && vec4_ok(kern, ks) &&
+                      vec4_ok(out, os) && B * C <= 65535;
+    if (fast) {
+        if (K == 5) launch_fwd_tile<5>(st, in, is, kern, ks, out, os, (int)B, (int)C, (int)Ho, (int)Wo);
+        else if (K == 3) launch_fwd_tile<3>(st, in, is, kern, ks, out, os, (int)B, (int)C, (int)Ho, (int)Wo);
+        else launch_fwd_tile<1>(st, in, is, kern, ks, out, os, (int)B, (int)C, (int)Ho, (int)Wo);
+        return check_launch("fac_fwd_tile_f32");
+    }
+    const int64_t total = B * C * Ho * Wo;
+    {
+        ProfScope ps("fac_fwd_generic_f32", st);
+        hipLaunchKernelGGL(fac_fwd_generic_f32, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, in, is, kern, ks,
+                           out, os, total, (int)C, (int)Ho, (int)Wo, K);
+    }
+    return check_launch("fac_fwd_generic_f32");
+}
+
+extern "C" int ebfi_fac_backward(const void *input, const int64_t input_shape[4], const int64_t input_stride[4],
+                                 const void *kernel, const int64_t kernel_shape[4], const int64_t kernel_stride[4],
+                                 int kernel_size, const void *grad_output, const int64_t grad_output_stride[4],
+                                 void *grad_input, const int64_t grad_input_stride[4], void *grad_kernel,
+                                 const int64_t grad_kernel_stride[4], int dtype, void *stream) {
+    if (!input || !kernel || !grad_output || !input_shape || !input_stride || !kernel_shape || !kernel_stride ||
+        !grad_output_stride)
+        return fail(EBFI_ERR_ARG, "fac_backward: null argument");
+    if ((grad_input && !grad_input_stride) || (grad_kernel && !grad_kernel_stride))
+        return fail(EBFI_ERR_ARG, "fac_backward: gradient pointer without strides");
+    if (dtype != EBFI_F32) return fail(EBFI_ERR_UNSUPPORTED, "fac_backward: dtype %d not implemented (fp32 only)", dtype);
+    int64_t B, C, Ho, Wo;
+    const int K = kernel_size;
+    if (int rc = check_shapes(input_shape, kernel_shape, K, &B, &C, &Ho, &Wo)) return rc;
+    if (!grad_input && !grad_kernel) return EBFI_OK;
+    if (B * C * Ho * Wo == 0) return EBFI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float *in = static_cast<const float *>(input);
+    const float *kern = static_cast<const float *>(kernel);
+    const float *go = static_cast<const float *>(grad_output);
+    float *gin = static_cast<float *>(grad_input);
+    float *gk = static_cast<float *>(grad_kernel);
+    const Str4 is = str4(input_stride), ks = str4(kernel_stride), gs = str4(grad_output_stride);
+    const Str4 gis = gin ? str4(grad_input_stride) : Str4{0, 0, 0, 1};
+    const Str4 gks = gk ? str4(grad_kernel_stride) : Str4{0, 0, 0, 1};
+
+    const bool fast = (K == 1 || K == 3 || K == 5) && (Wo % 4 == 0) && is.s3 == 1 && vec4_ok(kern, ks) &&
+                      vec4_ok(go, gs) && (!gk || vec4_ok(gk, gks)) && (!gin || gis.s3 == 1) && B * C <= 65535;
+    if (fast) {
+        if (K == 5) launch_bwd_rows<5>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, (int)B, (int)C, (int)Ho, (int)Wo);
+        else if (K == 3) launch_bwd_rows<3>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, (int)B, (int)C, (int)Ho, (int)Wo);
+        else launch_bwd_rows<1>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, (int)B, (int)C, (int)Ho, (int)Wo);
+        return check_launch("fac_bwd_rows_f32");
+    }
+    if (gin) {
+        const int64_t total = B * C * (Ho + K - 1) * (Wo + K - 1);
+        ProfScope ps("fac_bwd_input_generic_f32", st);
+        hipLaunchKernelGGL(fac_bwd_input_generic_f32, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, kern, ks,
+                           go, gs, gin, gis, total, (int)C, (int)Ho, (int)Wo, K);
+    }
+    if (int rc = check_launch("fac_bwd_input_generic_f32")) return rc;
+    if (gk) {
+        const int64_t total = B * C * K * K * Ho * Wo;
+        ProfScope ps("fac_bwd_kernel_generic_f32", st);
+        hipLaunchKernelGGL(fac_bwd_kernel_generic_f32, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, in, is,
+                           go, gs, gk, gks, total, (int)C, (int)Ho, (int)Wo, K);
+    }
+    return check_launch("fac_bwd_kernel_generic_f32");
+}

@@ -1,0 +1,153 @@
+"""ctypes binding of libebfi_hip.so (the C ABI declared in include/ebfi_hip.h).
+
+This is the only place the host code touches the native library.  Loading is lazy and LOUD: if the
+shared object is missing, cannot be loaded or lacks a declared symbol, the first use of any op
+raises ``EbfiNativeError`` -- there is no CPU or PyTorch fallback anywhere in this package.
+"""
+import ctypes
+import os
+import re
+import subprocess
+import threading
+
+PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # .../ebfi-be_amd
+REPO_ROOT = os.path.dirname(PKG_ROOT)
+LIB_PATH = os.path.join(PKG_ROOT, "lib", "libebfi_hip.so")
+HEADER = os.path.join(REPO_ROOT, "include", "ebfi_hip.h")
+BUILD_SCRIPT = os.path.join(PKG_ROOT, "csrc", "build.sh")
+
+EBFI_F32, EBFI_BF16 = 0, 1
+
+
+class EbfiNativeError(RuntimeError):
+    pass
+
+
+_lock = threading.Lock()
+_lib = None
+
+_c = ctypes
+_vp, _i, _i64, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t
+_p64 = _c.POINTER(_c.c_int64)
+
+# name -> (restype, argtypes); must list every function the header declares (tests check that)
+SIGNATURES = {
+    "ebfi_abi_version": (_i, []),
+    "ebfi_last_error": (_c.c_char_p, []),
+    "ebfi_fac_forward": (_i, [_vp, _p64, _p64, _vp, _p64, _p64, _i, _vp, _p64, _p64, _i, _vp]),
+    "ebfi_fac_backward": (_i, [_vp, _p64, _p64, _vp, _p64, _p64, _i, _vp, _p64, _vp, _p64, _vp, _p64, _i, _vp]),
+    "ebfi_dcn_forward": (_i, [_vp] * 6 + [_i] * 14 + [_i, _vp]),
+    "ebfi_dcn_backward_workspace": (_sz, [_i] * 14 + [_i]),
+    "ebfi_dcn_backward": (_i, [_vp] * 11 + [_i] * 14 + [_vp, _sz, _i, _vp]),
+    "ebfi_events_workspace": (_sz, [_i]),
+    "ebfi_events_to_stack": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "ebfi_frame2lap": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "ebfi_frame2dcp": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ebfi_prof_enable": (None, [_i]),
+    "ebfi_prof_reset": (None, []),
+    "ebfi_prof_collect": (_i, [_c.POINTER(_i)]),
+    "ebfi_prof_num_kernels": (_i, []),
+    "ebfi_prof_get": (_i, [_i, _c.POINTER(_c.c_char_p), _c.POINTER(_i64), _c.POINTER(_c.c_double)]),
+}
+
+
+def declared_symbols():
+    """Function names declared in include/ebfi_hip.h (used by the export test)."""
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ebfi_[a-z0-9_]+)\s*\(", text)))
+
+
+def build(verbose=False):
+    """Compile libebfi_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["bash", BUILD_SCRIPT], stdout=out)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise EbfiNativeError(
+                "native library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or ebfi-be_amd/csrc/build.sh).  There is no CPU fallback." % LIB_PATH)
+        try:
+            h = ctypes.CDLL(LIB_PATH)
+        except OSError as e:
+            raise EbfiNativeError("cannot load %s: %s" % (LIB_PATH, e)) from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(h, name)
+            except AttributeError as e:
+                raise EbfiNativeError("%s does not export %s" % (LIB_PATH, name)) from e
+            fn.restype = res
+            fn.argtypes = args
+        if h.ebfi_abi_version() != 1:
+            raise EbfiNativeError("ABI version mismatch: library %d, binding 1" % h.ebfi_abi_version())
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().ebfi_last_error()
+        raise EbfiNativeError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def i64x4(vals):
+    return (_c.c_int64 * 4)(*[int(v) for v in vals])
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return _vp(t.data_ptr()) if t is not None else _vp(0)
+
+
+def stream_ptr(device=None):
+    import torch
+    return _vp(torch.cuda.current_stream(device).cuda_stream)
+
+
+def dtype_code(t):
+    import torch
+    if t.dtype == torch.float32:
+        return EBFI_F32
+    if t.dtype == torch.bfloat16:
+        return EBFI_BF16
+    raise EbfiNativeError("unsupported dtype %s (float32 / bfloat16 only)" % t.dtype)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise NotImplementedError(
+                "ebfi_amd ops run on an MI355X through libebfi_hip.so only; got a %s tensor "
+                "(the reference's FAC has no CPU path either: KernelConv2D.py:38-39)" % t.device)
+
+
+# ------------------------------------------------------------------ profiler helpers
+def prof_enable(on=True):
+    lib().ebfi_prof_enable(1 if on else 0)
+
+
+def prof_reset():
+    lib().ebfi_prof_reset()
+
+
+def prof_collect():
+    """{kernel name: (launches, total_ms)}; call after torch.cuda.synchronize()."""
+    h = lib()
+    dropped = _i(0)
+    h.ebfi_prof_collect(ctypes.byref(dropped))
+    out = {}
+    for k in range(h.ebfi_prof_num_kernels()):
+        name, n, ms = _c.c_char_p(), _i64(0), _c.c_double(0)
+        h.ebfi_prof_get(k, ctypes.byref(name), ctypes.byref(n), ctypes.byref(ms))
+        out[name.value.decode()] = (n.value, ms.value)
+    out["__dropped__"] = (dropped.value, 0.0)
+    return out

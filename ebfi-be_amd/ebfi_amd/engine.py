@@ -1,0 +1,77 @@
+"""Training / inference engine for the hot path: what train_ours.py:250-277 and
+infer_ours.py:113-118 do per step, minus the reference's I/O, logging and bookkeeping.
+
+One process per GPU.  A step = forward -> Lap+census loss -> backward -> ONE flat RCCL gradient
+all-reduce (ebfi_amd.dp) -> Adam.  Synthetic batches follow SURVEY.md section 8(d).
+"""
+import contextlib
+
+import torch
+
+from .dp import FlatGradBucket, broadcast_parameters
+from .loss import TrainLoss
+from .model import EVFIAutoEx
+
+# config/train_ours.yml:28-57 of the reference (the hot-path hyper-parameters)
+DEFAULT_MODEL_ARGS = dict(
+    FrameBasech=64, EventBasech=64, InterCH=64, TB=16, norm=None, activation="LeakyReLU",
+    UseGTEx=False, FixEx=None, BlurryFashion="RGBLap", BLInch=4, UseEvents=True, LoadPretrainEX=False,
+    PretrainedEXPath=None, FrozenEX=False, step=12, DualPath=True, residual=True, DetailEnabled=True,
+    channels=[16, 24, 32, 64])
+
+
+def synthetic_batch(B, H, W, TB=16, device="cuda", seed=123, rank=0):
+    """Frame in [0,1], Event = Poisson(0.35) integer counts, T in [0,1),
+    GTEx in [0.55,0.95), random GT frame.  Seed = reference default (train_ours.py:806) + rank."""
+    g = torch.Generator(device="cpu").manual_seed(seed + rank)
+    frame = torch.rand(B, 3, H, W, generator=g)
+    event = torch.poisson(torch.full((B, TB, 2, H, W), 0.35), generator=g)
+    t = torch.rand(B, 1, generator=g)
+    gtex = torch.rand(B, 1, generator=g) * 0.4 + 0.55
+    target = torch.rand(B, 3, H, W, generator=g)
+    return tuple(v.to(device) for v in (frame, event, t, gtex, target))
+
+
+class Engine:
+    def __init__(self, model_args=None, device="cuda", precision="fp32", lr=1e-4, seed=None, train=True):
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.device = torch.device(device)
+        self.precision = precision
+        if seed is not None:
+            torch.manual_seed(seed)
+        self.model_args = dict(DEFAULT_MODEL_ARGS, **(model_args or {}))
+        self.model = EVFIAutoEx(**self.model_args).to(self.device)
+        broadcast_parameters(self.model, 0)
+        self.iteration = 0
+        if train:
+            self.model.train()
+            self.loss = TrainLoss(self.model_args.get("DetailEnabled", True)).to(self.device)
+            self.bucket = FlatGradBucket(self.model)
+            fused = self.device.type == "cuda"
+            self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, betas=(0.9, 0.999), amsgrad=False,
+                                              fused=fused)
+        else:
+            self.model.eval()
+
+    def _autocast(self):
+        if self.precision == "bf16":
+            return torch.autocast(self.device.type, dtype=torch.bfloat16)
+        return contextlib.nullcontext()
+
+    def train_step(self, frame, event, t, gtex, target):
+        """One optimiser step on this rank's batch; returns the (unreduced) loss tensor."""
+        self.bucket.zero()
+        with self._autocast():
+            sharp_pre, sharp = self.model(frame, event, t, gtex)
+        loss = self.loss(sharp_pre.float(), sharp.float(), target, self.iteration)
+        loss.backward()
+        self.bucket.all_reduce_mean()
+        self.optimizer.step()
+        self.iteration += 1
+        return loss.detach()
+
+    @torch.no_grad()
+    def infer(self, frame, event, t, gtex=None):
+        with self._autocast():
+            return self.model(frame, event, t, gtex)[-1]

@@ -1,0 +1,84 @@
+"""Filter-Adaptive Convolution -- host side.
+
+Mirrors the reference's ``models/FAC/kernelconv2d/KernelConv2D.py``: ``KernelConv2DFunction``
+(:12-58, ``apply(input_pad, kernel, kernel_size)`` -> output, backward returns
+``(grad_input, grad_kernel, None)``) and the ``KernelConv2D`` module (:77-87, replicate-pad by
+K//2 then the op).  Same argument checks, same error on CPU tensors (NotImplementedError,
+:38-39,55-56); the compute is ``ebfi_fac_forward`` / ``ebfi_fac_backward`` of libebfi_hip.so.
+"""
+import torch
+from torch import nn
+from torch.autograd import Function
+
+from . import _native as N
+
+
+def fac_forward(input_pad, kernel, kernel_size, out=None):
+    """Raw op on already padded input.  Any strides are accepted by the native side."""
+    N.require_gpu(input_pad, kernel)
+    B, C = input_pad.size(0), input_pad.size(1)
+    Ho, Wo = kernel.size(2), kernel.size(3)
+    if out is None:
+        out = torch.empty((B, C, Ho, Wo), dtype=input_pad.dtype, device=input_pad.device)
+    with torch.cuda.device_of(input_pad):
+        rc = N.lib().ebfi_fac_forward(
+            N.ptr(input_pad), N.i64x4(input_pad.shape), N.i64x4(input_pad.stride()),
+            N.ptr(kernel), N.i64x4(kernel.shape), N.i64x4(kernel.stride()), int(kernel_size),
+            N.ptr(out), N.i64x4(out.shape), N.i64x4(out.stride()),
+            N.dtype_code(input_pad), N.stream_ptr(input_pad.device))
+    N.check(rc, "ebfi_fac_forward")
+    return out
+
+
+def fac_backward(input_pad, kernel, kernel_size, grad_output, need_input=True, need_kernel=True):
+    N.require_gpu(input_pad, kernel, grad_output)
+    gin = torch.empty_like(input_pad, memory_format=torch.contiguous_format) if need_input else None
+    gk = torch.empty_like(kernel, memory_format=torch.contiguous_format) if need_kernel else None
+    unit = N.i64x4((0, 0, 0, 1))
+    with torch.cuda.device_of(input_pad):
+        rc = N.lib().ebfi_fac_backward(
+            N.ptr(input_pad), N.i64x4(input_pad.shape), N.i64x4(input_pad.stride()),
+            N.ptr(kernel), N.i64x4(kernel.shape), N.i64x4(kernel.stride()), int(kernel_size),
+            N.ptr(grad_output), N.i64x4(grad_output.stride()),
+            N.ptr(gin), N.i64x4(gin.stride()) if gin is not None else unit,
+            N.ptr(gk), N.i64x4(gk.stride()) if gk is not None else unit,
+            N.dtype_code(input_pad), N.stream_ptr(input_pad.device))
+    N.check(rc, "ebfi_fac_backward")
+    return gin, gk
+
+
+class KernelConv2DFunction(Function):
+    @staticmethod
+    def forward(ctx, input, kernel, kernel_size):
+        ctx.kernel_size = kernel_size
+        assert input.is_contiguous()
+        assert kernel.is_contiguous()
+        assert ctx.kernel_size == int((kernel.size(1) / input.size(1)) ** 0.5)
+        assert input.size(2) - kernel_size == kernel.size(2) - 1
+        assert input.size(3) - kernel_size == kernel.size(3) - 1
+        if not input.is_cuda:
+            raise NotImplementedError()  # as the reference: no CPU version
+        ctx.save_for_backward(input, kernel)
+        return fac_forward(input, kernel, kernel_size)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, kernel = ctx.saved_tensors
+        grad_output = grad_output.contiguous()
+        if not grad_output.is_cuda:
+            raise NotImplementedError()
+        gin, gk = fac_backward(input, kernel, ctx.kernel_size, grad_output,
+                               ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return gin, gk, None
+
+
+class KernelConv2D(nn.Module):
+    def __init__(self, kernel_size):
+        super().__init__()
+        assert kernel_size % 2 == 1
+        self.kernel_size = kernel_size
+        r = (kernel_size - 1) // 2
+        self.pad = nn.ReplicationPad2d([r, r, r, r])
+
+    def forward(self, input, kernel):
+        return KernelConv2DFunction.apply(self.pad(input), kernel, self.kernel_size)

@@ -1,0 +1,396 @@
+"""EVFIAutoEx -- the frame-synthesis network of EBFI-BE behind the reference's nn.Module API.
+
+Drop-in contract (reference models/Ours/model_singleframe.py:226-348): same constructor keywords,
+``forward(Frame[B,3,H,W], Event[B,TB,2,H,W], T[B,1], GTEx=None) -> (Sharp, Final)``,
+``LoadExposureDecision()``, and -- so that reference checkpoints load -- the same ``state_dict``
+key names and shapes (checked against tests/golden/state_dict_default.txt).
+
+What differs from the reference, on purpose:
+  * the FAC op inside ``Modification`` is the gfx950 kernel of libebfi_hip.so (ebfi_amd.fac);
+  * ``Frame2Lap`` / ``Frame2DCP`` run as device kernels (ebfi_amd.blur) instead of a
+    GPU -> host -> OpenCV -> GPU round trip inside forward (myutils/utils.py:15-49);
+  * the ``FixEx`` branch builds its tensor on the input's device instead of a hard ``.cuda()``
+    (model_singleframe.py:309);
+  * sub-modules are assembled from small builders rather than one class per block.
+Convolutions currently go through PyTorch-ROCm (MIOpen); DESIGN.md tracks their replacement.
+"""
+from math import ceil, floor
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .blur import Frame2DCP, Frame2Lap
+from .fac import KernelConv2D
+
+
+class BaseModel(nn.Module):
+    """models/model_misc/base.py:11-33: __str__ appends the parameter counts."""
+
+    def __str__(self):
+        trainable = sum(p.numel() for p in self.parameters() if p.requires_grad)
+        total = sum(p.numel() for p in self.parameters())
+        return super().__str__() + "\nTrainable parameters: {} \nAll parameters: {}".format(trainable, total)
+
+
+class ConvLayer(nn.Module):
+    """Conv2d (+BN/IN) (+activation); parameter container named ``conv2d`` like
+    models/model_misc/submodules.py:159-200."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, activation="ReLU", norm=None,
+                 BN_momentum=0.1):
+        super().__init__()
+        self.conv2d = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, bias=(norm != "BN"))
+        self.activation = getattr(nn, activation)() if activation is not None else None
+        self.norm = norm
+        if norm == "BN":
+            self.norm_layer = nn.BatchNorm2d(out_channels, momentum=BN_momentum)
+        elif norm == "IN":
+            self.norm_layer = nn.InstanceNorm2d(out_channels, track_running_stats=True)
+
+    def forward(self, x):
+        y = self.conv2d(x)
+        if self.norm in ("BN", "IN"):
+            y = self.norm_layer(y)
+        return y if self.activation is None else self.activation(y)
+
+
+def initialize_weights(nets, scale=1):
+    """models/model_misc/model_util.py:16-36."""
+    for net in nets if isinstance(nets, (list, tuple)) else [nets]:
+        for m in net.modules():
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                nn.init.kaiming_normal_(m.weight, a=0, mode="fan_in")
+                m.weight.data *= scale
+                if m.bias is not None:
+                    m.bias.data.zero_()
+            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias.data, 0.0)
+
+
+class CropSize:
+    """Zero-pad to a multiple of patch_size and crop back (model_util.py:158-189)."""
+
+    def __init__(self, width, height, patch_size):
+        self.width, self.height = width, height
+        self.wc = int(patch_size["w"] * ceil(width / patch_size["w"]))
+        self.hc = int(patch_size["h"] * ceil(height / patch_size["h"]))
+        dh, dw = self.hc - height, self.wc - width
+        self.pad = nn.ZeroPad2d((ceil(0.5 * dw), floor(0.5 * dw), ceil(0.5 * dh), floor(0.5 * dh)))
+
+    def crop(self, img):
+        cx, cy = floor(self.wc / 2), floor(self.hc / 2)
+        return img[..., cy - floor(self.height / 2): cy + ceil(self.height / 2),
+                   cx - floor(self.width / 2): cx + ceil(self.width / 2)]
+
+
+def _conv(cin, cout, k, s, p, norm, act):
+    return ConvLayer(in_channels=cin, out_channels=cout, kernel_size=k, stride=s, padding=p, norm=norm, activation=act)
+
+
+class ExposureDecision(BaseModel):
+    """Event / blur-level correlation -> exposure duty in [0,1]  (model_singleframe.py:23-76)."""
+
+    def __init__(self, EventInch=32, BLInch=1, InterCH=64, Group=4, norm=None, activation="LeakyReLU",
+                 LoadPretrain=False, PretrainedEXPath=None, Frozen=False):
+        super().__init__()
+        self.LoadPretrain, self.PretrainedEXPath, self.Frozen = LoadPretrain, PretrainedEXPath, Frozen
+        self.EventFeatExtract = _conv(EventInch, InterCH, 3, 1, 1, norm, activation)
+        self.BLFeatExtract = _conv(BLInch, InterCH, 3, 1, 1, norm, activation)
+        self.GroupNorm = nn.GroupNorm(Group, InterCH)
+        self.AVGPool = nn.AdaptiveAvgPool2d(1)
+        self.Conv1 = nn.Sequential(_conv(2 * InterCH, InterCH, 3, 1, 1, norm, activation),
+                                   _conv(InterCH, 1, 3, 1, 1, norm, None))
+        initialize_weights([self.EventFeatExtract, self.BLFeatExtract, self.GroupNorm, self.Conv1], 0.1)
+        self.load_pretrain()
+
+    def load_pretrain(self):
+        if self.LoadPretrain:
+            cpt = torch.load(self.PretrainedEXPath, map_location="cpu")
+            self.load_state_dict(cpt["model"]["states"])
+        if self.Frozen:
+            for p in self.parameters():
+                p.requires_grad = False
+            self.eval()
+
+    def forward(self, Event, BlurryLevel):
+        ev = self.EventFeatExtract(Event)
+        bl = self.BLFeatExtract(BlurryLevel)
+        atten = torch.sigmoid(self.AVGPool(self.GroupNorm(ev) * self.GroupNorm(bl)))
+        ex = self.Conv1(torch.cat([ev * atten, bl], dim=1))
+        return torch.sigmoid(self.AVGPool(ex).view(-1, 1))
+
+
+class ResidualControl(BaseModel):
+    """`step` rounds of exposure- and time-modulated residual refinement (model_singleframe.py:79-136)."""
+
+    def __init__(self, BLinch=2, Tinch=1, Basech=16, step=4, norm=None, activation="LeakyReLU"):
+        super().__init__()
+        self.step = step
+
+        def bank(make):
+            return nn.ModuleList([nn.Sequential(*make()) for _ in range(step)])
+
+        c3 = lambda cin: _conv(cin, Basech, 3, 1, 1, norm, activation)
+        self.Conv1 = bank(lambda: [_conv(BLinch, Basech, 1, 1, 0, norm, activation)])
+        self.Conv2 = bank(lambda: [_conv(Tinch, Basech, 1, 1, 0, norm, activation)])
+        self.Conv3 = bank(lambda: [c3(Basech), c3(Basech)])
+        self.Conv4 = bank(lambda: [c3(Basech), c3(Basech)])
+        self.Conv5 = bank(lambda: [c3(2 * Basech)])
+        initialize_weights([self.Conv1, self.Conv2, self.Conv3, self.Conv4, self.Conv5], 0.1)
+
+    def forward(self, data, Ex, T):
+        ex, t = Ex[:, :, None, None], T[:, :, None, None]
+        x = data
+        for i in range(self.step):
+            by_ex = self.Conv1[i](ex) * self.Conv3[i](x) + x
+            by_t = self.Conv2[i](t) * self.Conv4[i](x) + x
+            x = self.Conv5[i](torch.cat([by_ex, by_t], dim=1))
+        return x
+
+
+class Modification(BaseModel):
+    """Event features -> per-pixel 5x5 filters applied to themselves (FAC), then gate the frame
+    features (model_singleframe.py:139-165)."""
+
+    def __init__(self, FrameBasech=64, EventBasech=32, TB=16, KernelSize=5, norm=None, activation="LeakyReLU"):
+        super().__init__()
+        self.Conv1 = _conv(EventBasech, FrameBasech, 1, 1, 0, norm, activation)
+        self.Conv2 = _conv(FrameBasech, FrameBasech, 3, 1, 1, norm, activation)
+        self.KernelConv = _conv(2 * FrameBasech, FrameBasech * KernelSize ** 2, 3, 1, 1, norm, activation)
+        self.KPN = KernelConv2D(kernel_size=KernelSize)
+        self.Conv3 = _conv(FrameBasech, FrameBasech, 3, 1, 1, norm, activation)
+        initialize_weights([self.Conv1, self.Conv2, self.Conv3, self.KernelConv], 0.1)
+
+    def forward(self, FrameTensor, EventTensor):
+        ev = self.Conv1(EventTensor)
+        filters = self.KernelConv(torch.cat([ev, FrameTensor], dim=1))
+        ev1 = self.Conv3(self.KPN(ev, filters))
+        return FrameTensor * ev1 + self.Conv2(ev1)
+
+
+# ---------------------------------------------------------------------------- detail branch (R3D-18 U-Net)
+class identity(nn.Module):
+    def __init__(self, *args):
+        super().__init__()
+
+    def forward(self, x):
+        return x
+
+
+class SEGating(nn.Module):
+    """Channel gate from a global average (resnet_3D.py:89-105)."""
+
+    def __init__(self, inplanes, reduction=16):
+        super().__init__()
+        self.pool = nn.AdaptiveAvgPool3d(1)
+        self.attn_layer = nn.Sequential(nn.Conv3d(inplanes, inplanes, kernel_size=1, stride=1, bias=True), nn.Sigmoid())
+
+    def forward(self, x):
+        return x * self.attn_layer(self.pool(x))
+
+
+def _norm3d(bn, ch):
+    return nn.BatchNorm3d(ch) if bn else identity(ch)
+
+
+class BasicBlock(nn.Module):
+    """resnet_3D.py:108-141 (3x3x3 convs without bias, SE gate, residual)."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, bn=False):
+        super().__init__()
+        c3 = lambda cin, s: nn.Conv3d(cin, planes, kernel_size=(3, 3, 3), stride=s, padding=1, bias=False)
+        self.conv1 = nn.Sequential(c3(inplanes, stride), _norm3d(bn, planes), nn.ReLU(inplace=True))
+        self.conv2 = nn.Sequential(c3(planes, 1), _norm3d(bn, planes))
+        self.fg = SEGating(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        out = self.fg(self.conv2(self.conv1(x)))
+        res = x if self.downsample is None else self.downsample(x)
+        return self.relu(out + res)
+
+
+class VideoResNet(nn.Module):
+    """r3d_18 encoder returning all five scales (resnet_3D.py:218-292, 304-327)."""
+
+    def __init__(self, channels, bn=False, layers=(2, 2, 2, 2)):
+        super().__init__()
+        self.stem = nn.Sequential(
+            nn.Conv3d(3, channels[0], kernel_size=(3, 7, 7), stride=(1, 2, 2), padding=(1, 3, 3), bias=False),
+            _norm3d(bn, channels[0]), nn.ReLU(inplace=True))
+        inplanes = channels[0]
+        spatial = [1, 2, 2, 1]   # temporal stride is 1 everywhere; layer4 keeps H, W
+        for li in range(4):
+            planes = channels[li]
+            blocks = []
+            for bi in range(layers[li]):
+                ds, s = None, 1
+                if bi == 0 and (spatial[li] != 1 or inplanes != planes):   # resnet_3D.py:259-266
+                    s = (1, spatial[li], spatial[li])
+                    ds = nn.Sequential(nn.Conv3d(inplanes, planes, kernel_size=1, stride=s, bias=False),
+                                       _norm3d(bn, planes))
+                blocks.append(BasicBlock(inplanes, planes, s, ds, bn))
+                inplanes = planes
+            setattr(self, "layer%d" % (li + 1), nn.Sequential(*blocks))
+        for m in self.modules():
+            if isinstance(m, nn.Conv3d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm3d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        x0 = self.stem(x)
+        x1 = self.layer1(x0)
+        x2 = self.layer2(x1)
+        x3 = self.layer3(x2)
+        return x0, x1, x2, x3, self.layer4(x3)
+
+
+def r3d_18(bn=False, channels=(32, 64, 96, 128), **_):
+    return VideoResNet(list(channels), bn)
+
+
+class Conv_3d(nn.Module):
+    def __init__(self, in_ch, out_ch, kernel_size, stride=1, padding=0, bias=True, bn=False):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Conv3d(in_ch, out_ch, kernel_size=kernel_size, stride=stride, padding=padding, bias=bias),
+                                  SEGating(out_ch), _norm3d(bn, out_ch))
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class upConv3D(nn.Module):
+    def __init__(self, in_ch, out_ch, kernel_size, stride, padding, upmode="transpose", bn=False):
+        super().__init__()
+        self.upmode = upmode
+        if upmode == "transpose":
+            head = [nn.ConvTranspose3d(in_ch, out_ch, kernel_size=kernel_size, stride=stride, padding=padding)]
+        else:
+            head = [nn.Upsample(mode="trilinear", scale_factor=(1, 2, 2), align_corners=False),
+                    nn.Conv3d(in_ch, out_ch, kernel_size=1, stride=1)]
+        self.upconv = nn.Sequential(*head, SEGating(out_ch), _norm3d(bn, out_ch))
+
+    def forward(self, x):
+        return self.upconv(x)
+
+
+class UNet3d_18(nn.Module):
+    """(blurry frame, Sharp) stacked on a depth-2 axis -> residual detail (model_singleframe.py:170-223)."""
+
+    def __init__(self, channels=[32, 64, 96, 128], bn=True):
+        super().__init__()
+        self.channels = channels
+        c0, c1, c2, c3 = channels
+        self.lrelu = nn.LeakyReLU(0.2, True)
+        self.encoder = r3d_18(bn=bn, channels=channels)
+        up = dict(kernel_size=(3, 4, 4), stride=(1, 2, 2), padding=(1, 1, 1), upmode="transpose", bn=bn)
+        self.decoder = nn.Sequential(
+            Conv_3d(c3, c2, kernel_size=3, padding=1, bias=True, bn=bn),
+            upConv3D(2 * c2, c1, **up),
+            upConv3D(2 * c1, c0, **up),
+            Conv_3d(2 * c0, c0, kernel_size=3, padding=1, bias=True, bn=bn),
+            upConv3D(2 * c0, c0, **up))
+        self.feature_fuse = nn.Sequential(nn.Conv2d(2 * c0, c0, kernel_size=1, stride=1, bias=False),
+                                          nn.BatchNorm2d(c0) if bn else identity())
+        self.outconv = nn.Sequential(nn.ReflectionPad2d(3), nn.Conv2d(c0, 3, kernel_size=7, stride=1, padding=0))
+
+    def forward(self, img0, img1):
+        skips = self.encoder(torch.stack((img0, img1), dim=2))
+        y = skips[4]
+        for stage, skip in zip(self.decoder[:4], (skips[3], skips[2], skips[1], skips[0])):
+            y = torch.cat([self.lrelu(stage(y)), skip], dim=1)
+        y = self.lrelu(self.decoder[4](y))
+        y = torch.cat(torch.unbind(y, 2), 1)
+        return self.outconv(self.lrelu(self.feature_fuse(y)))
+
+
+# ---------------------------------------------------------------------------- the network
+class EVFIAutoEx(BaseModel):
+    def __init__(self, FrameBasech=64, EventBasech=64, InterCH=64, TB=16, norm=None, activation="LeakyReLU",
+                 # exposure decision
+                 BlurryFashion="DarkCh", BLInch=1, UseEvents=True, UseGTEx=False, FixEx=None, LoadPretrainEX=False,
+                 PretrainedEXPath=None, FrozenEX=False,
+                 # time-exposure control
+                 step=32, DualPath=True,
+                 # modification
+                 residual=True,
+                 # detail restoration
+                 DetailEnabled=True, channels=[32, 64, 96, 128]):
+        super().__init__()
+        self.TB, self.UseGTEx, self.FixEx = TB, UseGTEx, FixEx
+        self.BlurryFashion, self.DetailEnabled = BlurryFashion, DetailEnabled
+
+        self.FrameFeatExtract = _conv(3, FrameBasech, 3, 2, 1, norm, activation)
+        self.EventFeatExtract = _conv(2 * TB, EventBasech, 3, 2, 1, norm, activation)
+        if not UseGTEx and not FixEx and UseEvents:
+            self.ExposureDecision = ExposureDecision(EventInch=2 * TB, BLInch=BLInch, InterCH=InterCH, Group=4,
+                                                     norm=norm, activation=activation, LoadPretrain=LoadPretrainEX,
+                                                     PretrainedEXPath=PretrainedEXPath, Frozen=FrozenEX)
+        if DualPath:
+            self.ResidualControl = ResidualControl(BLinch=1, Tinch=1, Basech=EventBasech, step=step, norm=norm,
+                                                   activation=activation)
+        if residual:
+            self.Modification = Modification(FrameBasech=FrameBasech, EventBasech=EventBasech, TB=TB, KernelSize=5,
+                                             norm=norm, activation=activation)
+        self.Reconstruction = nn.Sequential(
+            nn.Sequential(_conv(FrameBasech, 4 * FrameBasech, 3, 1, 1, norm, None), nn.PixelShuffle(2),
+                          nn.LeakyReLU(inplace=True)),
+            _conv(FrameBasech, FrameBasech, 3, 1, 1, norm, activation),
+            _conv(FrameBasech, 3, 3, 1, 1, norm, "Sigmoid"))
+        if DetailEnabled:
+            self.Detail = UNet3d_18(channels=channels, bn=False)
+        initialize_weights([self.FrameFeatExtract, self.EventFeatExtract, self.Reconstruction], 0.1)
+
+    def LoadExposureDecision(self):
+        self.ExposureDecision.load_pretrain()
+
+    def _blurry_level(self, Frame):
+        kind = self.BlurryFashion
+        if kind == "DarkCh":
+            return Frame2DCP(Frame)
+        if kind == "Lap":
+            return Frame2Lap(Frame)
+        if kind == "RGB":
+            return Frame
+        if kind == "RGBDark":
+            return torch.cat([Frame, Frame2DCP(Frame)], dim=1)
+        if kind == "RGBLap":
+            return torch.cat([Frame, Frame2Lap(Frame)], dim=1)
+        raise Exception("Wrong blurry convertion fashion!!")
+
+    def _exposure(self, Frame, Event, GTEx):
+        if self.UseGTEx:
+            assert self.FixEx is None, "set UseGTEx, but FixEx is given!"
+            assert GTEx is not None, "set UseGTEx, but NO GTEx provided!"
+            return GTEx
+        if self.FixEx:
+            assert 0 <= self.FixEx <= 1, "Wrong FixEx!"
+            return torch.full((Frame.size(0), 1), float(self.FixEx), dtype=Frame.dtype, device=Frame.device)
+        return self.ExposureDecision(Event, self._blurry_level(Frame))
+
+    def forward(self, Frame, Event, T, GTEx=None):
+        H, W = Frame.size()[-2:]
+        cropper = CropSize(W, H, {"h": 8, "w": 8}) if (H % 8 or W % 8) else None
+        if cropper is not None:
+            Frame, Event = cropper.pad(Frame), cropper.pad(Event)
+        Event = Event.reshape(Event.size(0), -1, Event.size(3), Event.size(4))   # channel = tb*2 + polarity
+
+        frame_feat = self.FrameFeatExtract(Frame)
+        event_feat = self.EventFeatExtract(Event)
+        ex = self._exposure(Frame, Event, GTEx)
+        event_feat = self.ResidualControl(event_feat, ex, T)
+        Sharp = self.Reconstruction(self.Modification(frame_feat, event_feat))
+        Final = Sharp + self.Detail(img0=Frame, img1=Sharp) if self.DetailEnabled else Sharp
+
+        if cropper is not None:
+            Sharp = cropper.crop(Sharp).contiguous()
+            Final = cropper.crop(Final).contiguous() if self.DetailEnabled else Sharp
+        return Sharp, Final

@@ -1,0 +1,133 @@
+/*
+ * ebfi_hip.h -- C ABI of libebfi_hip.so: the MI355X (gfx950) kernels behind the EBFI-BE
+ * frame-synthesis hot path.  Plain pointers and sizes only; every pointer marked "device" is a
+ * HIP device address, `stream` is a hipStream_t (NULL = the legacy default stream).
+ *
+ * Conventions
+ *   - every entry point returns EBFI_OK (0) or a negative ebfi_status; it never throws and never
+ *     allocates device memory.  ebfi_last_error() returns a thread-local description of the last
+ *     failure on the calling thread.
+ *   - launches are asynchronous on `stream`; the library keeps no global mutable state besides the
+ *     optional profiler (ebfi_prof_*), so distinct streams/threads may call concurrently.
+ *   - dtype: element type of all floating tensors of the call (EBFI_F32 / EBFI_BF16, fp32
+ *     accumulation either way).  Shapes/strides are in ELEMENTS, NCHW order of the LOGICAL dims
+ *     (a channels-last tensor is passed with its real strides).
+ *
+ * Reference interfaces replaced (paths relative to the reference repo):
+ *   ebfi_fac_forward / ebfi_fac_backward
+ *       pybind module `kernelconv2d_cuda`: forward / backward
+ *       models/FAC/kernelconv2d/KernelConv2D_cuda.cpp:10-61, kernels KernelConv2D_kernel.cu:25-204
+ *   ebfi_dcn_forward / ebfi_dcn_backward
+ *       pybind module `_ext`: dcn_v2_forward / dcn_v2_backward
+ *       models/DCNv2/src/dcn_v2.h:9-92, src/vision.cpp:4-9, src/cuda/dcn_v2_cuda.cu:20-216,
+ *       src/cuda/dcn_v2_im2col_cuda.cu:125-402
+ *   ebfi_events_to_stack        dataloader/encodings.py:307-350 (events_to_stack)
+ *   ebfi_frame2lap / _frame2dcp myutils/utils.py:34-49 / :15-31
+ */
+#ifndef EBFI_HIP_H
+#define EBFI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EBFI_ABI_VERSION 1
+
+typedef enum {
+    EBFI_OK = 0,
+    EBFI_ERR_ARG = -1,         /* shape / stride / pointer precondition violated */
+    EBFI_ERR_LAUNCH = -2,      /* HIP reported a launch error */
+    EBFI_ERR_UNSUPPORTED = -3, /* dtype or configuration not implemented */
+    EBFI_ERR_WORKSPACE = -4    /* workspace missing or too small */
+} ebfi_status;
+
+typedef enum { EBFI_F32 = 0, EBFI_BF16 = 1 } ebfi_dtype;
+
+int ebfi_abi_version(void);
+const char *ebfi_last_error(void);
+
+/* ------------------------------------------------------------------ FAC (filter-adaptive conv)
+ * out[b,c,y,x] = sum_{ky,kx} input[b,c,y+ky,x+kx] * kernel[b, c*K*K + ky*K + kx, y, x]
+ * input  [B, C, Ho+K-1, Wo+K-1]  (already padded by the caller, KernelConv2D.py:85-87)
+ * kernel [B, C*K*K, Ho, Wo],  output [B, C, Ho, Wo].  Any strides; K >= 1.
+ * Unlike the reference the outputs need NOT be pre-zeroed: every element is written. */
+int ebfi_fac_forward(const void *input, const int64_t input_shape[4], const int64_t input_stride[4],
+                     const void *kernel, const int64_t kernel_shape[4], const int64_t kernel_stride[4],
+                     int kernel_size,
+                     void *output, const int64_t output_shape[4], const int64_t output_stride[4],
+                     int dtype, void *stream);
+
+/* grad_input [B,C,Ho+K-1,Wo+K-1], grad_kernel [B,C*K*K,Ho,Wo]; both fully overwritten.
+ * Either grad pointer may be NULL to skip it. */
+int ebfi_fac_backward(const void *input, const int64_t input_shape[4], const int64_t input_stride[4],
+                      const void *kernel, const int64_t kernel_shape[4], const int64_t kernel_stride[4],
+                      int kernel_size,
+                      const void *grad_output, const int64_t grad_output_stride[4],
+                      void *grad_input, const int64_t grad_input_stride[4],
+                      void *grad_kernel, const int64_t grad_kernel_stride[4],
+                      int dtype, void *stream);
+
+/* ------------------------------------------------------------------ DCNv2 (modulated deformable conv)
+ * All tensors contiguous NCHW:
+ *   input [B,C,H,W]  weight [Co,C,kh,kw]  bias [Co]
+ *   offset [B, dg*2*kh*kw, Ho, Wo]  (channel 2*(i*kw+j) = dy, +1 = dx inside each group block)
+ *   mask   [B, dg*kh*kw, Ho, Wo]    output [B,Co,Ho,Wo]
+ *   Ho = (H + 2*ph - (dh*(kh-1)+1))/sh + 1, likewise Wo.
+ * The column tensor of the reference never exists in memory. */
+int ebfi_dcn_forward(const void *input, const void *weight, const void *bias, const void *offset,
+                     const void *mask, void *output,
+                     int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw,
+                     int ph, int pw, int dh, int dw, int deformable_group,
+                     int dtype, void *stream);
+
+/* Bytes of scratch ebfi_dcn_backward needs (partial weight-gradient slabs). */
+size_t ebfi_dcn_backward_workspace(int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw,
+                                   int ph, int pw, int dh, int dw, int deformable_group, int dtype);
+
+/* All five gradients are fully (over)written; grad_input is accumulated with float atomics after
+ * being zeroed by the library (run-to-run differences in the last bits, like the reference's
+ * atomicAdd col2im, dcn_v2_im2col_cuda.cu:249).  Reference quirk kept: grad_input uses pad_h for
+ * both axes (dcn_v2_im2col_cuda.cu:368). */
+int ebfi_dcn_backward(const void *input, const void *weight, const void *bias, const void *offset,
+                      const void *mask, const void *grad_output,
+                      void *grad_input, void *grad_offset, void *grad_mask, void *grad_weight,
+                      void *grad_bias,
+                      int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw,
+                      int ph, int pw, int dh, int dw, int deformable_group,
+                      void *workspace, size_t workspace_bytes, int dtype, void *stream);
+
+/* ------------------------------------------------------------------ event voxel binning
+ * xs, ys, ts: float64[n] device (ts sorted, normalised as h5dataset.py:334), ps: float32[n].
+ * out: float32 [2, bins, H, W], fully overwritten (index 0 = positive, 1 = negative counts).
+ * Bit-exact with events_to_stack incl. its shared-edge and out-of-range behaviour.
+ * workspace: ebfi_events_workspace(bins) bytes. */
+size_t ebfi_events_workspace(int bins);
+int ebfi_events_to_stack(const double *xs, const double *ys, const double *ts, const float *ps,
+                         int64_t n, int bins, int H, int W, float *out,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------ blur-level maps
+ * frame: float32 [B,3,H,W] contiguous in [0,1]; out: float32 [B,1,H,W]. */
+int ebfi_frame2lap(const float *frame, float *out, int B, int H, int W, void *stream);
+int ebfi_frame2dcp(const float *frame, float *out, float *scratch /* [B,H,W] */, int B, int H, int W,
+                   int window, void *stream);
+
+/* ------------------------------------------------------------------ per-kernel device timing
+ * When enabled, every launch made by this library is bracketed by a hipEvent pair recorded on the
+ * launch stream.  ebfi_prof_collect() must be called after the stream(s) are synchronised; it
+ * folds the pending pairs into per-kernel totals.  Slots are bounded (EBFI_PROF_MAX_PENDING);
+ * launches beyond that are not timed (counted in *dropped). */
+#define EBFI_PROF_MAX_PENDING 8192
+void ebfi_prof_enable(int on);
+void ebfi_prof_reset(void);
+int ebfi_prof_collect(int *dropped);
+int ebfi_prof_num_kernels(void);
+int ebfi_prof_get(int index, const char **name, int64_t *launches, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EBFI_HIP_H */

@@ -1,0 +1,68 @@
+"""GPU parity: event voxel binning (bit-exact vs fixtures produced by the reference and vs the
+oracle) and the blur-level maps (bit-exact vs the oracle; OpenCV parity itself is unpinned)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import blur_ref, events_ref  # noqa: E402
+
+
+def _run(xs, ys, ts, ps, B, size):
+    from ebfi_amd.encodings import events_to_stack
+    d = lambda a, dt: torch.from_numpy(np.asarray(a)).to(dt).cuda()
+    return events_to_stack(d(xs, torch.float64), d(ys, torch.float64), d(ts, torch.float64), d(ps, torch.float32),
+                           B, size).cpu().numpy()
+
+
+def test_events_bit_exact_vs_reference_fixtures(golden_dir):
+    z = np.load(os.path.join(golden_dir, "events_to_stack.npz"))
+    names = sorted({k.split(".")[0] for k in z.files})
+    assert len(names) >= 9
+    for n in names:
+        out = _run(z[n + ".xs"], z[n + ".ys"], z[n + ".ts"], z[n + ".ps"], int(z[n + ".B"]), tuple(z[n + ".size"]))
+        assert out.dtype == np.float32 and np.array_equal(out, z[n + ".out"]), n
+
+
+def test_events_large_vs_oracle():
+    """SURVEY 8(d) density: ~0.35*H*W*16 events at 128x128, 5% out of range, repeated stamps."""
+    rng = np.random.default_rng(123)
+    H, W, B = 128, 128, 16
+    n = int(0.35 * H * W * B)
+    ts = np.sort(np.round(rng.random(n) * 5000) / 5000)
+    ts = (ts - ts[0]) / (ts[-1] - ts[0] + 1e-6)
+    xs = rng.integers(0, W, n).astype(np.float64)
+    ys = rng.integers(0, H, n).astype(np.float64)
+    bad = rng.random(n) < 0.05
+    xs[bad] += W
+    ps = rng.choice([-1.0, 1.0], n).astype(np.float32)
+    ref = events_ref.events_to_stack(xs, ys, ts, ps, B, (H, W))
+    out = _run(xs, ys, ts, ps, B, (H, W))
+    assert np.array_equal(out, ref)
+    assert out.sum() >= n * 0.9          # counts conserved up to the masked first-bin positives
+    assert (out >= 0).all() and np.array_equal(out, np.round(out))
+
+
+def test_events_degenerate():
+    z3 = _run([1., 2., 3.], [1., 1., 2.], [0., .5, 1.], [1., -1., 1.], 4, (6, 6))
+    assert z3.shape == (2, 4, 6, 6) and z3.sum() == 0
+    z0 = _run(np.arange(6.), np.arange(6.), np.zeros(6), np.ones(6), 4, (8, 8))
+    assert z0.sum() == 0
+
+
+def test_frame2lap_frame2dcp_vs_oracle():
+    from ebfi_amd.blur import Frame2DCP, Frame2Lap
+    torch.manual_seed(4)
+    for (B, H, W) in [(2, 32, 40), (1, 37, 29), (1, 128, 128)]:
+        f = torch.rand(B, 3, H, W)
+        f[0, :, 0, 0] = 1.0
+        f[0, :, -1, -1] = 0.0
+        lap = Frame2Lap(f.cuda()).cpu().numpy()
+        assert lap.shape == (B, 1, H, W)
+        assert np.array_equal(lap, blur_ref.frame2lap(f.numpy()))
+        dcp = Frame2DCP(f.cuda()).cpu().numpy()
+        assert np.array_equal(dcp, blur_ref.frame2dcp(f.numpy()))
+    assert np.abs(lap).max() > 50       # unnormalised Laplacian of uint8 grey levels

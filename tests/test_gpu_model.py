@@ -1,0 +1,123 @@
+"""GPU parity of the whole frame-synthesis path: the product EVFIAutoEx (HIP FAC kernel inside)
+vs fixtures produced by the reference's own modules, vs the functional CPU oracle, and one
+training step vs the oracle's autograd.  fp32, tolerance 1e-3 relative (BASELINE.json)."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import loss_ref, model_ref  # noqa: E402
+
+TOL = 1e-3
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def fix(golden_dir):
+    z = np.load(os.path.join(golden_dir, "model_small.npz"))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")}
+    cfg = ast.literal_eval(str(z["cfg"]))
+    return z, sd, cfg
+
+
+def _net(cfg, sd, **over):
+    from ebfi_amd.model import EVFIAutoEx
+    net = EVFIAutoEx(**dict(cfg, **over))
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected
+    return net.cuda().eval(), missing
+
+
+def test_forward_vs_reference_fixture(fix):
+    z, sd, cfg = fix
+    net, missing = _net(cfg, sd)
+    assert not missing
+    c = lambda k: torch.from_numpy(z[k]).cuda()
+    ev = c("in.Event").view(2, -1, 32, 40)
+    with torch.no_grad():
+        ex = net.ExposureDecision(ev, c("in.Blurry"))
+        assert _rel(ex, z["mid.Ex"]) < TOL
+        pe = net.ResidualControl(c("mid.EventFeat"), c("mid.Ex"), c("in.T"))
+        assert _rel(pe, z["mid.ResidualControl"]) < TOL
+        pf = net.Modification(c("mid.FrameFeat"), c("mid.ResidualControl"))      # HIP FAC inside
+        assert _rel(pf, z["mid.Modification"]) < TOL
+        det = net.Detail(img0=c("in.Frame"), img1=c("out.Sharp"))
+        assert _rel(det, z["mid.Detail"]) < TOL
+    net2, _ = _net(cfg, sd, UseGTEx=True)
+    with torch.no_grad():
+        sharp, final = net2(c("in.Frame"), c("in.Event"), c("in.T"), c("in.GTEx"))
+        assert _rel(sharp, z["gtex.Sharp"]) < TOL and _rel(final, z["gtex.Final"]) < TOL
+        so, fo = net2(c("odd.Frame"), c("odd.Event"), c("in.T")[:1], c("in.GTEx")[:1])
+        assert so.shape[-2:] == (27, 37)
+        assert _rel(so, z["odd.Sharp"]) < TOL and _rel(fo, z["odd.Final"]) < TOL
+
+
+def test_gradients_vs_reference_fixture(fix):
+    z, sd, cfg = fix
+    net, _ = _net(cfg, sd, UseGTEx=True)
+    net.train()
+    c = lambda k: torch.from_numpy(z[k]).cuda()
+    sharp, final = net(c("in.Frame"), c("in.Event"), c("in.T"), c("in.GTEx"))
+    ((sharp * c("gtex.wS")).sum() + (final * c("gtex.wF")).sum()).backward()
+    n = 0
+    for name, p in net.named_parameters():
+        key = "grad." + name
+        if key in z.files:
+            assert _rel(p.grad, z[key]) < TOL, name
+            n += 1
+    assert n > 80
+
+
+def test_full_width_forward_vs_oracle():
+    """config 1 of BASELINE.json (single 128x128 sample, default widths) against the CPU oracle,
+    including the device Frame2Lap inside forward (RGBLap branch)."""
+    from ebfi_amd.engine import DEFAULT_MODEL_ARGS, synthetic_batch
+    from ebfi_amd.model import EVFIAutoEx
+    torch.manual_seed(0)
+    net = EVFIAutoEx(**DEFAULT_MODEL_ARGS)
+    with torch.no_grad():           # O(1) activations instead of the x0.1 default init
+        for p in net.parameters():
+            if p.dim() > 1:
+                p.mul_(6.0)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    frame, event, t, gtex, _ = synthetic_batch(1, 128, 128, device="cpu")
+    ref_s, ref_f = model_ref.evfi_forward(sd, DEFAULT_MODEL_ARGS, frame, event, t)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        s, f = net(frame.cuda(), event.cuda(), t.cuda())
+    assert ref_s.std() > 0.01
+    assert _rel(s, ref_s) < TOL and _rel(f, ref_f) < TOL
+
+
+def test_train_step_vs_oracle(fix):
+    """One Engine.train_step (fwd, Lap+census loss, bwd, Adam) vs the oracle's loss and autograd
+    gradients on the small config."""
+    from ebfi_amd.engine import Engine
+    z, sd, cfg = fix
+    cfg2 = dict(cfg, UseGTEx=True)
+    eng = Engine(cfg2, device="cuda", precision="fp32", lr=1e-4)
+    eng.model.load_state_dict(sd, strict=False)
+    torch.manual_seed(9)
+    frame = torch.rand(2, 3, 64, 64)
+    event = torch.poisson(torch.full((2, cfg["TB"], 2, 64, 64), 0.35))
+    t, gtex, target = torch.rand(2, 1), torch.rand(2, 1) * 0.4 + 0.55, torch.rand(2, 3, 64, 64)
+    sdo = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()
+           if not k.startswith("ExposureDecision")}
+    s, f = model_ref.evfi_forward(sdo, cfg2, frame, event, t, gtex)
+    loss_ref_v = loss_ref.train_loss(s, f, target, iteration=0)
+    loss_ref_v.backward()
+    before = {k: v.detach().clone() for k, v in eng.model.state_dict().items()}
+    loss = eng.train_step(frame.cuda(), event.cuda(), t.cuda(), gtex.cuda(), target.cuda())
+    assert abs(loss.item() - loss_ref_v.item()) <= TOL * abs(loss_ref_v.item())
+    for name, p in eng.model.named_parameters():
+        assert _rel(p.grad, sdo[name].grad) < 5 * TOL, name       # grads still in the flat bucket
+    moved = sum((eng.model.state_dict()[k] - before[k]).abs().sum().item() for k in before)
+    assert moved > 0 and eng.iteration == 1

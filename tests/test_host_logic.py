@@ -1,0 +1,136 @@
+"""Host-side logic on CPU: module tree / state_dict contract, import-path shims, loss module vs
+the reference fixture, pad/crop helper, and the data-parallel gradient bucket over gloo (world 2)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ebfi_amd.engine import DEFAULT_MODEL_ARGS
+from ebfi_amd.loss import LaplacianLoss, Ternary, TrainLoss
+from ebfi_amd.model import CropSize, EVFIAutoEx
+
+
+def test_state_dict_matches_reference_names(golden_dir):
+    ref = [l.split() for l in open(os.path.join(golden_dir, "state_dict_default.txt"))]
+    net = EVFIAutoEx(**DEFAULT_MODEL_ARGS)
+    mine = [[k, "x".join(map(str, v.shape))] for k, v in net.state_dict().items()]
+    assert mine == ref
+    assert sum(p.numel() for p in net.parameters()) == 5693543
+
+
+def test_reference_import_paths():
+    from models.DCNv2.dcn_v2 import DCN, DCN_sep, DCNv2, dcn_v2_conv          # noqa: F401
+    from models.FAC.kernelconv2d.KernelConv2D import KernelConv2D, KernelConv2DFunction  # noqa: F401
+    from models.Ours.model_singleframe import EVFIAutoEx as E2
+    from myutils.utils import Frame2DCP, Frame2Lap, reduce_tensor               # noqa: F401
+    from dataloader.encodings import events_to_stack                           # noqa: F401
+    assert E2 is EVFIAutoEx
+    m = DCN_sep(4, 6, 3, 1, 1, deformable_groups=2)
+    assert sorted(n for n, _ in m.named_parameters()) == ["bias", "conv_offset_mask.bias",
+                                                          "conv_offset_mask.weight", "weight"]
+    assert m.conv_offset_mask.weight.abs().sum() == 0 and m.conv_offset_mask.out_channels == 2 * 3 * 9
+    assert m.bias.abs().sum() == 0 and m.weight.abs().max() <= 1.0 / (4 * 9) ** 0.5
+
+
+def test_model_variants_construct():
+    small = dict(DEFAULT_MODEL_ARGS, FrameBasech=8, EventBasech=8, InterCH=8, TB=4, step=2, channels=[4, 4, 8, 8])
+    a = EVFIAutoEx(**dict(small, UseGTEx=True))
+    assert not hasattr(a, "ExposureDecision")
+    b = EVFIAutoEx(**dict(small, DetailEnabled=False))
+    assert not hasattr(b, "Detail")
+    assert "Trainable parameters" in str(b)
+    # layer4 has no downsample when channels[2] == channels[3] (resnet_3D.py:259)
+    assert a.Detail.encoder.layer4[0].downsample is None and a.Detail.encoder.layer3[0].downsample is not None
+
+
+def test_cropsize_matches_oracle():
+    from oracle import model_ref
+    x = torch.arange(2 * 27 * 37, dtype=torch.float32).view(1, 2, 27, 37)
+    c = CropSize(37, 27, {"h": 8, "w": 8})
+    padded = c.pad(x)
+    assert padded.shape[-2:] == (32, 40)
+    assert torch.equal(padded, model_ref.pad_to_multiple(x, 27, 37))
+    assert torch.equal(c.crop(padded), x)
+
+
+def test_loss_matches_reference_fixture(golden_dir):
+    z = np.load(os.path.join(golden_dir, "loss_small.npz"))
+    x = torch.from_numpy(z["x"]).requires_grad_()
+    y = torch.from_numpy(z["y"])
+    lap, cen = LaplacianLoss()(x, y), Ternary()(x, y)
+    assert abs(lap.item() - float(z["lap"])) <= 1e-5 * float(z["lap"])
+    assert abs(cen.item() - float(z["census"])) <= 1e-5
+    (lap + cen).backward()
+    assert (x.grad - torch.from_numpy(z["grad_x"])).abs().max() <= 1e-4 * np.abs(z["grad_x"]).max()
+    tl = TrainLoss()
+    a = tl(x.detach(), y, y, iteration=0)
+    b = tl(x.detach(), y, y, iteration=20000)
+    assert abs(a.item() - (lap.item() + cen.item())) < 1e-2 and abs(b.item() - 0.1 * (lap.item() + cen.item())) < 1e-2
+
+
+# ----------------------------------------------------------------------------- data parallel (gloo, world 2)
+def _dp_worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ebfi_amd.dp import FlatGradBucket, broadcast_parameters, reduce_tensor
+    torch.manual_seed(100 + rank)                       # different init per rank on purpose
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(4, 2, 1))
+    broadcast_parameters(net, 0)
+    w0 = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    bucket = FlatGradBucket(net)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    torch.manual_seed(7)
+    data = torch.randn(4, 3, 8, 8)                      # global batch 4 -> 2 per rank
+    mine = data[rank * 2:(rank + 1) * 2]
+    bucket.zero()
+    net(mine).pow(2).sum().backward()                   # sum-reduced loss, like the reference's
+    assert bucket.views_intact()
+    local = bucket.flat.clone()
+    bucket.all_reduce_mean()
+    opt.step()
+    w1 = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    red = reduce_tensor(torch.tensor([float(rank + 1)]))
+    torch.save((rank, w0, local, bucket.flat.clone(), w1, red), os.path.join(outdir, 'r%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_allreduce_equals_large_batch_math(tmp_path):
+    ctx = mp.get_context("spawn")
+    port = 29500 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    res = [torch.load(os.path.join(str(tmp_path), "r%d.pt" % r)) for r in range(2)]
+    (_, w0a, la, ga, w1a, ra), (_, w0b, lb, gb, w1b, rb) = res
+    assert torch.equal(w0a, w0b)                        # broadcast made the replicas identical
+    assert torch.allclose(ga, (la + lb) / 2, atol=1e-6) and torch.equal(ga, gb)
+    assert torch.equal(w1a, w1b)                        # replicas stay in lock-step after the step
+    assert ra.item() == 1.5 and rb.item() == 1.5
+    # single-process reference: the same 4 samples at once; loss is a SUM so DP mean = grad / world
+    torch.manual_seed(100)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(4, 2, 1))
+    torch.manual_seed(7)
+    data = torch.randn(4, 3, 8, 8)
+    net(data).pow(2).sum().backward()
+    g = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    assert torch.allclose(ga, g / 2, atol=1e-5)
+
+
+def test_flat_bucket_single_process():
+    from ebfi_amd.dp import FlatGradBucket
+    net = torch.nn.Linear(3, 2)
+    b = FlatGradBucket(net)
+    net(torch.ones(1, 3)).sum().backward()
+    assert b.views_intact() and b.flat.abs().sum() > 0
+    before = b.flat.clone()
+    b.all_reduce_mean()                                 # no process group: no-op
+    assert torch.equal(before, b.flat)
+    b.zero()
+    assert net.weight.grad.abs().sum() == 0

@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Op-level roofline microbench for the hand-written kernels at the BASELINE.json sizes
+(B=8, 64 channels, feature resolution 128x128; `--hd` = 360x640).  Prints one JSON line per op
+with device time (hipEvent pairs recorded by libebfi_hip.so on the launch stream), algorithmic
+bytes / flops and the achieved fraction of the MI355X roofline.
+
+    python tools/opbench.py [--iters 20] [--B 8] [--hd]
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "ebfi-be_amd"))
+
+import torch  # noqa: E402
+
+HBM_PEAK, F32_MFMA_PEAK = 8000.0, 157.3     # GB/s, TFLOP/s (MI355X_MICROARCH.md)
+
+
+def timed(fn, iters, names):
+    from ebfi_amd import _native as N
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    N.prof_reset()
+    N.prof_enable(True)
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    N.prof_enable(False)
+    prof = N.prof_collect()
+    return {k: v[1] / max(v[0], 1) for k, v in prof.items() if k in names}, prof
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--B", type=int, default=8)
+    ap.add_argument("--hd", action="store_true")
+    ap.add_argument("--ops", default="fac,dcn")
+    a = ap.parse_args()
+    from ebfi_amd.dcn import dcn_v2_backward, dcn_v2_forward
+    from ebfi_amd.fac import fac_backward, fac_forward
+    B, C, K = a.B, 64, 5
+    h, w = (360, 640) if a.hd else (128, 128)
+    P = B * h * w
+    dev = "cuda"
+    torch.manual_seed(123)
+    lines = []
+    if "fac" in a.ops:
+        x = torch.randn(B, C, h + 4, w + 4, device=dev)
+        k = torch.randn(B, C * 25, h, w, device=dev)
+        g = torch.randn(B, C, h, w, device=dev)
+        out = torch.empty(B, C, h, w, device=dev)
+        t, _ = timed(lambda: fac_forward(x, k, K, out=out), a.iters, {"fac_fwd_tile_f32"})
+        by = 4 * P * C * 27
+        for n, ms in t.items():
+            lines.append({"op": "fac_forward", "kernel": n, "ms": round(ms, 4), "algorithmic_bytes": by,
+                          "GBps": round(by / ms / 1e6, 1), "frac_hbm": round(by / ms / 1e6 / HBM_PEAK, 4)})
+        t, _ = timed(lambda: fac_backward(x, k, K, g), a.iters, {"fac_bwd_rows_f32"})
+        by = 4 * P * C * 53
+        for n, ms in t.items():
+            lines.append({"op": "fac_backward", "kernel": n, "ms": round(ms, 4), "algorithmic_bytes": by,
+                          "GBps": round(by / ms / 1e6, 1), "frac_hbm": round(by / ms / 1e6 / HBM_PEAK, 4)})
+        del x, k, g, out
+        torch.cuda.empty_cache()
+    if "dcn" in a.ops:
+        dg = 8
+        x = torch.randn(B, C, h, w, device=dev)
+        off = torch.randn(B, dg * 18, h, w, device=dev) * 2
+        msk = torch.sigmoid(torch.randn(B, dg * 9, h, w, device=dev))
+        wt = torch.randn(C, C, 3, 3, device=dev) / 24
+        bias = torch.randn(C, device=dev)
+        g = torch.randn(B, C, h, w, device=dev)
+        cfg = ((1, 1), (1, 1), (1, 1), dg)
+        t, _ = timed(lambda: dcn_v2_forward(x, wt, bias, off, msk, *cfg), a.iters, {"dcn_fwd_f32"})
+        by = 4 * (P * (C + 2 * dg * 9 + dg * 9 + C) + C * C * 9)
+        fl = 2.0 * P * C * 9 * (4 + C)
+        for n, ms in t.items():
+            lines.append({"op": "dcn_forward", "kernel": n, "ms": round(ms, 4), "algorithmic_bytes": by,
+                          "GBps": round(by / ms / 1e6, 1), "frac_hbm": round(by / ms / 1e6 / HBM_PEAK, 4),
+                          "TFLOPs": round(fl / ms / 1e9, 2), "frac_f32_mfma": round(fl / ms / 1e9 / F32_MFMA_PEAK, 4)})
+        names = {"dcn_bwd_data_f32", "dcn_bwd_weight_f32", "dcn_bwd_reduce_f32"}
+        t, _ = timed(lambda: dcn_v2_backward(x, wt, bias, off, msk, g, *cfg), a.iters, names)
+        for n, ms in t.items():
+            lines.append({"op": "dcn_backward", "kernel": n, "ms": round(ms, 4)})
+    for l in lines:
+        l.update(B=B, h=h, w=w)
+        print(json.dumps(l), flush=True)
+    fwd = [l for l in lines if l["op"] in ("fac_forward", "dcn_forward")]
+    if len(fwd) == 2:
+        ms = sum(l["ms"] for l in fwd)
+        by = sum(l["algorithmic_bytes"] for l in fwd)
+        print(json.dumps({"op": "dcn+fac forward (BASELINE target >= 0.30)", "ms": round(ms, 4), "algorithmic_bytes": by,
+                          "GBps": round(by / ms / 1e6, 1), "frac_hbm": round(by / ms / 1e6 / HBM_PEAK, 4)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
