@@ -20,6 +20,8 @@ def fac_forward(input_pad, kernel, kernel_size, out=None):
     Ho, Wo = kernel.size(2), kernel.size(3)
     if out is None:
         out = torch.empty((B, C, Ho, Wo), dtype=input_pad.dtype, device=input_pad.device)
+    if out.numel() == 0:
+        return out
     with torch.cuda.device_of(input_pad):
         rc = N.lib().ebfi_fac_forward(
             N.ptr(input_pad), N.i64x4(input_pad.shape), N.i64x4(input_pad.stride()),
@@ -35,6 +37,8 @@ def fac_backward(input_pad, kernel, kernel_size, grad_output, need_input=True, n
     gin = torch.empty_like(input_pad, memory_format=torch.contiguous_format) if need_input else None
     gk = torch.empty_like(kernel, memory_format=torch.contiguous_format) if need_kernel else None
     unit = N.i64x4((0, 0, 0, 1))
+    if kernel.numel() == 0:
+        return gin, gk
     with torch.cuda.device_of(input_pad):
         rc = N.lib().ebfi_fac_backward(
             N.ptr(input_pad), N.i64x4(input_pad.shape), N.i64x4(input_pad.stride()),
