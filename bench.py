@@ -175,8 +175,14 @@ def main():
         roofline = None
         if ranked:
             d = per_kernel[ranked[0]]
+            traffic = None          # HBM bytes/launch from the committed rocprofv3 PMC passes, if any
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                    traffic = json.load(fh).get(ranked[0])
+            except (OSError, ValueError):
+                pass
             roofline = {"kernel": ranked[0], "bound": "hbm", "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": d["frac_of_hbm_peak"], "traffic": None,
+                        "unit": "GB/s", "frac": d["frac_of_hbm_peak"], "traffic": traffic,
                         "avg_launch_ms": d["avg_ms"], "algorithmic_bytes_per_launch": d["algorithmic_bytes"]}
         out = {
             "metric": "interpolated frames/sec (train fwd+bwd) at B=8 256x256",
