@@ -39,6 +39,10 @@ SIGNATURES = {
     "ebfi_dcn_forward": (_i, [_vp] * 6 + [_i] * 14 + [_i, _vp]),
     "ebfi_dcn_backward_workspace": (_sz, [_i] * 14 + [_i]),
     "ebfi_dcn_backward": (_i, [_vp] * 11 + [_i] * 14 + [_vp, _sz, _i, _vp]),
+    "ebfi_conv2d_forward": (_i, [_vp] * 4 + [_i] * 8 + [_i, _c.c_float, _i, _vp]),
+    "ebfi_conv2d_backward_data": (_i, [_vp] * 4 + [_i] * 8 + [_i, _c.c_float, _i, _vp]),
+    "ebfi_conv2d_backward_weight_workspace": (_sz, [_i] * 8 + [_i]),
+    "ebfi_conv2d_backward_weight": (_i, [_vp] * 5 + [_i] * 8 + [_i, _c.c_float, _vp, _sz, _i, _vp]),
     "ebfi_events_workspace": (_sz, [_i]),
     "ebfi_events_to_stack": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ebfi_frame2lap": (_i, [_vp, _vp, _i, _i, _i, _vp]),

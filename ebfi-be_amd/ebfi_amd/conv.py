@@ -1,0 +1,100 @@
+"""Conv2d + bias + activation as ONE op on the gfx950 kernels of csrc/conv2d.hip.
+
+The reference's ConvLayer (models/model_misc/submodules.py:159-200) is nn.Conv2d followed by an
+activation module; here the forward is one fused kernel (`ebfi_conv2d_forward`), and the backward
+runs the stride-1 data gradient on the same kernel with the activation derivative folded into its
+staging (`ebfi_conv2d_backward_data`) plus a deterministic weight/bias gradient
+(`ebfi_conv2d_backward_weight`).  Configurations the kernels do not cover (kernel sizes other than
+1/3, dilation, groups, feature maps smaller than one tile) stay on PyTorch-ROCm's conv; that is a
+GPU library path, never a CPU fallback.
+"""
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import _native as N
+
+ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
+
+
+def activation_code(module):
+    """nn activation module -> (code, slope) or None when it cannot be fused."""
+    if module is None:
+        return ACT_NONE, 0.0
+    if isinstance(module, torch.nn.LeakyReLU):
+        return ACT_LEAKY, float(module.negative_slope)
+    if isinstance(module, torch.nn.ReLU):
+        return ACT_LEAKY, 0.0
+    if isinstance(module, torch.nn.Sigmoid):
+        return ACT_SIGMOID, 0.0
+    return None
+
+
+def supported(x, weight, stride, padding, dilation=(1, 1), groups=1):
+    k = weight.shape[-1]
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and
+            weight.shape[-2] == k and k in (1, 3) and stride[0] == stride[1] and stride[0] in (1, 2) and
+            not (k == 1 and stride[0] != 1) and padding[0] == padding[1] and 0 <= padding[0] <= k and
+            tuple(dilation) == (1, 1) and groups == 1 and x.shape[-1] * x.shape[-2] >= 256)
+
+
+def _geo(x, weight, stride, pad):
+    B, Cin, H, W = x.shape
+    return [int(B), int(Cin), int(H), int(W), int(weight.shape[0]), int(weight.shape[-1]), int(stride), int(pad)]
+
+
+class ConvBiasAct(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, act, slope):
+        x, weight = x.contiguous(), weight.contiguous()
+        geo = _geo(x, weight, stride, pad)
+        k = geo[5]
+        Ho, Wo = (geo[2] + 2 * pad - k) // stride + 1, (geo[3] + 2 * pad - k) // stride + 1
+        out = torch.empty((geo[0], geo[4], Ho, Wo), dtype=x.dtype, device=x.device)
+        with torch.cuda.device_of(x):
+            rc = N.lib().ebfi_conv2d_forward(N.ptr(x), N.ptr(weight), N.ptr(bias.contiguous() if bias is not None else None),
+                                             N.ptr(out), *geo, act, slope, N.EBFI_F32, N.stream_ptr(x.device))
+        N.check(rc, "ebfi_conv2d_forward")
+        ctx.cfg = (stride, pad, act, slope, bias is not None)
+        ctx.save_for_backward(x, weight, out if act != ACT_NONE else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, weight, y = ctx.saved_tensors
+        stride, pad, act, slope, has_bias = ctx.cfg
+        gout = gout.contiguous()
+        geo = _geo(x, weight, stride, pad)
+        k = geo[5]
+        lib = N.lib()
+        gx = gw = gb = None
+        with torch.cuda.device_of(x):
+            st = N.stream_ptr(x.device)
+            if ctx.needs_input_grad[0]:
+                if stride == 1 and pad == k // 2:
+                    gx = torch.empty_like(x)
+                    rc = lib.ebfi_conv2d_backward_data(N.ptr(gout), N.ptr(y), N.ptr(weight), N.ptr(gx), *geo, act, slope,
+                                                       N.EBFI_F32, st)
+                    N.check(rc, "ebfi_conv2d_backward_data")
+                else:   # strided data gradient: PyTorch-ROCm (only the two stride-2 stems, whose inputs need no grad)
+                    gpre = gout if act == ACT_NONE else gout * _act_grad(y, act, slope)
+                    gx = torch.nn.grad.conv2d_input(x.shape, weight, gpre, stride=stride, padding=pad)
+            if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+                gw = torch.empty_like(weight)
+                gb = torch.empty(geo[4], dtype=x.dtype, device=x.device) if has_bias else None
+                need = int(lib.ebfi_conv2d_backward_weight_workspace(*geo, N.EBFI_F32))
+                ws = torch.empty(max(need, 4), dtype=torch.uint8, device=x.device)
+                rc = lib.ebfi_conv2d_backward_weight(N.ptr(x), N.ptr(gout), N.ptr(y), N.ptr(gw), N.ptr(gb), *geo, act, slope,
+                                                     N.ptr(ws), need, N.EBFI_F32, st)
+                N.check(rc, "ebfi_conv2d_backward_weight")
+        return gx, gw, gb, None, None, None, None
+
+
+def _act_grad(y, act, slope):
+    if act == ACT_LEAKY:
+        return torch.where(y > 0, torch.ones_like(y), torch.full_like(y, slope))
+    return y * (1 - y)
+
+
+def conv_bias_act(x, weight, bias, stride=1, padding=0, act=ACT_NONE, slope=0.0):
+    return ConvBiasAct.apply(x, weight, bias, int(stride), int(padding), int(act), float(slope))

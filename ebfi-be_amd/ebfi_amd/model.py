@@ -12,7 +12,8 @@ What differs from the reference, on purpose:
   * the ``FixEx`` branch builds its tensor on the input's device instead of a hard ``.cuda()``
     (model_singleframe.py:309);
   * sub-modules are assembled from small builders rather than one class per block.
-Convolutions currently go through PyTorch-ROCm (MIOpen); DESIGN.md tracks their replacement.
+2-D convolutions of ConvLayer run on the hand-written MFMA kernels (ebfi_amd.conv); the 3-D convs of
+the detail branch still go through PyTorch-ROCm (MIOpen), see DESIGN.md.
 """
 from math import ceil, floor
 
@@ -20,6 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import conv
 from .blur import Frame2DCP, Frame2Lap
 from .fac import KernelConv2D
 
@@ -49,7 +51,12 @@ class ConvLayer(nn.Module):
             self.norm_layer = nn.InstanceNorm2d(out_channels, track_running_stats=True)
 
     def forward(self, x):
-        y = self.conv2d(x)
+        c = self.conv2d
+        fuse = conv.activation_code(self.activation) if self.norm not in ("BN", "IN") else None
+        if fuse is not None and not torch.is_autocast_enabled() and \
+                conv.supported(x, c.weight, c.stride, c.padding, c.dilation, c.groups):
+            return conv.conv_bias_act(x, c.weight, c.bias, c.stride[0], c.padding[0], fuse[0], fuse[1])
+        y = c(x)       # shapes the gfx950 conv kernels do not cover: PyTorch-ROCm conv (still GPU)
         if self.norm in ("BN", "IN"):
             y = self.norm_layer(y)
         return y if self.activation is None else self.activation(y)

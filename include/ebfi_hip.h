@@ -21,6 +21,7 @@
  *       pybind module `_ext`: dcn_v2_forward / dcn_v2_backward
  *       models/DCNv2/src/dcn_v2.h:9-92, src/vision.cpp:4-9, src/cuda/dcn_v2_cuda.cu:20-216,
  *       src/cuda/dcn_v2_im2col_cuda.cu:125-402
+ *   ebfi_conv2d_*               nn.Conv2d + activation inside ConvLayer (models/model_misc/submodules.py:159-200)
  *   ebfi_events_to_stack        dataloader/encodings.py:307-350 (events_to_stack)
  *   ebfi_frame2lap / _frame2dcp myutils/utils.py:34-49 / :15-31
  */
@@ -98,6 +99,33 @@ int ebfi_dcn_backward(const void *input, const void *weight, const void *bias, c
                       int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw,
                       int ph, int pw, int dh, int dw, int deformable_group,
                       void *workspace, size_t workspace_bytes, int dtype, void *stream);
+
+/* ------------------------------------------------------------------ conv + bias + activation (ConvLayer)
+ * What the reference gets from nn.Conv2d + nn.LeakyReLU / nn.Sigmoid inside ConvLayer
+ * (models/model_misc/submodules.py:159-200).  Contiguous NCHW fp32.
+ *   input [B,Cin,H,W]  weight [Cout,Cin,k,k]  bias [Cout] or NULL  output [B,Cout,Ho,Wo]
+ *   k in {1,3}, stride in {1,2}, Ho = (H + 2*pad - k)/stride + 1.
+ *   act: 0 none, 1 LeakyReLU(slope), 2 Sigmoid -- fused into the epilogue. */
+int ebfi_conv2d_forward(const void *input, const void *weight, const void *bias, void *output,
+                        int B, int Cin, int H, int W, int Cout, int ksize, int stride, int pad,
+                        int act, float slope, int dtype, void *stream);
+
+/* grad_input = conv^T(grad_output * act'(saved_output)); stride 1, pad = k/2 only.
+ * saved_output is the forward OUTPUT (post-activation); may be NULL when act == 0. */
+int ebfi_conv2d_backward_data(const void *grad_output, const void *saved_output, const void *weight,
+                              void *grad_input, int B, int Cin, int H, int W, int Cout, int ksize,
+                              int stride, int pad, int act, float slope, int dtype, void *stream);
+
+size_t ebfi_conv2d_backward_weight_workspace(int B, int Cin, int H, int W, int Cout, int ksize,
+                                             int stride, int pad, int dtype);
+
+/* grad_weight [Cout,Cin,k,k] and (if non-NULL) grad_bias [Cout]; fully overwritten; deterministic
+ * (per-workgroup partial slabs in `workspace`, fixed-order reduction). */
+int ebfi_conv2d_backward_weight(const void *input, const void *grad_output, const void *saved_output,
+                                void *grad_weight, void *grad_bias,
+                                int B, int Cin, int H, int W, int Cout, int ksize, int stride, int pad,
+                                int act, float slope, void *workspace, size_t workspace_bytes,
+                                int dtype, void *stream);
 
 /* ------------------------------------------------------------------ event voxel binning
  * xs, ys, ts: float64[n] device (ts sorted, normalised as h5dataset.py:334), ps: float32[n].

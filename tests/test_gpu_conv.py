@@ -1,0 +1,97 @@
+"""GPU parity: conv + bias + activation kernels (C ABI) vs the CPU statement of the same op
+(torch CPU conv2d, as used by oracle/model_ref.conv_layer), forward and all three gradients."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return ((a.cpu() - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def _ref(x, w, b, stride, pad, act, slope):
+    y = F.conv2d(x, w, b, stride, pad)
+    if act == 1:
+        y = F.leaky_relu(y, slope)
+    elif act == 2:
+        y = torch.sigmoid(y)
+    return y
+
+
+CASES = [
+    # B, Cin, H, W, Cout, k, s, p, act, bias
+    (2, 64, 16, 64, 64, 3, 1, 1, 1, True),      # the ResidualControl shape, whole tiles
+    (1, 128, 13, 70, 64, 3, 1, 1, 1, True),     # ragged tiles
+    (2, 64, 12, 40, 200, 3, 1, 1, 1, True),     # Cout not a multiple of 64 (KernelConv-like)
+    (1, 3, 32, 48, 64, 3, 2, 1, 1, True),       # FrameFeatExtract: stride 2, tiny Cin
+    (1, 32, 34, 66, 64, 3, 2, 1, 1, True),      # EventFeatExtract: stride 2
+    (2, 4, 24, 40, 64, 3, 1, 1, 1, True),       # BLFeatExtract: Cin=4
+    (1, 64, 20, 36, 1, 3, 1, 1, 0, True),       # ExposureDecision.Conv1.1: Cout=1, no activation
+    (1, 64, 17, 33, 3, 3, 1, 1, 2, True),       # last reconstruction conv: Cout=3, sigmoid
+    (2, 64, 16, 32, 64, 1, 1, 0, 1, True),      # Modification.Conv1: 1x1
+    (1, 20, 16, 32, 24, 3, 1, 1, 0, False),     # odd channel counts, no bias
+    (1, 70, 16, 32, 64, 3, 1, 1, 1, True),      # Cin spills into a second 64-channel block
+]
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,s,p,act,has_bias", CASES)
+def test_conv_forward_backward_vs_cpu(B, Cin, H, W, Cout, k, s, p, act, has_bias):
+    from ebfi_amd.conv import conv_bias_act
+    torch.manual_seed(B + Cin + H + W + Cout + k + s + act)
+    x = torch.randn(B, Cin, H, W)
+    w = torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout) * 0.1 if has_bias else None
+    slope = 0.01
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    br = b.clone().requires_grad_() if has_bias else None
+    ref = _ref(xr, wr, br, s, p, act, slope)
+    g = torch.randn_like(ref)
+    ref.backward(g)
+    xd, wd = x.cuda().requires_grad_(), w.cuda().requires_grad_()
+    bd = b.cuda().requires_grad_() if has_bias else None
+    out = conv_bias_act(xd, wd, bd, s, p, act, slope)
+    assert out.shape == ref.shape
+    assert _rel(out.detach(), ref.detach()) < 2e-5
+    out.backward(g.cuda())
+    assert _rel(xd.grad, xr.grad) < 5e-5
+    assert _rel(wd.grad, wr.grad) < 5e-5
+    if has_bias:
+        assert _rel(bd.grad, br.grad) < 5e-5
+
+
+def test_convlayer_uses_native_kernels_and_matches():
+    from ebfi_amd import _native as N
+    from ebfi_amd.model import ConvLayer
+    torch.manual_seed(0)
+    layer = ConvLayer(64, 64, 3, 1, 1, activation="LeakyReLU").cuda()
+    x = torch.randn(1, 64, 32, 64).cuda()
+    N.prof_reset()
+    N.prof_enable(True)
+    y = layer(x)
+    y.sum().backward()
+    torch.cuda.synchronize()
+    N.prof_enable(False)
+    names = set(N.prof_collect())
+    assert {"conv_fwd_f32", "conv_wgrad_f32", "conv_wgrad_reduce_f32"} <= names
+    ref = F.leaky_relu(F.conv2d(x.cpu(), layer.conv2d.weight.detach().cpu(), layer.conv2d.bias.detach().cpu(), 1, 1), 0.01)
+    assert _rel(y.detach(), ref) < 2e-5
+
+
+def test_full_size_deterministic_weight_grad():
+    from ebfi_amd.conv import conv_bias_act
+    torch.manual_seed(1)
+    x = torch.randn(8, 64, 128, 128, device="cuda")
+    w = (torch.randn(64, 64, 3, 3, device="cuda") / 24).requires_grad_()
+    b = torch.zeros(64, device="cuda", requires_grad=True)
+    g = torch.randn(8, 64, 128, 128, device="cuda")
+    grads = []
+    for _ in range(2):
+        w.grad = None
+        conv_bias_act(x, w, b, 1, 1, 1, 0.01).backward(g)
+        grads.append(w.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    xs, ws = x[:1].cpu(), w.detach().cpu()
+    ref = F.leaky_relu(F.conv2d(xs, ws, None, 1, 1), 0.01)
+    assert _rel(conv_bias_act(x[:1].contiguous(), w.detach(), None, 1, 1, 1, 0.01), ref) < 2e-5
