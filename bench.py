@@ -126,6 +126,8 @@ def main():
 
     from ebfi_amd import _native as N
     from ebfi_amd.engine import DEFAULT_MODEL_ARGS, Engine, synthetic_batch
+    if os.environ.get("EBFI_MIOPEN_FIND", "0") == "1":      # let MIOpen time its candidates (3-D convs of Detail)
+        torch.backends.cudnn.benchmark = True
 
     eng = Engine(DEFAULT_MODEL_ARGS, device=device, precision=args.precision, lr=1e-4, seed=123)
     batch = synthetic_batch(B_PER_GPU, H, W, TB, device=device, seed=123, rank=rank)   # resident in HBM

@@ -47,14 +47,14 @@ __device__ __forceinline__ float act_grad(float y, int act, float slope) {
     return 1.f;
 }
 
-constexpr int TY = 4, TX = 64, CK = 8;
+constexpr int TY = 4, TX = 64;
 
 // ------------------------------------------------------------------------------------------------
 // forward (and stride-1 data gradient when transposed != 0)
 //   x    [B,Cin,H,W]   (for dgrad: grad_output [B,Cout_fwd,..])      dact_y: optional, same shape as x
 //   w    forward: [Cout,Cin,KS,KS];  transposed: [Cin,Cout,KS,KS] of the FORWARD conv (its Cout = our Cin)
 //   out  [B,Cout,Ho,Wo]
-template <int KS, int S, int MT>
+template <int KS, int S, int MT, int CK>
 __global__ __launch_bounds__(256) void conv_fwd_f32(const float *__restrict__ x, const float *__restrict__ dact_y,
                                                     const float *__restrict__ w, const float *__restrict__ bias,
                                                     float *__restrict__ out, ConvGeom g, int transposed, int act,
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void conv_fwd_f32(const float *__restrict__ x,
 constexpr int WTY = 2, WTX = 32, WNP = WTY * WTX;   // pixel tile of the contraction
 constexpr int GS = WNP + 1;                          // odd row stride of the grad_out image
 
-template <int KS, int S>
+template <int KS, int S, int CIB>
 __global__ __launch_bounds__(256) void conv_wgrad_f32(const float *__restrict__ x, const float *__restrict__ gout,
                                                       const float *__restrict__ yact, float *__restrict__ slab,
                                                       ConvGeom g, int dact, float dslope, int total_tiles,
@@ -181,14 +181,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const float *__restrict__ 
     constexpr int KK = KS * KS;
     constexpr int IH = S * (WTY - 1) + KS, IW = S * (WTX - 1) + KS;
     constexpr int PS = (IH * IW) | 1;      // odd plane stride -> conflict-free across channels
-    constexpr int NTW = (64 * KK + 63) / 64;   // n-tiles (of 32) per wave: the 64-ci block has 2*NTW tiles
+    constexpr int NTW = (CIB * KK + 63) / 64;  // n-tiles (of 32) per wave: the CIB-channel block has <= 2*NTW tiles
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sG = smem;                      // [64 co][GS]
-    float *sIn = smem + 64 * GS;           // [64 ci][PS]
+    float *sIn = smem + 64 * GS;           // [CIB ci][PS]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int co_base = blockIdx.y * 64, ci_base = blockIdx.z * 64;
-    const int ci_cnt = min(64, g.Cin - ci_base);
+    const int co_base = blockIdx.y * 64, ci_base = blockIdx.z * CIB;
+    const int ci_cnt = min(CIB, g.Cin - ci_base);
     const int ncols = ci_cnt * KK;         // valid (ci,tap) columns of this block
     const int mt = wave & 1, nh = wave >> 1;   // wave: co tile mt, n-tiles nh, nh+2, nh+4, ...
     const int tiles_x = (g.Wo + WTX - 1) / WTX, tiles_y = (g.Ho + WTY - 1) / WTY;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const float *__restrict__ 
             }
             sG[co * GS + p] = v;
         }
-        for (int i = tid; i < 64 * IH * IW; i += 256) {
+        for (int i = tid; i < CIB * IH * IW; i += 256) {
             const int ci = i / (IH * IW), rem = i - ci * (IH * IW);
             const int r = rem / IW, c = rem - r * IW;
             const int yy = iy0 + r, xx = ix0 + c;
@@ -272,19 +272,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const float *__restrict__ 
     if (need_bias && blockIdx.z == 0 && tid < 64 && co_base + tid < g.Cout) my[wsz + co_base + tid] = bsum;
 }
 
-__global__ void conv_wgrad_reduce_f32(const float *__restrict__ slab, int nslabs, int64_t n_weight, int64_t n_total,
-                                      float *__restrict__ gw, float *__restrict__ gb) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_total) return;
-    float s = 0.f;
-    for (int k = 0; k < nslabs; ++k) s += slab[(int64_t)k * n_total + j];
-    if (j < n_weight) gw[j] = s;
-    else if (gb) gb[j - n_weight] = s;
+// 64 consecutive elements per workgroup, 4 thread rows each summing every 4th slab (4 loads in
+// flight), then a fixed-order combine through LDS: deterministic, and short dependent chains.
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_f32(const float *__restrict__ slab, int nslabs,
+                                                             int64_t n_weight, int64_t n_total,
+                                                             float *__restrict__ gw, float *__restrict__ gb) {
+    __shared__ float part[4][64];
+    const int jj = threadIdx.x & 63, kq = threadIdx.x >> 6;
+    const int64_t j = (int64_t)blockIdx.x * 64 + jj;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (j < n_total) {
+        const float *p = slab + j;
+        int k = kq;
+        for (; k + 12 < nslabs; k += 16) {
+            s0 += p[(int64_t)k * n_total];
+            s1 += p[(int64_t)(k + 4) * n_total];
+            s2 += p[(int64_t)(k + 8) * n_total];
+            s3 += p[(int64_t)(k + 12) * n_total];
+        }
+        for (; k < nslabs; k += 4) s0 += p[(int64_t)k * n_total];
+    }
+    part[kq][jj] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (kq == 0 && j < n_total) {
+        const float s = (part[0][jj] + part[1][jj]) + (part[2][jj] + part[3][jj]);
+        if (j < n_weight) gw[j] = s;
+        else if (gb) gb[j - n_weight] = s;
+    }
 }
 
 int make_geom(ConvGeom &g, int B, int Cin, int H, int W, int Cout, int ks, int stride, int pad) {
     if (B < 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return fail(EBFI_ERR_ARG, "conv2d: non-positive dimension");
-    if (ks != 1 && ks != 3) return fail(EBFI_ERR_UNSUPPORTED, "conv2d: kernel size %d (1 and 3 implemented)", ks);
+    if (ks != 1 && ks != 3 && ks != 7) return fail(EBFI_ERR_UNSUPPORTED, "conv2d: kernel size %d (1, 3 and 7 implemented)", ks);
     if (stride != 1 && stride != 2) return fail(EBFI_ERR_UNSUPPORTED, "conv2d: stride %d (1 and 2 implemented)", stride);
     if (pad < 0 || pad > ks) return fail(EBFI_ERR_ARG, "conv2d: padding %d out of range", pad);
     g = ConvGeom{B, Cin, H, W, Cout, (H + 2 * pad - ks) / stride + 1, (W + 2 * pad - ks) / stride + 1, pad};
@@ -297,26 +316,29 @@ int make_geom(ConvGeom &g, int B, int Cin, int H, int W, int Cout, int ks, int s
 template <int KS, int S>
 int launch_fwd(hipStream_t st, const float *x, const float *dact_y, const float *w, const float *bias, float *out,
                const ConvGeom &g, int transposed, int act, float slope, int dact, float dslope) {
+    constexpr int CK = KS == 7 ? 2 : 8;      // input channels staged per chunk (LDS budget of the weight slice)
     const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, TY) * ceil_div(g.Wo, TX);
     if (tiles > 2147483647LL) return fail(EBFI_ERR_ARG, "conv2d: too many tiles");
     const char *name = transposed ? "conv_dgrad_f32" : "conv_fwd_f32";
     if (g.Cout <= 32) {
         dim3 grid((unsigned)tiles, (unsigned)ceil_div(g.Cout, 32));
         ProfScope ps(name, st);
-        hipLaunchKernelGGL((conv_fwd_f32<KS, S, 1>), grid, dim3(256), 0, st, x, dact_y, w, bias, out, g, transposed, act,
-                           slope, dact, dslope);
+        hipLaunchKernelGGL((conv_fwd_f32<KS, S, 1, CK>), grid, dim3(256), 0, st, x, dact_y, w, bias, out, g, transposed,
+                           act, slope, dact, dslope);
     } else {
         dim3 grid((unsigned)tiles, (unsigned)ceil_div(g.Cout, 64));
         ProfScope ps(name, st);
-        hipLaunchKernelGGL((conv_fwd_f32<KS, S, 2>), grid, dim3(256), 0, st, x, dact_y, w, bias, out, g, transposed, act,
-                           slope, dact, dslope);
+        hipLaunchKernelGGL((conv_fwd_f32<KS, S, 2, CK>), grid, dim3(256), 0, st, x, dact_y, w, bias, out, g, transposed,
+                           act, slope, dact, dslope);
     }
     return check_launch(name);
 }
 
-int wgrad_splits(const ConvGeom &g) {
+constexpr int wgrad_cib(int ks) { return ks == 7 ? 8 : 64; }
+
+int wgrad_splits(const ConvGeom &g, int ks) {
     const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, WTX);
-    const int64_t blocks = ceil_div(g.Cout, 64) * ceil_div(g.Cin, 64);
+    const int64_t blocks = ceil_div(g.Cout, 64) * ceil_div(g.Cin, wgrad_cib(ks));
     int64_t s = ceil_div(1024, blocks);          // aim at >= 1024 workgroups (4 per CU)
     if (s > tiles) s = tiles;
     if (s < 1) s = 1;
@@ -327,21 +349,20 @@ int wgrad_splits(const ConvGeom &g) {
 template <int KS, int S>
 int launch_wgrad(hipStream_t st, const float *x, const float *gout, const float *yact, float *slab, const ConvGeom &g,
                  int dact, float dslope, int nsplit, int need_bias) {
-    constexpr int KK = KS * KS;
+    constexpr int CIB = wgrad_cib(KS);
     constexpr int IH = S * (WTY - 1) + KS, IW = S * (WTX - 1) + KS;
     constexpr int PS = (IH * IW) | 1;
-    const size_t lds = (size_t)(64 * GS + 64 * PS) * sizeof(float);
+    const size_t lds = (size_t)(64 * GS + CIB * PS) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_f32<KS, S>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_f32<KS, S, CIB>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    (void)KK;
     const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, WTX);
-    dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, 64));
+    dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, CIB));
     ProfScope ps("conv_wgrad_f32", st);
-    hipLaunchKernelGGL((conv_wgrad_f32<KS, S>), grid, dim3(256), lds, st, x, gout, yact, slab, g, dact, dslope,
+    hipLaunchKernelGGL((conv_wgrad_f32<KS, S, CIB>), grid, dim3(256), lds, st, x, gout, yact, slab, g, dact, dslope,
                        (int)tiles, need_bias);
     return check_launch("conv_wgrad_f32");
 }
@@ -364,18 +385,21 @@ extern "C" int ebfi_conv2d_forward(const void *input, const void *weight, const 
     if (ksize == 3 && stride == 1) return launch_fwd<3, 1>(st, x, nullptr, w, bs, o, g, 0, act, slope, 0, 0.f);
     if (ksize == 3 && stride == 2) return launch_fwd<3, 2>(st, x, nullptr, w, bs, o, g, 0, act, slope, 0, 0.f);
     if (ksize == 1 && stride == 1) return launch_fwd<1, 1>(st, x, nullptr, w, bs, o, g, 0, act, slope, 0, 0.f);
+    if (ksize == 7 && stride == 1) return launch_fwd<7, 1>(st, x, nullptr, w, bs, o, g, 0, act, slope, 0, 0.f);
+    if (ksize == 7 && stride == 2) return launch_fwd<7, 2>(st, x, nullptr, w, bs, o, g, 0, act, slope, 0, 0.f);
     return fail(EBFI_ERR_UNSUPPORTED, "conv2d_forward: k=%d stride=%d not implemented", ksize, stride);
 }
 
-// grad_input[B,Cin,H,W] = conv^T(grad_output * act'(saved_output)); stride 1 and pad = ksize/2 only.
+// grad_input[B,Cin,H,W] = conv^T(grad_output * act'(saved_output)); stride 1 only (any pad <= k-1).
 extern "C" int ebfi_conv2d_backward_data(const void *grad_output, const void *saved_output, const void *weight,
                                          void *grad_input, int B, int Cin, int H, int W, int Cout, int ksize,
                                          int stride, int pad, int act, float slope, int dtype, void *stream) {
     if (!grad_output || !weight || !grad_input) return fail(EBFI_ERR_ARG, "conv2d_backward_data: null argument");
     if (dtype != EBFI_F32) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_data: dtype %d not implemented", dtype);
     if (act != ACT_NONE && !saved_output) return fail(EBFI_ERR_ARG, "conv2d_backward_data: activation needs saved_output");
-    if (stride != 1 || pad != ksize / 2)
-        return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_data: only stride 1 with 'same' padding (got s=%d p=%d k=%d)", stride, pad, ksize);
+    if (stride != 1 || pad > ksize - 1)
+        return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_data: stride 1 and pad <= k-1 only (got s=%d p=%d k=%d); strided layers "
+                    "zero-insert grad_output on the host side", stride, pad, ksize);
     ConvGeom f;   // geometry of the forward conv, to validate
     if (int rc = make_geom(f, B, Cin, H, W, Cout, ksize, stride, pad)) return rc;
     if (B == 0) return EBFI_OK;
@@ -386,6 +410,7 @@ extern "C" int ebfi_conv2d_backward_data(const void *grad_output, const void *sa
     const float *w = static_cast<const float *>(weight);
     float *gi = static_cast<float *>(grad_input);
     if (ksize == 3) return launch_fwd<3, 1>(st, go, yo, w, nullptr, gi, g, 1, ACT_NONE, 0.f, act, slope);
+    if (ksize == 7) return launch_fwd<7, 1>(st, go, yo, w, nullptr, gi, g, 1, ACT_NONE, 0.f, act, slope);
     return launch_fwd<1, 1>(st, go, yo, w, nullptr, gi, g, 1, ACT_NONE, 0.f, act, slope);
 }
 
@@ -394,7 +419,7 @@ extern "C" size_t ebfi_conv2d_backward_weight_workspace(int B, int Cin, int H, i
     (void)dtype;
     ConvGeom g;
     if (make_geom(g, B, Cin, H, W, Cout, ksize, stride, pad) != EBFI_OK) return 0;
-    return (size_t)wgrad_splits(g) * ((size_t)Cout * Cin * ksize * ksize + Cout) * sizeof(float);
+    return (size_t)wgrad_splits(g, ksize) * ((size_t)Cout * Cin * ksize * ksize + Cout) * sizeof(float);
 }
 
 // grad_weight[Cout,Cin,k,k] (and grad_bias[Cout] when non-NULL), both fully overwritten, deterministic.
@@ -420,17 +445,19 @@ extern "C" int ebfi_conv2d_backward_weight(const void *input, const void *grad_o
     const float *x = static_cast<const float *>(input), *go = static_cast<const float *>(grad_output);
     const float *yo = static_cast<const float *>(saved_output);
     float *slab = static_cast<float *>(workspace);
-    const int nsplit = wgrad_splits(g);
+    const int nsplit = wgrad_splits(g, ksize);
     const int need_bias = grad_bias != nullptr;
     int rc;
     if (ksize == 3 && stride == 1) rc = launch_wgrad<3, 1>(st, x, go, yo, slab, g, act, slope, nsplit, need_bias);
     else if (ksize == 3 && stride == 2) rc = launch_wgrad<3, 2>(st, x, go, yo, slab, g, act, slope, nsplit, need_bias);
     else if (ksize == 1 && stride == 1) rc = launch_wgrad<1, 1>(st, x, go, yo, slab, g, act, slope, nsplit, need_bias);
+    else if (ksize == 7 && stride == 1) rc = launch_wgrad<7, 1>(st, x, go, yo, slab, g, act, slope, nsplit, need_bias);
+    else if (ksize == 7 && stride == 2) rc = launch_wgrad<7, 2>(st, x, go, yo, slab, g, act, slope, nsplit, need_bias);
     else return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_weight: k=%d stride=%d not implemented", ksize, stride);
     if (rc) return rc;
     {
         ProfScope ps("conv_wgrad_reduce_f32", st);
-        hipLaunchKernelGGL(conv_wgrad_reduce_f32, dim3((unsigned)ceil_div(n_total, 256)), dim3(256), 0, st, slab, nsplit,
+        hipLaunchKernelGGL(conv_wgrad_reduce_f32, dim3((unsigned)ceil_div(n_total, 64)), dim3(256), 0, st, slab, nsplit,
                            n_weight, n_total, static_cast<float *>(grad_weight), static_cast<float *>(grad_bias));
     }
     return check_launch("conv_wgrad_reduce_f32");

@@ -33,7 +33,7 @@ def activation_code(module):
 def supported(x, weight, stride, padding, dilation=(1, 1), groups=1):
     k = weight.shape[-1]
     return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and
-            weight.shape[-2] == k and k in (1, 3) and stride[0] == stride[1] and stride[0] in (1, 2) and
+            weight.shape[-2] == k and k in (1, 3, 7) and stride[0] == stride[1] and stride[0] in (1, 2) and
             not (k == 1 and stride[0] != 1) and padding[0] == padding[1] and 0 <= padding[0] <= k and
             tuple(dilation) == (1, 1) and groups == 1 and x.shape[-1] * x.shape[-2] >= 256)
 
@@ -71,14 +71,21 @@ class ConvBiasAct(Function):
         with torch.cuda.device_of(x):
             st = N.stream_ptr(x.device)
             if ctx.needs_input_grad[0]:
-                if stride == 1 and pad == k // 2:
-                    gx = torch.empty_like(x)
+                gx = torch.empty_like(x)
+                if stride == 1:
                     rc = lib.ebfi_conv2d_backward_data(N.ptr(gout), N.ptr(y), N.ptr(weight), N.ptr(gx), *geo, act, slope,
                                                        N.EBFI_F32, st)
-                    N.check(rc, "ebfi_conv2d_backward_data")
-                else:   # strided data gradient: PyTorch-ROCm (only the two stride-2 stems, whose inputs need no grad)
+                else:
+                    # stride 2: zero-insert grad_output (times act') and run the stride-1 data gradient on it.
+                    # Only the small stems / down-sampling convs take this path.
                     gpre = gout if act == ACT_NONE else gout * _act_grad(y, act, slope)
-                    gx = torch.nn.grad.conv2d_input(x.shape, weight, gpre, stride=stride, padding=pad)
+                    uh, uw = geo[2] + 2 * pad - k + 1, geo[3] + 2 * pad - k + 1
+                    up = gout.new_zeros((geo[0], geo[4], uh, uw))
+                    up[:, :, ::stride, ::stride][:, :, :gout.shape[2], :gout.shape[3]] = gpre
+                    geo1 = geo[:6] + [1, pad]
+                    rc = lib.ebfi_conv2d_backward_data(N.ptr(up), N.ptr(None), N.ptr(weight), N.ptr(gx), *geo1, ACT_NONE, 0.0,
+                                                       N.EBFI_F32, st)
+                N.check(rc, "ebfi_conv2d_backward_data")
             if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
                 gw = torch.empty_like(weight)
                 gb = torch.empty(geo[4], dtype=x.dtype, device=x.device) if has_bias else None

@@ -1,0 +1,96 @@
+"""Depth-2 3-D convolutions of the detail branch as 2-D convolutions on the gfx950 conv kernels.
+
+UNet3d_18 (reference models/Ours/model_singleframe.py:170-223, models/model_misc/resnet_3D.py)
+stacks (blurry frame, Sharp) on a depth axis of length 2 and never changes that length (temporal
+stride 1, depth padding 1 for depth-3 kernels).  A contiguous [B, C, 2, H, W] tensor IS a
+[B, 2C, H, W] tensor (channel = c*2 + d), so
+
+  Conv3d k=(3,kh,kw), pad_d=1     ==  Conv2d with W2[(co,d),(ci,din)] = W[co,ci,din-d+1]
+  Conv3d k=(1,1,1)                ==  Conv2d 1x1 with a block-diagonal weight
+  ConvTranspose3d k=(3,4,4), stride (1,2,2), pad (1,1,1)
+                                  ==  Conv2d 3x3 (pad 1) to 8*Cout channels + PixelShuffle(2):
+                                      output parity (py,px) picks 2x2 of the 4x4 taps
+
+The folds are tiny differentiable tensor ops on the weights (autograd routes the gradient back to
+the original Conv3d / ConvTranspose3d parameters, so state_dict and optimizer are untouched); the
+convolutions themselves run through ebfi_amd.conv (fused bias + activation).
+"""
+import torch
+import torch.nn.functional as F
+
+from . import conv
+
+
+def usable(x):
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.shape[2] == 2 and \
+        not torch.is_autocast_enabled() and x.shape[-1] * x.shape[-2] >= 256
+
+
+def fold_conv3d_weight(w):
+    """[Co,Ci,kd,kh,kw] -> [2Co,2Ci,kh,kw] for depth-2 inputs with depth padding kd//2."""
+    Co, Ci, kd, kh, kw = w.shape
+    if kd == 3:
+        d0, d1 = w[:, :, 1:3], w[:, :, 0:2]            # out depth 0 sees kd = din+1, depth 1 sees kd = din
+    elif kd == 1:
+        z = torch.zeros_like(w)
+        d0, d1 = torch.cat([w, z], 2), torch.cat([z, w], 2)
+    else:
+        raise ValueError("depth kernel %d" % kd)
+    return torch.stack([d0, d1], dim=1).reshape(2 * Co, 2 * Ci, kh, kw)
+
+
+def conv3d_d2(x, m, act=conv.ACT_NONE, slope=0.0):
+    """x [B,Ci,2,H,W] through nn.Conv3d `m` (+ fused activation) -> [B,Co,2,Ho,Wo]."""
+    B, Ci, D, H, W = x.shape
+    kd, kh, kw = m.kernel_size
+    assert D == 2 and m.stride[0] == 1 and m.padding[0] == kd // 2 and kh == kw and m.stride[1] == m.stride[2]
+    assert m.padding[1] == m.padding[2] and m.dilation == (1, 1, 1) and m.groups == 1
+    x2 = x.reshape(B, 2 * Ci, H, W)
+    s = m.stride[1]
+    if kh == 1 and s != 1:                               # 1x1 strided shortcut: subsample, then 1x1
+        x2 = x2[:, :, ::s, ::s].contiguous()
+        s = 1
+    b2 = m.bias.repeat_interleave(2) if m.bias is not None else None
+    y2 = conv.conv_bias_act(x2, fold_conv3d_weight(m.weight), b2, s, m.padding[1], act, slope)
+    return y2.view(B, m.out_channels, 2, y2.shape[-2], y2.shape[-1])
+
+
+_KY = {}
+
+
+def _tap_select(device):
+    """4-tap transposed-conv kernel -> 3 window rows per output parity: (index, mask) of length 6."""
+    if device not in _KY:
+        _KY[device] = (torch.tensor([3, 1, 0, 0, 2, 0], device=device),
+                       torch.tensor([1., 1., 0., 0., 1., 1.], device=device))
+    return _KY[device]
+
+
+def fold_conv_transpose3d_weight(wt):
+    """[Ci,Co,3,4,4] (stride (1,2,2), pad (1,1,1)) -> [8Co, 2Ci, 3, 3]; out channel = ((co*2+d)*2+py)*2+px."""
+    Ci, Co, kd, kh, kw = wt.shape
+    assert (kd, kh, kw) == (3, 4, 4)
+    idx, mask = _tap_select(wt.device)
+    wd = torch.stack([wt[:, :, [1, 0]], wt[:, :, [2, 1]]], dim=2)           # [Ci,Co,d,din,4,4], kd = d-din+1
+    wy = wd.index_select(4, idx) * mask.view(6, 1)                           # [Ci,Co,d,din,(py,dy),4]
+    wx = wy.index_select(5, idx) * mask                                      # [Ci,Co,d,din,(py,dy),(px,dx)]
+    w8 = wx.view(Ci, Co, 2, 2, 2, 3, 2, 3).permute(1, 2, 4, 6, 0, 3, 5, 7)   # [Co,d,py,px,Ci,din,dy,dx]
+    return w8.reshape(8 * Co, 2 * Ci, 3, 3)
+
+
+def conv_transpose3d_d2(x, m):
+    """x [B,Ci,2,H,W] through nn.ConvTranspose3d `m` -> [B,Co,2,2H,2W]."""
+    B, Ci, D, H, W = x.shape
+    assert D == 2 and m.kernel_size == (3, 4, 4) and m.stride == (1, 2, 2) and m.padding == (1, 1, 1)
+    assert m.output_padding == (0, 0, 0) and m.dilation == (1, 1, 1) and m.groups == 1
+    b8 = m.bias.repeat_interleave(8) if m.bias is not None else None
+    y = conv.conv_bias_act(x.reshape(B, 2 * Ci, H, W), fold_conv_transpose3d_weight(m.weight), b8, 1, 1, conv.ACT_NONE, 0.0)
+    return F.pixel_shuffle(y, 2).view(B, m.out_channels, 2, 2 * H, 2 * W)
+
+
+def se_gate(x, attn_conv):
+    """SEGating (resnet_3D.py:89-105): x * sigmoid(W @ mean(x) + b) with the 1x1x1 conv as a matmul."""
+    pooled = x.mean(dim=(2, 3, 4))
+    w = attn_conv.weight.view(attn_conv.out_channels, attn_conv.in_channels)
+    gate = torch.sigmoid(F.linear(pooled, w, attn_conv.bias))
+    return x * gate[:, :, None, None, None]

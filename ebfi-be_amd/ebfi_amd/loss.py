@@ -1,8 +1,8 @@
 """Training loss of the hot path (device side).
 
 Reference: loss/restore.py:149-213 (LaplacianLoss: 5-level Laplacian pyramid, L1 *sum*, level
-weight 2**i), :111-145 (Ternary census, 7x7), combined as in train_ours.py:258-268.  Plain
-PyTorch-ROCm ops for now -- many small depthwise convs; fusing them is section 8(f) rank 3.
+weight 2**i), :111-145 (Ternary census, 7x7), combined as in train_ours.py:258-268.  Elementwise /
+shifted-slice PyTorch ops (no library convolution); a fused kernel is section 8(f) rank 3.
 """
 import torch
 import torch.nn as nn
@@ -10,14 +10,21 @@ import torch.nn.functional as F
 
 
 class GaussianConv(nn.Module):
+    """5x5 binomial blur with reflect padding (restore.py:149-163).  The kernel is separable
+    ([1,4,6,4,1]/16 twice), so it is applied as shifted-slice sums: no library convolution involved."""
+
     def __init__(self):
         super().__init__()
         k1 = torch.tensor([1., 4., 6., 4., 1.])
         self.kernel = nn.Parameter((k1[:, None] * k1[None, :] / 256).repeat(3, 1, 1, 1), requires_grad=False)
+        self.taps = (1.0 / 16, 4.0 / 16, 6.0 / 16, 4.0 / 16, 1.0 / 16)
 
     def forward(self, x, factor=1):
-        c = x.shape[1]
-        return F.conv2d(F.pad(x, (2, 2, 2, 2), mode="reflect"), factor * self.kernel[:c], groups=c)
+        H, W = x.shape[-2:]
+        p = F.pad(x, (2, 2, 2, 2), mode="reflect")
+        h = sum(t * p[..., :, j:j + W] for j, t in enumerate(self.taps))
+        v = sum(t * h[..., i:i + H, :] for i, t in enumerate(self.taps))
+        return v * factor if factor != 1 else v
 
 
 class LaplacianPyramid(nn.Module):
@@ -61,7 +68,11 @@ class Ternary(nn.Module):
 
     def transform(self, t):
         g = t.mean(dim=1, keepdim=True)
-        d = F.conv2d(g, self.w.to(g.dtype), padding=self.patch_size // 2) - g
+        H, W = g.shape[-2:]
+        k, r = self.patch_size, self.patch_size // 2
+        gp = F.pad(g, (r, r, r, r))                  # zero padding, like conv2d(padding=r)
+        patches = torch.cat([gp[..., i:i + H, j:j + W] for i in range(k) for j in range(k)], dim=1)
+        d = patches - g
         return d / torch.sqrt(0.81 + d ** 2)
 
     def forward(self, x, y):

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import conv
+from . import conv, fold3d
 from .blur import Frame2DCP, Frame2Lap
 from .fac import KernelConv2D
 
@@ -56,7 +56,10 @@ class ConvLayer(nn.Module):
         if fuse is not None and not torch.is_autocast_enabled() and \
                 conv.supported(x, c.weight, c.stride, c.padding, c.dilation, c.groups):
             return conv.conv_bias_act(x, c.weight, c.bias, c.stride[0], c.padding[0], fuse[0], fuse[1])
-        y = c(x)       # shapes the gfx950 conv kernels do not cover: PyTorch-ROCm conv (still GPU)
+        if x.shape[-2:] == (1, 1) and c.kernel_size == (1, 1) and c.groups == 1:
+            y = F.linear(x.flatten(1), c.weight.flatten(1), c.bias)[:, :, None, None]   # scalar-conditioned scales
+        else:
+            y = c(x)   # shapes the gfx950 conv kernels do not cover: PyTorch-ROCm conv (still GPU)
         if self.norm in ("BN", "IN"):
             y = self.norm_layer(y)
         return y if self.activation is None else self.activation(y)
@@ -195,6 +198,8 @@ class SEGating(nn.Module):
         self.attn_layer = nn.Sequential(nn.Conv3d(inplanes, inplanes, kernel_size=1, stride=1, bias=True), nn.Sigmoid())
 
     def forward(self, x):
+        if fold3d.usable(x):
+            return fold3d.se_gate(x, self.attn_layer[0])
         return x * self.attn_layer(self.pool(x))
 
 
@@ -216,6 +221,11 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        if fold3d.usable(x) and isinstance(self.conv1[1], identity):
+            out = fold3d.conv3d_d2(x, self.conv1[0], conv.ACT_LEAKY, 0.0)        # conv + ReLU fused
+            out = self.fg(fold3d.conv3d_d2(out, self.conv2[0]))
+            res = x if self.downsample is None else fold3d.conv3d_d2(x, self.downsample[0])
+            return torch.relu(out + res)
         out = self.fg(self.conv2(self.conv1(x)))
         res = x if self.downsample is None else self.downsample(x)
         return self.relu(out + res)
@@ -253,7 +263,10 @@ class VideoResNet(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
     def forward(self, x):
-        x0 = self.stem(x)
+        if fold3d.usable(x) and isinstance(self.stem[1], identity):
+            x0 = fold3d.conv3d_d2(x, self.stem[0], conv.ACT_LEAKY, 0.0)          # 3x7x7 stride (1,2,2) + ReLU
+        else:
+            x0 = self.stem(x)
         x1 = self.layer1(x0)
         x2 = self.layer2(x1)
         x3 = self.layer3(x2)
@@ -271,6 +284,8 @@ class Conv_3d(nn.Module):
                                   SEGating(out_ch), _norm3d(bn, out_ch))
 
     def forward(self, x):
+        if fold3d.usable(x) and isinstance(self.conv[2], identity):
+            return self.conv[1](fold3d.conv3d_d2(x, self.conv[0]))
         return self.conv(x)
 
 
@@ -286,6 +301,8 @@ class upConv3D(nn.Module):
         self.upconv = nn.Sequential(*head, SEGating(out_ch), _norm3d(bn, out_ch))
 
     def forward(self, x):
+        if fold3d.usable(x) and self.upmode == "transpose" and isinstance(self.upconv[2], identity):
+            return self.upconv[1](fold3d.conv_transpose3d_d2(x, self.upconv[0]))
         return self.upconv(x)
 
 
@@ -316,6 +333,11 @@ class UNet3d_18(nn.Module):
             y = torch.cat([self.lrelu(stage(y)), skip], dim=1)
         y = self.lrelu(self.decoder[4](y))
         y = torch.cat(torch.unbind(y, 2), 1)
+        ff, oc = self.feature_fuse[0], self.outconv[1]
+        if isinstance(self.feature_fuse[1], identity) and conv.supported(y, ff.weight, ff.stride, ff.padding) and \
+                not torch.is_autocast_enabled():
+            y = conv.conv_bias_act(y, ff.weight, None, 1, 0, conv.ACT_LEAKY, 0.2)  # 1x1 fuse + LeakyReLU(0.2)
+            return conv.conv_bias_act(self.outconv[0](y), oc.weight, oc.bias, 1, 0, conv.ACT_NONE, 0.0)
         return self.outconv(self.lrelu(self.feature_fuse(y)))
 
 

@@ -33,6 +33,9 @@ CASES = [
     (2, 64, 16, 32, 64, 1, 1, 0, 1, True),      # Modification.Conv1: 1x1
     (1, 20, 16, 32, 24, 3, 1, 1, 0, False),     # odd channel counts, no bias
     (1, 70, 16, 32, 64, 3, 1, 1, 1, True),      # Cin spills into a second 64-channel block
+    (1, 6, 40, 72, 32, 7, 2, 3, 1, False),      # detail-branch stem (folded 3x7x7): 7x7 stride 2
+    (1, 16, 38, 70, 3, 7, 1, 0, 0, True),       # detail-branch outconv: 7x7 valid conv on a reflection-padded map
+    (2, 12, 33, 47, 20, 3, 2, 1, 0, False),     # stride-2 data gradient through zero insertion, odd sizes
 ]
 
 

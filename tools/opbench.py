@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--B", type=int, default=8)
     ap.add_argument("--hd", action="store_true")
-    ap.add_argument("--ops", default="fac,dcn")
+    ap.add_argument("--ops", default="fac,dcn,conv")
     a = ap.parse_args()
     from ebfi_amd.dcn import dcn_v2_backward, dcn_v2_forward
     from ebfi_amd.fac import fac_backward, fac_forward
@@ -87,6 +87,28 @@ def main():
         t, _ = timed(lambda: dcn_v2_backward(x, wt, bias, off, msk, g, *cfg), a.iters, names)
         for n, ms in t.items():
             lines.append({"op": "dcn_backward", "kernel": n, "ms": round(ms, 4)})
+    if "conv" in a.ops:
+        from ebfi_amd.conv import conv_bias_act
+        names = {"conv_fwd_f32", "conv_dgrad_f32", "conv_wgrad_f32", "conv_wgrad_reduce_f32"}
+        for (cin, cout, hh, ww, tag) in [(64, 64, h, w, "ResidualControl 64->64"), (128, 64, h, w, "Conv5 128->64"),
+                                         (128, 1600, h, w, "KernelConv 128->1600"), (64, 64, 2 * h, 2 * w, "Recon 64->64 @2x")]:
+            x = torch.randn(B, cin, hh, ww, device=dev).requires_grad_()
+            wt = (torch.randn(cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5).requires_grad_()
+            bs = torch.zeros(cout, device=dev, requires_grad=True)
+            g = torch.randn(B, cout, hh, ww, device=dev)
+
+            def step():
+                x.grad = wt.grad = bs.grad = None
+                conv_bias_act(x, wt, bs, 1, 1, 1, 0.01).backward(g)
+            t, _ = timed(step, max(3, a.iters // 4), names)
+            fl = 2.0 * B * hh * ww * cin * cout * 9
+            for n, ms in sorted(t.items()):
+                e = {"op": "conv3x3 " + tag, "kernel": n, "ms": round(ms, 4)}
+                if n != "conv_wgrad_reduce_f32":
+                    e.update(TFLOPs=round(fl / ms / 1e9, 2), frac_f32_mfma=round(fl / ms / 1e9 / F32_MFMA_PEAK, 4))
+                lines.append(e)
+            del x, wt, bs, g
+            torch.cuda.empty_cache()
     for l in lines:
         l.update(B=B, h=h, w=w)
         print(json.dumps(l), flush=True)
