@@ -49,22 +49,41 @@ __device__ __forceinline__ float act_grad(float y, int act, float slope) {
 
 constexpr int TY = 4, TX = 64;
 
+// Staging loads go through buffer descriptors: one 32-bit offset VGPR per load instead of a 64-bit
+// address pair, and the hardware range check returns 0 for out-of-range offsets (zero padding and
+// channel tails for free).  SENT is added to running chunk offsets and must stay out of range without
+// wrapping: the launchers require every per-sample tensor to be smaller than 2 GiB.
+constexpr unsigned SENT = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+
 // ------------------------------------------------------------------------------------------------
-// forward (and stride-1 data gradient when transposed != 0)
+// forward (TR = false) and stride-1 data gradient (TR = true)
 //   x    [B,Cin,H,W]   (for dgrad: grad_output [B,Cout_fwd,..])      dact_y: optional, same shape as x
-//   w    forward: [Cout,Cin,KS,KS];  transposed: [Cin,Cout,KS,KS] of the FORWARD conv (its Cout = our Cin)
+//   w    forward: [Cout,Cin,KS,KS];  TR: the FORWARD conv's weight [Cin,Cout,KS,KS] (its Cout = our Cin)
 //   out  [B,Cout,Ho,Wo]
-template <int KS, int S, int MT, int CK>
+// Staging is organised so that everything address-related is computed once per workgroup: a thread owns
+// fixed tile positions (its image offsets and validity never change) and walks the chunk's channels, and
+// fixed weight-slice elements whose global offset just advances by a constant per chunk.  The loads of
+// chunk c+1 are issued into registers before the MFMA block of chunk c and committed to LDS after it.
+template <int KS, int S, int MT, int CK, bool TR>
 __global__ __launch_bounds__(256) void conv_fwd_f32(const float *__restrict__ x, const float *__restrict__ dact_y,
                                                     const float *__restrict__ w, const float *__restrict__ bias,
-                                                    float *__restrict__ out, ConvGeom g, int transposed, int act,
-                                                    float slope, int dact, float dslope) {
+                                                    float *__restrict__ out, ConvGeom g, int act, float slope, int dact,
+                                                    float dslope) {
     constexpr int KK = KS * KS;
     constexpr int IH = S * (TY - 1) + KS, IW = S * (TX - 1) + KS;
     constexpr int PS = IH * IW;            // plane stride of the staged input tile
     constexpr int COS = 32 * MT;           // weight-slice row length (output channels of this block)
+    constexpr int NPOS = (PS + 255) / 256; // tile positions owned by a thread
+    constexpr int WEL = KK * CK * COS;     // weight-slice elements
+    constexpr int NW = (WEL + 255) / 256;
     __shared__ float sIn[CK * PS];
-    __shared__ float sW[KK * CK * COS];
+    __shared__ float sW[WEL];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = (g.Wo + TX - 1) / TX, tiles_y = (g.Ho + TY - 1) / TY;
@@ -75,6 +94,11 @@ __global__ __launch_bounds__(256) void conv_fwd_f32(const float *__restrict__ x,
     const int y0 = ty * TY, x0 = tx * TX;
     const int co_base = blockIdx.y * COS;
     const int iy0 = S * y0 - g.pad, ix0 = S * x0 - g.pad;
+    const int HW = g.H * g.W;
+    const unsigned plane_bytes = (unsigned)HW * 4u, x_bytes = (unsigned)g.Cin * plane_bytes;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (int64_t)b * g.Cin * HW, x_bytes);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(dact ? dact_y + (int64_t)b * g.Cin * HW : x, dact ? x_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rwt = make_rsrc(w, (unsigned)g.Cout * (unsigned)g.Cin * KK * 4u);
 
     f32x16 acc[MT][2];
 #pragma unroll
@@ -84,47 +108,73 @@ __global__ __launch_bounds__(256) void conv_fwd_f32(const float *__restrict__ x,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    const float *xb = x + (int64_t)b * g.Cin * g.H * g.W;
-    const float *yb = dact ? dact_y + (int64_t)b * g.Cin * g.H * g.W : nullptr;
+    unsigned in_off[NPOS];                 // byte offset of the owned position inside a channel plane
+#pragma unroll
+    for (int q = 0; q < NPOS; ++q) {
+        const int pos = tid + q * 256;
+        const int r = pos / IW, c = pos - r * IW;
+        const int yy = iy0 + r, xx = ix0 + c;
+        in_off[q] = (pos < PS && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) ? (unsigned)(yy * g.W + xx) * 4u : SENT;
+    }
+    unsigned w_off[NW];                    // byte offset of the owned weight elements for chunk 0
+    int w_dst[NW];                         // their place in the LDS slice [tap][ci][co]
+#pragma unroll
+    for (int it = 0; it < NW; ++it) {
+        const int i = tid + it * 256;
+        int off, dst;
+        if (!TR) {   // W[co][ci][tap]: for fixed co the (ci,tap) run is contiguous in memory
+            const int co = i / (CK * KK), rem = i - co * (CK * KK);
+            const int ci = rem / KK, tap = rem - ci * KK;
+            off = ((co_base + co) * g.Cin + ci) * KK + tap;
+            dst = (tap * CK + ci) * COS + co;
+        } else {     // data gradient: k = forward out-channel, m = forward in-channel, taps flipped
+            const int ci = i / (COS * KK), rem = i - ci * (COS * KK);
+            const int co = rem / KK, tap = rem - co * KK;
+            off = (ci * g.Cout + co_base + co) * KK + tap;
+            dst = ((KK - 1 - tap) * CK + ci) * COS + co;
+        }
+        w_off[it] = i < WEL ? (unsigned)off * 4u : SENT;
+        w_dst[it] = dst;
+    }
+    // Rows co >= Cout / channels >= Cin of the slice may alias other (finite) weights or read 0 past the
+    // end: those rows are never stored, those channels meet zero-filled input, so no masking is needed.
+    const unsigned w_chunk = (unsigned)(TR ? CK * g.Cout * KK : CK * KK) * 4u;
 
-    for (int c0 = 0; c0 < g.Cin; c0 += CK) {
+    float rin[NPOS * CK], rw[NW];
+    auto prefetch = [&](int chunk) {
+        const unsigned cb = (unsigned)chunk * (unsigned)CK * plane_bytes;
+#pragma unroll
+        for (int q = 0; q < NPOS; ++q)
+#pragma unroll
+            for (int ci = 0; ci < CK; ++ci) {
+                const unsigned o = in_off[q] + cb + (unsigned)ci * plane_bytes;
+                float v = buf_ld(rx, o);
+                if (dact) v *= act_grad(buf_ld(ry, o), dact, dslope);
+                rin[q * CK + ci] = v;
+            }
+        const unsigned wb = (unsigned)chunk * w_chunk;
+#pragma unroll
+        for (int it = 0; it < NW; ++it) rw[it] = buf_ld(rwt, w_off[it] + wb);
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int q = 0; q < NPOS; ++q)
+            if (tid + q * 256 < PS) {
+#pragma unroll
+                for (int ci = 0; ci < CK; ++ci) sIn[ci * PS + tid + q * 256] = rin[q * CK + ci];
+            }
+#pragma unroll
+        for (int it = 0; it < NW; ++it)
+            if (tid + it * 256 < WEL) sW[w_dst[it]] = rw[it];
+    };
+
+    const int nchunks = (g.Cin + CK - 1) / CK;
+    prefetch(0);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        __syncthreads();          // previous chunk's operand reads are done
+        commit();
         __syncthreads();
-        // ---- input halo tile [CK][IH][IW], zero outside the image / beyond Cin
-        for (int i = tid; i < CK * PS; i += 256) {
-            const int ci = i / PS, rem = i - ci * PS;
-            const int r = rem / IW, c = rem - r * IW;
-            const int yy = iy0 + r, xx = ix0 + c;
-            float v = 0.f;
-            if (c0 + ci < g.Cin && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) {
-                const int64_t o = ((int64_t)(c0 + ci) * g.H + yy) * g.W + xx;
-                v = xb[o];
-                if (dact) v *= act_grad(yb[o], dact, dslope);
-            }
-            sIn[i] = v;
-        }
-        // ---- weight slice sW[tap][ci][co]
-        if (!transposed) {
-            // W[co][ci][tap]: for fixed co the (ci,tap) run is contiguous
-            for (int i = tid; i < COS * CK * KK; i += 256) {
-                const int co = i / (CK * KK), rem = i - co * (CK * KK);
-                const int ci = rem / KK, tap = rem - ci * KK;
-                float v = 0.f;
-                if (co_base + co < g.Cout && c0 + ci < g.Cin)
-                    v = w[((int64_t)(co_base + co) * g.Cin + c0 + ci) * KK + tap];
-                sW[(tap * CK + ci) * COS + co] = v;
-            }
-        } else {
-            // data gradient: k = forward out-channel (our ci), m = forward in-channel (our co), flipped taps
-            for (int i = tid; i < CK * COS * KK; i += 256) {
-                const int ci = i / (COS * KK), rem = i - ci * (COS * KK);
-                const int co = rem / KK, tap = rem - co * KK;
-                float v = 0.f;
-                if (co_base + co < g.Cout && c0 + ci < g.Cin)
-                    v = w[((int64_t)(c0 + ci) * g.Cout + co_base + co) * KK + tap];
-                sW[((KK - 1 - tap) * CK + ci) * COS + co] = v;
-            }
-        }
-        __syncthreads();
+        prefetch(chunk + 1);      // past the last chunk every offset is out of range: reads 0, never committed
         // ---- MFMA: wave owns output row `wave` of the tile (2 x-halves) x MT co tiles
         const float *bp = sIn + (lane >> 5) * PS + (S * wave) * IW + S * (lane & 31);
         const float *ap = sW + (lane >> 5) * COS + (lane & 31);
@@ -170,18 +220,33 @@ __global__ __launch_bounds__(256) void conv_fwd_f32(const float *__restrict__ x,
 
 // ------------------------------------------------------------------------------------------------
 // weight gradient: slab[split][co][ci*KK + tap] partial sums; slab[split][Cout*Cin*KK + co] bias partials
-constexpr int WTY = 2, WTX = 32, WNP = WTY * WTX;   // pixel tile of the contraction
-constexpr int GS = WNP + 1;                          // odd row stride of the grad_out image
+constexpr int WTY = 2;                 // output rows of a contraction tile
+constexpr int GSLOTS = 64, GS = GSLOTS + 1;   // grad_out image: 2 rows x 32 slots per channel, odd row stride
 
-template <int KS, int S, int CIB>
+template <int KS, int S>
+struct WCfg {
+    // output columns per tile chosen so that the staged input row fits 32 (or 64) lanes exactly
+    static constexpr int WTX = (KS == 1) ? 32 : (KS == 3) ? 30 : (S == 1 ? 26 : 28);
+    static constexpr int IH = S * (WTY - 1) + KS, IW = S * (WTX - 1) + KS;
+    static constexpr int IWP = IW <= 32 ? 32 : 64;              // lanes per staged input row
+    static constexpr int TROWS = 256 / IWP;                     // thread rows walking (row, channel)
+    static constexpr int CIB = KS == 7 ? 8 : (S == 2 ? 32 : 64);   // input channels per workgroup
+    static constexpr int PS = (IH * IW) | 1;                    // odd plane stride: conflict-free across channels
+    static constexpr int NI = IH * CIB / TROWS;                 // input elements per thread per tile
+    static constexpr int NTW = (CIB * KS * KS + 63) / 64;       // n-tiles (of 32 columns) per wave
+    static_assert(IW <= 64 && WTX % 2 == 0 && WTX <= 32 && CIB % TROWS == 0, "tile configuration");
+};
+
+template <int KS, int S>
 __global__ __launch_bounds__(256) void conv_wgrad_f32(const float *__restrict__ x, const float *__restrict__ gout,
                                                       const float *__restrict__ yact, float *__restrict__ slab,
                                                       ConvGeom g, int dact, float dslope, int total_tiles,
                                                       int need_bias) {
-    constexpr int KK = KS * KS;
-    constexpr int IH = S * (WTY - 1) + KS, IW = S * (WTX - 1) + KS;
-    constexpr int PS = (IH * IW) | 1;      // odd plane stride -> conflict-free across channels
-    constexpr int NTW = (CIB * KK + 63) / 64;  // n-tiles (of 32) per wave: the CIB-channel block has <= 2*NTW tiles
+    using C = WCfg<KS, S>;
+    constexpr int KK = KS * KS, WTX = C::WTX, IH = C::IH, IW = C::IW, IWP = C::IWP, TROWS = C::TROWS;
+    constexpr int CIB = C::CIB, PS = C::PS, NI = C::NI, NTW = C::NTW;
+    constexpr int NG = 64 / 4;             // grad_out channels per thread per tile (4 thread rows of 64 slots)
+    constexpr int CPR = CIB / TROWS;       // channel steps per input row
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sG = smem;                      // [64 co][GS]
     float *sIn = smem + 64 * GS;           // [CIB ci][PS]
@@ -192,6 +257,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const float *__restrict__ 
     const int ncols = ci_cnt * KK;         // valid (ci,tap) columns of this block
     const int mt = wave & 1, nh = wave >> 1;   // wave: co tile mt, n-tiles nh, nh+2, nh+4, ...
     const int tiles_x = (g.Wo + WTX - 1) / WTX, tiles_y = (g.Ho + WTY - 1) / WTY;
+    const int HW = g.H * g.W, HWo = g.Ho * g.Wo;
 
     f32x16 acc[NTW];
 #pragma unroll
@@ -209,46 +275,78 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const float *__restrict__ 
     }
     float bsum = 0.f;
 
-    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    // thread-fixed staging coordinates
+    const int gslot = tid & 63, gpy = gslot >> 5, gpx = gslot & 31, gco = tid >> 6;      // grad_out: slot, channel row
+    const int icol = tid & (IWP - 1), irow = tid / IWP;                                   // input: column, thread row
+    const unsigned go_bytes = (unsigned)g.Cout * (unsigned)HWo * 4u, x_bytes = (unsigned)g.Cin * (unsigned)HW * 4u;
+
+    float rg[NG], ri[NI];
+    auto prefetch = [&](int tile) {
         int t = tile;
         const int tx = t % tiles_x; t /= tiles_x;
         const int ty = t % tiles_y;
-        const int b = t / tiles_y;
+        const int b = t / tiles_y;                   // b >= B past the last tile: descriptors below get 0 records
         const int y0 = ty * WTY, x0 = tx * WTX;
         const int iy0 = S * y0 - g.pad, ix0 = S * x0 - g.pad;
-        __syncthreads();
-        for (int i = tid; i < 64 * WNP; i += 256) {
-            const int co = i / WNP, p = i - co * WNP;
-            const int yy = y0 + p / WTX, xx = x0 + p % WTX;
-            float v = 0.f;
-            if (co_base + co < g.Cout && yy < g.Ho && xx < g.Wo) {
-                const int64_t o = (((int64_t)b * g.Cout + co_base + co) * g.Ho + yy) * g.Wo + xx;
-                v = gout[o];
-                if (dact) v *= act_grad(yact[o], dact, dslope);
-            }
-            sG[co * GS + p] = v;
+        const bool live = tile < total_tiles;
+        const __amdgpu_buffer_rsrc_t rgo = make_rsrc(gout + (int64_t)(live ? b : 0) * g.Cout * HWo, live ? go_bytes : 0u);
+        const __amdgpu_buffer_rsrc_t rya = make_rsrc((dact ? yact : gout) + (int64_t)(live ? b : 0) * g.Cout * HWo,
+                                                     (live && dact) ? go_bytes : 0u);
+        const __amdgpu_buffer_rsrc_t rxi = make_rsrc(x + (int64_t)(live ? b : 0) * g.Cin * HW, live ? x_bytes : 0u);
+        // grad_out: this thread's pixel slot for channels gco, gco+4, ...
+        const int gy = y0 + gpy, gx = x0 + gpx;
+        const unsigned g0 = (gpx < WTX && gy < g.Ho && gx < g.Wo)
+                                ? (unsigned)((co_base + gco) * HWo + gy * g.Wo + gx) * 4u : SENT;
+#pragma unroll
+        for (int it = 0; it < NG; ++it) {
+            const unsigned o = g0 + (unsigned)(4 * it) * (unsigned)HWo * 4u;   // channels >= Cout fall out of range
+            float v = buf_ld(rgo, o);
+            if (dact) v *= act_grad(buf_ld(rya, o), dact, dslope);
+            rg[it] = v;
         }
-        for (int i = tid; i < CIB * IH * IW; i += 256) {
-            const int ci = i / (IH * IW), rem = i - ci * (IH * IW);
-            const int r = rem / IW, c = rem - r * IW;
-            const int yy = iy0 + r, xx = ix0 + c;
-            float v = 0.f;
-            if (ci < ci_cnt && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W)
-                v = x[(((int64_t)b * g.Cin + ci_base + ci) * g.H + yy) * g.W + xx];
-            sIn[ci * PS + rem] = v;
+        // input halo tile: this thread's column, rows r = 0..IH-1, channels irow, irow+TROWS, ...
+        const int xx = ix0 + icol;
+        const bool col_ok = icol < IW && xx >= 0 && xx < g.W;
+#pragma unroll
+        for (int r = 0; r < IH; ++r) {
+            const int yy = iy0 + r;
+            const unsigned base = (col_ok && yy >= 0 && yy < g.H)
+                                      ? (unsigned)((ci_base + irow) * HW + yy * g.W + xx) * 4u : SENT;
+#pragma unroll
+            for (int k = 0; k < CPR; ++k)
+                ri[r * CPR + k] = buf_ld(rxi, base + (unsigned)(k * TROWS) * (unsigned)HW * 4u);
         }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int it = 0; it < NG; ++it) sG[(gco + 4 * it) * GS + gslot] = rg[it];
+        if (icol < IW) {
+#pragma unroll
+            for (int r = 0; r < IH; ++r)
+#pragma unroll
+                for (int k = 0; k < CPR; ++k) sIn[(irow + k * TROWS) * PS + r * IW + icol] = ri[r * CPR + k];
+        }
+    };
+
+    prefetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
         __syncthreads();
+        commit();
+        __syncthreads();
+        prefetch(tile + gridDim.x);      // past the end: zero-record descriptors, nothing is read
         if (need_bias && blockIdx.z == 0 && tid < 64) {
             float s = 0.f;
-            for (int p = 0; p < WNP; ++p) s += sG[tid * GS + p];
+            for (int p = 0; p < GSLOTS; ++p) s += sG[tid * GS + p];   // unused slots hold zeros
             bsum += s;
         }
+        // k = output pixel; lane half h takes pixel 2*ks + h (same row: WTX is even)
         const float *ap = sG + (mt * 32 + (lane & 31)) * GS + (lane >> 5);
-#pragma unroll 4
-        for (int p = 0; p < WNP; p += 2) {
-            const int pp = p + (lane >> 5);
-            const int poff = (S * (pp / WTX)) * IW + S * (pp % WTX);
-            const float a = ap[p];
+        const int bh = S * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < WTY * WTX / 2; ++ks) {
+            const int py = (2 * ks) / WTX, px = (2 * ks) % WTX;
+            const float a = ap[py * 32 + px];
+            const int poff = (S * py) * IW + S * px + bh;
 #pragma unroll
             for (int q = 0; q < NTW; ++q) {
                 const float bv = boff[q] >= 0 ? sIn[boff[q] + poff] : 0.f;
@@ -308,37 +406,52 @@ int make_geom(ConvGeom &g, int B, int Cin, int H, int W, int Cout, int ks, int s
     if (pad < 0 || pad > ks) return fail(EBFI_ERR_ARG, "conv2d: padding %d out of range", pad);
     g = ConvGeom{B, Cin, H, W, Cout, (H + 2 * pad - ks) / stride + 1, (W + 2 * pad - ks) / stride + 1, pad};
     if (g.Ho <= 0 || g.Wo <= 0) return fail(EBFI_ERR_ARG, "conv2d: empty output");
-    if ((int64_t)B * Cin * H * W > (1LL << 40) || (int64_t)B * Cout * g.Ho * g.Wo > (1LL << 40))
-        return fail(EBFI_ERR_ARG, "conv2d: tensor too large");
+    // 32-bit buffer offsets with a 2^31 sentinel: one sample (plus one staged chunk) must stay below 2 GiB
+    const int64_t lim = (1LL << 31) - (1LL << 26);
+    if ((int64_t)(Cin + 64) * H * W * 4 >= lim || (int64_t)(Cout + 64) * g.Ho * g.Wo * 4 >= lim ||
+        (int64_t)(Cout + 64) * (Cin + 64) * ks * ks * 4 >= lim)
+        return fail(EBFI_ERR_ARG, "conv2d: one sample (or the weight) exceeds the 2 GiB reach of 32-bit buffer offsets");
     return EBFI_OK;
 }
 
-template <int KS, int S>
+template <int KS, int S, bool TR>
 int launch_fwd(hipStream_t st, const float *x, const float *dact_y, const float *w, const float *bias, float *out,
-               const ConvGeom &g, int transposed, int act, float slope, int dact, float dslope) {
+               const ConvGeom &g, int act, float slope, int dact, float dslope) {
     constexpr int CK = KS == 7 ? 2 : 8;      // input channels staged per chunk (LDS budget of the weight slice)
     const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, TY) * ceil_div(g.Wo, TX);
     if (tiles > 2147483647LL) return fail(EBFI_ERR_ARG, "conv2d: too many tiles");
-    const char *name = transposed ? "conv_dgrad_f32" : "conv_fwd_f32";
+    const char *name = TR ? "conv_dgrad_f32" : "conv_fwd_f32";
     if (g.Cout <= 32) {
         dim3 grid((unsigned)tiles, (unsigned)ceil_div(g.Cout, 32));
         ProfScope ps(name, st);
-        hipLaunchKernelGGL((conv_fwd_f32<KS, S, 1, CK>), grid, dim3(256), 0, st, x, dact_y, w, bias, out, g, transposed,
-                           act, slope, dact, dslope);
+        hipLaunchKernelGGL((conv_fwd_f32<KS, S, 1, CK, TR>), grid, dim3(256), 0, st, x, dact_y, w, bias, out, g, act, slope,
+                           dact, dslope);
     } else {
         dim3 grid((unsigned)tiles, (unsigned)ceil_div(g.Cout, 64));
         ProfScope ps(name, st);
-        hipLaunchKernelGGL((conv_fwd_f32<KS, S, 2, CK>), grid, dim3(256), 0, st, x, dact_y, w, bias, out, g, transposed,
-                           act, slope, dact, dslope);
+        hipLaunchKernelGGL((conv_fwd_f32<KS, S, 2, CK, TR>), grid, dim3(256), 0, st, x, dact_y, w, bias, out, g, act, slope,
+                           dact, dslope);
     }
     return check_launch(name);
 }
 
-constexpr int wgrad_cib(int ks) { return ks == 7 ? 8 : 64; }
+template <int KS, int S>
+int64_t wgrad_tiles(const ConvGeom &g) {
+    return (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, WCfg<KS, S>::WTX);
+}
 
-int wgrad_splits(const ConvGeom &g, int ks) {
-    const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, WTX);
-    const int64_t blocks = ceil_div(g.Cout, 64) * ceil_div(g.Cin, wgrad_cib(ks));
+int64_t wgrad_tiles_rt(const ConvGeom &g, int ks, int stride) {
+    if (ks == 3 && stride == 1) return wgrad_tiles<3, 1>(g);
+    if (ks == 3) return wgrad_tiles<3, 2>(g);
+    if (ks == 1) return wgrad_tiles<1, 1>(g);
+    return stride == 1 ? wgrad_tiles<7, 1>(g) : wgrad_tiles<7, 2>(g);
+}
+
+int wgrad_cib_rt(int ks, int stride) { return ks == 7 ? 8 : (stride == 2 ? 32 : 64); }
+
+int wgrad_splits(const ConvGeom &g, int ks, int stride) {
+    const int64_t tiles = wgrad_tiles_rt(g, ks, stride);
+    const int64_t blocks = ceil_div(g.Cout, 64) * ceil_div(g.Cin, wgrad_cib_rt(ks, stride));
     int64_t s = ceil_div(1024, blocks);          // aim at >= 1024 workgroups (4 per CU)
     if (s > tiles) s = tiles;
     if (s < 1) s = 1;
@@ -349,21 +462,19 @@ int wgrad_splits(const ConvGeom &g, int ks) {
 template <int KS, int S>
 int launch_wgrad(hipStream_t st, const float *x, const float *gout, const float *yact, float *slab, const ConvGeom &g,
                  int dact, float dslope, int nsplit, int need_bias) {
-    constexpr int CIB = wgrad_cib(KS);
-    constexpr int IH = S * (WTY - 1) + KS, IW = S * (WTX - 1) + KS;
-    constexpr int PS = (IH * IW) | 1;
-    const size_t lds = (size_t)(64 * GS + CIB * PS) * sizeof(float);
+    using C = WCfg<KS, S>;
+    const size_t lds = (size_t)(64 * GS + C::CIB * C::PS + 64) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_f32<KS, S, CIB>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_f32<KS, S>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, WTX);
-    dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, CIB));
+    const int64_t tiles = wgrad_tiles<KS, S>(g);
+    dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, C::CIB));
     ProfScope ps("conv_wgrad_f32", st);
-    hipLaunchKernelGGL((conv_wgrad_f32<KS, S, CIB>), grid, dim3(256), lds, st, x, gout, yact, slab, g, dact, dslope,
-                       (int)tiles, need_bias);
+    hipLaunchKernelGGL((conv_wgrad_f32<KS, S>), grid, dim3(256), lds, st, x, gout, yact, slab, g, dact, dslope, (int)tiles,
+                       need_bias);
     return check_launch("conv_wgrad_f32");
 }
 
@@ -382,11 +493,11 @@ extern "C" int ebfi_conv2d_forward(const void *input, const void *weight, const 
     const float *x = static_cast<const float *>(input), *w = static_cast<const float *>(weight);
     const float *bs = static_cast<const float *>(bias);
     float *o = static_cast<float *>(output);
-    if (ksize == 3 && stride == 1) return launch_fwd<3, 1>(st, x, nullptr, w, bs, o, g, 0, act, slope, 0, 0.f);
-    if (ksize == 3 && stride == 2) return launch_fwd<3, 2>(st, x, nullptr, w, bs, o, g, 0, act, slope, 0, 0.f);
-    if (ksize == 1 && stride == 1) return launch_fwd<1, 1>(st, x, nullptr, w, bs, o, g, 0, act, slope, 0, 0.f);
-    if (ksize == 7 && stride == 1) return launch_fwd<7, 1>(st, x, nullptr, w, bs, o, g, 0, act, slope, 0, 0.f);
-    if (ksize == 7 && stride == 2) return launch_fwd<7, 2>(st, x, nullptr, w, bs, o, g, 0, act, slope, 0, 0.f);
+    if (ksize == 3 && stride == 1) return launch_fwd<3, 1, false>(st, x, nullptr, w, bs, o, g, act, slope, 0, 0.f);
+    if (ksize == 3 && stride == 2) return launch_fwd<3, 2, false>(st, x, nullptr, w, bs, o, g, act, slope, 0, 0.f);
+    if (ksize == 1 && stride == 1) return launch_fwd<1, 1, false>(st, x, nullptr, w, bs, o, g, act, slope, 0, 0.f);
+    if (ksize == 7 && stride == 1) return launch_fwd<7, 1, false>(st, x, nullptr, w, bs, o, g, act, slope, 0, 0.f);
+    if (ksize == 7 && stride == 2) return launch_fwd<7, 2, false>(st, x, nullptr, w, bs, o, g, act, slope, 0, 0.f);
     return fail(EBFI_ERR_UNSUPPORTED, "conv2d_forward: k=%d stride=%d not implemented", ksize, stride);
 }
 
@@ -409,9 +520,9 @@ extern "C" int ebfi_conv2d_backward_data(const void *grad_output, const void *sa
     const float *go = static_cast<const float *>(grad_output), *yo = static_cast<const float *>(saved_output);
     const float *w = static_cast<const float *>(weight);
     float *gi = static_cast<float *>(grad_input);
-    if (ksize == 3) return launch_fwd<3, 1>(st, go, yo, w, nullptr, gi, g, 1, ACT_NONE, 0.f, act, slope);
-    if (ksize == 7) return launch_fwd<7, 1>(st, go, yo, w, nullptr, gi, g, 1, ACT_NONE, 0.f, act, slope);
-    return launch_fwd<1, 1>(st, go, yo, w, nullptr, gi, g, 1, ACT_NONE, 0.f, act, slope);
+    if (ksize == 3) return launch_fwd<3, 1, true>(st, go, yo, w, nullptr, gi, g, ACT_NONE, 0.f, act, slope);
+    if (ksize == 7) return launch_fwd<7, 1, true>(st, go, yo, w, nullptr, gi, g, ACT_NONE, 0.f, act, slope);
+    return launch_fwd<1, 1, true>(st, go, yo, w, nullptr, gi, g, ACT_NONE, 0.f, act, slope);
 }
 
 extern "C" size_t ebfi_conv2d_backward_weight_workspace(int B, int Cin, int H, int W, int Cout, int ksize, int stride,
@@ -419,7 +530,7 @@ extern "C" size_t ebfi_conv2d_backward_weight_workspace(int B, int Cin, int H, i
     (void)dtype;
     ConvGeom g;
     if (make_geom(g, B, Cin, H, W, Cout, ksize, stride, pad) != EBFI_OK) return 0;
-    return (size_t)wgrad_splits(g, ksize) * ((size_t)Cout * Cin * ksize * ksize + Cout) * sizeof(float);
+    return (size_t)wgrad_splits(g, ksize, stride) * ((size_t)Cout * Cin * ksize * ksize + Cout) * sizeof(float);
 }
 
 // grad_weight[Cout,Cin,k,k] (and grad_bias[Cout] when non-NULL), both fully overwritten, deterministic.
@@ -445,7 +556,7 @@ extern "C" int ebfi_conv2d_backward_weight(const void *input, const void *grad_o
     const float *x = static_cast<const float *>(input), *go = static_cast<const float *>(grad_output);
     const float *yo = static_cast<const float *>(saved_output);
     float *slab = static_cast<float *>(workspace);
-    const int nsplit = wgrad_splits(g, ksize);
+    const int nsplit = wgrad_splits(g, ksize, stride);
     const int need_bias = grad_bias != nullptr;
     int rc;
     if (ksize == 3 && stride == 1) rc = launch_wgrad<3, 1>(st, x, go, yo, slab, g, act, slope, nsplit, need_bias);
