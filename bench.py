@@ -29,18 +29,10 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-B_PER_GPU, H, W, TB, C_FEAT, K_FAC = 8, 256, 256, 16, 64, 5
+B_PER_GPU, H, W, TB = 8, 256, 256, 16
 
 
-def algorithmic_bytes(B):
-    """Bytes one launch must move; P = B*h*w feature pixels at h=H/2, w=W/2."""
-    P = B * (H // 2) * (W // 2)
-    e = 4
-    return {
-        "fac_fwd_tile_f32": e * P * C_FEAT * (1 + K_FAC ** 2 + 1),
-        "fac_bwd_rows_f32": e * P * C_FEAT * (K_FAC ** 2 + 1 + 1 + 1 + K_FAC ** 2),
-        "frame2lap": e * B * H * W * (3 + 1),
-    }
+F32_MFMA_PEAK_TFS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 
 
 def host_threads():
@@ -160,20 +152,25 @@ def main():
     elapsed = t_max.item()
 
     if rank == 0:
-        alg = algorithmic_bytes(B_PER_GPU)
+        # Per hand-written kernel: device time from the library's hipEvent pairs, algorithmic work from the
+        # launchers (SURVEY.md 8(d) formulas, un-padded).  Streaming kernels (AI < 1 FLOP/B) are priced against
+        # HBM, the conv / DCN GEMM kernels against the dense fp32 matrix peak.
         per_kernel = {}
-        for name, (launches, total_ms) in kernels.items():
+        for name, (launches, total_ms, flops, nbytes) in kernels.items():
             if name.startswith("__") or launches == 0:
                 continue
-            avg_ms = total_ms / launches
-            entry = {"launches": launches, "avg_ms": round(avg_ms, 5)}
-            if name in alg:
-                entry["algorithmic_bytes"] = alg[name]
-                entry["achieved_GBps"] = round(alg[name] / (avg_ms * 1e-3) / 1e9, 1)
-                entry["frac_of_hbm_peak"] = round(entry["achieved_GBps"] / HBM_PEAK_GBS, 4)
+            entry = {"launches": launches, "avg_ms": round(total_ms / launches, 5), "total_ms": round(total_ms, 3)}
+            secs = total_ms * 1e-3
+            if flops > 0 and (nbytes == 0 or flops / nbytes > 4.0):
+                entry.update(bound="mfma", algorithmic_flops_per_launch=flops / launches,
+                             achieved=round(flops / secs / 1e12, 2), peak=F32_MFMA_PEAK_TFS, unit="TFLOP/s")
+            elif nbytes > 0:
+                entry.update(bound="hbm", algorithmic_bytes_per_launch=nbytes / launches,
+                             achieved=round(nbytes / secs / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s")
+            if "achieved" in entry:
+                entry["frac"] = round(entry["achieved"] / entry["peak"], 4)
             per_kernel[name] = entry
-        ranked = sorted((k for k in per_kernel if "achieved_GBps" in per_kernel[k]),
-                        key=lambda k: -per_kernel[k]["avg_ms"] * per_kernel[k]["launches"])
+        ranked = sorted((k for k in per_kernel if "frac" in per_kernel[k]), key=lambda k: -per_kernel[k]["total_ms"])
         roofline = None
         if ranked:
             d = per_kernel[ranked[0]]
@@ -183,9 +180,10 @@ def main():
                     traffic = json.load(fh).get(ranked[0])
             except (OSError, ValueError):
                 pass
-            roofline = {"kernel": ranked[0], "bound": "hbm", "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": d["frac_of_hbm_peak"], "traffic": traffic,
-                        "avg_launch_ms": d["avg_ms"], "algorithmic_bytes_per_launch": d["algorithmic_bytes"]}
+            roofline = {"kernel": ranked[0], "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
+                        "unit": d["unit"], "frac": d["frac"], "traffic": traffic, "launches_per_step": d["launches"] / args.steps,
+                        "avg_launch_ms": d["avg_ms"],
+                        "share_of_step": round(d["total_ms"] / (1e3 * elapsed), 4)}
         out = {
             "metric": "interpolated frames/sec (train fwd+bwd) at B=8 256x256",
             "value": round(world * B_PER_GPU * args.steps / elapsed, 3),

@@ -73,7 +73,7 @@ extern "C" int ebfi_frame2lap(const float *frame, float *out, int B, int H, int 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t total = (int64_t)B * H * W;
     {
-        ProfScope ps("frame2lap", st);
+        ProfScope ps("frame2lap", st, 0.0, 16.0 * total);
         hipLaunchKernelGGL(frame2lap_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, frame, out, B, H, W);
     }
     return check_launch("frame2lap");

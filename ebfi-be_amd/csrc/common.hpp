@@ -19,7 +19,8 @@ int check_launch(const char *what);
 // RAII hipEvent bracket around one kernel launch (no-op unless ebfi_prof_enable(1)).
 class ProfScope {
   public:
-    ProfScope(const char *kernel_name, hipStream_t stream);
+    // flops / bytes: ALGORITHMIC work of this launch (0 = not tracked); summed per kernel name
+    ProfScope(const char *kernel_name, hipStream_t stream, double flops = 0.0, double bytes = 0.0);
     ~ProfScope();
     ProfScope(const ProfScope &) = delete;
     ProfScope &operator=(const ProfScope &) = delete;

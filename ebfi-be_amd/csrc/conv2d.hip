@@ -421,14 +421,15 @@ int launch_fwd(hipStream_t st, const float *x, const float *dact_y, const float 
     const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, TY) * ceil_div(g.Wo, TX);
     if (tiles > 2147483647LL) return fail(EBFI_ERR_ARG, "conv2d: too many tiles");
     const char *name = TR ? "conv_dgrad_f32" : "conv_fwd_f32";
+    const double flops = 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS;   // dense, un-padded
     if (g.Cout <= 32) {
         dim3 grid((unsigned)tiles, (unsigned)ceil_div(g.Cout, 32));
-        ProfScope ps(name, st);
+        ProfScope ps(name, st, flops);
         hipLaunchKernelGGL((conv_fwd_f32<KS, S, 1, CK, TR>), grid, dim3(256), 0, st, x, dact_y, w, bias, out, g, act, slope,
                            dact, dslope);
     } else {
         dim3 grid((unsigned)tiles, (unsigned)ceil_div(g.Cout, 64));
-        ProfScope ps(name, st);
+        ProfScope ps(name, st, flops);
         hipLaunchKernelGGL((conv_fwd_f32<KS, S, 2, CK, TR>), grid, dim3(256), 0, st, x, dact_y, w, bias, out, g, act, slope,
                            dact, dslope);
     }
@@ -472,7 +473,7 @@ int launch_wgrad(hipStream_t st, const float *x, const float *gout, const float 
     }
     const int64_t tiles = wgrad_tiles<KS, S>(g);
     dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, C::CIB));
-    ProfScope ps("conv_wgrad_f32", st);
+    ProfScope ps("conv_wgrad_f32", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS);
     hipLaunchKernelGGL((conv_wgrad_f32<KS, S>), grid, dim3(256), lds, st, x, gout, yact, slab, g, dact, dslope, (int)tiles,
                        need_bias);
     return check_launch("conv_wgrad_f32");

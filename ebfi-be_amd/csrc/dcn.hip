@@ -427,7 +427,9 @@ extern "C" int ebfi_dcn_forward(const void *input, const void *weight, const voi
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid((unsigned)(B * g.tiles_per_img), (unsigned)((Co + 63) / 64));
     {
-        ProfScope ps("dcn_fwd_f32", st);
+        const double P = (double)B * g.HWo;
+        ProfScope ps("dcn_fwd_f32", st, 2.0 * P * C * g.kk * (4 + Co),
+                     4.0 * (P * (C + 3.0 * deformable_group * g.kk + Co) + (double)Co * C * g.kk));
         hipLaunchKernelGGL(dcn_fwd_f32, grid, dim3(256), 0, st, static_cast<const float *>(input),
                            static_cast<const float *>(weight), static_cast<const float *>(bias),
                            static_cast<const float *>(offset), static_cast<const float *>(mask),

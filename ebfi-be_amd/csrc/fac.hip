@@ -269,13 +269,14 @@ int check_shapes(const int64_t *ish, const int64_t *ksh, int K, int64_t *B, int6
 template <int K>
 void launch_fwd_tile(hipStream_t st, const float *in, Str4 is, const float *kern, Str4 ks, float *out, Str4 os,
                      int B, int C, int Ho, int Wo) {
+    const double bytes = 4.0 * B * C * (double)Ho * Wo * (1 + K * K + 1);   // in + K*K filter planes + out
     if (Wo <= 64) {
         dim3 grid((unsigned)ceil_div(Wo, 64), (unsigned)ceil_div(Ho, 16), (unsigned)(B * C));
-        ProfScope ps("fac_fwd_tile_f32", st);
+        ProfScope ps("fac_fwd_tile_f32", st, 2.0 * B * C * (double)Ho * Wo * K * K, bytes);
         hipLaunchKernelGGL((fac_fwd_tile_f32<K, 16, 64>), grid, dim3(256), 0, st, in, is, kern, ks, out, os, C, Ho, Wo);
     } else {
         dim3 grid((unsigned)ceil_div(Wo, 128), (unsigned)ceil_div(Ho, 8), (unsigned)(B * C));
-        ProfScope ps("fac_fwd_tile_f32", st);
+        ProfScope ps("fac_fwd_tile_f32", st, 2.0 * B * C * (double)Ho * Wo * K * K, bytes);
         hipLaunchKernelGGL((fac_fwd_tile_f32<K, 8, 128>), grid, dim3(256), 0, st, in, is, kern, ks, out, os, C, Ho, Wo);
     }
 }
@@ -285,7 +286,8 @@ void launch_bwd_rows_t(hipStream_t st, const float *in, Str4 is, const float *ke
                        Str4 gs, float *gin, Str4 gis, float *gk, Str4 gks, int B, int C, int Ho, int Wo) {
     constexpr int ROWS = 4 * (64 / TPR);
     dim3 grid((unsigned)ceil_div(Ho + K - 1, ROWS), (unsigned)(B * C));
-    ProfScope ps("fac_bwd_rows_f32", st);
+    const double px = (double)B * C * Ho * Wo;     // filters + gout + in read, grad_in + grad_kernel written
+    ProfScope ps("fac_bwd_rows_f32", st, 4.0 * px * K * K, 4.0 * px * (K * K + 1 + 1 + (gin ? 1 : 0) + (gk ? K * K : 0)));
     hipLaunchKernelGGL((fac_bwd_rows_f32<K, TPR>), grid, dim3(256), 0, st, in, is, kern, ks, go, gs, gin, gis, gk, gks,
                        C, Ho, Wo);
 }

@@ -27,11 +27,13 @@ namespace {
 struct Pending {
     int kernel;
     hipEvent_t start, stop;
+    double flops, bytes;
 };
 struct KernelStat {
     std::string name;
     int64_t launches = 0;
     double total_ms = 0.0;
+    double flops = 0.0, bytes = 0.0;   // algorithmic work of the timed launches
 };
 struct Profiler {
     std::mutex mu;
@@ -44,7 +46,7 @@ struct Profiler {
     int kernel_id(const char *name) {
         for (size_t i = 0; i < stats.size(); ++i)
             if (stats[i].name == name) return (int)i;
-        stats.push_back(KernelStat{name, 0, 0.0});
+        stats.push_back(KernelStat{name, 0, 0.0, 0.0, 0.0});
         return (int)stats.size() - 1;
     }
     hipEvent_t get_event() {
@@ -64,7 +66,8 @@ Profiler &prof() {
 }
 }  // namespace
 
-ProfScope::ProfScope(const char *kernel_name, hipStream_t stream) : slot_(-1), stream_(stream) {
+ProfScope::ProfScope(const char *kernel_name, hipStream_t stream, double flops, double bytes)
+    : slot_(-1), stream_(stream) {
     Profiler &p = prof();
     if (!p.enabled) return;  // racy read is fine: enable/disable happens between timed regions
     std::lock_guard<std::mutex> lock(p.mu);
@@ -72,7 +75,7 @@ ProfScope::ProfScope(const char *kernel_name, hipStream_t stream) : slot_(-1), s
         ++p.dropped;
         return;
     }
-    Pending pe{p.kernel_id(kernel_name), p.get_event(), p.get_event()};
+    Pending pe{p.kernel_id(kernel_name), p.get_event(), p.get_event(), flops, bytes};
     if (!pe.start || !pe.stop) return;
     (void)hipEventRecord(pe.start, stream_);
     p.pending.push_back(pe);
@@ -123,6 +126,8 @@ int ebfi_prof_collect(int *dropped) {
             hipEventElapsedTime(&ms, pe.start, pe.stop) == hipSuccess) {
             p.stats[pe.kernel].launches += 1;
             p.stats[pe.kernel].total_ms += ms;
+            p.stats[pe.kernel].flops += pe.flops;
+            p.stats[pe.kernel].bytes += pe.bytes;
             ++n;
         }
         p.pool.push_back(pe.start);
@@ -146,6 +151,15 @@ int ebfi_prof_get(int index, const char **name, int64_t *launches, double *total
     if (name) *name = p.stats[index].name.c_str();
     if (launches) *launches = p.stats[index].launches;
     if (total_ms) *total_ms = p.stats[index].total_ms;
+    return EBFI_OK;
+}
+
+int ebfi_prof_get_work(int index, double *flops, double *bytes) {
+    Profiler &p = prof();
+    std::lock_guard<std::mutex> lock(p.mu);
+    if (index < 0 || index >= (int)p.stats.size()) return fail(EBFI_ERR_ARG, "prof index %d out of range", index);
+    if (flops) *flops = p.stats[index].flops;
+    if (bytes) *bytes = p.stats[index].bytes;
     return EBFI_OK;
 }
 

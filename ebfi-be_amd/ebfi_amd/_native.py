@@ -52,6 +52,7 @@ SIGNATURES = {
     "ebfi_prof_collect": (_i, [_c.POINTER(_i)]),
     "ebfi_prof_num_kernels": (_i, []),
     "ebfi_prof_get": (_i, [_i, _c.POINTER(_c.c_char_p), _c.POINTER(_i64), _c.POINTER(_c.c_double)]),
+    "ebfi_prof_get_work": (_i, [_i, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
 }
 
 
@@ -144,14 +145,17 @@ def prof_reset():
 
 
 def prof_collect():
-    """{kernel name: (launches, total_ms)}; call after torch.cuda.synchronize()."""
+    """{kernel name: (launches, total_ms, algorithmic flops, algorithmic bytes)}; call after
+    torch.cuda.synchronize()."""
     h = lib()
     dropped = _i(0)
     h.ebfi_prof_collect(ctypes.byref(dropped))
     out = {}
     for k in range(h.ebfi_prof_num_kernels()):
         name, n, ms = _c.c_char_p(), _i64(0), _c.c_double(0)
+        fl, by = _c.c_double(0), _c.c_double(0)
         h.ebfi_prof_get(k, ctypes.byref(name), ctypes.byref(n), ctypes.byref(ms))
-        out[name.value.decode()] = (n.value, ms.value)
-    out["__dropped__"] = (dropped.value, 0.0)
+        h.ebfi_prof_get_work(k, ctypes.byref(fl), ctypes.byref(by))
+        out[name.value.decode()] = (n.value, ms.value, fl.value, by.value)
+    out["__dropped__"] = (dropped.value, 0.0, 0.0, 0.0)
     return out

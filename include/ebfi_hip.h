@@ -154,6 +154,8 @@ void ebfi_prof_reset(void);
 int ebfi_prof_collect(int *dropped);
 int ebfi_prof_num_kernels(void);
 int ebfi_prof_get(int index, const char **name, int64_t *launches, double *total_ms);
+/* algorithmic work (SURVEY.md 8(d) formulas) summed over the timed launches of kernel `index` */
+int ebfi_prof_get_work(int index, double *flops, double *bytes);
 
 #ifdef __cplusplus
 }
