@@ -78,12 +78,15 @@ __global__ __launch_bounds__(256) void conv_fwd_f32(const float *__restrict__ x,
     constexpr int KK = KS * KS;
     constexpr int IH = S * (TY - 1) + KS, IW = S * (TX - 1) + KS;
     constexpr int PS = IH * IW;            // plane stride of the staged input tile
-    constexpr int COS = 32 * MT;           // weight-slice row length (output channels of this block)
+    constexpr int COS = 32 * MT;           // output channels of this block
+    // LDS weight slice [ci][tap][co]; the row stride is chosen so that the transposing commit is (nearly)
+    // conflict-free: forward walks rows (+1 bank per lane), the data gradient walks taps backwards and co.
+    constexpr int COSP = TR ? COS + 4 : COS + 1;
     constexpr int NPOS = (PS + 255) / 256; // tile positions owned by a thread
     constexpr int WEL = KK * CK * COS;     // weight-slice elements
     constexpr int NW = (WEL + 255) / 256;
     __shared__ float sIn[CK * PS];
-    __shared__ float sW[WEL];
+    __shared__ float sW[KK * CK * COSP];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = (g.Wo + TX - 1) / TX, tiles_y = (g.Ho + TY - 1) / TY;
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256) void conv_fwd_f32(const float *__restrict__ x,
         in_off[q] = (pos < PS && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) ? (unsigned)(yy * g.W + xx) * 4u : SENT;
     }
     unsigned w_off[NW];                    // byte offset of the owned weight elements for chunk 0
-    int w_dst[NW];                         // their place in the LDS slice [tap][ci][co]
+    int w_dst[NW];                         // their place in the LDS slice [ci][tap][co]
 #pragma unroll
     for (int it = 0; it < NW; ++it) {
         const int i = tid + it * 256;
@@ -126,12 +129,12 @@ __global__ __launch_bounds__(256) void conv_fwd_f32(const float *__restrict__ x,
             const int co = i / (CK * KK), rem = i - co * (CK * KK);
             const int ci = rem / KK, tap = rem - ci * KK;
             off = ((co_base + co) * g.Cin + ci) * KK + tap;
-            dst = (tap * CK + ci) * COS + co;
+            dst = (ci * KK + tap) * COSP + co;
         } else {     // data gradient: k = forward out-channel, m = forward in-channel, taps flipped
             const int ci = i / (COS * KK), rem = i - ci * (COS * KK);
             const int co = rem / KK, tap = rem - co * KK;
             off = (ci * g.Cout + co_base + co) * KK + tap;
-            dst = ((KK - 1 - tap) * CK + ci) * COS + co;
+            dst = (ci * KK + KK - 1 - tap) * COSP + co;
         }
         w_off[it] = i < WEL ? (unsigned)off * 4u : SENT;
         w_dst[it] = dst;
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256) void conv_fwd_f32(const float *__restrict__ x,
         prefetch(chunk + 1);      // past the last chunk every offset is out of range: reads 0, never committed
         // ---- MFMA: wave owns output row `wave` of the tile (2 x-halves) x MT co tiles
         const float *bp = sIn + (lane >> 5) * PS + (S * wave) * IW + S * (lane & 31);
-        const float *ap = sW + (lane >> 5) * COS + (lane & 31);
+        const float *ap = sW + (lane >> 5) * (KK * COSP) + (lane & 31);
 #pragma unroll
         for (int tap = 0; tap < KK; ++tap) {
             const int ky = tap / KS, kx = tap - ky * KS;
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(256) void conv_fwd_f32(const float *__restrict__ x,
             for (int cp = 0; cp < CK; cp += 2) {
                 float a[MT], bv[2];
 #pragma unroll
-                for (int m = 0; m < MT; ++m) a[m] = ap[(tap * CK + cp) * COS + m * 32];
+                for (int m = 0; m < MT; ++m) a[m] = ap[(cp * KK + tap) * COSP + m * 32];
 #pragma unroll
                 for (int n = 0; n < 2; ++n) bv[n] = bp[cp * PS + ky * IW + kx + n * 32 * S];
 #pragma unroll
@@ -231,7 +234,10 @@ struct WCfg {
     static constexpr int IWP = IW <= 32 ? 32 : 64;              // lanes per staged input row
     static constexpr int TROWS = 256 / IWP;                     // thread rows walking (row, channel)
     static constexpr int CIB = KS == 7 ? 8 : (S == 2 ? 32 : 64);   // input channels per workgroup
-    static constexpr int PS = (IH * IW) | 1;                    // odd plane stride: conflict-free across channels
+    // LDS image strides with IWS == KS and PS == KS*KS (mod 32): column n = ci*KK + ky*KS + kx of the GEMM then
+    // sits in bank n mod 32, so the 32 lanes of a B-operand fetch never collide
+    static constexpr int IWS = IW + ((KS - IW) % 32 + 32) % 32;
+    static constexpr int PS = IH * IWS + ((KS * KS - IH * IWS) % 32 + 32) % 32;
     static constexpr int NI = IH * CIB / TROWS;                 // input elements per thread per tile
     static constexpr int NTW = (CIB * KS * KS + 63) / 64;       // n-tiles (of 32 columns) per wave
     static_assert(IW <= 64 && WTX % 2 == 0 && WTX <= 32 && CIB % TROWS == 0, "tile configuration");
@@ -244,12 +250,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const float *__restrict__ 
                                                       int need_bias) {
     using C = WCfg<KS, S>;
     constexpr int KK = KS * KS, WTX = C::WTX, IH = C::IH, IW = C::IW, IWP = C::IWP, TROWS = C::TROWS;
-    constexpr int CIB = C::CIB, PS = C::PS, NI = C::NI, NTW = C::NTW;
+    constexpr int CIB = C::CIB, PS = C::PS, IWS = C::IWS, NI = C::NI, NTW = C::NTW;
     constexpr int NG = 64 / 4;             // grad_out channels per thread per tile (4 thread rows of 64 slots)
     constexpr int CPR = CIB / TROWS;       // channel steps per input row
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sG = smem;                      // [64 co][GS]
-    float *sIn = smem + 64 * GS;           // [CIB ci][PS]
+    float *sIn = smem + 64 * GS;           // [CIB ci][PS] + one all-zero plane
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int co_base = blockIdx.y * 64, ci_base = blockIdx.z * CIB;
@@ -264,16 +270,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const float *__restrict__ 
     for (int n = 0; n < NTW; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-    // per-lane LDS offset of column n = (nh + 2*q)*32 + (lane&31): ci*PS + ky*IW + kx
+    // per-lane LDS offset of column n = (nh + 2*q)*32 + (lane&31): ci*PS + ky*IWS + kx
     int boff[NTW];
 #pragma unroll
     for (int q = 0; q < NTW; ++q) {
         const int n = (nh + 2 * q) * 32 + (lane & 31);
         const int ci = n / KK, tap = n - ci * KK;
         const int ky = tap / KS, kx = tap - ky * KS;
-        boff[q] = (n < ncols) ? ci * PS + ky * IW + kx : -1;
+        boff[q] = (n < ncols) ? ci * PS + ky * IWS + kx : CIB * PS;   // unused columns read the all-zero plane
     }
     float bsum = 0.f;
+    for (int i = tid; i < PS; i += 256) sIn[CIB * PS + i] = 0.f;   // zero plane behind the channel planes
 
     // thread-fixed staging coordinates
     const int gslot = tid & 63, gpy = gslot >> 5, gpx = gslot & 31, gco = tid >> 6;      // grad_out: slot, channel row
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const float *__restrict__ 
 #pragma unroll
             for (int r = 0; r < IH; ++r)
 #pragma unroll
-                for (int k = 0; k < CPR; ++k) sIn[(irow + k * TROWS) * PS + r * IW + icol] = ri[r * CPR + k];
+                for (int k = 0; k < CPR; ++k) sIn[(irow + k * TROWS) * PS + r * IWS + icol] = ri[r * CPR + k];
         }
     };
 
@@ -346,11 +353,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const float *__restrict__ 
         for (int ks = 0; ks < WTY * WTX / 2; ++ks) {
             const int py = (2 * ks) / WTX, px = (2 * ks) % WTX;
             const float a = ap[py * 32 + px];
-            const int poff = (S * py) * IW + S * px + bh;
+            const int poff = (S * py) * IWS + S * px + bh;
 #pragma unroll
             for (int q = 0; q < NTW; ++q) {
-                const float bv = boff[q] >= 0 ? sIn[boff[q] + poff] : 0.f;
-                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[q], 0, 0, 0);
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, sIn[boff[q] + poff], acc[q], 0, 0, 0);
             }
         }
     }
@@ -464,7 +470,7 @@ template <int KS, int S>
 int launch_wgrad(hipStream_t st, const float *x, const float *gout, const float *yact, float *slab, const ConvGeom &g,
                  int dact, float dslope, int nsplit, int need_bias) {
     using C = WCfg<KS, S>;
-    const size_t lds = (size_t)(64 * GS + C::CIB * C::PS + 64) * sizeof(float);
+    const size_t lds = (size_t)(64 * GS + (C::CIB + 1) * C::PS + 64) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_f32<KS, S>),

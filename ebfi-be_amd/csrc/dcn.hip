@@ -49,6 +49,7 @@ struct Tap {
     float w1, w2, w3, w4;   // bilinear weights of (low,low) (low,high) (high,low) (high,high)
     int o1, o2, o3, o4;     // plane offsets of the four corners, -1 when outside the image
     float lh, lw;           // fractional parts (for the coordinate gradient)
+    int h0, w0;             // integer low corner (may be -1)
     bool valid;             // -1 < h < H and -1 < w < W   (dcn_v2_im2col_cuda.cu:180)
 };
 
@@ -58,8 +59,10 @@ __device__ __forceinline__ Tap make_tap(float h, float w, int H, int W) {
     t.w1 = t.w2 = t.w3 = t.w4 = 0.f;
     t.o1 = t.o2 = t.o3 = t.o4 = -1;
     t.lh = t.lw = 0.f;
+    t.h0 = t.w0 = 0;
     if (t.valid) {
         const int h0 = (int)floorf(h), w0 = (int)floorf(w);
+        t.h0 = h0; t.w0 = w0;
         const int h1 = h0 + 1, w1 = w0 + 1;
         const float lh = h - (float)h0, lw = w - (float)w0;
         const float hh = 1.f - lh, hw = 1.f - lw;
@@ -79,6 +82,27 @@ __device__ __forceinline__ void corners(const float *__restrict__ plane, const T
     v2 = t.o2 >= 0 ? plane[t.o2] : 0.f;
     v3 = t.o3 >= 0 ? plane[t.o3] : 0.f;
     v4 = t.o4 >= 0 ? plane[t.o4] : 0.f;
+}
+
+// Sample `n` consecutive channels of one (pixel, tap) into the LDS column image.  NCH > 0 unrolls exactly
+// NCH channels so that all 4*NCH corner gathers are in flight together; NCH == 0 is the generic loop.
+template <int NCH>
+__device__ __forceinline__ void sample_cols(const float *__restrict__ plane, int64_t plane_stride, const Tap &t,
+                                            float mask, float *col, int col_stride, int n) {
+    if constexpr (NCH > 0) {
+        float v[NCH][4];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) corners(plane + c * plane_stride, t, v[c][0], v[c][1], v[c][2], v[c][3]);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            col[c * col_stride] = (t.w1 * v[c][0] + t.w2 * v[c][1] + t.w3 * v[c][2] + t.w4 * v[c][3]) * mask;
+    } else {
+        for (int c = 0; c < n; ++c, plane += plane_stride) {
+            float v1, v2, v3, v4;
+            corners(plane, t, v1, v2, v3, v4);
+            col[c * col_stride] = (t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4) * mask;
+        }
+    }
 }
 
 struct Chunk {
@@ -128,35 +152,63 @@ __global__ __launch_bounds__(256) void dcn_fwd_f32(const float *__restrict__ x, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+    // Weight slice staging: a thread owns fixed (co, kl) elements; the global offset advances by a
+    // constant per chunk, so the loads can be issued before the sampling walk and committed after it.
+    constexpr int NWT = (64 * (KC + 2) + 255) / 256;
+    const int klmax = ((g.CB * g.kk) + 1) & ~1;          // rows of a full chunk, padded to even
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(wgt), 0, (unsigned)g.Co * (unsigned)g.Kd * 4u, 0x00020000);
+    unsigned w_off[NWT];
+    int w_dst[NWT];
+#pragma unroll
+    for (int it = 0; it < NWT; ++it) {
+        const int i = tid + it * 256;
+        const int co = i / klmax, kl = i - co * klmax;
+        // rows co >= Co are never stored and rows kl >= KL meet zero columns: no masking beyond the slice size
+        w_off[it] = (i < 64 * klmax) ? (unsigned)((co_base + co) * g.Kd + kl) * 4u : 0x80000000u;
+        w_dst[it] = kl * WSTR + co;
+    }
+    const int px = tid & (NP - 1), p = p0 + px;
+    const bool p_ok = p < g.HWo;
+    const int64_t plane_stride = (int64_t)g.H * g.W;
+
     for (int chunk = 0; chunk < g.nchunks; ++chunk) {
         const Chunk ck = get_chunk(g, chunk);
         const int KLp = (ck.KL + 1) & ~1;
+        float rwv[NWT];
+        const unsigned wb = (unsigned)(ck.cbase * g.kk) * 4u;
+#pragma unroll
+        for (int it = 0; it < NWT; ++it)
+            rwv[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, w_off[it] + wb, 0, 0));
         __syncthreads();   // previous chunk's MFMA reads are done
-        for (int i = tid; i < 64 * KLp; i += 256) {
-            const int co = i / KLp, kl = i - co * KLp;
-            float v = 0.f;
-            if (kl < ck.KL && co_base + co < g.Co)
-                v = wgt[(int64_t)(co_base + co) * g.Kd + (int64_t)ck.cbase * g.kk + kl];
-            sW[kl * WSTR + co] = v;
-        }
-        for (int it = tid; it < g.kk * NP; it += 256) {
-            const int px = it & (NP - 1), tap = it / NP;
-            const int p = p0 + px;
-            if (p < g.HWo) {
-                const TapPos tp = tap_pos(g, off, msk, b, ck.grp, tap, p, g.pw);
-                const Tap t = make_tap(tp.h, tp.w, g.H, g.W);
-                const float *plane = x + (int64_t)(b * g.C + ck.cbase) * g.H * g.W;
-                for (int cl = 0; cl < ck.cb; ++cl, plane += (int64_t)g.H * g.W) {
-                    float v1, v2, v3, v4;
-                    corners(plane, t, v1, v2, v3, v4);
-                    const float val = (t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4);
-                    sCol[(cl * g.kk + tap) * NP + px] = val * tp.mask;
+        // columns: a thread keeps its pixel and walks (tap, channel-half) items strided over the 4 waves;
+        // the offsets / mask of the next item are fetched while the current one is gathered
+        {
+            const int half_n = (ck.cb + 1) >> 1;               // channels of the first half
+            const int nitems = 2 * g.kk;
+            TapPos tp = {0.f, 0.f, 0.f};
+            if (p_ok && wave < nitems) tp = tap_pos(g, off, msk, b, ck.grp, wave >> 1, p, g.pw);
+            for (int item = wave; item < nitems; item += 4) {
+                const int tap = item >> 1, c_lo = (item & 1) ? half_n : 0;
+                const int n = (item & 1) ? ck.cb - half_n : half_n;
+                TapPos tp_next = {0.f, 0.f, 0.f};
+                if (p_ok && item + 4 < nitems) tp_next = tap_pos(g, off, msk, b, ck.grp, (item + 4) >> 1, p, g.pw);
+                float *col = sCol + (c_lo * g.kk + tap) * NP + px;
+                if (p_ok && n > 0) {
+                    const Tap t = make_tap(tp.h, tp.w, g.H, g.W);
+                    const float *plane = x + (int64_t)(b * g.C + ck.cbase + c_lo) * plane_stride;
+                    if (n == 4) sample_cols<4>(plane, plane_stride, t, tp.mask, col, g.kk * NP, 4);
+                    else sample_cols<0>(plane, plane_stride, t, tp.mask, col, g.kk * NP, n);
+                } else {
+                    for (int c = 0; c < n; ++c) col[c * g.kk * NP] = 0.f;
                 }
-            } else {
-                for (int cl = 0; cl < ck.cb; ++cl) sCol[(cl * g.kk + tap) * NP + px] = 0.f;
+                tp = tp_next;
             }
         }
         if (KLp != ck.KL && tid < NP) sCol[ck.KL * NP + tid] = 0.f;
+#pragma unroll
+        for (int it = 0; it < NWT; ++it)
+            if (tid + it * 256 < 64 * klmax) sW[w_dst[it]] = rwv[it];
         __syncthreads();
         if (tile_live) {
             const float *ap = sW + (lane >> 5) * WSTR + mt * 32 + (lane & 31);
@@ -166,122 +218,188 @@ __global__ __launch_bounds__(256) void dcn_fwd_f32(const float *__restrict__ x, 
         }
     }
     if (tile_live) {
-        const int p = p0 + nt * 32 + (lane & 31);
+        const int po = p0 + nt * 32 + (lane & 31);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (co < g.Co && p < g.HWo) out[(int64_t)(b * g.Co + co) * g.HWo + p] = acc[r] + bias[co];
+            if (co < g.Co && po < g.HWo) out[(int64_t)(b * g.Co + co) * g.HWo + po] = acc[r] + bias[co];
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ backward: data
-// grad_offset, grad_mask (plain stores, one owner per element) and grad_input (fp32 atomics).
+// grad_offset, grad_mask (plain stores, one owner per element) and grad_input.
+//
+// Workgroup = 16x16 output pixels of one sample, walked as 4 bands of 4x16 = 64 pixels.  Per
+// deformable-group chunk: colgrad = W^T . grad_out per band (16x16x4 fp32 MFMA, grad_out fragments
+// loaded straight into registers), the sampling walk, and the grad_input scatter -- which lands in an
+// LDS box covering the tile's footprint +- R pixels (ds_add_f32), flushed once per chunk with
+// CONTIGUOUS fp32 global atomics.  The reference issues 4 global atomics per (pixel, tap, channel)
+// (dcn_v2_im2col_cuda.cu:236-250); here that is ~3.5 per (pixel, channel), row-contiguous, which is what
+// the memory-side atomic units like.  Samples that fall outside the box (|offset| > R) go to global
+// memory directly; shapes whose footprint does not fit the box run with the box disabled.
+constexpr int BT = 16;                 // tile edge (output pixels)
+constexpr int BOX_CH = 8;              // channels the LDS box holds (one chunk of the model-shaped configs)
+constexpr int BOX_CELLS = 1024;        // cells per channel
+
+struct BoxGeom {
+    int use, R, BH, BW;                // box = tile footprint in input space +- R, BH x BW cells per channel
+};
+
 __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict__ x, const float *__restrict__ wgt,
                                                         const float *__restrict__ off, const float *__restrict__ msk,
                                                         const float *__restrict__ gout, float *__restrict__ gx,
-                                                        float *__restrict__ goff, float *__restrict__ gmsk, Geom g) {
-    __shared__ float sG[64 * S80];     // grad_out block  [co][px]
-    __shared__ float sWt[64 * S80];    // weight slice    [co][kl]
-    __shared__ float sCG[KCP * NP];    // column gradient [kl][px]
+                                                        float *__restrict__ goff, float *__restrict__ gmsk, Geom g,
+                                                        BoxGeom bx) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sWt = smem;                      // weight slice    [co][kl]   64 x S80
+    float *sCG = sWt + 64 * S80;            // column gradient [kl][px]   KCP x NP
+    float *sBox = sCG + KCP * NP;           // grad_input box  [ch][BH][BW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / g.tiles_per_img;
-    const int p0 = (blockIdx.x - b * g.tiles_per_img) * NP;
+    const int tiles_x = (g.Wo + BT - 1) / BT, tiles_y = (g.Ho + BT - 1) / BT;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int y0 = ty * BT, x0 = tx * BT;
     const int nco = (g.Co + 63) / 64;
     const int pad_w_quirk = g.ph;      // col2im is launched with (pad_h, pad_h): dcn_v2_im2col_cuda.cu:368
+    const int by0 = y0 * g.sh - g.ph - bx.R, bx0 = x0 * g.sw - pad_w_quirk - bx.R;   // box origin (input coords)
+    const unsigned go_bytes = (unsigned)g.Co * (unsigned)g.HWo * 4u;
+    const __amdgpu_buffer_rsrc_t rgo =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(gout + (int64_t)b * g.Co * g.HWo), 0, go_bytes, 0x00020000);
 
     for (int chunk = 0; chunk < g.nchunks; ++chunk) {
         const Chunk ck = get_chunk(g, chunk);
         const int mtiles = (ck.KL + 15) >> 4;
-        f32x4 acc[KCP / 16];
-#pragma unroll
-        for (int m = 0; m < KCP / 16; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const bool box_on = bx.use && ck.cb <= BOX_CH;
+        __syncthreads();                   // previous chunk's flush has read the box
+        if (box_on)
+            for (int i = tid; i < ck.cb * bx.BH * bx.BW; i += 256) sBox[i] = 0.f;
+        const bool first_sub = (chunk % g.nsub) == 0;   // first channel sub-block of this group
 
-        for (int cob = 0; cob < nco; ++cob) {
-            __syncthreads();   // previous readers of sG / sWt / sCG are done
-            if (chunk == 0 || nco > 1) {
-                for (int i = tid; i < 64 * NP; i += 256) {
-                    const int co = i / NP, px = i - co * NP;
-                    float v = 0.f;
-                    if (cob * 64 + co < g.Co && p0 + px < g.HWo)
-                        v = gout[(int64_t)(b * g.Co + cob * 64 + co) * g.HWo + p0 + px];
-                    sG[co * S80 + px] = v;
+        for (int band = 0; band < 4; ++band) {
+            // this lane's pixel for the MFMA B operand: n-tile `wave` = row band*4 + wave of the tile
+            const int q_ho = y0 + band * 4 + wave, q_wo = x0 + (lane & 15);
+            const bool q_ok = q_ho < g.Ho && q_wo < g.Wo;
+            f32x4 acc[KCP / 16];
+#pragma unroll
+            for (int m = 0; m < KCP / 16; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int cob = 0; cob < nco; ++cob) {
+                // grad_out fragments straight to registers: B[k = co][j = px]
+                float bv[16];
+                const unsigned gbase = q_ok ? (unsigned)((cob * 64 + (lane >> 4)) * g.HWo + q_ho * g.Wo + q_wo) * 4u
+                                            : 0x80000000u;
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks)   // rows co >= Co fall outside the descriptor and read 0
+                    bv[ks] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                        rgo, gbase + (unsigned)(4 * ks) * (unsigned)g.HWo * 4u, 0, 0));
+                if (band == 0 || nco > 1) {
+                    __syncthreads();       // previous readers of sWt are done
+                    for (int i = tid; i < 64 * KCP; i += 256) {
+                        const int co = i / KCP, kl = i - co * KCP;
+                        float v = 0.f;
+                        if (kl < ck.KL && cob * 64 + co < g.Co)
+                            v = wgt[(int64_t)(cob * 64 + co) * g.Kd + (int64_t)ck.cbase * g.kk + kl];
+                        sWt[co * S80 + kl] = v;
+                    }
+                    __syncthreads();
+                }
+                // colgrad[kl][px] += sum_co W[co][kl] * gout[co][px]
+                const float *ap = sWt + (lane >> 4) * S80 + (lane & 15);
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+#pragma unroll
+                    for (int m = 0; m < KCP / 16; ++m)
+                        if (m < mtiles)
+                            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[ks * 4 * S80 + m * 16], bv[ks], acc[m], 0, 0, 0);
                 }
             }
-            for (int i = tid; i < 64 * KCP; i += 256) {
-                const int co = i / KCP, kl = i - co * KCP;
-                float v = 0.f;
-                if (kl < ck.KL && cob * 64 + co < g.Co)
-                    v = wgt[(int64_t)(cob * 64 + co) * g.Kd + (int64_t)ck.cbase * g.kk + kl];
-                sWt[co * S80 + kl] = v;
-            }
-            __syncthreads();
-            // colgrad[kl][px] += sum_co W[co][kl] * gout[co][px];  wave owns pixel n-tile `wave`
-            const float *ap = sWt + (lane >> 4) * S80 + (lane & 15);
-            const float *bp = sG + (lane >> 4) * S80 + wave * 16 + (lane & 15);
-            for (int ks = 0; ks < 64; ks += 4) {
-                const float bv = bp[ks * S80];
+            __syncthreads();               // previous band's sampling has read sCG
 #pragma unroll
-                for (int m = 0; m < KCP / 16; ++m)
-                    if (m < mtiles)
-                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[ks * S80 + m * 16], bv, acc[m], 0, 0, 0);
+            for (int m = 0; m < KCP / 16; ++m)
+                if (m < mtiles) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        sCG[(m * 16 + (lane >> 4) * 4 + r) * NP + wave * 16 + (lane & 15)] = acc[m][r];
+                }
+            __syncthreads();
+
+            for (int it = tid; it < g.kk * NP; it += 256) {
+                const int px = it & (NP - 1), tap = it / NP;
+                const int ho = y0 + band * 4 + (px >> 4), wo = x0 + (px & 15);
+                if (ho >= g.Ho || wo >= g.Wo) continue;
+                const int p = ho * g.Wo + wo;
+                const TapPos tp = tap_pos(g, off, msk, b, ck.grp, tap, p, g.pw);
+                const Tap t = make_tap(tp.h, tp.w, g.H, g.W);
+                // grad_input positions follow the quirk; identical to `t` whenever pad_h == pad_w
+                Tap tq = t;
+                if (pad_w_quirk != g.pw) {
+                    const TapPos tpq = tap_pos(g, off, msk, b, ck.grp, tap, p, pad_w_quirk);
+                    tq = make_tap(tpq.h, tpq.w, g.H, g.W);
+                }
+                // box cell of the low corner, or -1 when any of the four corners would leave the box
+                int cell = -1;
+                if (box_on && tq.valid) {
+                    const int r0 = tq.h0 - by0, c0 = tq.w0 - bx0;
+                    if (r0 >= 0 && r0 + 1 < bx.BH && c0 >= 0 && c0 + 1 < bx.BW) cell = r0 * bx.BW + c0;
+                }
+                float val_h = 0.f, val_w = 0.f, mval = 0.f;
+                const float *plane = x + (int64_t)(b * g.C + ck.cbase) * g.H * g.W;
+                float *gplane = gx + (int64_t)(b * g.C + ck.cbase) * g.H * g.W;
+                float *bplane = sBox;
+                for (int cl = 0; cl < ck.cb; ++cl, plane += (int64_t)g.H * g.W, gplane += (int64_t)g.H * g.W,
+                         bplane += bx.BH * bx.BW) {
+                    const float cg = sCG[(cl * g.kk + tap) * NP + px];
+                    if (t.valid) {
+                        float v1, v2, v3, v4;
+                        corners(plane, t, v1, v2, v3, v4);
+                        mval += cg * (t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4);
+                        // d(sample)/dh and d(sample)/dw  (dmcn_get_coordinate_weight_cuda, :82-123)
+                        const float wh = -(1.f - t.lw) * v1 - t.lw * v2 + (1.f - t.lw) * v3 + t.lw * v4;
+                        const float ww = -(1.f - t.lh) * v1 + (1.f - t.lh) * v2 - t.lh * v3 + t.lh * v4;
+                        val_h += wh * cg * tp.mask;
+                        val_w += ww * cg * tp.mask;
+                    }
+                    if (tq.valid) {
+                        const float top = cg * tp.mask;
+                        if (cell >= 0) {   // whole 2x2 footprint inside the LDS box
+                            if (tq.o1 >= 0) atomicAdd(bplane + cell, tq.w1 * top);
+                            if (tq.o2 >= 0) atomicAdd(bplane + cell + 1, tq.w2 * top);
+                            if (tq.o3 >= 0) atomicAdd(bplane + cell + bx.BW, tq.w3 * top);
+                            if (tq.o4 >= 0) atomicAdd(bplane + cell + bx.BW + 1, tq.w4 * top);
+                        } else {
+                            if (tq.o1 >= 0) atomicAdd(gplane + tq.o1, tq.w1 * top);
+                            if (tq.o2 >= 0) atomicAdd(gplane + tq.o2, tq.w2 * top);
+                            if (tq.o3 >= 0) atomicAdd(gplane + tq.o3, tq.w3 * top);
+                            if (tq.o4 >= 0) atomicAdd(gplane + tq.o4, tq.w4 * top);
+                        }
+                    }
+                }
+                const int64_t ob = ((int64_t)(b * g.dg + ck.grp) * 2 * g.kk + 2 * tap) * g.HWo + p;
+                const int64_t mb = ((int64_t)(b * g.dg + ck.grp) * g.kk + tap) * g.HWo + p;
+                if (first_sub) {
+                    goff[ob] = val_h;
+                    goff[ob + g.HWo] = val_w;
+                    gmsk[mb] = mval;
+                } else {   // same thread owns this element in every sub-block: plain read-modify-write
+                    goff[ob] += val_h;
+                    goff[ob + g.HWo] += val_w;
+                    gmsk[mb] += mval;
+                }
             }
         }
-#pragma unroll
-        for (int m = 0; m < KCP / 16; ++m)
-            if (m < mtiles) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    sCG[(m * 16 + (lane >> 4) * 4 + r) * NP + wave * 16 + (lane & 15)] = acc[m][r];
-            }
+        // ---- flush the box: row-contiguous global atomics, untouched cells skipped
         __syncthreads();
-
-        const bool first_sub = (chunk % g.nsub) == 0;   // first channel sub-block of this group
-        for (int it = tid; it < g.kk * NP; it += 256) {
-            const int px = it & (NP - 1), tap = it / NP;
-            const int p = p0 + px;
-            if (p >= g.HWo) continue;
-            const TapPos tp = tap_pos(g, off, msk, b, ck.grp, tap, p, g.pw);
-            const Tap t = make_tap(tp.h, tp.w, g.H, g.W);
-            // grad_input positions follow the quirk; identical to `t` whenever pad_h == pad_w
-            Tap tq = t;
-            if (pad_w_quirk != g.pw) {
-                const TapPos tpq = tap_pos(g, off, msk, b, ck.grp, tap, p, pad_w_quirk);
-                tq = make_tap(tpq.h, tpq.w, g.H, g.W);
-            }
-            float val_h = 0.f, val_w = 0.f, mval = 0.f;
-            const float *plane = x + (int64_t)(b * g.C + ck.cbase) * g.H * g.W;
-            float *gplane = gx + (int64_t)(b * g.C + ck.cbase) * g.H * g.W;
-            for (int cl = 0; cl < ck.cb; ++cl, plane += (int64_t)g.H * g.W, gplane += (int64_t)g.H * g.W) {
-                const float cg = sCG[(cl * g.kk + tap) * NP + px];
-                if (t.valid) {
-                    float v1, v2, v3, v4;
-                    corners(plane, t, v1, v2, v3, v4);
-                    mval += cg * (t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4);
-                    // d(sample)/dh and d(sample)/dw  (dmcn_get_coordinate_weight_cuda, :82-123)
-                    const float wh = -(1.f - t.lw) * v1 - t.lw * v2 + (1.f - t.lw) * v3 + t.lw * v4;
-                    const float ww = -(1.f - t.lh) * v1 + (1.f - t.lh) * v2 - t.lh * v3 + t.lh * v4;
-                    val_h += wh * cg * tp.mask;
-                    val_w += ww * cg * tp.mask;
-                }
-                if (tq.valid) {
-                    const float top = cg * tp.mask;
-                    if (tq.o1 >= 0) atomicAdd(gplane + tq.o1, tq.w1 * top);
-                    if (tq.o2 >= 0) atomicAdd(gplane + tq.o2, tq.w2 * top);
-                    if (tq.o3 >= 0) atomicAdd(gplane + tq.o3, tq.w3 * top);
-                    if (tq.o4 >= 0) atomicAdd(gplane + tq.o4, tq.w4 * top);
-                }
-            }
-            const int64_t ob = ((int64_t)(b * g.dg + ck.grp) * 2 * g.kk + 2 * tap) * g.HWo + p;
-            const int64_t mb = ((int64_t)(b * g.dg + ck.grp) * g.kk + tap) * g.HWo + p;
-            if (first_sub) {
-                goff[ob] = val_h;
-                goff[ob + g.HWo] = val_w;
-                gmsk[mb] = mval;
-            } else {   // same thread owns this element in every sub-block: plain read-modify-write
-                goff[ob] += val_h;
-                goff[ob + g.HWo] += val_w;
-                gmsk[mb] += mval;
+        if (box_on) {
+            const int cells = bx.BH * bx.BW;
+            for (int i = tid; i < ck.cb * cells; i += 256) {
+                const float v = sBox[i];
+                if (v == 0.f) continue;
+                const int cl = i / cells, rem = i - cl * cells;
+                const int yy = by0 + rem / bx.BW, xx = bx0 + rem % bx.BW;
+                if (yy >= 0 && yy < g.H && xx >= 0 && xx < g.W)
+                    atomicAdd(gx + ((int64_t)(b * g.C + ck.cbase + cl) * g.H + yy) * g.W + xx, v);
             }
         }
     }
@@ -373,14 +491,32 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restric
     if (tid < 64 && co_base + tid < g.Co) my[(int64_t)g.Co * g.Kd + co_base + tid] = bsum;
 }
 
-__global__ void dcn_bwd_reduce_f32(const float *__restrict__ slab, int nslabs, int64_t n_weight, int64_t n_total,
-                                   float *__restrict__ gw, float *__restrict__ gb) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_total) return;
-    float s = 0.f;
-    for (int k = 0; k < nslabs; ++k) s += slab[(int64_t)k * n_total + j];
-    if (j < n_weight) gw[j] = s;
-    else gb[j - n_weight] = s;
+// 64 consecutive elements per workgroup, 4 thread rows each summing every 4th slab, fixed-order combine
+__global__ __launch_bounds__(256) void dcn_bwd_reduce_f32(const float *__restrict__ slab, int nslabs, int64_t n_weight,
+                                                          int64_t n_total, float *__restrict__ gw,
+                                                          float *__restrict__ gb) {
+    __shared__ float part[4][64];
+    const int jj = threadIdx.x & 63, kq = threadIdx.x >> 6;
+    const int64_t j = (int64_t)blockIdx.x * 64 + jj;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (j < n_total) {
+        const float *p = slab + j;
+        int k = kq;
+        for (; k + 12 < nslabs; k += 16) {
+            s0 += p[(int64_t)k * n_total];
+            s1 += p[(int64_t)(k + 4) * n_total];
+            s2 += p[(int64_t)(k + 8) * n_total];
+            s3 += p[(int64_t)(k + 12) * n_total];
+        }
+        for (; k < nslabs; k += 4) s0 += p[(int64_t)k * n_total];
+    }
+    part[kq][jj] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (kq == 0 && j < n_total) {
+        const float s = (part[0][jj] + part[1][jj]) + (part[2][jj] + part[3][jj]);
+        if (j < n_weight) gw[j] = s;
+        else gb[j - n_weight] = s;
+    }
 }
 
 int make_geom(Geom &g, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
@@ -474,10 +610,26 @@ extern "C" int ebfi_dcn_backward(const void *input, const void *weight, const vo
         return EBFI_OK;
     }
     {
+        // LDS box: tile footprint in input space (stride, dilation) + the largest halo R <= 8 that fits
+        BoxGeom bx{0, 0, 0, 0};
+        const int span_y = (BT - 1) * sh + (kh - 1) * dh + 2, span_x = (BT - 1) * sw + (kw - 1) * dw + 2;
+        for (int R = 8; R >= 0; --R)
+            if ((span_y + 2 * R) * (span_x + 2 * R) <= BOX_CELLS) {
+                bx = BoxGeom{1, R, span_y + 2 * R, span_x + 2 * R};
+                break;
+            }
+        const size_t lds = (size_t)(64 * S80 + KCP * NP + BOX_CH * BOX_CELLS) * sizeof(float);
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dcn_bwd_data_f32),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done = true;
+        }
+        const int64_t tiles = (int64_t)B * ceil_div(g.Ho, BT) * ceil_div(g.Wo, BT);
         ProfScope ps("dcn_bwd_data_f32", st);
-        hipLaunchKernelGGL(dcn_bwd_data_f32, dim3((unsigned)(B * g.tiles_per_img)), dim3(256), 0, st, x, wgt, off, msk,
-                           go, static_cast<float *>(grad_input), static_cast<float *>(grad_offset),
-                           static_cast<float *>(grad_mask), g);
+        hipLaunchKernelGGL(dcn_bwd_data_f32, dim3((unsigned)tiles), dim3(256), lds, st, x, wgt, off, msk, go,
+                           static_cast<float *>(grad_input), static_cast<float *>(grad_offset),
+                           static_cast<float *>(grad_mask), g, bx);
     }
     if (int rc = check_launch("dcn_bwd_data_f32")) return rc;
     const int nwg = weight_grid(g);
@@ -490,7 +642,7 @@ extern "C" int ebfi_dcn_backward(const void *input, const void *weight, const vo
     const int64_t n_weight = (int64_t)Co * g.Kd, n_total = n_weight + Co;
     {
         ProfScope ps("dcn_bwd_reduce_f32", st);
-        hipLaunchKernelGGL(dcn_bwd_reduce_f32, dim3((unsigned)ceil_div(n_total, 256)), dim3(256), 0, st,
+        hipLaunchKernelGGL(dcn_bwd_reduce_f32, dim3((unsigned)ceil_div(n_total, 64)), dim3(256), 0, st,
                            static_cast<const float *>(workspace), nwg, n_weight, n_total,
                            static_cast<float *>(grad_weight), static_cast<float *>(grad_bias));
     }
