@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""infer_ours.py -- MI355X counterpart of the reference inference entry point (infer_ours.py:156-172,
+:113-118): loads a checkpoint in the reference layout (`cpt['config']['model']`, `cpt['model']['states']`),
+builds the model by name and runs `model(Frame, Event, T, GTEx)[-1]` under no_grad.  Inputs are
+synthetic clips (BASELINE.json configs 1/2/5); metrics / PNG dumps / HDF5 lists are out of scope.
+
+    python infer_ours.py --model_path output/models/Ours/run/checkpoint-iteration100.pth --batch 4 --height 256 --width 256
+    python infer_ours.py --batch 1 --height 128 --width 128          # random-init weights
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from ebfi_amd.engine import DEFAULT_MODEL_ARGS, synthetic_batch  # noqa: E402
+from models.Ours.model_singleframe import EVFIAutoEx  # noqa: E402,F401  (resolved by name, like the reference's eval())
+
+
+def load_model(model_path, device):
+    if model_path is None:
+        name, margs, states = "EVFIAutoEx", dict(DEFAULT_MODEL_ARGS), None
+    else:
+        cpt = torch.load(model_path, map_location="cpu")
+        name, margs, states = cpt["config"]["model"]["name"], cpt["config"]["model"]["args"], cpt["model"]["states"]
+    model = globals()[name](**margs)
+    if states is not None:
+        model.load_state_dict(states)
+    return model.to(device).eval(), margs
+
+
+@torch.no_grad()
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model_path", default=None)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--width", type=int, default=256)
+    ap.add_argument("--num_ts", type=int, default=16, help="latent timestamps per clip (NumI of the reference loop)")
+    ap.add_argument("--seed", type=int, default=123)
+    a = ap.parse_args()
+    torch.manual_seed(a.seed)
+    device = torch.device("cuda", 0)
+    model, margs = load_model(a.model_path, device)
+    frame, event, _, gtex, _ = synthetic_batch(a.batch, a.height, a.width, margs["TB"], device=device, seed=a.seed)
+    preds = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.num_ts):                    # same Frame/Event for every timestamp, only T changes
+        t = torch.full((a.batch, 1), i / float(a.num_ts), device=device)
+        preds.append(model(frame, event, t, gtex)[-1])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = torch.stack(preds, 1)
+    print("interpolated %d frames of %dx%d in %.3f s: %.1f frames/s; output %s, mean %.4f"
+          % (a.batch * a.num_ts, a.height, a.width, dt, a.batch * a.num_ts / dt, tuple(out.shape), out.mean().item()))
+
+
+if __name__ == "__main__":
+    main()
