@@ -244,7 +244,7 @@ struct WCfg {
 };
 
 template <int KS, int S>
-__global__ __launch_bounds__(256) void conv_wgrad_f32(const float *__restrict__ x, const float *__restrict__ gout,
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const float *__restrict__ x, const float *__restrict__ gout,
                                                       const float *__restrict__ yact, float *__restrict__ slab,
                                                       ConvGeom g, int dact, float dslope, int total_tiles,
                                                       int need_bias) {
@@ -279,7 +279,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const float *__restrict__ 
         const int ky = tap / KS, kx = tap - ky * KS;
         boff[q] = (n < ncols) ? ci * PS + ky * IWS + kx : CIB * PS;   // unused columns read the all-zero plane
     }
-    float bsum = 0.f;
     for (int i = tid; i < PS; i += 256) sIn[CIB * PS + i] = 0.f;   // zero plane behind the channel planes
 
     // thread-fixed staging coordinates
@@ -288,6 +287,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const float *__restrict__ 
     const unsigned go_bytes = (unsigned)g.Cout * (unsigned)HWo * 4u, x_bytes = (unsigned)g.Cin * (unsigned)HW * 4u;
 
     float rg[NG], ri[NI];
+    float bsum = 0.f;                      // bias: channel (tid & 63), pixel-slot quarter (tid >> 6), all tiles
     auto prefetch = [&](int tile) {
         int t = tile;
         const int tx = t % tiles_x; t /= tiles_x;
@@ -341,10 +341,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const float *__restrict__ 
         commit();
         __syncthreads();
         prefetch(tile + gridDim.x);      // past the end: zero-record descriptors, nothing is read
-        if (need_bias && blockIdx.z == 0 && tid < 64) {
-            float s = 0.f;
-            for (int p = 0; p < GSLOTS; ++p) s += sG[tid * GS + p];   // unused slots hold zeros
-            bsum += s;
+        if (need_bias && blockIdx.z == 0) {   // all 256 threads: 16 of the 64 pixel slots of one channel each
+            const float *gp = sG + (tid & 63) * GS + (tid >> 6) * 16;
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int p = 0; p < 16; p += 2) { s0 += gp[p]; s1 += gp[p + 1]; }
+            bsum += s0 + s1;
         }
         // k = output pixel; lane half h takes pixel 2*ks + h (same row: WTX is even)
         const float *ap = sG + (mt * 32 + (lane & 31)) * GS + (lane >> 5);
@@ -373,7 +375,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const float *__restrict__ 
             if (co < g.Cout) my[((int64_t)co * g.Cin + ci_base) * KK + n] = acc[q][r];
         }
     }
-    if (need_bias && blockIdx.z == 0 && tid < 64 && co_base + tid < g.Cout) my[wsz + co_base + tid] = bsum;
+    if (need_bias && blockIdx.z == 0) {    // combine the four slot quarters in a fixed order
+        __syncthreads();
+        sG[tid] = bsum;
+        __syncthreads();
+        if (tid < 64 && co_base + tid < g.Cout)
+            my[wsz + co_base + tid] = (sG[tid] + sG[tid + 64]) + (sG[tid + 128] + sG[tid + 192]);
+    }
 }
 
 // 64 consecutive elements per workgroup, 4 thread rows each summing every 4th slab (4 loads in

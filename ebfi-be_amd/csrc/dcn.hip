@@ -418,7 +418,9 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restric
     const int co_base = blockIdx.y * 64;
     const int64_t slab_stride = (int64_t)g.Co * g.Kd + g.Co;
     float *my = slab + (int64_t)blockIdx.x * slab_stride;
-    float bsum = 0.f;
+    float bpart[16];                   // bias partials: pixel (tid & 63) of channels (tid >> 6) + 4k
+#pragma unroll
+    for (int k = 0; k < 16; ++k) bpart[k] = 0.f;
 
     for (int chunk = 0; chunk < g.nchunks; ++chunk) {
         const Chunk ck = get_chunk(g, chunk);
@@ -431,12 +433,15 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restric
             const int b = tile / g.tiles_per_img;
             const int p0 = (tile - b * g.tiles_per_img) * NP;
             __syncthreads();
-            for (int i = tid; i < 64 * NP; i += 256) {
-                const int co = i / NP, px = i - co * NP;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int i = tid + 256 * k;
+                const int co = i / NP, px = i - co * NP;      // co = (tid >> 6) + 4k, px = tid & 63
                 float v = 0.f;
                 if (co_base + co < g.Co && p0 + px < g.HWo)
                     v = gout[(int64_t)(b * g.Co + co_base + co) * g.HWo + p0 + px];
                 sGt[px * S81 + co] = v;
+                if (chunk == 0) bpart[k] += v;
             }
             // zero the kl padding columns [KL, ntiles*16) once per tile (cheap) so MFMA reads zeros
             for (int i = tid; i < NP * 16; i += 256) {
@@ -461,11 +466,6 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restric
                 }
             }
             __syncthreads();
-            if (chunk == 0 && tid < 64) {
-                float s = 0.f;
-                for (int px = 0; px < NP; ++px) s += sGt[px * S81 + tid];
-                bsum += s;
-            }
             // acc[co][kl] += sum_px gout[co][px] * col[kl][px];  wave owns co m-tile `wave`
             const float *ap = sGt + (lane >> 4) * S81 + wave * 16 + (lane & 15);
             const float *bp = sCt + (lane >> 4) * S81 + (lane & 15);
@@ -488,7 +488,14 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restric
                 }
             }
     }
-    if (tid < 64 && co_base + tid < g.Co) my[(int64_t)g.Co * g.Kd + co_base + tid] = bsum;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        float v = bpart[k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        const int co = co_base + wave + 4 * k;
+        if (lane == 0 && co < g.Co) my[(int64_t)g.Co * g.Kd + co] = v;
+    }
 }
 
 // 64 consecutive elements per workgroup, 4 thread rows each summing every 4th slab, fixed-order combine
