@@ -33,6 +33,7 @@ B_PER_GPU, H, W, TB = 8, 256, 256, 16
 
 
 F32_MFMA_PEAK_TFS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+BF16_MFMA_PEAK_TFS = 2500.0  # dense bf16 matrix peak (spec, without sparsity)
 
 
 def host_threads():
@@ -162,8 +163,9 @@ def main():
             entry = {"launches": launches, "avg_ms": round(total_ms / launches, 5), "total_ms": round(total_ms, 3)}
             secs = total_ms * 1e-3
             if flops > 0 and (nbytes == 0 or flops / nbytes > 4.0):
+                peak = BF16_MFMA_PEAK_TFS if name.endswith("_bf16") else F32_MFMA_PEAK_TFS
                 entry.update(bound="mfma", algorithmic_flops_per_launch=flops / launches,
-                             achieved=round(flops / secs / 1e12, 2), peak=F32_MFMA_PEAK_TFS, unit="TFLOP/s")
+                             achieved=round(flops / secs / 1e12, 2), peak=peak, unit="TFLOP/s")
             elif nbytes > 0:
                 entry.update(bound="hbm", algorithmic_bytes_per_launch=nbytes / launches,
                              achieved=round(nbytes / secs / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s")

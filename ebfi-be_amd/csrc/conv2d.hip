@@ -222,6 +222,185 @@ __global__ __launch_bounds__(256) void conv_fwd_f32(const float *__restrict__ x,
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 matrix-core variant of the forward / data-gradient kernel (fp32 tensors in HBM, bf16 MFMA
+// operands, fp32 accumulation): v_mfma_f32_32x32x16_bf16 runs at 16x the fp32 MFMA rate, which turns
+// the 3x3 convs from matrix-bound into HBM-bound.  Same tiling and software pipeline as conv_fwd_f32;
+// what changes is the operand images: MFMA wants 8 consecutive k (= channels) per lane, so LDS holds
+// channel-minor images [position][16 ch] and [tap][co][16 ch] with a 48-byte row pitch (16-byte aligned
+// for ds_read_b128 and 3*16 B => the 16 lanes of a read group hit 16 distinct 16-B slots).  A thread still
+// owns fixed tile positions: it loads their 16 channels (coalesced along x across threads), converts with
+// v_cvt_pk_bf16_f32 and writes two 16-byte pieces.  Weights are pre-packed once per call to bf16
+// [tap][co][ci16] (conv_pack_w_bf16) so their staging is plain 16-byte copies.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int CKB = 16;                // channels per chunk
+constexpr int PITCH = 24;              // bf16 elements per LDS row (16 data + 8 pad = 48 bytes)
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// W fp32 -> packed bf16.  forward: Wp[tap][co][ci] = W[co][ci][tap];  TR: Wp[tap][m][k] = W[k][m][KK-1-tap]
+// (rows = our output channels M, cols = our contraction channels K padded to K16 with zeros)
+__global__ void conv_pack_w_bf16(const float *__restrict__ w, __bf16 *__restrict__ wp, int M, int K, int K16, int KK,
+                                 int transposed) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)KK * M * K16;
+    if (idx >= total) return;
+    const int k = (int)(idx % K16);
+    const int m = (int)((idx / K16) % M);
+    const int tap = (int)(idx / ((int64_t)K16 * M));
+    float v = 0.f;
+    if (k < K) v = transposed ? w[((int64_t)k * M + m) * KK + (KK - 1 - tap)] : w[((int64_t)m * K + k) * KK + tap];
+    wp[idx] = (__bf16)v;
+}
+
+template <int KS, int MT>
+__global__ __launch_bounds__(256) void conv_fwd_bf16(const float *__restrict__ x, const float *__restrict__ dact_y,
+                                                     const __bf16 *__restrict__ wp, const float *__restrict__ bias,
+                                                     float *__restrict__ out, ConvGeom g, int K16, int act, float slope,
+                                                     int dact, float dslope) {
+    constexpr int S = 1;
+    constexpr int KK = KS * KS;
+    constexpr int IH = S * (TY - 1) + KS, IW = S * (TX - 1) + KS;
+    constexpr int PS = IH * IW;            // positions of the staged input tile
+    constexpr int COS = 32 * MT;
+    constexpr int NPOS = (PS + 255) / 256;
+    constexpr int WPIECES = KK * COS * 2;  // 16-byte pieces of the weight slice
+    constexpr int NWB = (WPIECES + 255) / 256;
+    __shared__ __attribute__((aligned(16))) __bf16 sIn[PS * PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 sW[KK * COS * PITCH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = (g.Wo + TX - 1) / TX, tiles_y = (g.Ho + TY - 1) / TY;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int y0 = ty * TY, x0 = tx * TX;
+    const int co_base = blockIdx.y * COS;
+    const int iy0 = S * y0 - g.pad, ix0 = S * x0 - g.pad;
+    const int HW = g.H * g.W;
+    const unsigned plane_bytes = (unsigned)HW * 4u, x_bytes = (unsigned)g.Cin * plane_bytes;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (int64_t)b * g.Cin * HW, x_bytes);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(dact ? dact_y + (int64_t)b * g.Cin * HW : x, dact ? x_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16 *>(wp), 0, (unsigned)KK * (unsigned)g.Cout * (unsigned)K16 * 2u, 0x00020000);
+
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    unsigned in_off[NPOS];
+#pragma unroll
+    for (int q = 0; q < NPOS; ++q) {
+        const int pos = tid + q * 256;
+        const int r = pos / IW, c = pos - r * IW;
+        const int yy = iy0 + r, xx = ix0 + c;
+        in_off[q] = (pos < PS && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) ? (unsigned)(yy * g.W + xx) * 4u : SENT;
+    }
+    unsigned w_off[NWB];                   // byte offset of the owned 16-byte weight pieces for chunk 0
+    int w_dst[NWB];                        // their element offset in the LDS slice
+#pragma unroll
+    for (int it = 0; it < NWB; ++it) {
+        const int i = tid + it * 256;
+        const int row = i >> 1, half = i & 1;          // row = tap*COS + co
+        const int tap = row / COS, co = row - tap * COS;
+        // rows co >= Cout alias other (finite) rows or fall past the end: never stored
+        w_off[it] = i < WPIECES ? (unsigned)(((tap * g.Cout + co_base + co) * K16 + half * 8) * 2) : SENT;
+        w_dst[it] = row * PITCH + half * 8;
+    }
+
+    float rin[NPOS * CKB];
+    u32x4 rw[NWB];
+    auto prefetch = [&](int chunk) {
+        const unsigned cb = (unsigned)chunk * (unsigned)CKB * plane_bytes;
+#pragma unroll
+        for (int q = 0; q < NPOS; ++q)
+#pragma unroll
+            for (int ci = 0; ci < CKB; ++ci) {
+                const unsigned o = in_off[q] + cb + (unsigned)ci * plane_bytes;
+                float v = buf_ld(rx, o);
+                if (dact) v *= act_grad(buf_ld(ry, o), dact, dslope);
+                rin[q * CKB + ci] = v;
+            }
+        const unsigned wb = (unsigned)chunk * (unsigned)(CKB * 2);
+#pragma unroll
+        for (int it = 0; it < NWB; ++it) rw[it] = __builtin_amdgcn_raw_buffer_load_b128(rwt, w_off[it] + wb, 0, 0);
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int q = 0; q < NPOS; ++q)
+            if (tid + q * 256 < PS) {
+                u32x4 lo, hi;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    lo[j] = pack_bf16(rin[q * CKB + 2 * j], rin[q * CKB + 2 * j + 1]);
+                    hi[j] = pack_bf16(rin[q * CKB + 8 + 2 * j], rin[q * CKB + 8 + 2 * j + 1]);
+                }
+                u32x4 *dst = reinterpret_cast<u32x4 *>(sIn + (tid + q * 256) * PITCH);
+                dst[0] = lo;
+                dst[1] = hi;
+            }
+#pragma unroll
+        for (int it = 0; it < NWB; ++it)
+            if (tid + it * 256 < WPIECES) *reinterpret_cast<u32x4 *>(sW + w_dst[it]) = rw[it];
+    };
+
+    const int nchunks = K16 / CKB;
+    prefetch(0);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        prefetch(chunk + 1);      // past the last chunk every offset is out of range: reads 0, never committed
+        // lane: column (pixel / out channel) lane&31, k-half lane>>5 (channels 8h..8h+7 of the chunk)
+        const __bf16 *bp = sIn + ((S * wave) * IW + S * (lane & 31)) * PITCH + (lane >> 5) * 8;
+        const __bf16 *ap = sW + (lane & 31) * PITCH + (lane >> 5) * 8;
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap) {
+            const int ky = tap / KS, kx = tap - ky * KS;
+            bf16x8 a[MT], bv[2];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const bf16x8 *>(ap + (tap * COS + m * 32) * PITCH);
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+                bv[n] = *reinterpret_cast<const bf16x8 *>(bp + (ky * IW + kx + n * 32 * S) * PITCH);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], bv[n], acc[m][n], 0, 0, 0);
+        }
+    }
+    const int yo = y0 + wave;
+    if (yo < g.Ho) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int xo = x0 + n * 32 + (lane & 31);
+                if (xo >= g.Wo) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co_base + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (co < g.Cout) {
+                        float v = acc[m][n][r];
+                        if (bias) v += bias[co];
+                        out[(((int64_t)b * g.Cout + co) * g.Ho + yo) * g.Wo + xo] = act_apply(v, act, slope);
+                    }
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight gradient: slab[split][co][ci*KK + tap] partial sums; slab[split][Cout*Cin*KK + co] bias partials
 constexpr int WTY = 2;                 // output rows of a contraction tile
 constexpr int GSLOTS = 64, GS = GSLOTS + 1;   // grad_out image: 2 rows x 32 slots per channel, odd row stride
@@ -493,7 +672,87 @@ int launch_wgrad(hipStream_t st, const float *x, const float *gout, const float 
     return check_launch("conv_wgrad_f32");
 }
 
+size_t bf16_pack_bytes(int M, int K, int ks) { return (size_t)ks * ks * M * (size_t)((K + 15) / 16 * 16) * 2; }
+
+// shared by forward (TR = 0) and data gradient (TR = 1); g is the geometry of the conv actually run
+template <int KS>
+int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const float *w, const float *bias, float *out,
+                    const ConvGeom &g, int transposed, int act, float slope, int dact, float dslope, void *workspace,
+                    size_t ws_bytes) {
+    const int K16 = (g.Cin + 15) / 16 * 16;
+    const size_t need = bf16_pack_bytes(g.Cout, g.Cin, KS);
+    if (!workspace || ws_bytes < need) return fail(EBFI_ERR_WORKSPACE, "conv2d bf16: workspace %zu bytes < required %zu", ws_bytes, need);
+    __bf16 *wp = static_cast<__bf16 *>(workspace);
+    const int64_t total = (int64_t)KS * KS * g.Cout * K16;
+    {
+        ProfScope ps("conv_pack_w_bf16", st);
+        hipLaunchKernelGGL(conv_pack_w_bf16, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, w, wp, g.Cout, g.Cin, K16,
+                           KS * KS, transposed);
+    }
+    if (int rc = check_launch("conv_pack_w_bf16")) return rc;
+    const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, TY) * ceil_div(g.Wo, TX);
+    if (tiles > 2147483647LL) return fail(EBFI_ERR_ARG, "conv2d: too many tiles");
+    const char *name = transposed ? "conv_dgrad_bf16" : "conv_fwd_bf16";
+    const double flops = 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS;
+    if (g.Cout <= 32) {
+        dim3 grid((unsigned)tiles, (unsigned)ceil_div(g.Cout, 32));
+        ProfScope ps(name, st, flops);
+        hipLaunchKernelGGL((conv_fwd_bf16<KS, 1>), grid, dim3(256), 0, st, x, dact_y, wp, bias, out, g, K16, act, slope, dact,
+                           dslope);
+    } else {
+        dim3 grid((unsigned)tiles, (unsigned)ceil_div(g.Cout, 64));
+        ProfScope ps(name, st, flops);
+        hipLaunchKernelGGL((conv_fwd_bf16<KS, 2>), grid, dim3(256), 0, st, x, dact_y, wp, bias, out, g, K16, act, slope, dact,
+                           dslope);
+    }
+    return check_launch(name);
+}
+
 }  // namespace
+
+extern "C" size_t ebfi_conv2d_bf16_workspace(int Cin, int Cout, int ksize) {
+    const int m = Cin > Cout ? Cin : Cout;
+    return bf16_pack_bytes(m, m, ksize);       // enough for the forward and the transposed (data-gradient) packing
+}
+
+// fp32 tensors, bf16 matrix-core operands, fp32 accumulation; ksize in {1,3}, stride 1.
+extern "C" int ebfi_conv2d_forward_bf16mma(const void *input, const void *weight, const void *bias, void *output, int B,
+                                           int Cin, int H, int W, int Cout, int ksize, int stride, int pad, int act,
+                                           float slope, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!input || !weight || !output) return fail(EBFI_ERR_ARG, "conv2d_forward_bf16mma: null argument");
+    if (act < 0 || act > 2) return fail(EBFI_ERR_ARG, "conv2d_forward_bf16mma: unknown activation %d", act);
+    if (stride != 1 || (ksize != 1 && ksize != 3))
+        return fail(EBFI_ERR_UNSUPPORTED, "conv2d_forward_bf16mma: k=%d stride=%d (k in {1,3}, stride 1)", ksize, stride);
+    ConvGeom g;
+    if (int rc = make_geom(g, B, Cin, H, W, Cout, ksize, stride, pad)) return rc;
+    if (B == 0) return EBFI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float *x = static_cast<const float *>(input), *w = static_cast<const float *>(weight);
+    const float *bs = static_cast<const float *>(bias);
+    float *o = static_cast<float *>(output);
+    if (ksize == 3) return launch_fwd_bf16<3>(st, x, nullptr, w, bs, o, g, 0, act, slope, 0, 0.f, workspace, workspace_bytes);
+    return launch_fwd_bf16<1>(st, x, nullptr, w, bs, o, g, 0, act, slope, 0, 0.f, workspace, workspace_bytes);
+}
+
+extern "C" int ebfi_conv2d_backward_data_bf16mma(const void *grad_output, const void *saved_output, const void *weight,
+                                                 void *grad_input, int B, int Cin, int H, int W, int Cout, int ksize,
+                                                 int stride, int pad, int act, float slope, void *workspace,
+                                                 size_t workspace_bytes, void *stream) {
+    if (!grad_output || !weight || !grad_input) return fail(EBFI_ERR_ARG, "conv2d_backward_data_bf16mma: null argument");
+    if (act != ACT_NONE && !saved_output) return fail(EBFI_ERR_ARG, "conv2d_backward_data_bf16mma: activation needs saved_output");
+    if (stride != 1 || pad > ksize - 1 || (ksize != 1 && ksize != 3))
+        return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_data_bf16mma: k=%d stride=%d pad=%d", ksize, stride, pad);
+    ConvGeom f;
+    if (int rc = make_geom(f, B, Cin, H, W, Cout, ksize, stride, pad)) return rc;
+    if (B == 0) return EBFI_OK;
+    ConvGeom g{B, Cout, f.Ho, f.Wo, Cin, H, W, ksize - 1 - pad};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float *go = static_cast<const float *>(grad_output), *yo = static_cast<const float *>(saved_output);
+    const float *w = static_cast<const float *>(weight);
+    float *gi = static_cast<float *>(grad_input);
+    if (ksize == 3) return launch_fwd_bf16<3>(st, go, yo, w, nullptr, gi, g, 1, ACT_NONE, 0.f, act, slope, workspace, workspace_bytes);
+    return launch_fwd_bf16<1>(st, go, yo, w, nullptr, gi, g, 1, ACT_NONE, 0.f, act, slope, workspace, workspace_bytes);
+}
 
 extern "C" int ebfi_conv2d_forward(const void *input, const void *weight, const void *bias, void *output, int B, int Cin,
                                    int H, int W, int Cout, int ksize, int stride, int pad, int act, float slope,

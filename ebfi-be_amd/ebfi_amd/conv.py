@@ -16,6 +16,30 @@ from . import _native as N
 
 ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
 
+# Matrix-core operand precision of forward / data-gradient convs: "fp32" (exact, parity mode) or "bf16"
+# (fp32 tensors, bf16 MFMA operands, fp32 accumulation; 3x3/1x1 stride-1 convs only, the rest stays fp32).
+_COMPUTE = "fp32"
+
+
+def set_compute_dtype(mode):
+    global _COMPUTE
+    if mode not in ("fp32", "bf16"):
+        raise ValueError("compute dtype must be 'fp32' or 'bf16'")
+    _COMPUTE = mode
+
+
+def get_compute_dtype():
+    return _COMPUTE
+
+
+def _bf16_ok(k, stride):
+    return _COMPUTE == "bf16" and k in (1, 3) and stride == 1
+
+
+def _bf16_ws(lib, geo, device):
+    need = int(lib.ebfi_conv2d_bf16_workspace(geo[1], geo[4], geo[5]))
+    return torch.empty(max(need, 16), dtype=torch.uint8, device=device), need
+
 
 def activation_code(module):
     """nn activation module -> (code, slope) or None when it cannot be fused."""
@@ -51,9 +75,16 @@ class ConvBiasAct(Function):
         k = geo[5]
         Ho, Wo = (geo[2] + 2 * pad - k) // stride + 1, (geo[3] + 2 * pad - k) // stride + 1
         out = torch.empty((geo[0], geo[4], Ho, Wo), dtype=x.dtype, device=x.device)
+        lib = N.lib()
+        bptr = N.ptr(bias.contiguous() if bias is not None else None)
         with torch.cuda.device_of(x):
-            rc = N.lib().ebfi_conv2d_forward(N.ptr(x), N.ptr(weight), N.ptr(bias.contiguous() if bias is not None else None),
-                                             N.ptr(out), *geo, act, slope, N.EBFI_F32, N.stream_ptr(x.device))
+            if _bf16_ok(k, stride):
+                ws, need = _bf16_ws(lib, geo, x.device)
+                rc = lib.ebfi_conv2d_forward_bf16mma(N.ptr(x), N.ptr(weight), bptr, N.ptr(out), *geo, act, slope,
+                                                     N.ptr(ws), need, N.stream_ptr(x.device))
+            else:
+                rc = lib.ebfi_conv2d_forward(N.ptr(x), N.ptr(weight), bptr, N.ptr(out), *geo, act, slope, N.EBFI_F32,
+                                             N.stream_ptr(x.device))
         N.check(rc, "ebfi_conv2d_forward")
         ctx.cfg = (stride, pad, act, slope, bias is not None)
         ctx.save_for_backward(x, weight, out if act != ACT_NONE else None)
@@ -72,7 +103,11 @@ class ConvBiasAct(Function):
             st = N.stream_ptr(x.device)
             if ctx.needs_input_grad[0]:
                 gx = torch.empty_like(x)
-                if stride == 1:
+                if _bf16_ok(k, stride):
+                    ws, need = _bf16_ws(lib, geo, x.device)
+                    rc = lib.ebfi_conv2d_backward_data_bf16mma(N.ptr(gout), N.ptr(y), N.ptr(weight), N.ptr(gx), *geo, act,
+                                                               slope, N.ptr(ws), need, st)
+                elif stride == 1:
                     rc = lib.ebfi_conv2d_backward_data(N.ptr(gout), N.ptr(y), N.ptr(weight), N.ptr(gx), *geo, act, slope,
                                                        N.EBFI_F32, st)
                 else:

@@ -54,18 +54,25 @@ class Engine:
         else:
             self.model.eval()
 
+    @contextlib.contextmanager
     def _autocast(self):
-        if self.precision == "bf16":
-            return torch.autocast(self.device.type, dtype=torch.bfloat16)
-        return contextlib.nullcontext()
+        """precision 'bf16' = bf16 matrix-core operands for the 3x3 / 1x1 convs (fp32 storage and
+        accumulation, ebfi_amd.conv); everything else, and precision 'fp32', computes in fp32."""
+        from . import conv
+        prev = conv.get_compute_dtype()
+        conv.set_compute_dtype(self.precision)
+        try:
+            yield
+        finally:
+            conv.set_compute_dtype(prev)
 
     def train_step(self, frame, event, t, gtex, target):
         """One optimiser step on this rank's batch; returns the (unreduced) loss tensor."""
         self.bucket.zero()
         with self._autocast():
             sharp_pre, sharp = self.model(frame, event, t, gtex)
-        loss = self.loss(sharp_pre.float(), sharp.float(), target, self.iteration)
-        loss.backward()
+            loss = self.loss(sharp_pre.float(), sharp.float(), target, self.iteration)
+            loss.backward()
         self.bucket.all_reduce_mean()
         self.optimizer.step()
         self.iteration += 1

@@ -127,6 +127,18 @@ int ebfi_conv2d_backward_weight(const void *input, const void *grad_output, cons
                                 int act, float slope, void *workspace, size_t workspace_bytes,
                                 int dtype, void *stream);
 
+/* bf16 matrix-core variants: fp32 tensors in memory, operands rounded to bf16 for v_mfma_f32_32x32x16_bf16,
+ * fp32 accumulation (16x the fp32 MFMA rate).  k in {1,3}, stride 1.  `workspace` receives the weight
+ * re-packed to bf16 [tap][co][ci16] (ebfi_conv2d_bf16_workspace bytes). */
+size_t ebfi_conv2d_bf16_workspace(int Cin, int Cout, int ksize);
+int ebfi_conv2d_forward_bf16mma(const void *input, const void *weight, const void *bias, void *output,
+                                int B, int Cin, int H, int W, int Cout, int ksize, int stride, int pad,
+                                int act, float slope, void *workspace, size_t workspace_bytes, void *stream);
+int ebfi_conv2d_backward_data_bf16mma(const void *grad_output, const void *saved_output, const void *weight,
+                                      void *grad_input, int B, int Cin, int H, int W, int Cout, int ksize,
+                                      int stride, int pad, int act, float slope,
+                                      void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------ event voxel binning
  * xs, ys, ts: float64[n] device (ts sorted, normalised as h5dataset.py:334), ps: float32[n].
  * out: float32 [2, bins, H, W], fully overwritten (index 0 = positive, 1 = negative counts).

@@ -98,3 +98,45 @@ def test_full_size_deterministic_weight_grad():
     xs, ws = x[:1].cpu(), w.detach().cpu()
     ref = F.leaky_relu(F.conv2d(xs, ws, None, 1, 1), 0.01)
     assert _rel(conv_bias_act(x[:1].contiguous(), w.detach(), None, 1, 1, 1, 0.01), ref) < 2e-5
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,act", [(2, 64, 16, 64, 64, 3, 1), (1, 128, 13, 70, 200, 3, 1), (1, 20, 17, 33, 24, 3, 0),
+                                                  (2, 64, 16, 32, 64, 1, 1), (1, 64, 17, 33, 3, 3, 2), (1, 4, 24, 40, 64, 3, 1)])
+def test_bf16_mma_mode_vs_fp32_reference(B, Cin, H, W, Cout, k, act):
+    """bf16 matrix-core operands (fp32 storage / accumulation): forward and data gradient within bf16
+    rounding of the fp32 CPU statement (operands rounded to 8 significant bits => ~1e-2 relative)."""
+    from ebfi_amd import conv
+    torch.manual_seed(B + Cin + H + W + Cout + k)
+    x = torch.randn(B, Cin, H, W)
+    w = torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout) * 0.1
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = _ref(xr, wr, br, 1, k // 2, act, 0.01)
+    g = torch.randn_like(ref)
+    ref.backward(g)
+    xd, wd, bd = x.cuda().requires_grad_(), w.cuda().requires_grad_(), b.cuda().requires_grad_()
+    conv.set_compute_dtype("bf16")
+    try:
+        out = conv.conv_bias_act(xd, wd, bd, 1, k // 2, act, 0.01)
+        out.backward(g.cuda())
+    finally:
+        conv.set_compute_dtype("fp32")
+    assert _rel(out.detach(), ref.detach()) < 2e-2
+    # The activation derivative is taken from the op's OWN (bf16-computed) output, as autograd does; a few
+    # pre-activations within bf16 noise of zero flip slope w.r.t. the fp32 run, so the reference gradient is
+    # evaluated with the same derivative mask: grad_in = conv^T(g * act'(out_gpu)).
+    y = out.detach().cpu()
+    gpre = g if act == 0 else g * (torch.where(y > 0, torch.ones_like(y), torch.full_like(y, 0.01)) if act == 1 else y * (1 - y))
+    gx_ref = torch.nn.grad.conv2d_input(x.shape, w, gpre, stride=1, padding=k // 2)
+    assert _rel(xd.grad, gx_ref) < 2e-2
+    gw_ref = torch.nn.grad.conv2d_weight(x, w.shape, gpre, stride=1, padding=k // 2)
+    assert _rel(wd.grad, gw_ref) < 5e-5 and _rel(bd.grad, gpre.sum(dim=(0, 2, 3))) < 5e-5   # weight gradient stays fp32
+    # exactness check: with operands that are already bf16-representable the bf16 path is exact up to fp32 accumulation
+    xq, wq = x.bfloat16().float(), w.bfloat16().float()
+    refq = _ref(xq, wq, b, 1, k // 2, act, 0.01)
+    conv.set_compute_dtype("bf16")
+    try:
+        outq = conv.conv_bias_act(xq.cuda(), wq.cuda(), b.cuda(), 1, k // 2, act, 0.01)
+    finally:
+        conv.set_compute_dtype("fp32")
+    assert _rel(outq, refq) < 2e-5
