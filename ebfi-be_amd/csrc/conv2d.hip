@@ -563,6 +563,178 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const float *__restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 matrix-core weight gradient (KS in {1,3}, stride 1): M = out channels, N = (tap, ci), K = pixels.
+// MFMA wants 8 consecutive k = 8 consecutive PIXELS per lane.  NCHW gives exactly that for grad_out
+// ([co][2 rows x 32 slots], pitch 72 = 9*16 B).  For the input operand the 8 pixels start at x + kx, which
+// is only 16-byte aligned for kx = 0 -- so the halo tile is stored KS times, shifted by kx
+// (copy_kx[ci][r][x] = in[ci][r][x+kx]); every B fragment is then one aligned ds_read_b128 and the 32
+// lanes of an n-tile (32 consecutive channels of one tap) step by an odd multiple of 16 B: conflict-free.
+// Staging keeps fp32 -> bf16 conversion in registers: a thread owns a pixel PAIR, so copies 0 and 2 are
+// plain packed 32-bit stores and copy 1 takes its second half from the next lane (one shuffle).
+template <int KS>
+struct WCfgB {
+    static constexpr int WTX = WCfg<KS, 1>::WTX, IH = WTY - 1 + KS, IW = WTX - 1 + KS;   // IW == 32
+    static constexpr int CIB = 32, ROWP = 40;                       // channels per workgroup; row pitch (elements)
+    static constexpr int PLANE = IH * ROWP + ((IH * 5) % 2 == 0 ? 8 : 0);   // odd multiple of 16 bytes
+    static constexpr int GP = 72;                                   // grad_out pitch (elements)
+    static constexpr int NI = IH * CIB / 16;                        // input pixel pairs per thread per tile
+    static constexpr int NTAP = (KS * KS + 1) / 2;                  // taps per wave (two wave groups split the taps)
+    static constexpr int LDS_ELEMS = 64 * GP + KS * CIB * PLANE + ROWP;
+    static_assert(IW == 32, "staging assumes 16 pixel pairs per row");
+};
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16(const float *__restrict__ x, const float *__restrict__ gout,
+                                                         const float *__restrict__ yact, float *__restrict__ slab,
+                                                         ConvGeom g, int dact, float dslope, int total_tiles,
+                                                         int need_bias) {
+    using C = WCfgB<KS>;
+    constexpr int KK = KS * KS, WTX = C::WTX, CIB = C::CIB, ROWP = C::ROWP, PLANE = C::PLANE, GP = C::GP;
+    constexpr int NI = C::NI, NTAP = C::NTAP;
+    extern __shared__ __attribute__((aligned(16))) __bf16 smemb[];
+    __bf16 *sG = smemb;                    // [64 co][GP]
+    __bf16 *sB = smemb + 64 * GP;          // [KS copies][CIB][PLANE]
+    unsigned *sG32 = reinterpret_cast<unsigned *>(sG), *sB32 = reinterpret_cast<unsigned *>(sB);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co_base = blockIdx.y * 64, ci_base = blockIdx.z * CIB;
+    const int ci_cnt = min(CIB, g.Cin - ci_base);
+    const int mt = wave & 1, th = wave >> 1;   // wave: co tile mt, taps th*NTAP .. (n-tile = one tap x 32 channels)
+    const int tiles_x = (g.Wo + WTX - 1) / WTX, tiles_y = (g.Ho + WTY - 1) / WTY;
+    const int HW = g.H * g.W, HWo = g.Ho * g.Wo;
+
+    f32x16 acc[NTAP];
+#pragma unroll
+    for (int q = 0; q < NTAP; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    // pad columns of the shifted copies are never written by the staging: zero them once (they meet zero
+    // grad_out slots, but must be finite)
+    for (int i = tid; i < (KS * CIB * PLANE + ROWP) / 2; i += 256) sB32[i] = 0u;
+
+    // thread-fixed staging coordinates: grad_out pixel pair gp of channel rows grow + 8*it; input pixel pair pc
+    // of (row, channel) pairs walked by thread row trow
+    const int gp = tid & 31, grow = tid >> 5, gpy = gp >> 4, gpx = 2 * (gp & 15);
+    const int pc = tid & 15, trow = tid >> 4;
+    const unsigned go_bytes = (unsigned)g.Cout * (unsigned)HWo * 4u, x_bytes = (unsigned)g.Cin * (unsigned)HW * 4u;
+
+    float rg[16], ri[2 * NI];
+    float bsum = 0.f;                      // bias: channel (tid & 63), slot quarter (tid >> 6)
+    auto prefetch = [&](int tile) {
+        int t = tile;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        const int b = t / tiles_y;
+        const int y0 = ty * WTY, x0 = tx * WTX;
+        const int iy0 = y0 - g.pad, ix0 = x0 - g.pad;
+        const bool live = tile < total_tiles;
+        const __amdgpu_buffer_rsrc_t rgo = make_rsrc(gout + (int64_t)(live ? b : 0) * g.Cout * HWo, live ? go_bytes : 0u);
+        const __amdgpu_buffer_rsrc_t rya = make_rsrc((dact ? yact : gout) + (int64_t)(live ? b : 0) * g.Cout * HWo,
+                                                     (live && dact) ? go_bytes : 0u);
+        const __amdgpu_buffer_rsrc_t rxi = make_rsrc(x + (int64_t)(live ? b : 0) * g.Cin * HW, live ? x_bytes : 0u);
+        const int gy = y0 + gpy, gx0 = x0 + gpx;
+        const bool row_ok = gpx < WTX && gy < g.Ho;
+        const unsigned base = (unsigned)((co_base + grow) * HWo + gy * g.Wo + gx0) * 4u;
+        const unsigned g0 = (row_ok && gx0 < g.Wo) ? base : SENT, g1 = (row_ok && gx0 + 1 < g.Wo) ? base + 4u : SENT;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const unsigned step = (unsigned)(8 * it) * (unsigned)HWo * 4u;   // channels >= Cout fall out of range
+            float v0 = buf_ld(rgo, g0 + step), v1 = buf_ld(rgo, g1 + step);
+            if (dact) {
+                v0 *= act_grad(buf_ld(rya, g0 + step), dact, dslope);
+                v1 *= act_grad(buf_ld(rya, g1 + step), dact, dslope);
+            }
+            rg[2 * it] = v0;
+            rg[2 * it + 1] = v1;
+        }
+        const int xx = ix0 + 2 * pc;
+        const bool c0_ok = xx >= 0 && xx < g.W, c1_ok = xx + 1 >= 0 && xx + 1 < g.W;
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int r = it / (CIB / 16), ci = trow + 16 * (it % (CIB / 16));
+            const int yy = iy0 + r;
+            const bool r_ok = yy >= 0 && yy < g.H;
+            const unsigned o = (unsigned)((ci_base + ci) * HW + yy * g.W + xx) * 4u;   // channels >= Cin: out of range
+            ri[2 * it] = buf_ld(rxi, (r_ok && c0_ok) ? o : SENT);
+            ri[2 * it + 1] = buf_ld(rxi, (r_ok && c1_ok) ? o + 4u : SENT);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) sG32[((grow + 8 * it) * GP) / 2 + gp] = pack_bf16(rg[2 * it], rg[2 * it + 1]);
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int r = it / (CIB / 16), ci = trow + 16 * (it % (CIB / 16));
+            const float v0 = ri[2 * it], v1 = ri[2 * it + 1];
+            const int e = (ci * PLANE + r * ROWP) / 2 + pc;           // 32-bit index of pixel pair pc in copy 0
+            sB32[e] = pack_bf16(v0, v1);
+            if constexpr (KS == 3) {
+                const float nx = __shfl_down(v0, 1, 16);               // first pixel of the next pair (same row)
+                sB32[(CIB * PLANE) / 2 + e] = pack_bf16(v1, pc < 15 ? nx : 0.f);          // copy 1: in[x+1]
+                if (pc > 0) sB32[(2 * CIB * PLANE) / 2 + e - 1] = pack_bf16(v0, v1);       // copy 2: in[x+2]
+            }
+        }
+    };
+
+    prefetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        prefetch(tile + gridDim.x);
+        if (need_bias && blockIdx.z == 0) {   // 16 of the 64 pixel slots of one channel per thread (bf16-rounded values)
+            const bf16x8 *gq = reinterpret_cast<const bf16x8 *>(sG + (tid & 63) * GP + (tid >> 6) * 16);
+            const bf16x8 u = gq[0], v = gq[1];
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (float)u[j] + (float)v[j];
+            bsum += s;
+        }
+        // k-step kk = 16 pixel slots: row kk>>1, columns (kk&1)*16 + 8h .. +7
+        const __bf16 *ap = sG + (mt * 32 + (lane & 31)) * GP + (lane >> 5) * 8;
+        const __bf16 *bp = sB + (lane & 31) * PLANE + (lane >> 5) * 8;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(ap + kk * 16);
+#pragma unroll
+            for (int j = 0; j < NTAP; ++j) {
+                const int q = th * NTAP + j;               // wave-uniform
+                if (q < KK) {
+                    const int ky = q / KS, kx = q - ky * KS;
+                    const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(bp + kx * CIB * PLANE + ((kk >> 1) + ky) * ROWP +
+                                                                        (kk & 1) * 16);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv, acc[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- partial slab: column (tap q, channel lane&31)
+    const int64_t wsz = (int64_t)g.Cout * g.Cin * KK;
+    float *my = slab + (int64_t)blockIdx.x * (wsz + g.Cout);
+    const int ci = lane & 31;
+    if (ci < ci_cnt) {
+#pragma unroll
+        for (int j = 0; j < NTAP; ++j) {
+            const int q = th * NTAP + j;
+            if (q >= KK) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < g.Cout) my[((int64_t)co * g.Cin + ci_base + ci) * KK + q] = acc[j][r];
+            }
+        }
+    }
+    if (need_bias && blockIdx.z == 0) {    // combine the four slot quarters in a fixed order
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(smemb);
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < 64 && co_base + tid < g.Cout)
+            my[wsz + co_base + tid] = (red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]);
+    }
+}
+
 // 64 consecutive elements per workgroup, 4 thread rows each summing every 4th slab (4 loads in
 // flight), then a fixed-order combine through LDS: deterministic, and short dependent chains.
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_f32(const float *__restrict__ slab, int nslabs,
@@ -643,9 +815,9 @@ int64_t wgrad_tiles_rt(const ConvGeom &g, int ks, int stride) {
 
 int wgrad_cib_rt(int ks, int stride) { return ks == 7 ? 8 : (stride == 2 ? 32 : 64); }
 
-int wgrad_splits(const ConvGeom &g, int ks, int stride) {
+int wgrad_splits(const ConvGeom &g, int ks, int stride, bool bf16mma = false) {
     const int64_t tiles = wgrad_tiles_rt(g, ks, stride);
-    const int64_t blocks = ceil_div(g.Cout, 64) * ceil_div(g.Cin, wgrad_cib_rt(ks, stride));
+    const int64_t blocks = ceil_div(g.Cout, 64) * ceil_div(g.Cin, bf16mma ? 32 : wgrad_cib_rt(ks, stride));
     int64_t s = ceil_div(1024, blocks);          // aim at >= 1024 workgroups (4 per CU)
     if (s > tiles) s = tiles;
     if (s < 1) s = 1;
@@ -670,6 +842,25 @@ int launch_wgrad(hipStream_t st, const float *x, const float *gout, const float 
     hipLaunchKernelGGL((conv_wgrad_f32<KS, S>), grid, dim3(256), lds, st, x, gout, yact, slab, g, dact, dslope, (int)tiles,
                        need_bias);
     return check_launch("conv_wgrad_f32");
+}
+
+template <int KS>
+int launch_wgrad_bf16(hipStream_t st, const float *x, const float *gout, const float *yact, float *slab, const ConvGeom &g,
+                      int dact, float dslope, int nsplit, int need_bias) {
+    using C = WCfgB<KS>;
+    const size_t lds = (size_t)C::LDS_ELEMS * 2;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_bf16<KS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int64_t tiles = wgrad_tiles<KS, 1>(g);
+    dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, C::CIB));
+    ProfScope ps("conv_wgrad_bf16", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS);
+    hipLaunchKernelGGL((conv_wgrad_bf16<KS>), grid, dim3(256), lds, st, x, gout, yact, slab, g, dact, dslope, (int)tiles,
+                       need_bias);
+    return check_launch("conv_wgrad_bf16");
 }
 
 size_t bf16_pack_bytes(int M, int K, int ks) { return (size_t)ks * ks * M * (size_t)((K + 15) / 16 * 16) * 2; }
@@ -813,7 +1004,9 @@ extern "C" int ebfi_conv2d_backward_weight(const void *input, const void *grad_o
                                            int ksize, int stride, int pad, int act, float slope, void *workspace,
                                            size_t workspace_bytes, int dtype, void *stream) {
     if (!input || !grad_output || !grad_weight) return fail(EBFI_ERR_ARG, "conv2d_backward_weight: null argument");
-    if (dtype != EBFI_F32) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_weight: dtype %d not implemented", dtype);
+    const bool bf16mma = dtype == EBFI_F32_BF16MMA && stride == 1 && (ksize == 1 || ksize == 3);
+    if (dtype != EBFI_F32 && dtype != EBFI_F32_BF16MMA)
+        return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_weight: dtype %d not implemented", dtype);
     if (act != ACT_NONE && !saved_output) return fail(EBFI_ERR_ARG, "conv2d_backward_weight: activation needs saved_output");
     ConvGeom g;
     if (int rc = make_geom(g, B, Cin, H, W, Cout, ksize, stride, pad)) return rc;
@@ -830,10 +1023,12 @@ extern "C" int ebfi_conv2d_backward_weight(const void *input, const void *grad_o
     const float *x = static_cast<const float *>(input), *go = static_cast<const float *>(grad_output);
     const float *yo = static_cast<const float *>(saved_output);
     float *slab = static_cast<float *>(workspace);
-    const int nsplit = wgrad_splits(g, ksize, stride);
+    const int nsplit = wgrad_splits(g, ksize, stride);   // same split count for both operand precisions (workspace size)
     const int need_bias = grad_bias != nullptr;
     int rc;
-    if (ksize == 3 && stride == 1) rc = launch_wgrad<3, 1>(st, x, go, yo, slab, g, act, slope, nsplit, need_bias);
+    if (bf16mma && ksize == 3) rc = launch_wgrad_bf16<3>(st, x, go, yo, slab, g, act, slope, nsplit, need_bias);
+    else if (bf16mma) rc = launch_wgrad_bf16<1>(st, x, go, yo, slab, g, act, slope, nsplit, need_bias);
+    else if (ksize == 3 && stride == 1) rc = launch_wgrad<3, 1>(st, x, go, yo, slab, g, act, slope, nsplit, need_bias);
     else if (ksize == 3 && stride == 2) rc = launch_wgrad<3, 2>(st, x, go, yo, slab, g, act, slope, nsplit, need_bias);
     else if (ksize == 1 && stride == 1) rc = launch_wgrad<1, 1>(st, x, go, yo, slab, g, act, slope, nsplit, need_bias);
     else if (ksize == 7 && stride == 1) rc = launch_wgrad<7, 1>(st, x, go, yo, slab, g, act, slope, nsplit, need_bias);

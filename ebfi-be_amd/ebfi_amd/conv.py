@@ -126,8 +126,9 @@ class ConvBiasAct(Function):
                 gb = torch.empty(geo[4], dtype=x.dtype, device=x.device) if has_bias else None
                 need = int(lib.ebfi_conv2d_backward_weight_workspace(*geo, N.EBFI_F32))
                 ws = torch.empty(max(need, 4), dtype=torch.uint8, device=x.device)
+                mode = N.EBFI_F32_BF16MMA if _bf16_ok(k, stride) else N.EBFI_F32
                 rc = lib.ebfi_conv2d_backward_weight(N.ptr(x), N.ptr(gout), N.ptr(y), N.ptr(gw), N.ptr(gb), *geo, act, slope,
-                                                     N.ptr(ws), need, N.EBFI_F32, st)
+                                                     N.ptr(ws), need, mode, st)
                 N.check(rc, "ebfi_conv2d_backward_weight")
         return gx, gw, gb, None, None, None, None
 

