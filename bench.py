@@ -94,33 +94,75 @@ def note(msg):
     print("[bench %7.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
 
 
+def kernel_table(kernels, elapsed, steps):
+    """Per hand-written kernel: device time from the library's hipEvent pairs, algorithmic work from the
+    launchers (SURVEY.md 8(d) formulas, un-padded).  Streaming kernels (AI < 4 FLOP/B) are priced against HBM,
+    the conv / DCN GEMM kernels against the dense matrix peak of their operand type."""
+    per_kernel = {}
+    for name, (launches, total_ms, flops, nbytes) in kernels.items():
+        if name.startswith("__") or launches == 0:
+            continue
+        entry = {"launches": launches, "avg_ms": round(total_ms / launches, 5), "total_ms": round(total_ms, 3)}
+        secs = total_ms * 1e-3
+        if flops > 0 and (nbytes == 0 or flops / nbytes > 4.0):
+            peak = BF16_MFMA_PEAK_TFS if name.endswith("_bf16") else F32_MFMA_PEAK_TFS
+            entry.update(bound="mfma", algorithmic_flops_per_launch=flops / launches,
+                         achieved=round(flops / secs / 1e12, 2), peak=peak, unit="TFLOP/s")
+        elif nbytes > 0:
+            entry.update(bound="hbm", algorithmic_bytes_per_launch=nbytes / launches,
+                         achieved=round(nbytes / secs / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s")
+        if "achieved" in entry:
+            entry["frac"] = round(entry["achieved"] / entry["peak"], 4)
+        per_kernel[name] = entry
+    ranked = sorted((k for k in per_kernel if "frac" in per_kernel[k]), key=lambda k: -per_kernel[k]["total_ms"])
+    roofline = None
+    if ranked:
+        d = per_kernel[ranked[0]]
+        traffic = None          # HBM bytes/launch from the committed rocprofv3 PMC passes, if any
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                traffic = json.load(fh).get(ranked[0])
+        except (OSError, ValueError):
+            pass
+        roofline = {"kernel": ranked[0], "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
+                    "unit": d["unit"], "frac": d["frac"], "traffic": traffic, "launches_per_step": d["launches"] / steps,
+                    "avg_launch_ms": d["avg_ms"], "share_of_step": round(d["total_ms"] / (1e3 * elapsed), 4)}
+    return per_kernel, roofline
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 = exact fp32 matrix cores (the parity-checked path, default); bf16 = bf16 operands for the convs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bf16-leg", action="store_true", help="skip the secondary bf16-operand measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # Rehearsal hook for a one-GPU box: EBFI_BENCH_REHEARSAL=1 puts every rank on device 0 and uses gloo, so the
+    # multi-rank code path (barriers, flat-bucket all-reduce, max-over-ranks timing) can be exercised without 8 GPUs.
+    rehearsal = os.environ.get("EBFI_BENCH_REHEARSAL", "0") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from ebfi_amd import _native as N
     from ebfi_amd.engine import DEFAULT_MODEL_ARGS, Engine, synthetic_batch
-    if os.environ.get("EBFI_MIOPEN_FIND", "0") == "1":      # let MIOpen time its candidates (3-D convs of Detail)
-        torch.backends.cudnn.benchmark = True
 
     eng = Engine(DEFAULT_MODEL_ARGS, device=device, precision=args.precision, lr=1e-4, seed=123)
     batch = synthetic_batch(B_PER_GPU, H, W, TB, device=device, seed=123, rank=rank)   # resident in HBM
@@ -130,62 +172,44 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    note("engine + batch ready on %s (rank %d/%d)" % (device, rank, world))
-    for i in range(args.warmup):
-        eng.train_step(*batch)
-        torch.cuda.synchronize(device)
-        note("warm-up step %d done" % i)
-    sync()
-    N.prof_reset()
-    N.prof_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = eng.train_step(*batch)
-    sync()
-    elapsed = time.perf_counter() - t0
-    note("timed region: %d steps in %.3f s" % (args.steps, elapsed))
-    N.prof_enable(False)
-    kernels = N.prof_collect()
+    def timed_run(tag):
+        for i in range(args.warmup):
+            eng.train_step(*batch)
+            torch.cuda.synchronize(device)
+            note("%s warm-up step %d done" % (tag, i))
+        sync()
+        N.prof_reset()
+        N.prof_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = eng.train_step(*batch)
+        sync()
+        elapsed = time.perf_counter() - t0
+        N.prof_enable(False)
+        kernels = N.prof_collect()
+        t_max = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
+        if world > 1:
+            dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        note("%s timed region: %d steps in %.3f s (max over ranks %.3f s)" % (tag, args.steps, elapsed, t_max.item()))
+        return t_max.item(), kernels, float(loss.item())
 
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    elapsed = t_max.item()
+    note("engine + batch ready on %s (rank %d/%d)" % (device, rank, world))
+    elapsed, kernels, loss = timed_run(args.precision)
+    bf16_leg = None
+    if args.precision == "fp32" and not args.no_bf16_leg:
+        eng.precision = "bf16"
+        e2, k2, l2 = timed_run("bf16-leg")
+        eng.precision = "fp32"
+        pk2, rf2 = kernel_table(k2, e2, args.steps)
+        bf16_leg = {"note": "same step with bf16 matrix-core operands for the 3x3/1x1 convs (fp32 storage and accumulation); "
+                            "informational, parity bar of this mode is 2e-2 (tests/test_gpu_conv.py)",
+                    "value": round(world * B_PER_GPU * args.steps / e2, 3), "unit": "frames/s",
+                    "ms_per_step": round(1e3 * e2 / args.steps, 3), "roofline": rf2,
+                    "kernels": {k: {f: v[f] for f in ("launches", "total_ms", "achieved", "unit", "frac") if f in v}
+                                for k, v in pk2.items()}}
 
     if rank == 0:
-        # Per hand-written kernel: device time from the library's hipEvent pairs, algorithmic work from the
-        # launchers (SURVEY.md 8(d) formulas, un-padded).  Streaming kernels (AI < 1 FLOP/B) are priced against
-        # HBM, the conv / DCN GEMM kernels against the dense fp32 matrix peak.
-        per_kernel = {}
-        for name, (launches, total_ms, flops, nbytes) in kernels.items():
-            if name.startswith("__") or launches == 0:
-                continue
-            entry = {"launches": launches, "avg_ms": round(total_ms / launches, 5), "total_ms": round(total_ms, 3)}
-            secs = total_ms * 1e-3
-            if flops > 0 and (nbytes == 0 or flops / nbytes > 4.0):
-                peak = BF16_MFMA_PEAK_TFS if name.endswith("_bf16") else F32_MFMA_PEAK_TFS
-                entry.update(bound="mfma", algorithmic_flops_per_launch=flops / launches,
-                             achieved=round(flops / secs / 1e12, 2), peak=peak, unit="TFLOP/s")
-            elif nbytes > 0:
-                entry.update(bound="hbm", algorithmic_bytes_per_launch=nbytes / launches,
-                             achieved=round(nbytes / secs / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s")
-            if "achieved" in entry:
-                entry["frac"] = round(entry["achieved"] / entry["peak"], 4)
-            per_kernel[name] = entry
-        ranked = sorted((k for k in per_kernel if "frac" in per_kernel[k]), key=lambda k: -per_kernel[k]["total_ms"])
-        roofline = None
-        if ranked:
-            d = per_kernel[ranked[0]]
-            traffic = None          # HBM bytes/launch from the committed rocprofv3 PMC passes, if any
-            try:
-                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-                    traffic = json.load(fh).get(ranked[0])
-            except (OSError, ValueError):
-                pass
-            roofline = {"kernel": ranked[0], "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
-                        "unit": d["unit"], "frac": d["frac"], "traffic": traffic, "launches_per_step": d["launches"] / args.steps,
-                        "avg_launch_ms": d["avg_ms"],
-                        "share_of_step": round(d["total_ms"] / (1e3 * elapsed), 4)}
+        per_kernel, roofline = kernel_table(kernels, elapsed, args.steps)
         out = {
             "metric": "interpolated frames/sec (train fwd+bwd) at B=8 256x256",
             "value": round(world * B_PER_GPU * args.steps / elapsed, 3),
@@ -197,10 +221,11 @@ def main():
             "config": {"workload": "EVFIAutoEx (config/train_ours.yml defaults, 5.69 M params) train step: fwd + "
                                    "Lap/census loss + bwd + flat grad all-reduce + Adam; B=%d per GPU, %dx%d frames, "
                                    "TB=%d event bins, Poisson(0.35) event counts" % (B_PER_GPU, H, W, TB),
-                       "global_batch": world * B_PER_GPU, "parallelism": "dp%d" % world,
-                       "loss": float(loss.item())},
+                       "global_batch": world * B_PER_GPU, "parallelism": "dp%d" % world, "loss": loss,
+                       "rehearsal_single_device_gloo": rehearsal},
             "roofline": roofline,
             "kernels": per_kernel,
+            "bf16_mode": bf16_leg,
         }
         if world == 1 and not args.no_cpu_baseline:
             note("cpu baseline (oracle on host cores) ...")

@@ -721,7 +721,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16(const float *__restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co < g.Cout) my[((int64_t)co * g.Cin + ci_base + ci) * KK + q] = acc[j][r];
+                if (co < g.Cout) my[((int64_t)co * KK + q) * g.Cin + ci_base + ci] = acc[j][r];   // [co][tap][ci]: lanes contiguous
             }
         }
     }
@@ -737,9 +737,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16(const float *__restric
 
 // 64 consecutive elements per workgroup, 4 thread rows each summing every 4th slab (4 loads in
 // flight), then a fixed-order combine through LDS: deterministic, and short dependent chains.
+// perm_cin > 0: the slabs hold the weight part as [co][tap][ci] (bf16 kernel); gw is always [co][ci][tap].
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_f32(const float *__restrict__ slab, int nslabs,
                                                              int64_t n_weight, int64_t n_total,
-                                                             float *__restrict__ gw, float *__restrict__ gb) {
+                                                             float *__restrict__ gw, float *__restrict__ gb,
+                                                             int perm_cin, int perm_kk) {
     __shared__ float part[4][64];
     const int jj = threadIdx.x & 63, kq = threadIdx.x >> 6;
     const int64_t j = (int64_t)blockIdx.x * 64 + jj;
@@ -759,8 +761,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_f32(const float *__rest
     __syncthreads();
     if (kq == 0 && j < n_total) {
         const float s = (part[0][jj] + part[1][jj]) + (part[2][jj] + part[3][jj]);
-        if (j < n_weight) gw[j] = s;
-        else if (gb) gb[j - n_weight] = s;
+        if (j < n_weight) {
+            int64_t o = j;
+            if (perm_cin > 0) {
+                const int ci = (int)(j % perm_cin);
+                const int q = (int)((j / perm_cin) % perm_kk);
+                const int64_t co = j / ((int64_t)perm_cin * perm_kk);
+                o = (co * perm_cin + ci) * perm_kk + q;
+            }
+            gw[o] = s;
+        } else if (gb) gb[j - n_weight] = s;
     }
 }
 
@@ -819,6 +829,7 @@ int wgrad_splits(const ConvGeom &g, int ks, int stride, bool bf16mma = false) {
     const int64_t tiles = wgrad_tiles_rt(g, ks, stride);
     const int64_t blocks = ceil_div(g.Cout, 64) * ceil_div(g.Cin, bf16mma ? 32 : wgrad_cib_rt(ks, stride));
     int64_t s = ceil_div(1024, blocks);          // aim at >= 1024 workgroups (4 per CU)
+    (void)bf16mma;
     if (s > tiles) s = tiles;
     if (s < 1) s = 1;
     if (s > 512) s = 512;
@@ -1023,7 +1034,12 @@ extern "C" int ebfi_conv2d_backward_weight(const void *input, const void *grad_o
     const float *x = static_cast<const float *>(input), *go = static_cast<const float *>(grad_output);
     const float *yo = static_cast<const float *>(saved_output);
     float *slab = static_cast<float *>(workspace);
-    const int nsplit = wgrad_splits(g, ksize, stride);   // same split count for both operand precisions (workspace size)
+    int nsplit = wgrad_splits(g, ksize, stride);
+    if (bf16mma) {   // half-size channel blocks and short tiles: fewer, longer-lived workgroups (workspace is sized for the fp32 count)
+        const int64_t blocks = ceil_div(Cout, 64) * ceil_div(Cin, 32);
+        const int64_t want = ceil_div(768, blocks);
+        if (want < nsplit) nsplit = (int)(want < 1 ? 1 : want);
+    }
     const int need_bias = grad_bias != nullptr;
     int rc;
     if (bf16mma && ksize == 3) rc = launch_wgrad_bf16<3>(st, x, go, yo, slab, g, act, slope, nsplit, need_bias);
@@ -1038,7 +1054,8 @@ extern "C" int ebfi_conv2d_backward_weight(const void *input, const void *grad_o
     {
         ProfScope ps("conv_wgrad_reduce_f32", st);
         hipLaunchKernelGGL(conv_wgrad_reduce_f32, dim3((unsigned)ceil_div(n_total, 64)), dim3(256), 0, st, slab, nsplit,
-                           n_weight, n_total, static_cast<float *>(grad_weight), static_cast<float *>(grad_bias));
+                           n_weight, n_total, static_cast<float *>(grad_weight), static_cast<float *>(grad_bias),
+                           bf16mma ? Cin : 0, ksize * ksize);
     }
     return check_launch("conv_wgrad_reduce_f32");
 }

@@ -35,3 +35,20 @@ def test_train_resume_infer(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(PKG, "infer_ours.py"), "--model_path", str(ckpt), "--batch", "2",
                         "--height", "64", "--width", "64", "--num_ts", "3"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "interpolated 6 frames" in r.stdout, r.stderr[-2000:]
+
+
+def test_bench_two_rank_rehearsal():
+    """bench.py's multi-rank path (barrier, flat-bucket gradient all-reduce, max-over-ranks timing, rank-0 JSON)
+    rehearsed with 2 ranks sharing the one GPU over gloo (EBFI_BENCH_REHEARSAL=1); the real N>1 runs use RCCL."""
+    import json
+    env = dict(os.environ, EBFI_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29631", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-bf16-leg"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["cpu_baseline"] is None and d["roofline"]["kernel"].startswith("conv_")

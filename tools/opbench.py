@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--B", type=int, default=8)
     ap.add_argument("--hd", action="store_true")
     ap.add_argument("--ops", default="fac,dcn,conv")
+    ap.add_argument("--bf16", action="store_true", help="bf16 matrix-core operands for the conv kernels")
     a = ap.parse_args()
     from ebfi_amd.dcn import dcn_v2_backward, dcn_v2_forward
     from ebfi_amd.fac import fac_backward, fac_forward
@@ -88,8 +89,12 @@ def main():
         for n, ms in t.items():
             lines.append({"op": "dcn_backward", "kernel": n, "ms": round(ms, 4)})
     if "conv" in a.ops:
+        from ebfi_amd import conv as convmod
         from ebfi_amd.conv import conv_bias_act
-        names = {"conv_fwd_f32", "conv_dgrad_f32", "conv_wgrad_f32", "conv_wgrad_reduce_f32"}
+        sfx = "bf16" if a.bf16 else "f32"
+        convmod.set_compute_dtype("bf16" if a.bf16 else "fp32")
+        names = {"conv_fwd_" + sfx, "conv_dgrad_" + sfx, "conv_wgrad_" + sfx, "conv_wgrad_reduce_f32", "conv_pack_w_bf16"}
+        peak = 2500.0 if a.bf16 else F32_MFMA_PEAK
         for (cin, cout, hh, ww, tag) in [(64, 64, h, w, "ResidualControl 64->64"), (128, 64, h, w, "Conv5 128->64"),
                                          (128, 1600, h, w, "KernelConv 128->1600"), (64, 64, 2 * h, 2 * w, "Recon 64->64 @2x")]:
             x = torch.randn(B, cin, hh, ww, device=dev).requires_grad_()
@@ -104,8 +109,8 @@ def main():
             fl = 2.0 * B * hh * ww * cin * cout * 9
             for n, ms in sorted(t.items()):
                 e = {"op": "conv3x3 " + tag, "kernel": n, "ms": round(ms, 4)}
-                if n != "conv_wgrad_reduce_f32":
-                    e.update(TFLOPs=round(fl / ms / 1e9, 2), frac_f32_mfma=round(fl / ms / 1e9 / F32_MFMA_PEAK, 4))
+                if n not in ("conv_wgrad_reduce_f32", "conv_pack_w_bf16"):
+                    e.update(TFLOPs=round(fl / ms / 1e9, 2), frac_mfma_peak=round(fl / ms / 1e9 / peak, 4))
                 lines.append(e)
             del x, wt, bs, g
             torch.cuda.empty_cache()
