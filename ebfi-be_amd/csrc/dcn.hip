@@ -50,6 +50,8 @@ struct Tap {
     int o1, o2, o3, o4;     // plane offsets of the four corners, -1 when outside the image
     float lh, lw;           // fractional parts (for the coordinate gradient)
     int h0, w0;             // integer low corner (may be -1)
+    int q0, q1;             // offsets of the 2-pixel pair (columns c, c+1) in the low / high row, -1 = row outside
+    float mlx, mly, mhx, mhy;   // which pair element is the low-column / high-column corner (0/1 masks)
     bool valid;             // -1 < h < H and -1 < w < W   (dcn_v2_im2col_cuda.cu:180)
 };
 
@@ -60,6 +62,8 @@ __device__ __forceinline__ Tap make_tap(float h, float w, int H, int W) {
     t.o1 = t.o2 = t.o3 = t.o4 = -1;
     t.lh = t.lw = 0.f;
     t.h0 = t.w0 = 0;
+    t.q0 = t.q1 = -1;
+    t.mlx = t.mly = t.mhx = t.mhy = 0.f;
     if (t.valid) {
         const int h0 = (int)floorf(h), w0 = (int)floorf(w);
         t.h0 = h0; t.w0 = w0;
@@ -72,16 +76,33 @@ __device__ __forceinline__ Tap make_tap(float h, float w, int H, int W) {
         if (h0 >= 0 && w1 <= W - 1) t.o2 = h0 * W + w1;
         if (h1 <= H - 1 && w0 >= 0) t.o3 = h1 * W + w0;
         if (h1 <= H - 1 && w1 <= W - 1) t.o4 = h1 * W + w1;
+        // the two corners of a row are adjacent in memory: fetch them as ONE 8-byte access at column c
+        // (half the gather instructions through the texture addresser).  c is clamped so the pair stays
+        // inside the row; the masks say which element plays which corner (a corner outside reads as 0).
+        const int c = w0 < 0 ? 0 : (w0 > W - 2 ? W - 2 : w0);
+        t.mlx = (w0 == c) ? 1.f : 0.f;          // low corner  = pair.x
+        t.mly = (w0 == c + 1) ? 1.f : 0.f;      // low corner  = pair.y  (w0 == W-1)
+        t.mhx = (w1 == c) ? 1.f : 0.f;          // high corner = pair.x  (w0 == -1)
+        t.mhy = (w1 == c + 1) ? 1.f : 0.f;      // high corner = pair.y
+        t.q0 = h0 >= 0 ? h0 * W + c : -1;
+        t.q1 = h1 <= H - 1 ? h1 * W + c : -1;
     }
     return t;
 }
 
+struct __attribute__((packed, aligned(4))) Pair {
+    float x, y;
+};
+// W >= 2 is required for the paired fetch (checked by the launchers; W == 1 never occurs on this path)
 __device__ __forceinline__ void corners(const float *__restrict__ plane, const Tap &t, float &v1, float &v2,
                                         float &v3, float &v4) {
-    v1 = t.o1 >= 0 ? plane[t.o1] : 0.f;
-    v2 = t.o2 >= 0 ? plane[t.o2] : 0.f;
-    v3 = t.o3 >= 0 ? plane[t.o3] : 0.f;
-    v4 = t.o4 >= 0 ? plane[t.o4] : 0.f;
+    Pair a = {0.f, 0.f}, b = {0.f, 0.f};
+    if (t.q0 >= 0) a = *reinterpret_cast<const Pair *>(plane + t.q0);
+    if (t.q1 >= 0) b = *reinterpret_cast<const Pair *>(plane + t.q1);
+    v1 = a.x * t.mlx + a.y * t.mly;
+    v2 = a.x * t.mhx + a.y * t.mhy;
+    v3 = b.x * t.mlx + b.y * t.mly;
+    v4 = b.x * t.mhx + b.y * t.mhy;
 }
 
 // Sample `n` consecutive channels of one (pixel, tap) into the LDS column image.  NCH > 0 unrolls exactly
@@ -533,6 +554,7 @@ int make_geom(Geom &g, int B, int C, int H, int W, int Co, int kh, int kw, int s
         return fail(EBFI_ERR_ARG, "dcn: non-positive dimension");
     if (C % dg != 0) return fail(EBFI_ERR_ARG, "dcn: channels %d not divisible by deformable_group %d", C, dg);
     if (kh * kw > KC) return fail(EBFI_ERR_UNSUPPORTED, "dcn: kernel %dx%d has more than %d taps", kh, kw, KC);
+    if (W < 2) return fail(EBFI_ERR_UNSUPPORTED, "dcn: input width %d < 2 (corner pairs are fetched as 8-byte accesses)", W);
     g = Geom{B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, dg, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     g.Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1;
     g.Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;
