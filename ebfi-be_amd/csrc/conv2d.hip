@@ -405,10 +405,11 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16(const float *__restrict__ x
 constexpr int WTY = 2;                 // output rows of a contraction tile
 constexpr int GSLOTS = 64, GS = GSLOTS + 1;   // grad_out image: 2 rows x 32 slots per channel, odd row stride
 
-template <int KS, int S>
+template <int KS, int S, int WTXO = 0>
 struct WCfg {
-    // output columns per tile chosen so that the staged input row fits 32 (or 64) lanes exactly
-    static constexpr int WTX = (KS == 1) ? 32 : (KS == 3) ? 30 : (S == 1 ? 26 : 28);
+    // output columns per tile: the staged input row must fit 32 (or 64) lanes; 3x3 stride-1 may pick 26/28/30
+    // (WTXO) so that ceil(Wo / WTX) * WTX wastes as few columns as possible (128 -> 26: 1.5 % instead of 15 %)
+    static constexpr int WTX = WTXO ? WTXO : ((KS == 1) ? 32 : (KS == 3) ? 30 : (S == 1 ? 26 : 28));
     static constexpr int IH = S * (WTY - 1) + KS, IW = S * (WTX - 1) + KS;
     static constexpr int IWP = IW <= 32 ? 32 : 64;              // lanes per staged input row
     static constexpr int TROWS = 256 / IWP;                     // thread rows walking (row, channel)
@@ -422,12 +423,12 @@ struct WCfg {
     static_assert(IW <= 64 && WTX % 2 == 0 && WTX <= 32 && CIB % TROWS == 0, "tile configuration");
 };
 
-template <int KS, int S>
+template <int KS, int S, int WTXO>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const float *__restrict__ x, const float *__restrict__ gout,
                                                       const float *__restrict__ yact, float *__restrict__ slab,
-                                                      ConvGeom g, int dact, float dslope, int total_tiles,
-                                                      int need_bias) {
-    using C = WCfg<KS, S>;
+                                                      float *__restrict__ gpre_out, ConvGeom g, int dact, float dslope,
+                                                      int total_tiles, int need_bias) {
+    using C = WCfg<KS, S, WTXO>;
     constexpr int KK = KS * KS, WTX = C::WTX, IH = C::IH, IW = C::IW, IWP = C::IWP, TROWS = C::TROWS;
     constexpr int CIB = C::CIB, PS = C::PS, IWS = C::IWS, NI = C::NI, NTW = C::NTW;
     constexpr int NG = 64 / 4;             // grad_out channels per thread per tile (4 thread rows of 64 slots)
@@ -503,9 +504,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const float *__restrict
                 ri[r * CPR + k] = buf_ld(rxi, base + (unsigned)(k * TROWS) * (unsigned)HW * 4u);
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int tile) {
 #pragma unroll
         for (int it = 0; it < NG; ++it) sG[(gco + 4 * it) * GS + gslot] = rg[it];
+        if (gpre_out != nullptr && blockIdx.z == 0) {   // side output: grad_out * act'(y), consumed by the data gradient
+            int t = tile;
+            const int tx = t % tiles_x; t /= tiles_x;
+            const int ty = t % tiles_y;
+            const int b = t / tiles_y;
+            const int gy = ty * WTY + gpy, gx = tx * WTX + gpx;
+            if (gpx < WTX && gy < g.Ho && gx < g.Wo) {
+                float *dst = gpre_out + ((int64_t)b * g.Cout + co_base + gco) * HWo + gy * g.Wo + gx;
+#pragma unroll
+                for (int it = 0; it < NG; ++it)
+                    if (co_base + gco + 4 * it < g.Cout) dst[(int64_t)(4 * it) * HWo] = rg[it];
+            }
+        }
         if (icol < IW) {
 #pragma unroll
             for (int r = 0; r < IH; ++r)
@@ -517,7 +531,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const float *__restrict
     prefetch(blockIdx.x);
     for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
         __syncthreads();
-        commit();
+        commit(tile);
         __syncthreads();
         prefetch(tile + gridDim.x);      // past the end: zero-record descriptors, nothing is read
         if (need_bias && blockIdx.z == 0) {   // all 256 threads: 16 of the 64 pixel slots of one channel each
@@ -811,16 +825,26 @@ int launch_fwd(hipStream_t st, const float *x, const float *dact_y, const float 
     return check_launch(name);
 }
 
-template <int KS, int S>
-int64_t wgrad_tiles(const ConvGeom &g) {
-    return (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, WCfg<KS, S>::WTX);
+// tile width of the fp32 3x3 stride-1 weight-gradient kernel: fewest wasted columns among 26 / 28 / 30
+int pick_wtx(int Wo) {
+    int best = 30;
+    int64_t best_cols = ceil_div(Wo, 30) * 30;
+    for (int w : {28, 26}) {
+        const int64_t cols = ceil_div(Wo, w) * w;
+        if (cols < best_cols) { best = w; best_cols = cols; }
+    }
+    return best;
+}
+
+int wgrad_wtx_rt(const ConvGeom &g, int ks, int stride) {
+    if (ks == 3 && stride == 1) return pick_wtx(g.Wo);
+    if (ks == 3) return WCfg<3, 2>::WTX;
+    if (ks == 1) return WCfg<1, 1>::WTX;
+    return stride == 1 ? WCfg<7, 1>::WTX : WCfg<7, 2>::WTX;
 }
 
 int64_t wgrad_tiles_rt(const ConvGeom &g, int ks, int stride) {
-    if (ks == 3 && stride == 1) return wgrad_tiles<3, 1>(g);
-    if (ks == 3) return wgrad_tiles<3, 2>(g);
-    if (ks == 1) return wgrad_tiles<1, 1>(g);
-    return stride == 1 ? wgrad_tiles<7, 1>(g) : wgrad_tiles<7, 2>(g);
+    return (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, wgrad_wtx_rt(g, ks, stride));
 }
 
 int wgrad_cib_rt(int ks, int stride) { return ks == 7 ? 8 : (stride == 2 ? 32 : 64); }
@@ -836,23 +860,34 @@ int wgrad_splits(const ConvGeom &g, int ks, int stride, bool bf16mma = false) {
     return (int)s;
 }
 
-template <int KS, int S>
-int launch_wgrad(hipStream_t st, const float *x, const float *gout, const float *yact, float *slab, const ConvGeom &g,
-                 int dact, float dslope, int nsplit, int need_bias) {
-    using C = WCfg<KS, S>;
+template <int KS, int S, int WTXO>
+int launch_wgrad_t(hipStream_t st, const float *x, const float *gout, const float *yact, float *slab, float *gpre_out,
+                   const ConvGeom &g, int dact, float dslope, int nsplit, int need_bias) {
+    using C = WCfg<KS, S, WTXO>;
     const size_t lds = (size_t)(64 * GS + (C::CIB + 1) * C::PS + 64) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_f32<KS, S>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_f32<KS, S, WTXO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    const int64_t tiles = wgrad_tiles<KS, S>(g);
+    const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, C::WTX);
     dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, C::CIB));
     ProfScope ps("conv_wgrad_f32", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS);
-    hipLaunchKernelGGL((conv_wgrad_f32<KS, S>), grid, dim3(256), lds, st, x, gout, yact, slab, g, dact, dslope, (int)tiles,
-                       need_bias);
+    hipLaunchKernelGGL((conv_wgrad_f32<KS, S, WTXO>), grid, dim3(256), lds, st, x, gout, yact, slab, gpre_out, g, dact,
+                       dslope, (int)tiles, need_bias);
     return check_launch("conv_wgrad_f32");
+}
+
+template <int KS, int S>
+int launch_wgrad(hipStream_t st, const float *x, const float *gout, const float *yact, float *slab, float *gpre_out,
+                 const ConvGeom &g, int dact, float dslope, int nsplit, int need_bias) {
+    if (KS == 3 && S == 1) {
+        const int w = pick_wtx(g.Wo);
+        if (w == 26) return launch_wgrad_t<KS, S, 26>(st, x, gout, yact, slab, gpre_out, g, dact, dslope, nsplit, need_bias);
+        if (w == 28) return launch_wgrad_t<KS, S, 28>(st, x, gout, yact, slab, gpre_out, g, dact, dslope, nsplit, need_bias);
+    }
+    return launch_wgrad_t<KS, S, 0>(st, x, gout, yact, slab, gpre_out, g, dact, dslope, nsplit, need_bias);
 }
 
 template <int KS>
@@ -866,7 +901,7 @@ int launch_wgrad_bf16(hipStream_t st, const float *x, const float *gout, const f
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    const int64_t tiles = wgrad_tiles<KS, 1>(g);
+    const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, C::WTX);
     dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, C::CIB));
     ProfScope ps("conv_wgrad_bf16", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS);
     hipLaunchKernelGGL((conv_wgrad_bf16<KS>), grid, dim3(256), lds, st, x, gout, yact, slab, g, dact, dslope, (int)tiles,
@@ -1010,10 +1045,25 @@ extern "C" size_t ebfi_conv2d_backward_weight_workspace(int B, int Cin, int H, i
 }
 
 // grad_weight[Cout,Cin,k,k] (and grad_bias[Cout] when non-NULL), both fully overwritten, deterministic.
+extern "C" int ebfi_conv2d_backward_weight_ex(const void *input, const void *grad_output, const void *saved_output,
+                                              void *grad_weight, void *grad_bias, void *grad_preact_out, int B, int Cin,
+                                              int H, int W, int Cout, int ksize, int stride, int pad, int act, float slope,
+                                              void *workspace, size_t workspace_bytes, int dtype, void *stream);
+
 extern "C" int ebfi_conv2d_backward_weight(const void *input, const void *grad_output, const void *saved_output,
                                            void *grad_weight, void *grad_bias, int B, int Cin, int H, int W, int Cout,
                                            int ksize, int stride, int pad, int act, float slope, void *workspace,
                                            size_t workspace_bytes, int dtype, void *stream) {
+    return ebfi_conv2d_backward_weight_ex(input, grad_output, saved_output, grad_weight, grad_bias, nullptr, B, Cin, H, W,
+                                          Cout, ksize, stride, pad, act, slope, workspace, workspace_bytes, dtype, stream);
+}
+
+// Same, plus an optional side output grad_preact_out[B,Cout,Ho,Wo] = grad_output * act'(saved_output) (fp32 kernels
+// only): lets the caller run the data gradient on it without re-reading the saved activation.
+extern "C" int ebfi_conv2d_backward_weight_ex(const void *input, const void *grad_output, const void *saved_output,
+                                              void *grad_weight, void *grad_bias, void *grad_preact_out, int B, int Cin,
+                                              int H, int W, int Cout, int ksize, int stride, int pad, int act, float slope,
+                                              void *workspace, size_t workspace_bytes, int dtype, void *stream) {
     if (!input || !grad_output || !grad_weight) return fail(EBFI_ERR_ARG, "conv2d_backward_weight: null argument");
     const bool bf16mma = dtype == EBFI_F32_BF16MMA && stride == 1 && (ksize == 1 || ksize == 3);
     if (dtype != EBFI_F32 && dtype != EBFI_F32_BF16MMA)
@@ -1041,14 +1091,16 @@ extern "C" int ebfi_conv2d_backward_weight(const void *input, const void *grad_o
         if (want < nsplit) nsplit = (int)(want < 1 ? 1 : want);
     }
     const int need_bias = grad_bias != nullptr;
+    float *gpre = static_cast<float *>(grad_preact_out);
+    if (gpre && bf16mma) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_weight_ex: grad_preact_out with bf16 operands");
     int rc;
     if (bf16mma && ksize == 3) rc = launch_wgrad_bf16<3>(st, x, go, yo, slab, g, act, slope, nsplit, need_bias);
     else if (bf16mma) rc = launch_wgrad_bf16<1>(st, x, go, yo, slab, g, act, slope, nsplit, need_bias);
-    else if (ksize == 3 && stride == 1) rc = launch_wgrad<3, 1>(st, x, go, yo, slab, g, act, slope, nsplit, need_bias);
-    else if (ksize == 3 && stride == 2) rc = launch_wgrad<3, 2>(st, x, go, yo, slab, g, act, slope, nsplit, need_bias);
-    else if (ksize == 1 && stride == 1) rc = launch_wgrad<1, 1>(st, x, go, yo, slab, g, act, slope, nsplit, need_bias);
-    else if (ksize == 7 && stride == 1) rc = launch_wgrad<7, 1>(st, x, go, yo, slab, g, act, slope, nsplit, need_bias);
-    else if (ksize == 7 && stride == 2) rc = launch_wgrad<7, 2>(st, x, go, yo, slab, g, act, slope, nsplit, need_bias);
+    else if (ksize == 3 && stride == 1) rc = launch_wgrad<3, 1>(st, x, go, yo, slab, gpre, g, act, slope, nsplit, need_bias);
+    else if (ksize == 3 && stride == 2) rc = launch_wgrad<3, 2>(st, x, go, yo, slab, gpre, g, act, slope, nsplit, need_bias);
+    else if (ksize == 1 && stride == 1) rc = launch_wgrad<1, 1>(st, x, go, yo, slab, gpre, g, act, slope, nsplit, need_bias);
+    else if (ksize == 7 && stride == 1) rc = launch_wgrad<7, 1>(st, x, go, yo, slab, gpre, g, act, slope, nsplit, need_bias);
+    else if (ksize == 7 && stride == 2) rc = launch_wgrad<7, 2>(st, x, go, yo, slab, gpre, g, act, slope, nsplit, need_bias);
     else return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_weight: k=%d stride=%d not implemented", ksize, stride);
     if (rc) return rc;
     {

@@ -43,6 +43,7 @@ SIGNATURES = {
     "ebfi_conv2d_backward_data": (_i, [_vp] * 4 + [_i] * 8 + [_i, _c.c_float, _i, _vp]),
     "ebfi_conv2d_backward_weight_workspace": (_sz, [_i] * 8 + [_i]),
     "ebfi_conv2d_backward_weight": (_i, [_vp] * 5 + [_i] * 8 + [_i, _c.c_float, _vp, _sz, _i, _vp]),
+    "ebfi_conv2d_backward_weight_ex": (_i, [_vp] * 6 + [_i] * 8 + [_i, _c.c_float, _vp, _sz, _i, _vp]),
     "ebfi_conv2d_bf16_workspace": (_sz, [_i, _i, _i]),
     "ebfi_conv2d_forward_bf16mma": (_i, [_vp] * 4 + [_i] * 8 + [_i, _c.c_float, _vp, _sz, _vp]),
     "ebfi_conv2d_backward_data_bf16mma": (_i, [_vp] * 4 + [_i] * 8 + [_i, _c.c_float, _vp, _sz, _vp]),

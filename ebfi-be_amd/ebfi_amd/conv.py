@@ -99,21 +99,41 @@ class ConvBiasAct(Function):
         k = geo[5]
         lib = N.lib()
         gx = gw = gb = None
+        need_x = ctx.needs_input_grad[0]
+        need_w = ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])
+        bf16 = _bf16_ok(k, stride)
         with torch.cuda.device_of(x):
             st = N.stream_ptr(x.device)
-            if ctx.needs_input_grad[0]:
+            gpre = None       # grad_output * act'(y): by-product of the fp32 weight-gradient kernel
+            if need_w:
+                gw = torch.empty_like(weight)
+                gb = torch.empty(geo[4], dtype=x.dtype, device=x.device) if has_bias else None
+                need = int(lib.ebfi_conv2d_backward_weight_workspace(*geo, N.EBFI_F32))
+                ws = torch.empty(max(need, 4), dtype=torch.uint8, device=x.device)
+                if need_x and act != ACT_NONE and not bf16:
+                    gpre = torch.empty_like(gout)
+                rc = lib.ebfi_conv2d_backward_weight_ex(N.ptr(x), N.ptr(gout), N.ptr(y), N.ptr(gw), N.ptr(gb), N.ptr(gpre),
+                                                        *geo, act, slope, N.ptr(ws), need,
+                                                        N.EBFI_F32_BF16MMA if bf16 else N.EBFI_F32, st)
+                N.check(rc, "ebfi_conv2d_backward_weight")
+            if need_x:
                 gx = torch.empty_like(x)
-                if _bf16_ok(k, stride):
+                if bf16:
                     ws, need = _bf16_ws(lib, geo, x.device)
                     rc = lib.ebfi_conv2d_backward_data_bf16mma(N.ptr(gout), N.ptr(y), N.ptr(weight), N.ptr(gx), *geo, act,
                                                                slope, N.ptr(ws), need, st)
                 elif stride == 1:
-                    rc = lib.ebfi_conv2d_backward_data(N.ptr(gout), N.ptr(y), N.ptr(weight), N.ptr(gx), *geo, act, slope,
-                                                       N.EBFI_F32, st)
+                    if gpre is not None:    # derivative already folded in: plain transposed conv
+                        rc = lib.ebfi_conv2d_backward_data(N.ptr(gpre), N.ptr(None), N.ptr(weight), N.ptr(gx), *geo, ACT_NONE,
+                                                           0.0, N.EBFI_F32, st)
+                    else:
+                        rc = lib.ebfi_conv2d_backward_data(N.ptr(gout), N.ptr(y), N.ptr(weight), N.ptr(gx), *geo, act, slope,
+                                                           N.EBFI_F32, st)
                 else:
                     # stride 2: zero-insert grad_output (times act') and run the stride-1 data gradient on it.
                     # Only the small stems / down-sampling convs take this path.
-                    gpre = gout if act == ACT_NONE else gout * _act_grad(y, act, slope)
+                    if gpre is None:
+                        gpre = gout if act == ACT_NONE else gout * _act_grad(y, act, slope)
                     uh, uw = geo[2] + 2 * pad - k + 1, geo[3] + 2 * pad - k + 1
                     up = gout.new_zeros((geo[0], geo[4], uh, uw))
                     up[:, :, ::stride, ::stride][:, :, :gout.shape[2], :gout.shape[3]] = gpre
@@ -121,15 +141,6 @@ class ConvBiasAct(Function):
                     rc = lib.ebfi_conv2d_backward_data(N.ptr(up), N.ptr(None), N.ptr(weight), N.ptr(gx), *geo1, ACT_NONE, 0.0,
                                                        N.EBFI_F32, st)
                 N.check(rc, "ebfi_conv2d_backward_data")
-            if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-                gw = torch.empty_like(weight)
-                gb = torch.empty(geo[4], dtype=x.dtype, device=x.device) if has_bias else None
-                need = int(lib.ebfi_conv2d_backward_weight_workspace(*geo, N.EBFI_F32))
-                ws = torch.empty(max(need, 4), dtype=torch.uint8, device=x.device)
-                mode = N.EBFI_F32_BF16MMA if _bf16_ok(k, stride) else N.EBFI_F32
-                rc = lib.ebfi_conv2d_backward_weight(N.ptr(x), N.ptr(gout), N.ptr(y), N.ptr(gw), N.ptr(gb), *geo, act, slope,
-                                                     N.ptr(ws), need, mode, st)
-                N.check(rc, "ebfi_conv2d_backward_weight")
         return gx, gw, gb, None, None, None, None
 
 

@@ -129,6 +129,15 @@ int ebfi_conv2d_backward_weight(const void *input, const void *grad_output, cons
                                 int act, float slope, void *workspace, size_t workspace_bytes,
                                 int dtype, void *stream);
 
+/* Same as ebfi_conv2d_backward_weight plus an optional side output
+ * grad_preact_out [B,Cout,Ho,Wo] = grad_output * act'(saved_output) (fp32 kernels only; NULL to skip):
+ * the caller can then run ebfi_conv2d_backward_data on it with act = 0 and no saved activation. */
+int ebfi_conv2d_backward_weight_ex(const void *input, const void *grad_output, const void *saved_output,
+                                   void *grad_weight, void *grad_bias, void *grad_preact_out,
+                                   int B, int Cin, int H, int W, int Cout, int ksize, int stride, int pad,
+                                   int act, float slope, void *workspace, size_t workspace_bytes,
+                                   int dtype, void *stream);
+
 /* bf16 matrix-core variants: fp32 tensors in memory, operands rounded to bf16 for v_mfma_f32_32x32x16_bf16,
  * fp32 accumulation (16x the fp32 MFMA rate).  k in {1,3}, stride 1.  `workspace` receives the weight
  * re-packed to bf16 [tap][co][ci16] (ebfi_conv2d_bf16_workspace bytes). */
