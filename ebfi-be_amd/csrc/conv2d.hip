@@ -47,6 +47,16 @@ __device__ __forceinline__ float act_grad(float y, int act, float slope) {
     return 1.f;
 }
 
+// Activation derivative with the activation kind as a COMPILE-TIME constant: a runtime `if (dact)` around the
+// extra load makes hipcc branch around every unrolled load and wait for each one separately (dependent memory
+// round trips instead of one batch) -- that alone cost the weight-gradient kernel more than half of its time.
+template <int DACT>
+__device__ __forceinline__ float act_grad_c(float y, float slope) {
+    if constexpr (DACT == ACT_LEAKY) return y > 0.f ? 1.f : slope;
+    else if constexpr (DACT == ACT_SIGMOID) return y * (1.f - y);
+    else return 1.f;
+}
+
 constexpr int TY = 4, TX = 64;
 
 // Staging loads go through buffer descriptors: one 32-bit offset VGPR per load instead of a 64-bit
@@ -70,10 +80,10 @@ __device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, unsigned byte_
 // fixed tile positions (its image offsets and validity never change) and walks the chunk's channels, and
 // fixed weight-slice elements whose global offset just advances by a constant per chunk.  The loads of
 // chunk c+1 are issued into registers before the MFMA block of chunk c and committed to LDS after it.
-template <int KS, int S, int MT, int CK, bool TR>
+template <int KS, int S, int MT, int CK, bool TR, int DACT>
 __global__ __launch_bounds__(256) void conv_fwd_f32(const float *__restrict__ x, const float *__restrict__ dact_y,
                                                     const float *__restrict__ w, const float *__restrict__ bias,
-                                                    float *__restrict__ out, ConvGeom g, int act, float slope, int dact,
+                                                    float *__restrict__ out, ConvGeom g, int act, float slope,
                                                     float dslope) {
     constexpr int KK = KS * KS;
     constexpr int IH = S * (TY - 1) + KS, IW = S * (TX - 1) + KS;
@@ -100,7 +110,7 @@ __global__ __launch_bounds__(256) void conv_fwd_f32(const float *__restrict__ x,
     const int HW = g.H * g.W;
     const unsigned plane_bytes = (unsigned)HW * 4u, x_bytes = (unsigned)g.Cin * plane_bytes;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (int64_t)b * g.Cin * HW, x_bytes);
-    const __amdgpu_buffer_rsrc_t ry = make_rsrc(dact ? dact_y + (int64_t)b * g.Cin * HW : x, dact ? x_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(DACT ? dact_y + (int64_t)b * g.Cin * HW : x, DACT ? x_bytes : 0u);
     const __amdgpu_buffer_rsrc_t rwt = make_rsrc(w, (unsigned)g.Cout * (unsigned)g.Cin * KK * 4u);
 
     f32x16 acc[MT][2];
@@ -152,7 +162,7 @@ __global__ __launch_bounds__(256) void conv_fwd_f32(const float *__restrict__ x,
             for (int ci = 0; ci < CK; ++ci) {
                 const unsigned o = in_off[q] + cb + (unsigned)ci * plane_bytes;
                 float v = buf_ld(rx, o);
-                if (dact) v *= act_grad(buf_ld(ry, o), dact, dslope);
+                if constexpr (DACT != 0) v *= act_grad_c<DACT>(buf_ld(ry, o), dslope);
                 rin[q * CK + ci] = v;
             }
         const unsigned wb = (unsigned)chunk * w_chunk;
@@ -257,11 +267,11 @@ __global__ void conv_pack_w_bf16(const float *__restrict__ w, __bf16 *__restrict
     wp[idx] = (__bf16)v;
 }
 
-template <int KS, int MT>
+template <int KS, int MT, int DACT>
 __global__ __launch_bounds__(256) void conv_fwd_bf16(const float *__restrict__ x, const float *__restrict__ dact_y,
                                                      const __bf16 *__restrict__ wp, const float *__restrict__ bias,
                                                      float *__restrict__ out, ConvGeom g, int K16, int act, float slope,
-                                                     int dact, float dslope) {
+                                                     float dslope) {
     constexpr int S = 1;
     constexpr int KK = KS * KS;
     constexpr int IH = S * (TY - 1) + KS, IW = S * (TX - 1) + KS;
@@ -285,7 +295,7 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16(const float *__restrict__ x
     const int HW = g.H * g.W;
     const unsigned plane_bytes = (unsigned)HW * 4u, x_bytes = (unsigned)g.Cin * plane_bytes;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (int64_t)b * g.Cin * HW, x_bytes);
-    const __amdgpu_buffer_rsrc_t ry = make_rsrc(dact ? dact_y + (int64_t)b * g.Cin * HW : x, dact ? x_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(DACT ? dact_y + (int64_t)b * g.Cin * HW : x, DACT ? x_bytes : 0u);
     const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<__bf16 *>(wp), 0, (unsigned)KK * (unsigned)g.Cout * (unsigned)K16 * 2u, 0x00020000);
 
@@ -327,7 +337,7 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16(const float *__restrict__ x
             for (int ci = 0; ci < CKB; ++ci) {
                 const unsigned o = in_off[q] + cb + (unsigned)ci * plane_bytes;
                 float v = buf_ld(rx, o);
-                if (dact) v *= act_grad(buf_ld(ry, o), dact, dslope);
+                if constexpr (DACT != 0) v *= act_grad_c<DACT>(buf_ld(ry, o), dslope);
                 rin[q * CKB + ci] = v;
             }
         const unsigned wb = (unsigned)chunk * (unsigned)(CKB * 2);
@@ -423,10 +433,10 @@ struct WCfg {
     static_assert(IW <= 64 && WTX % 2 == 0 && WTX <= 32 && CIB % TROWS == 0, "tile configuration");
 };
 
-template <int KS, int S, int WTXO>
+template <int KS, int S, int WTXO, int DACT>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const float *__restrict__ x, const float *__restrict__ gout,
                                                       const float *__restrict__ yact, float *__restrict__ slab,
-                                                      float *__restrict__ gpre_out, ConvGeom g, int dact, float dslope,
+                                                      float *__restrict__ gpre_out, ConvGeom g, float dslope,
                                                       int total_tiles, int need_bias) {
     using C = WCfg<KS, S, WTXO>;
     constexpr int KK = KS * KS, WTX = C::WTX, IH = C::IH, IW = C::IW, IWP = C::IWP, TROWS = C::TROWS;
@@ -477,8 +487,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const float *__restrict
         const int iy0 = S * y0 - g.pad, ix0 = S * x0 - g.pad;
         const bool live = tile < total_tiles;
         const __amdgpu_buffer_rsrc_t rgo = make_rsrc(gout + (int64_t)(live ? b : 0) * g.Cout * HWo, live ? go_bytes : 0u);
-        const __amdgpu_buffer_rsrc_t rya = make_rsrc((dact ? yact : gout) + (int64_t)(live ? b : 0) * g.Cout * HWo,
-                                                     (live && dact) ? go_bytes : 0u);
+        const __amdgpu_buffer_rsrc_t rya = make_rsrc((DACT ? yact : gout) + (int64_t)(live ? b : 0) * g.Cout * HWo,
+                                                     (live && DACT) ? go_bytes : 0u);
         const __amdgpu_buffer_rsrc_t rxi = make_rsrc(x + (int64_t)(live ? b : 0) * g.Cin * HW, live ? x_bytes : 0u);
         // grad_out: this thread's pixel slot for channels gco, gco+4, ...
         const int gy = y0 + gpy, gx = x0 + gpx;
@@ -488,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const float *__restrict
         for (int it = 0; it < NG; ++it) {
             const unsigned o = g0 + (unsigned)(4 * it) * (unsigned)HWo * 4u;   // channels >= Cout fall out of range
             float v = buf_ld(rgo, o);
-            if (dact) v *= act_grad(buf_ld(rya, o), dact, dslope);
+            if constexpr (DACT != 0) v *= act_grad_c<DACT>(buf_ld(rya, o), dslope);
             rg[it] = v;
         }
         // input halo tile: this thread's column, rows r = 0..IH-1, channels irow, irow+TROWS, ...
@@ -598,11 +608,10 @@ struct WCfgB {
     static_assert(IW == 32, "staging assumes 16 pixel pairs per row");
 };
 
-template <int KS>
+template <int KS, int DACT>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16(const float *__restrict__ x, const float *__restrict__ gout,
                                                          const float *__restrict__ yact, float *__restrict__ slab,
-                                                         ConvGeom g, int dact, float dslope, int total_tiles,
-                                                         int need_bias) {
+                                                         ConvGeom g, float dslope, int total_tiles, int need_bias) {
     using C = WCfgB<KS>;
     constexpr int KK = KS * KS, WTX = C::WTX, CIB = C::CIB, ROWP = C::ROWP, PLANE = C::PLANE, GP = C::GP;
     constexpr int NI = C::NI, NTAP = C::NTAP;
@@ -644,8 +653,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16(const float *__restric
         const int iy0 = y0 - g.pad, ix0 = x0 - g.pad;
         const bool live = tile < total_tiles;
         const __amdgpu_buffer_rsrc_t rgo = make_rsrc(gout + (int64_t)(live ? b : 0) * g.Cout * HWo, live ? go_bytes : 0u);
-        const __amdgpu_buffer_rsrc_t rya = make_rsrc((dact ? yact : gout) + (int64_t)(live ? b : 0) * g.Cout * HWo,
-                                                     (live && dact) ? go_bytes : 0u);
+        const __amdgpu_buffer_rsrc_t rya = make_rsrc((DACT ? yact : gout) + (int64_t)(live ? b : 0) * g.Cout * HWo,
+                                                     (live && DACT) ? go_bytes : 0u);
         const __amdgpu_buffer_rsrc_t rxi = make_rsrc(x + (int64_t)(live ? b : 0) * g.Cin * HW, live ? x_bytes : 0u);
         const int gy = y0 + gpy, gx0 = x0 + gpx;
         const bool row_ok = gpx < WTX && gy < g.Ho;
@@ -655,9 +664,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16(const float *__restric
         for (int it = 0; it < 8; ++it) {
             const unsigned step = (unsigned)(8 * it) * (unsigned)HWo * 4u;   // channels >= Cout fall out of range
             float v0 = buf_ld(rgo, g0 + step), v1 = buf_ld(rgo, g1 + step);
-            if (dact) {
-                v0 *= act_grad(buf_ld(rya, g0 + step), dact, dslope);
-                v1 *= act_grad(buf_ld(rya, g1 + step), dact, dslope);
+            if constexpr (DACT != 0) {
+                v0 *= act_grad_c<DACT>(buf_ld(rya, g0 + step), dslope);
+                v1 *= act_grad_c<DACT>(buf_ld(rya, g1 + step), dslope);
             }
             rg[2 * it] = v0;
             rg[2 * it + 1] = v1;
@@ -803,9 +812,9 @@ int make_geom(ConvGeom &g, int B, int Cin, int H, int W, int Cout, int ks, int s
     return EBFI_OK;
 }
 
-template <int KS, int S, bool TR>
-int launch_fwd(hipStream_t st, const float *x, const float *dact_y, const float *w, const float *bias, float *out,
-               const ConvGeom &g, int act, float slope, int dact, float dslope) {
+template <int KS, int S, bool TR, int DACT>
+int launch_fwd_d(hipStream_t st, const float *x, const float *dact_y, const float *w, const float *bias, float *out,
+                 const ConvGeom &g, int act, float slope, float dslope) {
     constexpr int CK = KS == 7 ? 2 : 8;      // input channels staged per chunk (LDS budget of the weight slice)
     const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, TY) * ceil_div(g.Wo, TX);
     if (tiles > 2147483647LL) return fail(EBFI_ERR_ARG, "conv2d: too many tiles");
@@ -814,15 +823,25 @@ int launch_fwd(hipStream_t st, const float *x, const float *dact_y, const float 
     if (g.Cout <= 32) {
         dim3 grid((unsigned)tiles, (unsigned)ceil_div(g.Cout, 32));
         ProfScope ps(name, st, flops);
-        hipLaunchKernelGGL((conv_fwd_f32<KS, S, 1, CK, TR>), grid, dim3(256), 0, st, x, dact_y, w, bias, out, g, act, slope,
-                           dact, dslope);
+        hipLaunchKernelGGL((conv_fwd_f32<KS, S, 1, CK, TR, DACT>), grid, dim3(256), 0, st, x, dact_y, w, bias, out, g, act,
+                           slope, dslope);
     } else {
         dim3 grid((unsigned)tiles, (unsigned)ceil_div(g.Cout, 64));
         ProfScope ps(name, st, flops);
-        hipLaunchKernelGGL((conv_fwd_f32<KS, S, 2, CK, TR>), grid, dim3(256), 0, st, x, dact_y, w, bias, out, g, act, slope,
-                           dact, dslope);
+        hipLaunchKernelGGL((conv_fwd_f32<KS, S, 2, CK, TR, DACT>), grid, dim3(256), 0, st, x, dact_y, w, bias, out, g, act,
+                           slope, dslope);
     }
     return check_launch(name);
+}
+
+template <int KS, int S, bool TR>
+int launch_fwd(hipStream_t st, const float *x, const float *dact_y, const float *w, const float *bias, float *out,
+               const ConvGeom &g, int act, float slope, int dact, float dslope) {
+    if constexpr (TR) {
+        if (dact == ACT_LEAKY) return launch_fwd_d<KS, S, TR, ACT_LEAKY>(st, x, dact_y, w, bias, out, g, act, slope, dslope);
+        if (dact == ACT_SIGMOID) return launch_fwd_d<KS, S, TR, ACT_SIGMOID>(st, x, dact_y, w, bias, out, g, act, slope, dslope);
+    }
+    return launch_fwd_d<KS, S, TR, ACT_NONE>(st, x, dact_y, w, bias, out, g, act, slope, dslope);
 }
 
 // tile width of the fp32 3x3 stride-1 weight-gradient kernel: fewest wasted columns among 26 / 28 / 30
@@ -860,23 +879,31 @@ int wgrad_splits(const ConvGeom &g, int ks, int stride, bool bf16mma = false) {
     return (int)s;
 }
 
-template <int KS, int S, int WTXO>
-int launch_wgrad_t(hipStream_t st, const float *x, const float *gout, const float *yact, float *slab, float *gpre_out,
-                   const ConvGeom &g, int dact, float dslope, int nsplit, int need_bias) {
+template <int KS, int S, int WTXO, int DACT>
+int launch_wgrad_d(hipStream_t st, const float *x, const float *gout, const float *yact, float *slab, float *gpre_out,
+                   const ConvGeom &g, float dslope, int nsplit, int need_bias) {
     using C = WCfg<KS, S, WTXO>;
     const size_t lds = (size_t)(64 * GS + (C::CIB + 1) * C::PS + 64) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_f32<KS, S, WTXO>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_f32<KS, S, WTXO, DACT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, C::WTX);
     dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, C::CIB));
     ProfScope ps("conv_wgrad_f32", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS);
-    hipLaunchKernelGGL((conv_wgrad_f32<KS, S, WTXO>), grid, dim3(256), lds, st, x, gout, yact, slab, gpre_out, g, dact,
-                       dslope, (int)tiles, need_bias);
+    hipLaunchKernelGGL((conv_wgrad_f32<KS, S, WTXO, DACT>), grid, dim3(256), lds, st, x, gout, yact, slab, gpre_out, g, dslope,
+                       (int)tiles, need_bias);
     return check_launch("conv_wgrad_f32");
+}
+
+template <int KS, int S, int WTXO>
+int launch_wgrad_t(hipStream_t st, const float *x, const float *gout, const float *yact, float *slab, float *gpre_out,
+                   const ConvGeom &g, int dact, float dslope, int nsplit, int need_bias) {
+    if (dact == ACT_LEAKY) return launch_wgrad_d<KS, S, WTXO, ACT_LEAKY>(st, x, gout, yact, slab, gpre_out, g, dslope, nsplit, need_bias);
+    if (dact == ACT_SIGMOID) return launch_wgrad_d<KS, S, WTXO, ACT_SIGMOID>(st, x, gout, yact, slab, gpre_out, g, dslope, nsplit, need_bias);
+    return launch_wgrad_d<KS, S, WTXO, ACT_NONE>(st, x, gout, yact, slab, gpre_out, g, dslope, nsplit, need_bias);
 }
 
 template <int KS, int S>
@@ -890,23 +917,31 @@ int launch_wgrad(hipStream_t st, const float *x, const float *gout, const float 
     return launch_wgrad_t<KS, S, 0>(st, x, gout, yact, slab, gpre_out, g, dact, dslope, nsplit, need_bias);
 }
 
-template <int KS>
-int launch_wgrad_bf16(hipStream_t st, const float *x, const float *gout, const float *yact, float *slab, const ConvGeom &g,
-                      int dact, float dslope, int nsplit, int need_bias) {
+template <int KS, int DACT>
+int launch_wgrad_bf16_d(hipStream_t st, const float *x, const float *gout, const float *yact, float *slab, const ConvGeom &g,
+                        float dslope, int nsplit, int need_bias) {
     using C = WCfgB<KS>;
     const size_t lds = (size_t)C::LDS_ELEMS * 2;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_bf16<KS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_bf16<KS, DACT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, C::WTX);
     dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, C::CIB));
     ProfScope ps("conv_wgrad_bf16", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS);
-    hipLaunchKernelGGL((conv_wgrad_bf16<KS>), grid, dim3(256), lds, st, x, gout, yact, slab, g, dact, dslope, (int)tiles,
+    hipLaunchKernelGGL((conv_wgrad_bf16<KS, DACT>), grid, dim3(256), lds, st, x, gout, yact, slab, g, dslope, (int)tiles,
                        need_bias);
     return check_launch("conv_wgrad_bf16");
+}
+
+template <int KS>
+int launch_wgrad_bf16(hipStream_t st, const float *x, const float *gout, const float *yact, float *slab, const ConvGeom &g,
+                      int dact, float dslope, int nsplit, int need_bias) {
+    if (dact == ACT_LEAKY) return launch_wgrad_bf16_d<KS, ACT_LEAKY>(st, x, gout, yact, slab, g, dslope, nsplit, need_bias);
+    if (dact == ACT_SIGMOID) return launch_wgrad_bf16_d<KS, ACT_SIGMOID>(st, x, gout, yact, slab, g, dslope, nsplit, need_bias);
+    return launch_wgrad_bf16_d<KS, ACT_NONE>(st, x, gout, yact, slab, g, dslope, nsplit, need_bias);
 }
 
 size_t bf16_pack_bytes(int M, int K, int ks) { return (size_t)ks * ks * M * (size_t)((K + 15) / 16 * 16) * 2; }
@@ -931,16 +966,23 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
     if (tiles > 2147483647LL) return fail(EBFI_ERR_ARG, "conv2d: too many tiles");
     const char *name = transposed ? "conv_dgrad_bf16" : "conv_fwd_bf16";
     const double flops = 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS;
-    if (g.Cout <= 32) {
-        dim3 grid((unsigned)tiles, (unsigned)ceil_div(g.Cout, 32));
+    const int mt = g.Cout <= 32 ? 1 : 2;
+    dim3 grid((unsigned)tiles, (unsigned)ceil_div(g.Cout, 32 * mt));
+    {
         ProfScope ps(name, st, flops);
-        hipLaunchKernelGGL((conv_fwd_bf16<KS, 1>), grid, dim3(256), 0, st, x, dact_y, wp, bias, out, g, K16, act, slope, dact,
-                           dslope);
-    } else {
-        dim3 grid((unsigned)tiles, (unsigned)ceil_div(g.Cout, 64));
-        ProfScope ps(name, st, flops);
-        hipLaunchKernelGGL((conv_fwd_bf16<KS, 2>), grid, dim3(256), 0, st, x, dact_y, wp, bias, out, g, K16, act, slope, dact,
-                           dslope);
+#define EBFI_LAUNCH_BF16(MT_, DA_)                                                                                     \
+    hipLaunchKernelGGL((conv_fwd_bf16<KS, MT_, DA_>), grid, dim3(256), 0, st, x, dact_y, wp, bias, out, g, K16, act, slope, \
+                       dslope)
+        if (mt == 1) {
+            if (dact == ACT_LEAKY) EBFI_LAUNCH_BF16(1, ACT_LEAKY);
+            else if (dact == ACT_SIGMOID) EBFI_LAUNCH_BF16(1, ACT_SIGMOID);
+            else EBFI_LAUNCH_BF16(1, ACT_NONE);
+        } else {
+            if (dact == ACT_LEAKY) EBFI_LAUNCH_BF16(2, ACT_LEAKY);
+            else if (dact == ACT_SIGMOID) EBFI_LAUNCH_BF16(2, ACT_SIGMOID);
+            else EBFI_LAUNCH_BF16(2, ACT_NONE);
+        }
+#undef EBFI_LAUNCH_BF16
     }
     return check_launch(name);
 }
