@@ -54,9 +54,10 @@ class LaplacianLoss(nn.Module):
         super().__init__()
         self.lap = LaplacianPyramid()
 
-    def forward(self, x, y):
-        return sum((2 ** i) * F.l1_loss(a, b, reduction="sum")
-                   for i, (a, b) in enumerate(zip(self.lap(x), self.lap(y))))
+    def forward(self, x, y, y_pyramid=None):
+        """y_pyramid: optional precomputed pyramid of the target (it is shared by both loss terms of a step)."""
+        yp = y_pyramid if y_pyramid is not None else self.lap(y)
+        return sum((2 ** i) * F.l1_loss(a, b, reduction="sum") for i, (a, b) in enumerate(zip(self.lap(x), yp)))
 
 
 class Ternary(nn.Module):
@@ -75,8 +76,9 @@ class Ternary(nn.Module):
         d = patches - g
         return d / torch.sqrt(0.81 + d ** 2)
 
-    def forward(self, x, y):
-        diff = self.transform(x) - self.transform(y).detach()
+    def forward(self, x, y, y_transform=None):
+        ty = y_transform if y_transform is not None else self.transform(y).detach()
+        diff = self.transform(x) - ty
         dist = (diff ** 2 / (0.1 + diff ** 2)).mean(dim=1, keepdim=True)
         p = self.patch_size // 2
         mask = torch.zeros_like(dist)
@@ -92,7 +94,10 @@ class TrainLoss(nn.Module):
         self.Lap, self.census, self.detail_enabled = LaplacianLoss(), Ternary(), detail_enabled
 
     def forward(self, sharp_pre, sharp, target, iteration=0, accu_step=1):
-        term = lambda p: self.Lap(p, target) + self.census(p, target)
+        with torch.no_grad():     # the target side of both terms is the same: compute it once
+            yp = self.Lap.lap(target)
+            ty = self.census.transform(target)
+        term = lambda p: self.Lap(p, target, yp) + self.census(p, target, ty)
         if not self.detail_enabled:
             return term(sharp) / accu_step
         if iteration < 10e3:

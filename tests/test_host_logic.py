@@ -87,8 +87,8 @@ def _dp_worker(rank, world, port, outdir):
     mine = data[rank * 2:(rank + 1) * 2]
     bucket.zero()
     net(mine).pow(2).sum().backward()                   # sum-reduced loss, like the reference's
+    local = bucket.gather().clone()
     assert bucket.views_intact()
-    local = bucket.flat.clone()
     bucket.all_reduce_mean()
     opt.step()
     w1 = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
@@ -128,9 +128,10 @@ def test_flat_bucket_single_process():
     net = torch.nn.Linear(3, 2)
     b = FlatGradBucket(net)
     net(torch.ones(1, 3)).sum().backward()
-    assert b.views_intact() and b.flat.abs().sum() > 0
-    before = b.flat.clone()
-    b.all_reduce_mean()                                 # no process group: no-op
-    assert torch.equal(before, b.flat)
+    before = torch.cat([net.weight.grad.reshape(-1), net.bias.grad.reshape(-1)])
+    b.all_reduce_mean()                                 # no process group: just packs
+    assert b.views_intact() and torch.equal(before, b.flat) and b.flat.abs().sum() > 0
+    b.flat.mul_(2.0)
+    assert torch.equal(net.weight.grad.reshape(-1), before[:6] * 2)      # .grad are views of the flat buffer
     b.zero()
-    assert net.weight.grad.abs().sum() == 0
+    assert net.weight.grad is None and net.bias.grad is None
