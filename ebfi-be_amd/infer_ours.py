@@ -46,6 +46,7 @@ def main():
     device = torch.device("cuda", 0)
     model, margs = load_model(a.model_path, device)
     frame, event, _, gtex, _ = synthetic_batch(a.batch, a.height, a.width, margs["TB"], device=device, seed=a.seed)
+    model(frame, event, torch.zeros(a.batch, 1, device=device), gtex)      # untimed warm-up (module load, allocator)
     preds = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
