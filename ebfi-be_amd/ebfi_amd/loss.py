@@ -8,6 +8,35 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _native as N
+
+
+class _Gauss5(torch.autograd.Function):
+    """5x5 binomial blur with reflect padding on the gfx950 kernel pair (csrc/imgops.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, factor):
+        x = x.contiguous()
+        ctx.factor = float(factor)
+        out = torch.empty_like(x)
+        H, W = x.shape[-2:]
+        with torch.cuda.device_of(x):
+            rc = N.lib().ebfi_gauss5_forward(N.ptr(x), N.ptr(out), x.numel() // (H * W), H, W, ctx.factor,
+                                             N.stream_ptr(x.device))
+        N.check(rc, "ebfi_gauss5_forward")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        gin = torch.empty_like(g)
+        H, W = g.shape[-2:]
+        with torch.cuda.device_of(g):
+            rc = N.lib().ebfi_gauss5_backward(N.ptr(g), N.ptr(gin), g.numel() // (H * W), H, W, ctx.factor,
+                                              N.stream_ptr(g.device))
+        N.check(rc, "ebfi_gauss5_backward")
+        return gin, None
+
 
 class GaussianConv(nn.Module):
     """5x5 binomial blur with reflect padding (restore.py:149-163).  The kernel is separable
@@ -21,7 +50,9 @@ class GaussianConv(nn.Module):
 
     def forward(self, x, factor=1):
         H, W = x.shape[-2:]
-        p = F.pad(x, (2, 2, 2, 2), mode="reflect")
+        if x.is_cuda and x.dtype == torch.float32 and H >= 3 and W >= 3:
+            return _Gauss5.apply(x, factor)
+        p = F.pad(x, (2, 2, 2, 2), mode="reflect")     # CPU tensors (host-logic tests): shifted-slice sums
         h = sum(t * p[..., :, j:j + W] for j, t in enumerate(self.taps))
         v = sum(t * h[..., i:i + H, :] for i, t in enumerate(self.taps))
         return v * factor if factor != 1 else v

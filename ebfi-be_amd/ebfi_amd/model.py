@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import conv, fold3d
+from . import conv, fold3d, norm
 from .blur import Frame2DCP, Frame2Lap
 from .fac import KernelConv2D
 
@@ -127,7 +127,7 @@ class ExposureDecision(BaseModel):
     def forward(self, Event, BlurryLevel):
         ev = self.EventFeatExtract(Event)
         bl = self.BLFeatExtract(BlurryLevel)
-        atten = torch.sigmoid(self.AVGPool(self.GroupNorm(ev) * self.GroupNorm(bl)))
+        atten = torch.sigmoid(self.AVGPool(norm.group_norm(ev, self.GroupNorm) * norm.group_norm(bl, self.GroupNorm)))
         ex = self.Conv1(torch.cat([ev * atten, bl], dim=1))
         return torch.sigmoid(self.AVGPool(ex).view(-1, 1))
 

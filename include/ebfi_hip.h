@@ -22,6 +22,8 @@
  *       models/DCNv2/src/dcn_v2.h:9-92, src/vision.cpp:4-9, src/cuda/dcn_v2_cuda.cu:20-216,
  *       src/cuda/dcn_v2_im2col_cuda.cu:125-402
  *   ebfi_conv2d_*               nn.Conv2d + activation inside ConvLayer (models/model_misc/submodules.py:159-200)
+ *   ebfi_groupnorm_*            nn.GroupNorm of ExposureDecision (models/Ours/model_singleframe.py:36,66-67)
+ *   ebfi_gauss5_*               GaussianConv of the Laplacian-pyramid loss (loss/restore.py:149-163)
  *   ebfi_events_to_stack        dataloader/encodings.py:307-350 (events_to_stack)
  *   ebfi_frame2lap / _frame2dcp myutils/utils.py:34-49 / :15-31
  */
@@ -165,6 +167,28 @@ int ebfi_events_to_stack(const double *xs, const double *ys, const double *ts, c
 int ebfi_frame2lap(const float *frame, float *out, int B, int H, int W, void *stream);
 int ebfi_frame2dcp(const float *frame, float *out, float *scratch /* [B,H,W] */, int B, int H, int W,
                    int window, void *stream);
+
+/* ------------------------------------------------------------------ GroupNorm (exposure-decision head)
+ * nn.GroupNorm(groups, C) on contiguous NCHW fp32 (reference models/Ours/model_singleframe.py:36,66-67).
+ * HW = H*W must be a multiple of 4.  mean / rstd [B*groups] are written by forward and read by backward.
+ * workspace: ebfi_groupnorm_workspace(B, C) bytes for forward, that + 2*B*groups*4 for backward.
+ * gamma / beta / grad_gamma / grad_beta may be NULL.  Deterministic (fixed-order double-precision sums). */
+size_t ebfi_groupnorm_workspace(int B, int C);
+int ebfi_groupnorm_forward(const float *x, const float *gamma, const float *beta, float *y, float *mean, float *rstd,
+                           int B, int C, int64_t HW, int groups, float eps,
+                           void *workspace, size_t workspace_bytes, void *stream);
+int ebfi_groupnorm_backward(const float *grad_y, const float *x, const float *gamma, const float *mean,
+                            const float *rstd, float *grad_x, float *grad_gamma, float *grad_beta,
+                            int B, int C, int64_t HW, int groups,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------ loss image operators
+ * 5x5 binomial blur ([1,4,6,4,1]/16 twice, times `factor`) with reflect padding over `planes` contiguous
+ * H x W planes: the GaussianConv of the reference's Laplacian-pyramid loss (loss/restore.py:149-163).
+ * backward is its exact adjoint.  H, W >= 3. */
+int ebfi_gauss5_forward(const float *input, float *output, int64_t planes, int H, int W, float factor, void *stream);
+int ebfi_gauss5_backward(const float *grad_output, float *grad_input, int64_t planes, int H, int W, float factor,
+                         void *stream);
 
 /* ------------------------------------------------------------------ per-kernel device timing
  * When enabled, every launch made by this library is bracketed by a hipEvent pair recorded on the

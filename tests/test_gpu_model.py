@@ -123,3 +123,46 @@ def test_train_step_vs_oracle(fix):
         assert _rel(p.grad, sdo[name].grad) < 5 * TOL, name       # grads still in the flat bucket
     moved = sum((eng.model.state_dict()[k] - before[k]).abs().sum().item() for k in before)
     assert moved > 0 and eng.iteration == 1
+
+
+def test_gauss5_kernel_pair_vs_reference_conv():
+    """The loss's GaussianConv on the native kernel: forward vs the depthwise reflect-padded conv of the
+    reference (loss/restore.py:149-163), backward vs autograd of that conv (exact adjoint incl. borders)."""
+    import torch.nn.functional as F
+    from ebfi_amd.loss import GaussianConv
+    torch.manual_seed(3)
+    k1 = torch.tensor([1., 4., 6., 4., 1.])
+    kern = (k1[:, None] * k1[None, :] / 256).repeat(3, 1, 1, 1)
+    for (B, H, W, factor) in [(2, 16, 16, 1.0), (1, 5, 7, 4.0), (2, 64, 48, 4.0), (1, 3, 3, 1.0)]:
+        x = torch.randn(B, 3, H, W, requires_grad=True)
+        ref = F.conv2d(F.pad(x, (2, 2, 2, 2), mode="reflect"), factor * kern, groups=3)
+        g = torch.randn_like(ref)
+        ref.backward(g)
+        xd = x.detach().cuda().requires_grad_()
+        out = GaussianConv().cuda()(xd, factor)
+        out.backward(g.cuda())
+        assert _rel(out.detach(), ref.detach()) < 1e-5, (H, W)
+        assert _rel(xd.grad, x.grad) < 1e-5, (H, W)
+
+
+def test_groupnorm_kernels_vs_torch_cpu():
+    import torch.nn as nn
+    from ebfi_amd.norm import group_norm
+    torch.manual_seed(5)
+    for (B, C, G, H, W) in [(2, 8, 4, 8, 12), (3, 64, 4, 32, 32), (1, 6, 3, 5, 4)]:
+        gn = nn.GroupNorm(G, C)
+        with torch.no_grad():
+            gn.weight.copy_(torch.randn(C))
+            gn.bias.copy_(torch.randn(C))
+        x = (torch.randn(B, C, H, W) * 2 + 0.7).requires_grad_()
+        ref = gn(x)
+        g = torch.randn_like(ref)
+        ref.backward(g)
+        gnd = nn.GroupNorm(G, C).cuda()
+        gnd.load_state_dict(gn.state_dict())
+        xd = x.detach().cuda().requires_grad_()
+        out = group_norm(xd, gnd)
+        out.backward(g.cuda())
+        assert _rel(out.detach(), ref.detach()) < 1e-5
+        assert _rel(xd.grad, x.grad) < 2e-5
+        assert _rel(gnd.weight.grad, gn.weight.grad) < 2e-5 and _rel(gnd.bias.grad, gn.bias.grad) < 2e-5
