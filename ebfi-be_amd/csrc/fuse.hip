@@ -1,0 +1,112 @@
+// Fused elementwise stages between the convolutions of the hot path (each replaces a chain of PyTorch
+// elementwise / cat / reduction launches over full feature maps).
+//
+// scale_residual_cat: one round of ResidualControl (reference models/Ours/model_singleframe.py:79-136)
+//     by_ex = Conv1(ex) * Conv3(x) + x ;  by_t = Conv2(t) * Conv4(x) + x ;  cat([by_ex, by_t], 1)
+// with a0 = Conv3(x), a1 = Conv4(x) [B,C,H,W] and the per-sample channel scales s0 = Conv1(ex), s1 = Conv2(t) [B,C].
+#include "common.hpp"
+
+using namespace ebfi;
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void src_fwd_kernel(const float *__restrict__ a0, const float *__restrict__ s0,
+                                                      const float *__restrict__ a1, const float *__restrict__ s1,
+                                                      const float *__restrict__ x, float *__restrict__ out, int C, int64_t HW4,
+                                                      int64_t total4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int64_t bc = i / HW4, r = i - bc * HW4;
+    const int64_t b = bc / C, c = bc - b * C;
+    const f4 xv = reinterpret_cast<const f4 *>(x)[i];
+    const f4 v0 = reinterpret_cast<const f4 *>(a0)[i], v1 = reinterpret_cast<const f4 *>(a1)[i];
+    const float k0 = s0[bc], k1 = s1[bc];
+    f4 *o = reinterpret_cast<f4 *>(out);
+    o[(b * 2 * C + c) * HW4 + r] = v0 * k0 + xv;
+    o[(b * 2 * C + C + c) * HW4 + r] = v1 * k1 + xv;
+}
+
+// one workgroup per (b, c) plane: grad_a0 = g0*s0, grad_a1 = g1*s1, grad_x = g0 + g1,
+// grad_s0[b,c] = sum g0*a0, grad_s1[b,c] = sum g1*a1   (fixed-order reduction -> deterministic)
+__global__ __launch_bounds__(256) void src_bwd_kernel(const float *__restrict__ gout, const float *__restrict__ a0,
+                                                      const float *__restrict__ s0, const float *__restrict__ a1,
+                                                      const float *__restrict__ s1, float *__restrict__ ga0,
+                                                      float *__restrict__ ga1, float *__restrict__ gx, float *__restrict__ gs0,
+                                                      float *__restrict__ gs1, int C, int64_t HW4) {
+    __shared__ float red[2][4];
+    const int64_t bc = blockIdx.x;
+    const int64_t b = bc / C, c = bc - b * C;
+    const f4 *g0 = reinterpret_cast<const f4 *>(gout) + (b * 2 * C + c) * HW4;
+    const f4 *g1 = reinterpret_cast<const f4 *>(gout) + (b * 2 * C + C + c) * HW4;
+    const f4 *p0 = reinterpret_cast<const f4 *>(a0) + bc * HW4, *p1 = reinterpret_cast<const f4 *>(a1) + bc * HW4;
+    f4 *o0 = reinterpret_cast<f4 *>(ga0) + bc * HW4, *o1 = reinterpret_cast<f4 *>(ga1) + bc * HW4;
+    f4 *ox = reinterpret_cast<f4 *>(gx) + bc * HW4;
+    const float k0 = s0[bc], k1 = s1[bc];
+    float d0 = 0.f, d1 = 0.f;
+    for (int64_t i = threadIdx.x; i < HW4; i += 256) {
+        const f4 u0 = g0[i], u1 = g1[i], v0 = p0[i], v1 = p1[i];
+        o0[i] = u0 * k0;
+        o1[i] = u1 * k1;
+        ox[i] = u0 + u1;
+        d0 += (u0.x * v0.x + u0.y * v0.y) + (u0.z * v0.z + u0.w * v0.w);
+        d1 += (u1.x * v1.x + u1.y * v1.y) + (u1.z * v1.z + u1.w * v1.w);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        d0 += __shfl_xor(d0, d, 64);
+        d1 += __shfl_xor(d1, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = d0;
+        red[1][threadIdx.x >> 6] = d1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        gs0[bc] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        gs1[bc] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+int check_planes(const char *who, int B, int C, int64_t HW) {
+    if (B < 0 || C <= 0 || HW <= 0) return fail(EBFI_ERR_ARG, "%s: bad dimensions", who);
+    if (HW % 4 != 0) return fail(EBFI_ERR_UNSUPPORTED, "%s: H*W must be a multiple of 4 (got %lld)", who, (long long)HW);
+    if ((int64_t)B * C > 2147483647LL) return fail(EBFI_ERR_ARG, "%s: too many planes", who);
+    return EBFI_OK;
+}
+
+}  // namespace
+
+// out [B,2C,H,W]: out[:, :C] = s0[b,c]*a0 + x, out[:, C:] = s1[b,c]*a1 + x
+extern "C" int ebfi_scale_residual_cat_forward(const float *a0, const float *s0, const float *a1, const float *s1,
+                                               const float *x, float *out, int B, int C, int64_t HW, void *stream) {
+    if (!a0 || !s0 || !a1 || !s1 || !x || !out) return fail(EBFI_ERR_ARG, "scale_residual_cat_forward: null argument");
+    if (int rc = check_planes("scale_residual_cat_forward", B, C, HW)) return rc;
+    if (B == 0) return EBFI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t total4 = (int64_t)B * C * HW / 4;
+    {
+        ProfScope ps("scale_residual_cat_fwd", st, 0.0, 20.0 * B * C * (double)HW);
+        hipLaunchKernelGGL(src_fwd_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, a0, s0, a1, s1, x, out, C, HW / 4,
+                           total4);
+    }
+    return check_launch("scale_residual_cat_fwd");
+}
+
+// adjoint of the above for grad_out [B,2C,H,W]: grad_a0, grad_a1, grad_x [B,C,H,W]; grad_s0, grad_s1 [B,C]
+extern "C" int ebfi_scale_residual_cat_backward(const float *grad_out, const float *a0, const float *s0, const float *a1,
+                                                const float *s1, float *grad_a0, float *grad_a1, float *grad_x,
+                                                float *grad_s0, float *grad_s1, int B, int C, int64_t HW, void *stream) {
+    if (!grad_out || !a0 || !s0 || !a1 || !s1 || !grad_a0 || !grad_a1 || !grad_x || !grad_s0 || !grad_s1)
+        return fail(EBFI_ERR_ARG, "scale_residual_cat_backward: null argument");
+    if (int rc = check_planes("scale_residual_cat_backward", B, C, HW)) return rc;
+    if (B == 0) return EBFI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    {
+        ProfScope ps("scale_residual_cat_bwd", st, 0.0, 28.0 * B * C * (double)HW);
+        hipLaunchKernelGGL(src_bwd_kernel, dim3((unsigned)(B * C)), dim3(256), 0, st, grad_out, a0, s0, a1, s1, grad_a0, grad_a1,
+                           grad_x, grad_s0, grad_s1, C, HW / 4);
+    }
+    return check_launch("scale_residual_cat_bwd");
+}

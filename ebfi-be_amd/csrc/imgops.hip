@@ -74,6 +74,109 @@ __global__ void gauss5_bwd_kernel(const float *__restrict__ gout, float *__restr
     gin[idx] = acc * factor;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// census (Ternary) loss, reference loss/restore.py:108-145 with patch 7:
+//   g = mean_c(img);  d_k(q) = g(q + k) - g(q) over the 49 taps k (zero outside the image);
+//   t = d / sqrt(0.81 + d^2);  u = t_x - t_y;  dist(q) = mean_k u^2 / (0.1 + u^2);
+//   loss = sum_{q interior by 3} dist(q) / (B*H*W).
+// The reference materialises five [B,49,H,W] tensors per image; here a 16x16 pixel tile keeps the two gray
+// images (halo 3, zeros outside the image) in LDS, the forward writes one partial sum per tile (reduced in
+// fixed order by the caller) and the backward recomputes the 49-tap terms instead of storing them.
+constexpr int CT = 16, CR = 3, CTW = CT + 2 * CR;   // tile, halo, LDS tile width
+
+__device__ __forceinline__ void census_stage(const float *__restrict__ x, const float *__restrict__ y, int C, int H, int W,
+                                             int b, int ty0, int tx0, float (*gx)[CTW + 1], float (*gy)[CTW + 1]) {
+    const int64_t hw = (int64_t)H * W;
+    const float invc = 1.f / (float)C;
+    for (int i = threadIdx.x; i < CTW * CTW; i += CT * CT) {
+        const int ly = i / CTW, lx = i - ly * CTW;
+        const int py = ty0 + ly - CR, px = tx0 + lx - CR;
+        float sx = 0.f, sy = 0.f;
+        if (py >= 0 && py < H && px >= 0 && px < W) {
+            const int64_t o = (int64_t)b * C * hw + (int64_t)py * W + px;
+            for (int c = 0; c < C; ++c) {
+                sx += x[o + c * hw];
+                sy += y[o + c * hw];
+            }
+            sx *= invc;
+            sy *= invc;
+        }
+        gx[ly][lx] = sx;
+        gy[ly][lx] = sy;
+    }
+}
+
+__device__ __forceinline__ float census_t(float d) { return d * rsqrtf(0.81f + d * d); }
+
+__global__ __launch_bounds__(CT *CT) void census_fwd_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                            float *__restrict__ partial, int C, int H, int W) {
+    __shared__ float gx[CTW][CTW + 1], gy[CTW][CTW + 1];
+    __shared__ float red[4];
+    const int b = blockIdx.z, ty0 = blockIdx.y * CT, tx0 = blockIdx.x * CT;
+    census_stage(x, y, C, H, W, b, ty0, tx0, gx, gy);
+    __syncthreads();
+    const int ly = threadIdx.x / CT, lx = threadIdx.x % CT;
+    const int py = ty0 + ly, px = tx0 + lx;
+    float acc = 0.f;
+    if (py >= CR && py < H - CR && px >= CR && px < W - CR) {
+        const float cx = gx[ly + CR][lx + CR], cy = gy[ly + CR][lx + CR];
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const float u = census_t(gx[ly + i][lx + j] - cx) - census_t(gy[ly + i][lx + j] - cy);
+                const float q = u * u;
+                acc += q / (0.1f + q);
+            }
+        acc *= (1.f / 49.f);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        partial[((int64_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// dL/dd of one (pixel q, tap) term given the two differences; scale applied by the caller
+__device__ __forceinline__ float census_dterm(float dx, float dy) {
+    const float rx = rsqrtf(0.81f + dx * dx);
+    const float u = dx * rx - census_t(dy);
+    const float den = 0.1f + u * u;
+    return (0.2f * u / (den * den)) * (0.81f * rx * rx * rx);
+}
+
+// grad_x[b,c,p] = (1/C) * scale * ( sum_k G(p-k, k) - sum_k G(p, k) ),  scale = grad_loss / (49*B*H*W),
+// G(q,k) = [q interior] * census_dterm(gx(q+k) - gx(q), gy(q+k) - gy(q))
+__global__ __launch_bounds__(CT *CT) void census_bwd_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                            const float *__restrict__ grad_loss, float *__restrict__ grad_x,
+                                                            int C, int H, int W, float norm) {
+    __shared__ float gx[CTW][CTW + 1], gy[CTW][CTW + 1];
+    const int b = blockIdx.z, ty0 = blockIdx.y * CT, tx0 = blockIdx.x * CT;
+    census_stage(x, y, C, H, W, b, ty0, tx0, gx, gy);
+    __syncthreads();
+    const int ly = threadIdx.x / CT, lx = threadIdx.x % CT;
+    const int py = ty0 + ly, px = tx0 + lx;
+    if (py >= H || px >= W) return;
+    const float cx = gx[ly + CR][lx + CR], cy = gy[ly + CR][lx + CR];
+    const bool self_in = py >= CR && py < H - CR && px >= CR && px < W - CR;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            // this pixel as the tap (i,j) of centre q = p - k, i.e. q = (py - (i-3), px - (j-3))
+            const int qy = py - (i - CR), qx = px - (j - CR);
+            if (qy >= CR && qy < H - CR && qx >= CR && qx < W - CR)
+                acc += census_dterm(cx - gx[ly + 2 * CR - i][lx + 2 * CR - j], cy - gy[ly + 2 * CR - i][lx + 2 * CR - j]);
+            // this pixel as the centre of its own 49 terms
+            if (self_in) acc -= census_dterm(gx[ly + i][lx + j] - cx, gy[ly + i][lx + j] - cy);
+        }
+    const float g = acc * norm * grad_loss[0] / (float)C;
+    const int64_t hw = (int64_t)H * W;
+    for (int c = 0; c < C; ++c) grad_x[((int64_t)b * C + c) * hw + (int64_t)py * W + px] = g;
+}
+
 }  // namespace
 
 extern "C" int ebfi_gauss5_forward(const float *input, float *output, int64_t planes, int H, int W, float factor,
@@ -103,4 +206,35 @@ extern "C" int ebfi_gauss5_backward(const float *grad_output, float *grad_input,
                            planes, H, W, factor);
     }
     return check_launch("gauss5_bwd");
+}
+
+extern "C" int64_t ebfi_census_partials(int B, int H, int W) { return (int64_t)B * ceil_div(H, CT) * ceil_div(W, CT); }
+
+// partial[ebfi_census_partials(B,H,W)]: per-tile sums of dist over interior pixels; loss = sum(partial) / (B*H*W)
+extern "C" int ebfi_census_forward(const float *x, const float *y, float *partial, int B, int C, int H, int W, void *stream) {
+    if (!x || !y || !partial) return fail(EBFI_ERR_ARG, "census_forward: null argument");
+    if (B < 0 || C <= 0 || H <= 0 || W <= 0 || B > 65535) return fail(EBFI_ERR_ARG, "census_forward: bad dimensions");
+    if (B == 0) return EBFI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    {
+        ProfScope ps("census_fwd", st, 0.0, 8.0 * B * C * (double)H * W);
+        hipLaunchKernelGGL(census_fwd_kernel, dim3(ceil_div(W, CT), ceil_div(H, CT), B), dim3(CT * CT), 0, st, x, y, partial, C, H, W);
+    }
+    return check_launch("census_fwd");
+}
+
+// grad_x = d loss / d x given grad_loss (a 1-element device array); y is treated as a constant (detached target)
+extern "C" int ebfi_census_backward(const float *x, const float *y, const float *grad_loss, float *grad_x, int B, int C, int H,
+                                    int W, void *stream) {
+    if (!x || !y || !grad_loss || !grad_x) return fail(EBFI_ERR_ARG, "census_backward: null argument");
+    if (B < 0 || C <= 0 || H <= 0 || W <= 0 || B > 65535) return fail(EBFI_ERR_ARG, "census_backward: bad dimensions");
+    if (B == 0) return EBFI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float norm = (float)(1.0 / (49.0 * (double)B * (double)H * (double)W));
+    {
+        ProfScope ps("census_bwd", st, 0.0, 12.0 * B * C * (double)H * W);
+        hipLaunchKernelGGL(census_bwd_kernel, dim3(ceil_div(W, CT), ceil_div(H, CT), B), dim3(CT * CT), 0, st, x, y, grad_loss,
+                           grad_x, C, H, W, norm);
+    }
+    return check_launch("census_bwd");
 }

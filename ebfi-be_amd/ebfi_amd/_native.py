@@ -51,9 +51,14 @@ SIGNATURES = {
     "ebfi_events_to_stack": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ebfi_frame2lap": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "ebfi_frame2dcp": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ebfi_scale_residual_cat_forward": (_i, [_vp] * 6 + [_i, _i, _i64, _vp]),
+    "ebfi_scale_residual_cat_backward": (_i, [_vp] * 10 + [_i, _i, _i64, _vp]),
     "ebfi_groupnorm_workspace": (_sz, [_i, _i]),
     "ebfi_groupnorm_forward": (_i, [_vp] * 6 + [_i, _i, _i64, _i, _c.c_float, _vp, _sz, _vp]),
     "ebfi_groupnorm_backward": (_i, [_vp] * 8 + [_i, _i, _i64, _i, _vp, _sz, _vp]),
+    "ebfi_census_partials": (_i64, [_i, _i, _i]),
+    "ebfi_census_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ebfi_census_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ebfi_gauss5_forward": (_i, [_vp, _vp, _i64, _i, _i, _c.c_float, _vp]),
     "ebfi_gauss5_backward": (_i, [_vp, _vp, _i64, _i, _i, _c.c_float, _vp]),
     "ebfi_prof_enable": (None, [_i]),

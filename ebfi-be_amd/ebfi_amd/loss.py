@@ -1,8 +1,9 @@
 """Training loss of the hot path (device side).
 
 Reference: loss/restore.py:149-213 (LaplacianLoss: 5-level Laplacian pyramid, L1 *sum*, level
-weight 2**i), :111-145 (Ternary census, 7x7), combined as in train_ours.py:258-268.  Elementwise /
-shifted-slice PyTorch ops (no library convolution); a fused kernel is section 8(f) rank 3.
+weight 2**i), :111-145 (Ternary census, 7x7), combined as in train_ours.py:258-268.  On the GPU the 5x5
+blur and the whole census term run as kernel pairs of libebfi_hip.so (csrc/imgops.hip); CPU tensors (host-logic
+tests) take the equivalent shifted-slice formulation below.
 """
 import torch
 import torch.nn as nn
@@ -36,6 +37,33 @@ class _Gauss5(torch.autograd.Function):
                                               N.stream_ptr(g.device))
         N.check(rc, "ebfi_gauss5_backward")
         return gin, None
+
+
+class _Census(torch.autograd.Function):
+    """Whole Ternary loss (transform of both images, distance, mask, mean) on the kernel pair of csrc/imgops.hip."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = x.contiguous(), y.contiguous()
+        B, C, H, W = x.shape
+        lib = N.lib()
+        partial = torch.empty(int(lib.ebfi_census_partials(B, H, W)), dtype=torch.float32, device=x.device)
+        with torch.cuda.device_of(x):
+            rc = lib.ebfi_census_forward(N.ptr(x), N.ptr(y), N.ptr(partial), B, C, H, W, N.stream_ptr(x.device))
+        N.check(rc, "ebfi_census_forward")
+        ctx.save_for_backward(x, y)
+        return partial.sum() / float(B * H * W)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        B, C, H, W = x.shape
+        g = g.contiguous().float().reshape(1)
+        gx = torch.empty_like(x)
+        with torch.cuda.device_of(x):
+            rc = N.lib().ebfi_census_backward(N.ptr(x), N.ptr(y), N.ptr(g), N.ptr(gx), B, C, H, W, N.stream_ptr(x.device))
+        N.check(rc, "ebfi_census_backward")
+        return gx, None
 
 
 class GaussianConv(nn.Module):
@@ -108,6 +136,9 @@ class Ternary(nn.Module):
         return d / torch.sqrt(0.81 + d ** 2)
 
     def forward(self, x, y, y_transform=None):
+        if x.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32 and self.patch_size == 7 and \
+                not y.requires_grad and x.shape[-1] > 6 and x.shape[-2] > 6:
+            return _Census.apply(x, y)
         ty = y_transform if y_transform is not None else self.transform(y).detach()
         diff = self.transform(x) - ty
         dist = (diff ** 2 / (0.1 + diff ** 2)).mean(dim=1, keepdim=True)
@@ -127,7 +158,7 @@ class TrainLoss(nn.Module):
     def forward(self, sharp_pre, sharp, target, iteration=0, accu_step=1):
         with torch.no_grad():     # the target side of both terms is the same: compute it once
             yp = self.Lap.lap(target)
-            ty = self.census.transform(target)
+            ty = None if target.is_cuda else self.census.transform(target)   # the GPU census kernel works on the images
         term = lambda p: self.Lap(p, target, yp) + self.census(p, target, ty)
         if not self.detail_enabled:
             return term(sharp) / accu_step

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import conv, fold3d, norm
+from . import conv, fold3d, fused, norm
 from .blur import Frame2DCP, Frame2Lap
 from .fac import KernelConv2D
 
@@ -154,9 +154,8 @@ class ResidualControl(BaseModel):
         ex, t = Ex[:, :, None, None], T[:, :, None, None]
         x = data
         for i in range(self.step):
-            by_ex = self.Conv1[i](ex) * self.Conv3[i](x) + x
-            by_t = self.Conv2[i](t) * self.Conv4[i](x) + x
-            x = self.Conv5[i](torch.cat([by_ex, by_t], dim=1))
+            # cat([Conv1(ex)*Conv3(x) + x, Conv2(t)*Conv4(x) + x], 1) as one fused stage
+            x = self.Conv5[i](fused.scale_residual_cat(self.Conv3[i](x), self.Conv1[i](ex), self.Conv4[i](x), self.Conv2[i](t), x))
         return x
 
 

@@ -22,7 +22,9 @@
  *       models/DCNv2/src/dcn_v2.h:9-92, src/vision.cpp:4-9, src/cuda/dcn_v2_cuda.cu:20-216,
  *       src/cuda/dcn_v2_im2col_cuda.cu:125-402
  *   ebfi_conv2d_*               nn.Conv2d + activation inside ConvLayer (models/model_misc/submodules.py:159-200)
+ *   ebfi_scale_residual_cat_*   exposure/time-scaled residual + concat of ResidualControl (model_singleframe.py:124-134)
  *   ebfi_groupnorm_*            nn.GroupNorm of ExposureDecision (models/Ours/model_singleframe.py:36,66-67)
+ *   ebfi_census_*               Ternary census loss (loss/restore.py:108-145)
  *   ebfi_gauss5_*               GaussianConv of the Laplacian-pyramid loss (loss/restore.py:149-163)
  *   ebfi_events_to_stack        dataloader/encodings.py:307-350 (events_to_stack)
  *   ebfi_frame2lap / _frame2dcp myutils/utils.py:34-49 / :15-31
@@ -168,6 +170,16 @@ int ebfi_frame2lap(const float *frame, float *out, int B, int H, int W, void *st
 int ebfi_frame2dcp(const float *frame, float *out, float *scratch /* [B,H,W] */, int B, int H, int W,
                    int window, void *stream);
 
+/* ------------------------------------------------------------------ fused stages between the convolutions
+ * One round of ResidualControl (models/Ours/model_singleframe.py:124-134):
+ *   out[:, :C] = s0[b,c] * a0 + x,  out[:, C:] = s1[b,c] * a1 + x      (a0/a1/x [B,C,H,W], s0/s1 [B,C], out [B,2C,H,W])
+ * backward is its adjoint (grad_s* reduced per plane in fixed order).  HW = H*W, a multiple of 4. */
+int ebfi_scale_residual_cat_forward(const float *a0, const float *s0, const float *a1, const float *s1, const float *x,
+                                    float *out, int B, int C, int64_t HW, void *stream);
+int ebfi_scale_residual_cat_backward(const float *grad_out, const float *a0, const float *s0, const float *a1,
+                                     const float *s1, float *grad_a0, float *grad_a1, float *grad_x,
+                                     float *grad_s0, float *grad_s1, int B, int C, int64_t HW, void *stream);
+
 /* ------------------------------------------------------------------ GroupNorm (exposure-decision head)
  * nn.GroupNorm(groups, C) on contiguous NCHW fp32 (reference models/Ours/model_singleframe.py:36,66-67).
  * HW = H*W must be a multiple of 4.  mean / rstd [B*groups] are written by forward and read by backward.
@@ -189,6 +201,15 @@ int ebfi_groupnorm_backward(const float *grad_y, const float *x, const float *ga
 int ebfi_gauss5_forward(const float *input, float *output, int64_t planes, int H, int W, float factor, void *stream);
 int ebfi_gauss5_backward(const float *grad_output, float *grad_input, int64_t planes, int H, int W, float factor,
                          void *stream);
+
+/* Census (Ternary, 7x7) loss of loss/restore.py:108-145 on [B,C,H,W] fp32 images, gray = channel mean.
+ * forward writes ebfi_census_partials(B,H,W) per-tile sums; loss = sum(partial) / (B*H*W) (summed by the caller
+ * in fixed order -> deterministic).  backward: grad_x = grad_loss[0] * d loss / d x; y is a constant (the
+ * reference detaches the target transform, restore.py:138). */
+int64_t ebfi_census_partials(int B, int H, int W);
+int ebfi_census_forward(const float *x, const float *y, float *partial, int B, int C, int H, int W, void *stream);
+int ebfi_census_backward(const float *x, const float *y, const float *grad_loss, float *grad_x,
+                         int B, int C, int H, int W, void *stream);
 
 /* ------------------------------------------------------------------ per-kernel device timing
  * When enabled, every launch made by this library is bracketed by a hipEvent pair recorded on the

@@ -166,3 +166,39 @@ def test_groupnorm_kernels_vs_torch_cpu():
         assert _rel(out.detach(), ref.detach()) < 1e-5
         assert _rel(xd.grad, x.grad) < 2e-5
         assert _rel(gnd.weight.grad, gn.weight.grad) < 2e-5 and _rel(gnd.bias.grad, gn.bias.grad) < 2e-5
+
+
+def test_census_kernel_pair_vs_slice_formulation():
+    from ebfi_amd.loss import Ternary
+    torch.manual_seed(9)
+    tern = Ternary()
+    for (B, C, H, W) in [(2, 3, 20, 37), (1, 3, 16, 16), (1, 1, 7, 9), (2, 3, 64, 48)]:
+        x = torch.rand(B, C, H, W, requires_grad=True)
+        y = torch.rand(B, C, H, W)
+        ref = tern(x, y)                       # CPU tensors: slice formulation (pinned by tests/golden/loss_small.npz)
+        (ref * 3.0).backward()
+        xd = x.detach().cuda().requires_grad_()
+        out = tern.cuda()(xd, y.cuda())
+        (out * 3.0).backward()
+        tern.cpu()
+        assert abs(out.item() - ref.item()) <= 2e-6 + 1e-5 * abs(ref.item())
+        assert _rel(xd.grad, x.grad) < 5e-5
+
+
+def test_scale_residual_cat_kernel_pair():
+    from ebfi_amd.fused import scale_residual_cat
+    torch.manual_seed(11)
+    for (B, C, H, W) in [(2, 4, 8, 8), (3, 16, 12, 20), (1, 64, 32, 32)]:
+        cpu = [torch.randn(B, C, H, W), torch.randn(B, C, 1, 1), torch.randn(B, C, H, W), torch.randn(B, C, 1, 1),
+               torch.randn(B, C, H, W)]
+        ref_in = [t.clone().requires_grad_() for t in cpu]
+        a0, s0, a1, s1, x = ref_in
+        ref = torch.cat([s0 * a0 + x, s1 * a1 + x], dim=1)
+        g = torch.randn_like(ref)
+        ref.backward(g)
+        dev_in = [t.cuda().requires_grad_() for t in cpu]
+        out = scale_residual_cat(*dev_in)
+        out.backward(g.cuda())
+        assert _rel(out.detach(), ref.detach()) < 1e-6
+        for d, r in zip(dev_in, ref_in):
+            assert d.grad.shape == r.grad.shape and _rel(d.grad, r.grad) < 1e-5
