@@ -69,6 +69,20 @@ __global__ __launch_bounds__(256) void src_bwd_kernel(const float *__restrict__ 
     }
 }
 
+// out[i] = sum_r src[idx[i*R + r]]  (idx < 0: structural zero).  Used for the weight re-layouts ("folds") of the
+// depth-2 3-D convolutions: forward map with R = 1, its transpose with R = max fan-out of a source element.
+__global__ void gather_sum_kernel(const float *__restrict__ src, const int *__restrict__ idx, float *__restrict__ out,
+                                  int64_t n_out, int R) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    float acc = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const int j = idx[i * R + r];
+        if (j >= 0) acc += src[j];
+    }
+    out[i] = acc;
+}
+
 int check_planes(const char *who, int B, int C, int64_t HW) {
     if (B < 0 || C <= 0 || HW <= 0) return fail(EBFI_ERR_ARG, "%s: bad dimensions", who);
     if (HW % 4 != 0) return fail(EBFI_ERR_UNSUPPORTED, "%s: H*W must be a multiple of 4 (got %lld)", who, (long long)HW);
@@ -109,4 +123,14 @@ extern "C" int ebfi_scale_residual_cat_backward(const float *grad_out, const flo
                            grad_x, grad_s0, grad_s1, C, HW / 4);
     }
     return check_launch("scale_residual_cat_bwd");
+}
+
+// out[i] = sum_{r<R} src[idx[i*R+r]] with negative indices skipped (idx [n_out*R] int32; caller guarantees idx < len(src))
+extern "C" int ebfi_gather_sum(const float *src, const int32_t *idx, float *out, int64_t n_out, int R, void *stream) {
+    if (!src || !idx || !out) return fail(EBFI_ERR_ARG, "gather_sum: null argument");
+    if (n_out < 0 || R <= 0) return fail(EBFI_ERR_ARG, "gather_sum: bad dimensions");
+    if (n_out == 0) return EBFI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(gather_sum_kernel, dim3((unsigned)ceil_div(n_out, 256)), dim3(256), 0, st, src, idx, out, n_out, R);
+    return check_launch("gather_sum");
 }

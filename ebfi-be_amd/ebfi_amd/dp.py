@@ -89,13 +89,17 @@ class FlatGradBucket:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
         return self.flat
 
-    def all_reduce_mean(self):
-        """gather() + average over ranks in place (one collective; no-op on one rank).  Returns the flat buffer."""
-        self.gather()
+    def reduce_mean_packed(self):
+        """Average the already packed buffer over ranks in place (one collective; no-op on one rank)."""
         if is_distributed():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.mul_(1.0 / dist.get_world_size())
         return self.flat
+
+    def all_reduce_mean(self):
+        """gather() + average over ranks in place.  Returns the flat buffer."""
+        self.gather()
+        return self.reduce_mean_packed()
 
     def views_intact(self):
         """True while every param.grad aliases the flat buffer (debug / test helper)."""

@@ -33,7 +33,7 @@ def synthetic_batch(B, H, W, TB=16, device="cuda", seed=123, rank=0):
 
 
 class Engine:
-    def __init__(self, model_args=None, device="cuda", precision="fp32", lr=1e-4, seed=None, train=True):
+    def __init__(self, model_args=None, device="cuda", precision="fp32", lr=1e-4, seed=None, train=True, graph=False):
         if precision not in ("fp32", "bf16"):
             raise ValueError("precision must be 'fp32' or 'bf16'")
         self.device = torch.device(device)
@@ -44,6 +44,10 @@ class Engine:
         self.model = EVFIAutoEx(**self.model_args).to(self.device)
         broadcast_parameters(self.model, 0)
         self.iteration = 0
+        # graph=True: forward + loss + backward + gradient packing are captured once into a hipGraph (per input shape,
+        # precision and loss phase) and replayed; the all-reduce and the optimiser step stay eager (train_step_graph).
+        self.use_graph = bool(graph) and self.device.type == "cuda"
+        self._graphs = {}
         if train:
             self.model.train()
             self.loss = TrainLoss(self.model_args.get("DetailEnabled", True)).to(self.device)
@@ -66,17 +70,62 @@ class Engine:
         finally:
             conv.set_compute_dtype(prev)
 
-    def train_step(self, frame, event, t, gtex, target):
-        """One optimiser step on this rank's batch; returns the (unreduced) loss tensor."""
-        self.bucket.zero()
+    def _fwd_bwd(self, frame, event, t, gtex, target):
         with self._autocast():
             sharp_pre, sharp = self.model(frame, event, t, gtex)
             loss = self.loss(sharp_pre.float(), sharp.float(), target, self.iteration)
             loss.backward()
+        return loss.detach()
+
+    def train_step(self, frame, event, t, gtex, target):
+        """One optimiser step on this rank's batch; returns the (unreduced) loss tensor."""
+        if self.use_graph:
+            return self.train_step_graph(frame, event, t, gtex, target)
+        self.bucket.zero()
+        loss = self._fwd_bwd(frame, event, t, gtex, target)
         self.bucket.all_reduce_mean()
         self.optimizer.step()
         self.iteration += 1
-        return loss.detach()
+        return loss
+
+    def train_step_graph(self, frame, event, t, gtex, target):
+        """Same step with the ~2000 launches of forward + loss + backward + gradient packing replayed from one
+        hipGraph.  Inputs are copied into static buffers; gradients live in the graph's memory pool, `param.grad`
+        are views of the packed buffer, so the eager all-reduce / Adam that follow see ordinary tensors."""
+        inputs = (frame, event, t, gtex, target)
+        phase = self.iteration < 10e3                      # TrainLoss switches its weighting at 10k iterations
+        key = (self.precision, phase) + tuple((tuple(v.shape), v.dtype) for v in inputs)
+        entry = self._graphs.get(key)
+        if entry is None:
+            static_in = [torch.empty_like(v) for v in inputs]
+            for s, v in zip(static_in, inputs):
+                s.copy_(v)
+            side = torch.cuda.Stream(self.device)          # warm-up off the default stream (allocator, lazy inits)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self.bucket.zero()
+                    self._fwd_bwd(*static_in)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            self.bucket.zero()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                loss = self._fwd_bwd(*static_in)
+                flat = self.bucket.gather()
+            entry = (graph, static_in, loss, flat, [p.grad for p in self.bucket.params])
+            self._graphs[key] = entry
+        graph, static_in, loss, flat, grads = entry
+        for s, v in zip(static_in, inputs):
+            if s.data_ptr() != v.data_ptr():
+                s.copy_(v)
+        graph.replay()
+        self.bucket.flat = flat
+        for p, g in zip(self.bucket.params, grads):        # (another shape's graph may have re-pointed them)
+            p.grad = g
+        self.bucket.reduce_mean_packed()
+        self.optimizer.step()
+        self.iteration += 1
+        return loss.clone()
 
     @torch.no_grad()
     def infer(self, frame, event, t, gtex=None):

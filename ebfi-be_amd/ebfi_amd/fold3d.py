@@ -11,13 +11,17 @@ stride 1, depth padding 1 for depth-3 kernels).  A contiguous [B, C, 2, H, W] te
                                   ==  Conv2d 3x3 (pad 1) to 8*Cout channels + PixelShuffle(2):
                                       output parity (py,px) picks 2x2 of the 4x4 taps
 
-The folds are tiny differentiable tensor ops on the weights (autograd routes the gradient back to
-the original Conv3d / ConvTranspose3d parameters, so state_dict and optimizer are untouched); the
-convolutions themselves run through ebfi_amd.conv (fused bias + activation).
+The folds are 0/1 linear maps on the weights (autograd routes the gradient back to the original
+Conv3d / ConvTranspose3d parameters, so state_dict and optimizer are untouched).  ``fold_*_weight`` below
+state them as tensor ops; on the GPU they run as ONE gather launch each way (`ebfi_gather_sum`) through
+index tables derived once per weight shape by pushing element ids through those same tensor ops.
+The convolutions themselves run through ebfi_amd.conv (fused bias + activation).
 """
+import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import _native as N
 from . import conv
 
 
@@ -39,6 +43,67 @@ def fold_conv3d_weight(w):
     return torch.stack([d0, d1], dim=1).reshape(2 * Co, 2 * Ci, kh, kw)
 
 
+_MAPS = {}
+
+
+def _index_tables(kind, fold_fn, shape, device):
+    """(forward idx [n_out] int32, adjoint idx [n_src, R] int32, folded shape) of the 0/1 map `fold_fn`."""
+    key = (kind, tuple(shape), str(device))
+    if key not in _MAPS:
+        n = int(np.prod(shape))
+        ids = torch.arange(1, n + 1, dtype=torch.float64).view(*shape)       # element id + 1; 0 = structural zero
+        folded = fold_fn(ids)
+        fwd = folded.round().to(torch.int64).flatten().numpy() - 1
+        dest = np.nonzero(fwd >= 0)[0]
+        order = np.argsort(fwd[dest], kind="stable")
+        srcs, dest = fwd[dest][order], dest[order]
+        counts = np.bincount(srcs, minlength=n)
+        R = int(max(1, counts.max()))
+        starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
+        inv = np.full((n, R), -1, dtype=np.int32)
+        inv[srcs, np.arange(len(srcs)) - starts[srcs]] = dest
+        _MAPS[key] = (torch.from_numpy(fwd.astype(np.int32)).to(device), torch.from_numpy(inv).to(device), R,
+                      tuple(folded.shape))
+    return _MAPS[key]
+
+
+class _LinearMap(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, fwd_idx, inv_idx, R, out_shape):
+        w = w.contiguous()
+        out = torch.empty(out_shape, dtype=w.dtype, device=w.device)
+        with torch.cuda.device_of(w):
+            rc = N.lib().ebfi_gather_sum(N.ptr(w), N.ptr(fwd_idx), N.ptr(out), out.numel(), 1, N.stream_ptr(w.device))
+        N.check(rc, "ebfi_gather_sum")
+        ctx.inv, ctx.R, ctx.in_shape = inv_idx, R, w.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        gw = torch.empty(ctx.in_shape, dtype=g.dtype, device=g.device)
+        with torch.cuda.device_of(g):
+            rc = N.lib().ebfi_gather_sum(N.ptr(g), N.ptr(ctx.inv), N.ptr(gw), gw.numel(), ctx.R, N.stream_ptr(g.device))
+        N.check(rc, "ebfi_gather_sum")
+        return gw, None, None, None, None
+
+
+def folded(kind, fold_fn, w):
+    """`fold_fn(w)`; for fp32 GPU tensors through the cached index tables (one launch forward, one backward)."""
+    if not (w.is_cuda and w.dtype == torch.float32):
+        return fold_fn(w)
+    fwd_idx, inv_idx, R, out_shape = _index_tables(kind, fold_fn, w.shape, w.device)
+    return _LinearMap.apply(w, fwd_idx, inv_idx, R, out_shape)
+
+
+def _rep2(b):
+    return b.repeat_interleave(2)
+
+
+def _rep8(b):
+    return b.repeat_interleave(8)
+
+
 def conv3d_d2(x, m, act=conv.ACT_NONE, slope=0.0):
     """x [B,Ci,2,H,W] through nn.Conv3d `m` (+ fused activation) -> [B,Co,2,Ho,Wo]."""
     B, Ci, D, H, W = x.shape
@@ -50,8 +115,8 @@ def conv3d_d2(x, m, act=conv.ACT_NONE, slope=0.0):
     if kh == 1 and s != 1:                               # 1x1 strided shortcut: subsample, then 1x1
         x2 = x2[:, :, ::s, ::s].contiguous()
         s = 1
-    b2 = m.bias.repeat_interleave(2) if m.bias is not None else None
-    y2 = conv.conv_bias_act(x2, fold_conv3d_weight(m.weight), b2, s, m.padding[1], act, slope)
+    b2 = folded("rep2", _rep2, m.bias) if m.bias is not None else None
+    y2 = conv.conv_bias_act(x2, folded("conv3d", fold_conv3d_weight, m.weight), b2, s, m.padding[1], act, slope)
     return y2.view(B, m.out_channels, 2, y2.shape[-2], y2.shape[-1])
 
 
@@ -83,8 +148,9 @@ def conv_transpose3d_d2(x, m):
     B, Ci, D, H, W = x.shape
     assert D == 2 and m.kernel_size == (3, 4, 4) and m.stride == (1, 2, 2) and m.padding == (1, 1, 1)
     assert m.output_padding == (0, 0, 0) and m.dilation == (1, 1, 1) and m.groups == 1
-    b8 = m.bias.repeat_interleave(8) if m.bias is not None else None
-    y = conv.conv_bias_act(x.reshape(B, 2 * Ci, H, W), fold_conv_transpose3d_weight(m.weight), b8, 1, 1, conv.ACT_NONE, 0.0)
+    b8 = folded("rep8", _rep8, m.bias) if m.bias is not None else None
+    y = conv.conv_bias_act(x.reshape(B, 2 * Ci, H, W), folded("convT3d", fold_conv_transpose3d_weight, m.weight), b8, 1, 1,
+                           conv.ACT_NONE, 0.0)
     return F.pixel_shuffle(y, 2).view(B, m.out_channels, 2, 2 * H, 2 * W)
 
 

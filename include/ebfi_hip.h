@@ -180,6 +180,11 @@ int ebfi_scale_residual_cat_backward(const float *grad_out, const float *a0, con
                                      const float *s1, float *grad_a0, float *grad_a1, float *grad_x,
                                      float *grad_s0, float *grad_s1, int B, int C, int64_t HW, void *stream);
 
+/* Sparse 0/1 linear map: out[i] = sum_{r<R} src[idx[i*R+r]], negative indices skipped.  Carries the weight
+ * re-layouts that turn the depth-2 Conv3d / ConvTranspose3d of the detail branch (models/model_misc/resnet_3D.py,
+ * model_singleframe.py:170-223) into 2-D convolutions, and their adjoints. */
+int ebfi_gather_sum(const float *src, const int32_t *idx, float *out, int64_t n_out, int R, void *stream);
+
 /* ------------------------------------------------------------------ GroupNorm (exposure-decision head)
  * nn.GroupNorm(groups, C) on contiguous NCHW fp32 (reference models/Ours/model_singleframe.py:36,66-67).
  * HW = H*W must be a multiple of 4.  mean / rstd [B*groups] are written by forward and read by backward.

@@ -52,3 +52,20 @@ def test_bench_two_rank_rehearsal():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["cpu_baseline"] is None and d["roofline"]["kernel"].startswith("conv_")
+
+
+def test_graph_replay_step_equals_eager_step():
+    """Engine(graph=True) replays fwd + loss + bwd + gradient packing from one hipGraph: same losses and
+    parameters as the eager engine over several steps (inputs change between steps)."""
+    import torch
+    from ebfi_amd.engine import Engine, synthetic_batch
+    cfg = dict(step=2, channels=[8, 8, 16, 16])
+    engines = [Engine(cfg, device="cuda", seed=7, graph=g) for g in (False, True)]
+    engines[1].model.load_state_dict(engines[0].model.state_dict())
+    for it in range(4):
+        batch = synthetic_batch(2, 64, 64, device="cuda", seed=100 + it)
+        losses = [e.train_step(*batch) for e in engines]
+        assert torch.allclose(losses[0], losses[1], rtol=1e-5, atol=0), (it, losses)
+    assert len(engines[1]._graphs) == 1 and engines[1].bucket.views_intact()
+    for (n, a), b in zip(engines[0].model.named_parameters(), engines[1].model.parameters()):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), n

@@ -135,3 +135,24 @@ def test_flat_bucket_single_process():
     assert torch.equal(net.weight.grad.reshape(-1), before[:6] * 2)      # .grad are views of the flat buffer
     b.zero()
     assert net.weight.grad is None and net.bias.grad is None
+
+
+def test_fold_index_tables_reproduce_the_tensor_folds():
+    """The gather tables the GPU path uses for the Conv3d/ConvTranspose3d weight folds are derived from the
+    tensor-op statement of the folds; applied with plain indexing they must reproduce it and its adjoint."""
+    from ebfi_amd import fold3d
+    torch.manual_seed(2)
+    cases = [("conv3d", fold3d.fold_conv3d_weight, (4, 3, 3, 3, 3)), ("conv3d", fold3d.fold_conv3d_weight, (4, 3, 1, 1, 1)),
+             ("conv3d", fold3d.fold_conv3d_weight, (2, 3, 3, 7, 7)), ("convT3d", fold3d.fold_conv_transpose3d_weight, (3, 2, 3, 4, 4)),
+             ("rep2", fold3d._rep2, (5,)), ("rep8", fold3d._rep8, (3,))]
+    for kind, fn, shape in cases:
+        fwd, inv, R, oshape = fold3d._index_tables(kind, fn, shape, "cpu")
+        w = torch.randn(*shape, dtype=torch.float64, requires_grad=True)
+        ref = fn(w)
+        zero = torch.zeros(1, dtype=torch.float64)
+        got = torch.cat([w.detach().flatten(), zero])[fwd.long()].view(oshape)
+        assert torch.equal(got, ref.detach()), kind
+        g = torch.randn_like(ref)
+        ref.backward(g)
+        gw = torch.cat([g.flatten(), zero])[inv.long()].sum(-1).view(shape)
+        assert inv.shape == (w.numel(), R) and torch.allclose(gw, w.grad, atol=1e-12), kind
