@@ -61,6 +61,7 @@ def main():
     ap.add_argument("-seed", "--seed", type=int, default=123)
     ap.add_argument("--iterations", type=int, default=None)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--graph", action="store_true", help="replay forward+loss+backward from a captured hipGraph")
     args = ap.parse_args()
     with open(args.config) as fh:
         config = yaml.safe_load(fh)
@@ -71,7 +72,8 @@ def main():
     assert config["model"]["name"] == "EVFIAutoEx", "only the EVFIAutoEx hot path is implemented"
 
     eng = Engine(config["model"]["args"], device=device, precision=args.precision,
-                 lr=float(config["optimizer"]["args"]["lr"]), seed=args.seed)     # same init on every rank
+                 lr=float(config["optimizer"]["args"]["lr"]), seed=args.seed,      # same init on every rank
+                 graph=args.graph or bool(tr.get("graph", False)))
     start = 0
     if args.resume:
         cpt = torch.load(args.resume, map_location=device)
