@@ -478,6 +478,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const float *__restrict
 
     float rg[NG], ri[NI];
     float bsum = 0.f;                      // bias: channel (tid & 63), pixel-slot quarter (tid >> 6), all tiles
+    // grad_out * act'(y): the y values are fetched in NYG small groups spread over the MFMA block of the running
+    // tile, each multiplied into rg a few k-steps later.  Loading all of them up front next to rg/ri does not fit the
+    // register budget (the compiler then waits for them right away, i.e. for the whole prefetch, before the MFMAs).
+    constexpr int NYG = 4, YG = NG / NYG;
+    unsigned g0_next = SENT;
+    __amdgpu_buffer_rsrc_t rya_next = make_rsrc(gout, 0u);
+    float ry[YG];
+    auto dact_load = [&](int grp) {
+#pragma unroll
+        for (int j = 0; j < YG; ++j)
+            ry[j] = buf_ld(rya_next, g0_next + (unsigned)(4 * (grp * YG + j)) * (unsigned)HWo * 4u);
+    };
+    auto dact_apply = [&](int grp) {
+#pragma unroll
+        for (int j = 0; j < YG; ++j) rg[grp * YG + j] *= act_grad_c<DACT>(ry[j], dslope);
+    };
     auto prefetch = [&](int tile) {
         int t = tile;
         const int tx = t % tiles_x; t /= tiles_x;
@@ -494,13 +510,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const float *__restrict
         const int gy = y0 + gpy, gx = x0 + gpx;
         const unsigned g0 = (gpx < WTX && gy < g.Ho && gx < g.Wo)
                                 ? (unsigned)((co_base + gco) * HWo + gy * g.Wo + gx) * 4u : SENT;
+        g0_next = g0;
+        rya_next = rya;
 #pragma unroll
-        for (int it = 0; it < NG; ++it) {
-            const unsigned o = g0 + (unsigned)(4 * it) * (unsigned)HWo * 4u;   // channels >= Cout fall out of range
-            float v = buf_ld(rgo, o);
-            if constexpr (DACT != 0) v *= act_grad_c<DACT>(buf_ld(rya, o), dslope);
-            rg[it] = v;
-        }
+        for (int it = 0; it < NG; ++it)   // channels >= Cout fall out of range; the act' factor is applied later (dact_group)
+            rg[it] = buf_ld(rgo, g0 + (unsigned)(4 * it) * (unsigned)HWo * 4u);
         // input halo tile: this thread's column, rows r = 0..IH-1, channels irow, irow+TROWS, ...
         const int xx = ix0 + icol;
         const bool col_ok = icol < IW && xx >= 0 && xx < g.W;
@@ -539,6 +553,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const float *__restrict
     };
 
     prefetch(blockIdx.x);
+    if constexpr (DACT != 0) {             // first tile: no MFMA block to hide behind yet
+#pragma unroll
+        for (int grp = 0; grp < NYG; ++grp) {
+            dact_load(grp);
+            dact_apply(grp);
+        }
+    }
     for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
         __syncthreads();
         commit(tile);
@@ -554,15 +575,34 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const float *__restrict
         // k = output pixel; lane half h takes pixel 2*ks + h (same row: WTX is even)
         const float *ap = sG + (mt * 32 + (lane & 31)) * GS + (lane >> 5);
         const int bh = S * (lane >> 5);
+        auto ksteps = [&](int k0, int k1) {
 #pragma unroll
-        for (int ks = 0; ks < WTY * WTX / 2; ++ks) {
-            const int py = (2 * ks) / WTX, px = (2 * ks) % WTX;
-            const float a = ap[py * 32 + px];
-            const int poff = (S * py) * IWS + S * px + bh;
+            for (int ks = k0; ks < k1; ++ks) {
+                const int py = (2 * ks) / WTX, px = (2 * ks) % WTX;
+                const float a = ap[py * 32 + px];
+                const int poff = (S * py) * IWS + S * px + bh;
 #pragma unroll
-            for (int q = 0; q < NTW; ++q) {
-                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, sIn[boff[q] + poff], acc[q], 0, 0, 0);
+                for (int q = 0; q < NTW; ++q) {
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, sIn[boff[q] + poff], acc[q], 0, 0, 0);
+                }
             }
+        };
+        constexpr int KSTEPS = WTY * WTX / 2;
+        if constexpr (DACT != 0) {
+            constexpr int SEG = KSTEPS / (NYG + 1);       // k-steps between a group's loads and its multiply
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int grp = 0; grp < NYG; ++grp) {
+                dact_load(grp);
+                __builtin_amdgcn_sched_barrier(0);
+                ksteps(grp * SEG, (grp + 1) * SEG);
+                __builtin_amdgcn_sched_barrier(0);
+                dact_apply(grp);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            ksteps(NYG * SEG, KSTEPS);
+        } else {
+            ksteps(0, KSTEPS);
         }
     }
     // ---- write this workgroup's partial slab
@@ -871,8 +911,10 @@ int wgrad_cib_rt(int ks, int stride) { return ks == 7 ? 8 : (stride == 2 ? 32 : 
 int wgrad_splits(const ConvGeom &g, int ks, int stride, bool bf16mma = false) {
     const int64_t tiles = wgrad_tiles_rt(g, ks, stride);
     const int64_t blocks = ceil_div(g.Cout, 64) * ceil_div(g.Cin, bf16mma ? 32 : wgrad_cib_rt(ks, stride));
-    int64_t s = ceil_div(1024, blocks);          // aim at >= 1024 workgroups (4 per CU)
-    (void)bf16mma;
+    // The fp32 kernel is resident at 2 workgroups per CU (registers and LDS): 512 slots.  Fill ONE round of them as
+    // completely as possible -- e.g. 50 (co, ci) blocks x 10 splits = 500 -- rather than 1050 workgroups, whose third,
+    // almost empty round costs a full workgroup duration.  More than 512 (co, ci) blocks: no pixel split needed.
+    int64_t s = bf16mma ? ceil_div(1024, blocks) : (blocks <= 512 ? 512 / blocks : 1);
     if (s > tiles) s = tiles;
     if (s < 1) s = 1;
     if (s > 512) s = 512;
