@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16"],
                     help="fp32 = exact fp32 matrix cores (the parity-checked path, default); bf16 = bf16 operands for the convs")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel of the step eagerly instead of replaying the captured hipGraph")

@@ -254,8 +254,9 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
 
 // W fp32 -> packed bf16.  forward: Wp[tap][co][ci] = W[co][ci][tap];  TR: Wp[tap][m][k] = W[k][m][KK-1-tap]
 // (rows = our output channels M, cols = our contraction channels K padded to K16 with zeros)
+// split != 0: a second image with the rounding remainders follows, wp[total + idx] = bf16(w - float(bf16(w)))
 __global__ void conv_pack_w_bf16(const float *__restrict__ w, __bf16 *__restrict__ wp, int M, int K, int K16, int KK,
-                                 int transposed) {
+                                 int transposed, int split) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)KK * M * K16;
     if (idx >= total) return;
@@ -264,7 +265,9 @@ __global__ void conv_pack_w_bf16(const float *__restrict__ w, __bf16 *__restrict
     const int tap = (int)(idx / ((int64_t)K16 * M));
     float v = 0.f;
     if (k < K) v = transposed ? w[((int64_t)k * M + m) * KK + (KK - 1 - tap)] : w[((int64_t)m * K + k) * KK + tap];
-    wp[idx] = (__bf16)v;
+    const __bf16 h = (__bf16)v;
+    wp[idx] = h;
+    if (split) wp[total + idx] = (__bf16)(v - (float)h);
 }
 
 template <int KS, int MT, int DACT>
@@ -387,6 +390,171 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16(const float *__restrict__ x
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], bv[n], acc[m][n], 0, 0, 0);
+        }
+    }
+    const int yo = y0 + wave;
+    if (yo < g.Ho) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int xo = x0 + n * 32 + (lane & 31);
+                if (xo >= g.Wo) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co_base + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (co < g.Cout) {
+                        float v = acc[m][n][r];
+                        if (bias) v += bias[co];
+                        out[(((int64_t)b * g.Cout + co) * g.Ho + yo) * g.Wo + xo] = act_apply(v, act, slope);
+                    }
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Split-precision variant ("bf16x3"): every fp32 operand is carried as hi = bf16(v) and lo = bf16(v - hi), and a
+// product is accumulated as hi*hi + hi*lo + lo*hi on the bf16 matrix cores (fp32 accumulation).  The dropped lo*lo
+// term and the rounding of lo are ~2^-17 relative: results agree with the exact-fp32 kernels to ~1e-5, at 3/16 of
+// their MFMA time.  Both images cost the LDS bytes of fp32, so the tile is 8 rows x 64 px for 512 threads (one weight
+// slice per CU instead of two): 119 KB of LDS, one workgroup of 8 waves per CU.
+constexpr int TYB = 8, NTB = 512;
+
+template <int KS, int MT, int DACT>
+__global__ __launch_bounds__(NTB) void conv_fwd_bf16x3(const float *__restrict__ x, const float *__restrict__ dact_y,
+                                                       const __bf16 *__restrict__ wp, const float *__restrict__ bias,
+                                                       float *__restrict__ out, ConvGeom g, int K16, int act, float slope,
+                                                       float dslope) {
+    constexpr int S = 1;
+    constexpr int KK = KS * KS;
+    constexpr int IH = S * (TYB - 1) + KS, IW = S * (TX - 1) + KS;
+    constexpr int PS = IH * IW;            // positions of the staged input tile
+    constexpr int COS = 32 * MT;
+    constexpr int NPOS = (PS + NTB - 1) / NTB;
+    constexpr int WPIECES = KK * COS * 2;  // 16-byte pieces of ONE weight image (hi or lo)
+    constexpr int NWB = (2 * WPIECES + NTB - 1) / NTB;
+    constexpr int INE = PS * PITCH, WE = KK * COS * PITCH;   // elements per image
+    extern __shared__ __attribute__((aligned(16))) __bf16 smx[];
+    __bf16 *sInH = smx, *sInL = smx + INE, *sWH = smx + 2 * INE, *sWL = smx + 2 * INE + WE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = (g.Wo + TX - 1) / TX, tiles_y = (g.Ho + TYB - 1) / TYB;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int y0 = ty * TYB, x0 = tx * TX;
+    const int co_base = blockIdx.y * COS;
+    const int iy0 = S * y0 - g.pad, ix0 = S * x0 - g.pad;
+    const int HW = g.H * g.W;
+    const unsigned plane_bytes = (unsigned)HW * 4u, x_bytes = (unsigned)g.Cin * plane_bytes;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (int64_t)b * g.Cin * HW, x_bytes);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(DACT ? dact_y + (int64_t)b * g.Cin * HW : x, DACT ? x_bytes : 0u);
+    const unsigned img_bytes = (unsigned)KK * (unsigned)g.Cout * (unsigned)K16 * 2u;   // one packed weight image
+    const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(wp), 0, 2u * img_bytes, 0x00020000);
+
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    unsigned in_off[NPOS];
+#pragma unroll
+    for (int q = 0; q < NPOS; ++q) {
+        const int pos = tid + q * NTB;
+        const int r = pos / IW, c = pos - r * IW;
+        const int yy = iy0 + r, xx = ix0 + c;
+        in_off[q] = (pos < PS && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) ? (unsigned)(yy * g.W + xx) * 4u : SENT;
+    }
+    unsigned w_off[NWB];                   // byte offset of the owned 16-byte weight pieces for chunk 0 (hi image, then lo)
+    int w_dst[NWB];                        // their element offset from sWH
+#pragma unroll
+    for (int it = 0; it < NWB; ++it) {
+        const int i = tid + it * NTB;
+        const int sel = i >= WPIECES ? 1 : 0, j = i - sel * WPIECES;
+        const int row = j >> 1, half = j & 1;          // row = tap*COS + co
+        const int tap = row / COS, co = row - tap * COS;
+        w_off[it] = i < 2 * WPIECES ? (unsigned)sel * img_bytes + (unsigned)(((tap * g.Cout + co_base + co) * K16 + half * 8) * 2)
+                                    : SENT;
+        w_dst[it] = sel * WE + row * PITCH + half * 8;
+    }
+
+    float rin[NPOS * CKB];
+    u32x4 rw[NWB];
+    auto prefetch = [&](int chunk) {
+        const unsigned cb = (unsigned)chunk * (unsigned)CKB * plane_bytes;
+#pragma unroll
+        for (int q = 0; q < NPOS; ++q)
+#pragma unroll
+            for (int ci = 0; ci < CKB; ++ci) {
+                const unsigned o = in_off[q] + cb + (unsigned)ci * plane_bytes;
+                float v = buf_ld(rx, o);
+                if constexpr (DACT != 0) v *= act_grad_c<DACT>(buf_ld(ry, o), dslope);
+                rin[q * CKB + ci] = v;
+            }
+        const unsigned wb = (unsigned)chunk * (unsigned)(CKB * 2);
+#pragma unroll
+        for (int it = 0; it < NWB; ++it) rw[it] = __builtin_amdgcn_raw_buffer_load_b128(rwt, w_off[it] + wb, 0, 0);
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int q = 0; q < NPOS; ++q)
+            if (tid + q * NTB < PS) {
+                u32x4 h0, h1, l0, l1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v0 = rin[q * CKB + 2 * j], v1 = rin[q * CKB + 2 * j + 1];
+                    const __bf16 a0 = (__bf16)v0, a1 = (__bf16)v1;
+                    const unsigned hp = pack_bf16((float)a0, (float)a1);
+                    const unsigned lp = pack_bf16(v0 - (float)a0, v1 - (float)a1);
+                    if (j < 4) { h0[j] = hp; l0[j] = lp; } else { h1[j - 4] = hp; l1[j - 4] = lp; }
+                }
+                u32x4 *dh = reinterpret_cast<u32x4 *>(sInH + (tid + q * NTB) * PITCH);
+                u32x4 *dl = reinterpret_cast<u32x4 *>(sInL + (tid + q * NTB) * PITCH);
+                dh[0] = h0; dh[1] = h1;
+                dl[0] = l0; dl[1] = l1;
+            }
+#pragma unroll
+        for (int it = 0; it < NWB; ++it)
+            if (tid + it * NTB < 2 * WPIECES) *reinterpret_cast<u32x4 *>(sWH + w_dst[it]) = rw[it];
+    };
+
+    const int nchunks = K16 / CKB;
+    prefetch(0);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        prefetch(chunk + 1);      // past the last chunk every offset is out of range: reads 0, never committed
+        // lane: column (pixel / out channel) lane&31, k-half lane>>5 (channels 8h..8h+7 of the chunk)
+        const int boff = ((S * wave) * IW + S * (lane & 31)) * PITCH + (lane >> 5) * 8;
+        const int aoff = (lane & 31) * PITCH + (lane >> 5) * 8;
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap) {
+            const int ky = tap / KS, kx = tap - ky * KS;
+            bf16x8 ah[MT], al[MT], bh[2], bl[2];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                ah[m] = *reinterpret_cast<const bf16x8 *>(sWH + aoff + (tap * COS + m * 32) * PITCH);
+                al[m] = *reinterpret_cast<const bf16x8 *>(sWL + aoff + (tap * COS + m * 32) * PITCH);
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                bh[n] = *reinterpret_cast<const bf16x8 *>(sInH + boff + (ky * IW + kx + n * 32 * S) * PITCH);
+                bl[n] = *reinterpret_cast<const bf16x8 *>(sInL + boff + (ky * IW + kx + n * 32 * S) * PITCH);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+                }
         }
     }
     const int yo = y0 + wave;
@@ -988,28 +1156,57 @@ int launch_wgrad_bf16(hipStream_t st, const float *x, const float *gout, const f
 
 size_t bf16_pack_bytes(int M, int K, int ks) { return (size_t)ks * ks * M * (size_t)((K + 15) / 16 * 16) * 2; }
 
-// shared by forward (TR = 0) and data gradient (TR = 1); g is the geometry of the conv actually run
+// shared by forward (TR = 0) and data gradient (TR = 1); g is the geometry of the conv actually run.
+// x3 != 0: split-precision kernel (hi/lo operand images, three MFMAs per product).
 template <int KS>
 int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const float *w, const float *bias, float *out,
                     const ConvGeom &g, int transposed, int act, float slope, int dact, float dslope, void *workspace,
-                    size_t ws_bytes) {
+                    size_t ws_bytes, int x3 = 0) {
     const int K16 = (g.Cin + 15) / 16 * 16;
-    const size_t need = bf16_pack_bytes(g.Cout, g.Cin, KS);
+    const size_t need = bf16_pack_bytes(g.Cout, g.Cin, KS) * (x3 ? 2 : 1);
     if (!workspace || ws_bytes < need) return fail(EBFI_ERR_WORKSPACE, "conv2d bf16: workspace %zu bytes < required %zu", ws_bytes, need);
     __bf16 *wp = static_cast<__bf16 *>(workspace);
     const int64_t total = (int64_t)KS * KS * g.Cout * K16;
     {
         ProfScope ps("conv_pack_w_bf16", st);
         hipLaunchKernelGGL(conv_pack_w_bf16, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, w, wp, g.Cout, g.Cin, K16,
-                           KS * KS, transposed);
+                           KS * KS, transposed, x3);
     }
     if (int rc = check_launch("conv_pack_w_bf16")) return rc;
-    const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, TY) * ceil_div(g.Wo, TX);
+    const int ty = x3 ? TYB : TY;
+    const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, ty) * ceil_div(g.Wo, TX);
     if (tiles > 2147483647LL) return fail(EBFI_ERR_ARG, "conv2d: too many tiles");
-    const char *name = transposed ? "conv_dgrad_bf16" : "conv_fwd_bf16";
+    const char *name = x3 ? (transposed ? "conv_dgrad_bf16x3" : "conv_fwd_bf16x3") : (transposed ? "conv_dgrad_bf16" : "conv_fwd_bf16");
     const double flops = 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS;
     const int mt = g.Cout <= 32 ? 1 : 2;
     dim3 grid((unsigned)tiles, (unsigned)ceil_div(g.Cout, 32 * mt));
+    if (x3) {
+        constexpr int PSX = (TYB - 1 + KS) * (TX - 1 + KS);
+        const size_t lds = (size_t)(2 * PSX * PITCH + 2 * KS * KS * 32 * mt * PITCH) * sizeof(__bf16);
+        ProfScope ps(name, st, flops);
+#define EBFI_LAUNCH_X3(MT_, DA_)                                                                                          \
+    do {                                                                                                                 \
+        static bool attr_done = false;                                                                                   \
+        if (!attr_done) {                                                                                                \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_fwd_bf16x3<KS, MT_, DA_>),                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                           \
+            attr_done = true;                                                                                            \
+        }                                                                                                                \
+        hipLaunchKernelGGL((conv_fwd_bf16x3<KS, MT_, DA_>), grid, dim3(NTB), lds, st, x, dact_y, wp, bias, out, g, K16, act,  \
+                           slope, dslope);                                                                               \
+    } while (0)
+        if (mt == 1) {
+            if (dact == ACT_LEAKY) EBFI_LAUNCH_X3(1, ACT_LEAKY);
+            else if (dact == ACT_SIGMOID) EBFI_LAUNCH_X3(1, ACT_SIGMOID);
+            else EBFI_LAUNCH_X3(1, ACT_NONE);
+        } else {
+            if (dact == ACT_LEAKY) EBFI_LAUNCH_X3(2, ACT_LEAKY);
+            else if (dact == ACT_SIGMOID) EBFI_LAUNCH_X3(2, ACT_SIGMOID);
+            else EBFI_LAUNCH_X3(2, ACT_NONE);
+        }
+#undef EBFI_LAUNCH_X3
+        return check_launch(name);
+    }
     {
         ProfScope ps(name, st, flops);
 #define EBFI_LAUNCH_BF16(MT_, DA_)                                                                                     \
@@ -1033,17 +1230,17 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
 
 extern "C" size_t ebfi_conv2d_bf16_workspace(int Cin, int Cout, int ksize) {
     const int m = Cin > Cout ? Cin : Cout;
-    return bf16_pack_bytes(m, m, ksize);       // enough for the forward and the transposed (data-gradient) packing
+    return 2 * bf16_pack_bytes(m, m, ksize);   // forward or transposed (data-gradient) packing, hi and lo images
 }
 
-// fp32 tensors, bf16 matrix-core operands, fp32 accumulation; ksize in {1,3}, stride 1.
-extern "C" int ebfi_conv2d_forward_bf16mma(const void *input, const void *weight, const void *bias, void *output, int B,
-                                           int Cin, int H, int W, int Cout, int ksize, int stride, int pad, int act,
-                                           float slope, void *workspace, size_t workspace_bytes, void *stream) {
-    if (!input || !weight || !output) return fail(EBFI_ERR_ARG, "conv2d_forward_bf16mma: null argument");
-    if (act < 0 || act > 2) return fail(EBFI_ERR_ARG, "conv2d_forward_bf16mma: unknown activation %d", act);
+namespace {
+int conv_forward_bf16_impl(const char *who, int x3, const void *input, const void *weight, const void *bias, void *output, int B,
+                           int Cin, int H, int W, int Cout, int ksize, int stride, int pad, int act, float slope,
+                           void *workspace, size_t workspace_bytes, void *stream) {
+    if (!input || !weight || !output) return fail(EBFI_ERR_ARG, "%s: null argument", who);
+    if (act < 0 || act > 2) return fail(EBFI_ERR_ARG, "%s: unknown activation %d", who, act);
     if (stride != 1 || (ksize != 1 && ksize != 3))
-        return fail(EBFI_ERR_UNSUPPORTED, "conv2d_forward_bf16mma: k=%d stride=%d (k in {1,3}, stride 1)", ksize, stride);
+        return fail(EBFI_ERR_UNSUPPORTED, "%s: k=%d stride=%d (k in {1,3}, stride 1)", who, ksize, stride);
     ConvGeom g;
     if (int rc = make_geom(g, B, Cin, H, W, Cout, ksize, stride, pad)) return rc;
     if (B == 0) return EBFI_OK;
@@ -1051,18 +1248,17 @@ extern "C" int ebfi_conv2d_forward_bf16mma(const void *input, const void *weight
     const float *x = static_cast<const float *>(input), *w = static_cast<const float *>(weight);
     const float *bs = static_cast<const float *>(bias);
     float *o = static_cast<float *>(output);
-    if (ksize == 3) return launch_fwd_bf16<3>(st, x, nullptr, w, bs, o, g, 0, act, slope, 0, 0.f, workspace, workspace_bytes);
-    return launch_fwd_bf16<1>(st, x, nullptr, w, bs, o, g, 0, act, slope, 0, 0.f, workspace, workspace_bytes);
+    if (ksize == 3) return launch_fwd_bf16<3>(st, x, nullptr, w, bs, o, g, 0, act, slope, 0, 0.f, workspace, workspace_bytes, x3);
+    return launch_fwd_bf16<1>(st, x, nullptr, w, bs, o, g, 0, act, slope, 0, 0.f, workspace, workspace_bytes, x3);
 }
 
-extern "C" int ebfi_conv2d_backward_data_bf16mma(const void *grad_output, const void *saved_output, const void *weight,
-                                                 void *grad_input, int B, int Cin, int H, int W, int Cout, int ksize,
-                                                 int stride, int pad, int act, float slope, void *workspace,
-                                                 size_t workspace_bytes, void *stream) {
-    if (!grad_output || !weight || !grad_input) return fail(EBFI_ERR_ARG, "conv2d_backward_data_bf16mma: null argument");
-    if (act != ACT_NONE && !saved_output) return fail(EBFI_ERR_ARG, "conv2d_backward_data_bf16mma: activation needs saved_output");
+int conv_backward_data_bf16_impl(const char *who, int x3, const void *grad_output, const void *saved_output, const void *weight,
+                                 void *grad_input, int B, int Cin, int H, int W, int Cout, int ksize, int stride, int pad,
+                                 int act, float slope, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!grad_output || !weight || !grad_input) return fail(EBFI_ERR_ARG, "%s: null argument", who);
+    if (act != ACT_NONE && !saved_output) return fail(EBFI_ERR_ARG, "%s: activation needs saved_output", who);
     if (stride != 1 || pad > ksize - 1 || (ksize != 1 && ksize != 3))
-        return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_data_bf16mma: k=%d stride=%d pad=%d", ksize, stride, pad);
+        return fail(EBFI_ERR_UNSUPPORTED, "%s: k=%d stride=%d pad=%d", who, ksize, stride, pad);
     ConvGeom f;
     if (int rc = make_geom(f, B, Cin, H, W, Cout, ksize, stride, pad)) return rc;
     if (B == 0) return EBFI_OK;
@@ -1071,8 +1267,42 @@ extern "C" int ebfi_conv2d_backward_data_bf16mma(const void *grad_output, const 
     const float *go = static_cast<const float *>(grad_output), *yo = static_cast<const float *>(saved_output);
     const float *w = static_cast<const float *>(weight);
     float *gi = static_cast<float *>(grad_input);
-    if (ksize == 3) return launch_fwd_bf16<3>(st, go, yo, w, nullptr, gi, g, 1, ACT_NONE, 0.f, act, slope, workspace, workspace_bytes);
-    return launch_fwd_bf16<1>(st, go, yo, w, nullptr, gi, g, 1, ACT_NONE, 0.f, act, slope, workspace, workspace_bytes);
+    if (ksize == 3)
+        return launch_fwd_bf16<3>(st, go, yo, w, nullptr, gi, g, 1, ACT_NONE, 0.f, act, slope, workspace, workspace_bytes, x3);
+    return launch_fwd_bf16<1>(st, go, yo, w, nullptr, gi, g, 1, ACT_NONE, 0.f, act, slope, workspace, workspace_bytes, x3);
+}
+}  // namespace
+
+// fp32 tensors, bf16 matrix-core operands, fp32 accumulation; ksize in {1,3}, stride 1.
+extern "C" int ebfi_conv2d_forward_bf16mma(const void *input, const void *weight, const void *bias, void *output, int B,
+                                           int Cin, int H, int W, int Cout, int ksize, int stride, int pad, int act,
+                                           float slope, void *workspace, size_t workspace_bytes, void *stream) {
+    return conv_forward_bf16_impl("conv2d_forward_bf16mma", 0, input, weight, bias, output, B, Cin, H, W, Cout, ksize, stride, pad,
+                                  act, slope, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ebfi_conv2d_backward_data_bf16mma(const void *grad_output, const void *saved_output, const void *weight,
+                                                 void *grad_input, int B, int Cin, int H, int W, int Cout, int ksize,
+                                                 int stride, int pad, int act, float slope, void *workspace,
+                                                 size_t workspace_bytes, void *stream) {
+    return conv_backward_data_bf16_impl("conv2d_backward_data_bf16mma", 0, grad_output, saved_output, weight, grad_input, B, Cin,
+                                        H, W, Cout, ksize, stride, pad, act, slope, workspace, workspace_bytes, stream);
+}
+
+// Split-precision ("bf16x3") counterparts: operands as bf16 hi + lo pairs, three MFMAs per product, ~1e-5 of fp32.
+extern "C" int ebfi_conv2d_forward_bf16x3(const void *input, const void *weight, const void *bias, void *output, int B,
+                                          int Cin, int H, int W, int Cout, int ksize, int stride, int pad, int act,
+                                          float slope, void *workspace, size_t workspace_bytes, void *stream) {
+    return conv_forward_bf16_impl("conv2d_forward_bf16x3", 1, input, weight, bias, output, B, Cin, H, W, Cout, ksize, stride, pad,
+                                  act, slope, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ebfi_conv2d_backward_data_bf16x3(const void *grad_output, const void *saved_output, const void *weight,
+                                                void *grad_input, int B, int Cin, int H, int W, int Cout, int ksize,
+                                                int stride, int pad, int act, float slope, void *workspace,
+                                                size_t workspace_bytes, void *stream) {
+    return conv_backward_data_bf16_impl("conv2d_backward_data_bf16x3", 1, grad_output, saved_output, weight, grad_input, B, Cin,
+                                        H, W, Cout, ksize, stride, pad, act, slope, workspace, workspace_bytes, stream);
 }
 
 extern "C" int ebfi_conv2d_forward(const void *input, const void *weight, const void *bias, void *output, int B, int Cin,

@@ -16,15 +16,20 @@ from . import _native as N
 
 ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
 
-# Matrix-core operand precision of forward / data-gradient convs: "fp32" (exact, parity mode) or "bf16"
-# (fp32 tensors, bf16 MFMA operands, fp32 accumulation; 3x3/1x1 stride-1 convs only, the rest stays fp32).
+# Matrix-core operand precision of the 3x3 / 1x1 stride-1 convs (everything else always runs the exact fp32 kernels):
+#   "fp32"    exact fp32 matrix cores everywhere
+#   "bf16x3"  forward and data gradient with split bf16 operands (hi + lo, three MFMAs per product: ~1e-5 of fp32);
+#             the weight gradient stays on the exact fp32 kernel (it also hands grad * act' to the data gradient)
+#   "bf16"    single bf16 rounding of the operands for forward, data and weight gradient (~3e-3; parity bar 2e-2)
+# fp32 tensors in memory and fp32 accumulation in every mode.
 _COMPUTE = "fp32"
+MODES = ("fp32", "bf16x3", "bf16")
 
 
 def set_compute_dtype(mode):
     global _COMPUTE
-    if mode not in ("fp32", "bf16"):
-        raise ValueError("compute dtype must be 'fp32' or 'bf16'")
+    if mode not in MODES:
+        raise ValueError("compute dtype must be one of %s" % (MODES,))
     _COMPUTE = mode
 
 
@@ -34,6 +39,10 @@ def get_compute_dtype():
 
 def _bf16_ok(k, stride):
     return _COMPUTE == "bf16" and k in (1, 3) and stride == 1
+
+
+def _x3_ok(k, stride):
+    return _COMPUTE == "bf16x3" and k in (1, 3) and stride == 1
 
 
 def _bf16_ws(lib, geo, device):
@@ -78,10 +87,10 @@ class ConvBiasAct(Function):
         lib = N.lib()
         bptr = N.ptr(bias.contiguous() if bias is not None else None)
         with torch.cuda.device_of(x):
-            if _bf16_ok(k, stride):
+            if _bf16_ok(k, stride) or _x3_ok(k, stride):
                 ws, need = _bf16_ws(lib, geo, x.device)
-                rc = lib.ebfi_conv2d_forward_bf16mma(N.ptr(x), N.ptr(weight), bptr, N.ptr(out), *geo, act, slope,
-                                                     N.ptr(ws), need, N.stream_ptr(x.device))
+                fn = lib.ebfi_conv2d_forward_bf16mma if _COMPUTE == "bf16" else lib.ebfi_conv2d_forward_bf16x3
+                rc = fn(N.ptr(x), N.ptr(weight), bptr, N.ptr(out), *geo, act, slope, N.ptr(ws), need, N.stream_ptr(x.device))
             else:
                 rc = lib.ebfi_conv2d_forward(N.ptr(x), N.ptr(weight), bptr, N.ptr(out), *geo, act, slope, N.EBFI_F32,
                                              N.stream_ptr(x.device))
@@ -122,6 +131,11 @@ class ConvBiasAct(Function):
                     ws, need = _bf16_ws(lib, geo, x.device)
                     rc = lib.ebfi_conv2d_backward_data_bf16mma(N.ptr(gout), N.ptr(y), N.ptr(weight), N.ptr(gx), *geo, act,
                                                                slope, N.ptr(ws), need, st)
+                elif _x3_ok(k, stride):     # split-precision data gradient (on grad * act' when the weight gradient left it)
+                    ws, need = _bf16_ws(lib, geo, x.device)
+                    src, sy, a = (gpre, None, ACT_NONE) if gpre is not None else (gout, y, act)
+                    rc = lib.ebfi_conv2d_backward_data_bf16x3(N.ptr(src), N.ptr(sy), N.ptr(weight), N.ptr(gx), *geo, a,
+                                                              slope if a != ACT_NONE else 0.0, N.ptr(ws), need, st)
                 elif stride == 1:
                     if gpre is not None:    # derivative already folded in: plain transposed conv
                         rc = lib.ebfi_conv2d_backward_data(N.ptr(gpre), N.ptr(None), N.ptr(weight), N.ptr(gx), *geo, ACT_NONE,

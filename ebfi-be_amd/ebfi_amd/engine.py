@@ -34,8 +34,8 @@ def synthetic_batch(B, H, W, TB=16, device="cuda", seed=123, rank=0):
 
 class Engine:
     def __init__(self, model_args=None, device="cuda", precision="fp32", lr=1e-4, seed=None, train=True, graph=False):
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' or 'bf16'")
+        if precision not in ("fp32", "bf16x3", "bf16"):
+            raise ValueError("precision must be 'fp32', 'bf16x3' or 'bf16'")
         self.device = torch.device(device)
         self.precision = precision
         if seed is not None:

@@ -144,7 +144,8 @@ int ebfi_conv2d_backward_weight_ex(const void *input, const void *grad_output, c
 
 /* bf16 matrix-core variants: fp32 tensors in memory, operands rounded to bf16 for v_mfma_f32_32x32x16_bf16,
  * fp32 accumulation (16x the fp32 MFMA rate).  k in {1,3}, stride 1.  `workspace` receives the weight
- * re-packed to bf16 [tap][co][ci16] (ebfi_conv2d_bf16_workspace bytes). */
+ * re-packed to bf16 [tap][co][ci16] (ebfi_conv2d_bf16_workspace bytes: room for the hi and lo images of the
+ * split-precision variants below). */
 size_t ebfi_conv2d_bf16_workspace(int Cin, int Cout, int ksize);
 int ebfi_conv2d_forward_bf16mma(const void *input, const void *weight, const void *bias, void *output,
                                 int B, int Cin, int H, int W, int Cout, int ksize, int stride, int pad,
@@ -153,6 +154,18 @@ int ebfi_conv2d_backward_data_bf16mma(const void *grad_output, const void *saved
                                       void *grad_input, int B, int Cin, int H, int W, int Cout, int ksize,
                                       int stride, int pad, int act, float slope,
                                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* Split-precision ("bf16x3") variants: every fp32 operand is carried as hi = bf16(v), lo = bf16(v - hi) and each
+ * product is accumulated as hi*hi + hi*lo + lo*hi on the bf16 matrix cores (fp32 accumulation).  Results agree with
+ * the exact fp32 kernels to ~1e-5 relative (tests/test_gpu_conv.py), at 3/16 of their matrix-core time.  Same
+ * arguments, workspace (ebfi_conv2d_bf16_workspace) and limits as the *_bf16mma functions. */
+int ebfi_conv2d_forward_bf16x3(const void *input, const void *weight, const void *bias, void *output,
+                               int B, int Cin, int H, int W, int Cout, int ksize, int stride, int pad,
+                               int act, float slope, void *workspace, size_t workspace_bytes, void *stream);
+int ebfi_conv2d_backward_data_bf16x3(const void *grad_output, const void *saved_output, const void *weight,
+                                     void *grad_input, int B, int Cin, int H, int W, int Cout, int ksize,
+                                     int stride, int pad, int act, float slope,
+                                     void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------ event voxel binning
  * xs, ys, ts: float64[n] device (ts sorted, normalised as h5dataset.py:334), ps: float32[n].

@@ -1,6 +1,7 @@
 """GPU parity of the whole frame-synthesis path: the product EVFIAutoEx (HIP FAC kernel inside)
 vs fixtures produced by the reference's own modules, vs the functional CPU oracle, and one
-training step vs the oracle's autograd.  fp32, tolerance 1e-3 relative (BASELINE.json)."""
+training step vs the oracle's autograd.  Tolerance 1e-3 relative (BASELINE.json), checked in both parity-grade
+conv modes: exact fp32 matrix cores and split-precision bf16x3."""
 import ast
 import os
 
@@ -28,6 +29,14 @@ def fix(golden_dir):
     return z, sd, cfg
 
 
+@pytest.fixture(params=["fp32", "bf16x3"])
+def mode(request):
+    from ebfi_amd import conv
+    conv.set_compute_dtype(request.param)
+    yield request.param
+    conv.set_compute_dtype("fp32")
+
+
 def _net(cfg, sd, **over):
     from ebfi_amd.model import EVFIAutoEx
     net = EVFIAutoEx(**dict(cfg, **over))
@@ -36,7 +45,7 @@ def _net(cfg, sd, **over):
     return net.cuda().eval(), missing
 
 
-def test_forward_vs_reference_fixture(fix):
+def test_forward_vs_reference_fixture(fix, mode):
     z, sd, cfg = fix
     net, missing = _net(cfg, sd)
     assert not missing
@@ -60,7 +69,7 @@ def test_forward_vs_reference_fixture(fix):
         assert _rel(so, z["odd.Sharp"]) < TOL and _rel(fo, z["odd.Final"]) < TOL
 
 
-def test_gradients_vs_reference_fixture(fix):
+def test_gradients_vs_reference_fixture(fix, mode):
     z, sd, cfg = fix
     net, _ = _net(cfg, sd, UseGTEx=True)
     net.train()
@@ -76,7 +85,7 @@ def test_gradients_vs_reference_fixture(fix):
     assert n > 80
 
 
-def test_full_width_forward_vs_oracle():
+def test_full_width_forward_vs_oracle(mode):
     """config 1 of BASELINE.json (single 128x128 sample, default widths) against the CPU oracle,
     including the device Frame2Lap inside forward (RGBLap branch)."""
     from ebfi_amd.engine import DEFAULT_MODEL_ARGS, synthetic_batch
@@ -99,13 +108,13 @@ def test_full_width_forward_vs_oracle():
     assert _rel(s, ref_s) < TOL and _rel(f, ref_f) < TOL
 
 
-def test_train_step_vs_oracle(fix):
+def test_train_step_vs_oracle(fix, mode):
     """One Engine.train_step (fwd, Lap+census loss, bwd, Adam) vs the oracle's loss and autograd
     gradients on the small config."""
     from ebfi_amd.engine import Engine
     z, sd, cfg = fix
     cfg2 = dict(cfg, UseGTEx=True)
-    eng = Engine(cfg2, device="cuda", precision="fp32", lr=1e-4)
+    eng = Engine(cfg2, device="cuda", precision=mode, lr=1e-4)
     eng.model.load_state_dict(sd, strict=False)
     torch.manual_seed(9)
     frame = torch.rand(2, 3, 64, 64)

@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--hd", action="store_true")
     ap.add_argument("--ops", default="fac,dcn,conv")
     ap.add_argument("--bf16", action="store_true", help="bf16 matrix-core operands for the conv kernels")
+    ap.add_argument("--x3", action="store_true", help="split-precision (bf16 hi+lo, 3 MFMAs) forward / data gradient")
     a = ap.parse_args()
     from ebfi_amd.dcn import dcn_v2_backward, dcn_v2_forward
     from ebfi_amd.fac import fac_backward, fac_forward
@@ -92,8 +93,9 @@ def main():
         from ebfi_amd import conv as convmod
         from ebfi_amd.conv import conv_bias_act
         sfx = "bf16" if a.bf16 else "f32"
-        convmod.set_compute_dtype("bf16" if a.bf16 else "fp32")
-        names = {"conv_fwd_" + sfx, "conv_dgrad_" + sfx, "conv_wgrad_" + sfx, "conv_wgrad_reduce_f32", "conv_pack_w_bf16"}
+        convmod.set_compute_dtype("bf16" if a.bf16 else ("bf16x3" if a.x3 else "fp32"))
+        names = {"conv_fwd_" + sfx, "conv_dgrad_" + sfx, "conv_wgrad_" + sfx, "conv_wgrad_reduce_f32", "conv_pack_w_bf16",
+                 "conv_fwd_bf16x3", "conv_dgrad_bf16x3"}
         peak = 2500.0 if a.bf16 else F32_MFMA_PEAK
         for (cin, cout, hh, ww, tag) in [(64, 64, h, w, "ResidualControl 64->64"), (128, 64, h, w, "Conv5 128->64"),
                                          (128, 1600, h, w, "KernelConv 128->1600"), (64, 64, 2 * h, 2 * w, "Recon 64->64 @2x")]:
