@@ -796,6 +796,206 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const float *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// Split-precision weight gradient (KS in {1,3}, stride 1).  Same GEMM view and the same LDS images as
+// conv_wgrad_f32 -- grad_out [64 co][2 rows x 32 slots], input halo tile [ci][row][col] with the conflict-free
+// strides of WCfg -- but every 32-bit LDS word holds the PAIR (bf16 hi << 16 | bf16 lo) of its fp32 value, split
+// once at commit time.  A v_mfma_f32_32x32x16_bf16 lane needs 8 consecutive k = 8 consecutive pixel slots: it reads
+// the 8 words (any alignment: they are dwords, so the kx-shifted windows need no extra copies), and two v_perm_b32
+// per word pair peel the hi and the lo vector apart.  Products accumulate as lo*hi + hi*lo + hi*hi in fp32.
+// The matrix work per tile drops to 3/16 of the fp32 kernel's, so the tile loop is paced by staging: 512 threads
+// (8 waves: 2 co tiles x 4 column groups) share one 121 KB double-buffered image per CU -- tile t+1 is committed
+// into the other buffer right after the MFMAs of tile t (one barrier per tile) while its global loads, issued before
+// those MFMAs, are in flight.  Slab layout and the reduce kernel are those of the fp32 path.
+constexpr int WXT = 512;
+
+__device__ __forceinline__ unsigned split_word(float v) {
+    const __bf16 h = (__bf16)v;
+    const float hf = (float)h;
+    return pack_bf16(v - hf, hf);          // low half: remainder, high half: leading 8 significant bits
+}
+__device__ __forceinline__ float join_word(unsigned w) { return __uint_as_float(w & 0xffff0000u) + __uint_as_float(w << 16); }
+
+__device__ __forceinline__ void peel(const unsigned (&w)[8], bf16x8 &hi, bf16x8 &lo) {
+    u32x4 h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = __builtin_amdgcn_perm(w[2 * i + 1], w[2 * i], 0x07060302u);
+        l[i] = __builtin_amdgcn_perm(w[2 * i + 1], w[2 * i], 0x05040100u);
+    }
+    hi = __builtin_bit_cast(bf16x8, h);
+    lo = __builtin_bit_cast(bf16x8, l);
+}
+
+template <int KS, int WTXO, int DACT>
+__global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x, const float *__restrict__ gout,
+                                                     const float *__restrict__ yact, float *__restrict__ slab,
+                                                     float *__restrict__ gpre_out, ConvGeom g, float dslope, int total_tiles,
+                                                     int need_bias) {
+    using C = WCfg<KS, 1, WTXO>;
+    constexpr int KK = KS * KS, WTX = C::WTX, IH = C::IH, IW = C::IW, IWP = C::IWP;
+    constexpr int CIB = C::CIB, PS = C::PS, IWS = C::IWS;
+    constexpr int TROWS = WXT / IWP;       // thread rows walking (row, channel) of the input tile
+    constexpr int CPR = CIB / TROWS;       // channel steps per input row
+    constexpr int NI = IH * CPR;           // input elements per thread per tile
+    constexpr int NG = 64 / (WXT / 64);    // grad_out channels per thread per tile (8 thread rows of 64 slots)
+    constexpr int NTW = (CIB * KK + 127) / 128;   // n-tiles (of 32 columns) per wave: 4 column groups
+    constexpr int BUF = 64 * GS + (CIB + 1) * PS; // words per buffer: grad_out image, channel planes, zero plane
+    static_assert(IWP == 32 && CIB % TROWS == 0 && WTX <= 32, "tile configuration");
+    extern __shared__ __attribute__((aligned(16))) unsigned smw[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co_base = blockIdx.y * 64, ci_base = blockIdx.z * CIB;
+    const int ci_cnt = min(CIB, g.Cin - ci_base);
+    const int ncols = ci_cnt * KK;
+    const int mt = wave & 1, nq = wave >> 1;   // wave: co tile mt, n-tiles nq, nq+4, nq+8, ...
+    const int tiles_x = (g.Wo + WTX - 1) / WTX, tiles_y = (g.Ho + WTY - 1) / WTY;
+    const int HW = g.H * g.W, HWo = g.Ho * g.Wo;
+
+    f32x16 acc[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    // per-lane word offset of column n = (nq + 4q)*32 + (lane&31) inside a buffer, at k-half (lane>>5)
+    int boff[NTW];
+#pragma unroll
+    for (int q = 0; q < NTW; ++q) {
+        const int n = (nq + 4 * q) * 32 + (lane & 31);
+        const int ci = n / KK, tap = n - ci * KK;
+        const int ky = tap / KS, kx = tap - ky * KS;
+        boff[q] = 64 * GS + ((n < ncols) ? ci * PS + ky * IWS + kx : CIB * PS) + 8 * (lane >> 5);
+    }
+    const int aoff = (mt * 32 + (lane & 31)) * GS + 8 * (lane >> 5);
+    // both buffers start as zero words (= +0.0 pairs): pad slots / pad columns / the zero plane are never written later
+    for (int i = tid; i < 2 * BUF; i += WXT) smw[i] = 0u;
+
+    // thread-fixed staging coordinates
+    const int gslot = tid & 63, gpy = gslot >> 5, gpx = gslot & 31, gco = tid >> 6;   // grad_out: slot, channel row (0..7)
+    const int icol = tid & (IWP - 1), irow = tid / IWP;                              // input: column, thread row (0..15)
+    const unsigned go_bytes = (unsigned)g.Cout * (unsigned)HWo * 4u, x_bytes = (unsigned)g.Cin * (unsigned)HW * 4u;
+
+    float rg[NG], ry[NG], ri[NI];
+    float bacc[NG];                        // bias: this thread's slot of channels gco + 8*it, summed over its tiles
+#pragma unroll
+    for (int it = 0; it < NG; ++it) bacc[it] = 0.f;
+    auto prefetch = [&](int tile) {
+        int t = tile;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        const int b = t / tiles_y;
+        const int y0 = ty * WTY, x0 = tx * WTX;
+        const int iy0 = y0 - g.pad, ix0 = x0 - g.pad;
+        const bool live = tile < total_tiles;
+        const __amdgpu_buffer_rsrc_t rgo = make_rsrc(gout + (int64_t)(live ? b : 0) * g.Cout * HWo, live ? go_bytes : 0u);
+        const __amdgpu_buffer_rsrc_t rya = make_rsrc((DACT ? yact : gout) + (int64_t)(live ? b : 0) * g.Cout * HWo,
+                                                     (live && DACT) ? go_bytes : 0u);
+        const __amdgpu_buffer_rsrc_t rxi = make_rsrc(x + (int64_t)(live ? b : 0) * g.Cin * HW, live ? x_bytes : 0u);
+        const int gy = y0 + gpy, gx = x0 + gpx;
+        const unsigned g0 = (gpx < WTX && gy < g.Ho && gx < g.Wo) ? (unsigned)((co_base + gco) * HWo + gy * g.Wo + gx) * 4u : SENT;
+#pragma unroll
+        for (int it = 0; it < NG; ++it) {
+            const unsigned o = g0 + (unsigned)(8 * it) * (unsigned)HWo * 4u;   // channels >= Cout fall out of range
+            rg[it] = buf_ld(rgo, o);
+            if constexpr (DACT != 0) ry[it] = buf_ld(rya, o);
+        }
+        const int xx = ix0 + icol;
+        const bool col_ok = icol < IW && xx >= 0 && xx < g.W;
+#pragma unroll
+        for (int r = 0; r < IH; ++r) {
+            const int yy = iy0 + r;
+            const unsigned base = (col_ok && yy >= 0 && yy < g.H) ? (unsigned)((ci_base + irow) * HW + yy * g.W + xx) * 4u : SENT;
+#pragma unroll
+            for (int k = 0; k < CPR; ++k) ri[r * CPR + k] = buf_ld(rxi, base + (unsigned)(k * TROWS) * (unsigned)HW * 4u);
+        }
+    };
+    auto commit = [&](int tile, int buf) {
+        unsigned *sG = smw + buf * BUF, *sIn = sG + 64 * GS;
+#pragma unroll
+        for (int it = 0; it < NG; ++it) {
+            if constexpr (DACT != 0) rg[it] *= act_grad_c<DACT>(ry[it], dslope);
+            bacc[it] += rg[it];
+            sG[(gco + 8 * it) * GS + gslot] = split_word(rg[it]);
+        }
+        if (gpre_out != nullptr && blockIdx.z == 0) {   // side output: grad_out * act'(y), consumed by the data gradient
+            int t = tile;
+            const int tx = t % tiles_x; t /= tiles_x;
+            const int ty = t % tiles_y;
+            const int b = t / tiles_y;
+            const int gy = ty * WTY + gpy, gx = tx * WTX + gpx;
+            const bool ok = tile < total_tiles && gpx < WTX && gy < g.Ho && gx < g.Wo;
+            float *dst = gpre_out + ((int64_t)b * g.Cout + co_base + gco) * HWo + gy * g.Wo + gx;
+#pragma unroll
+            for (int it = 0; it < NG; ++it)
+                if (ok && co_base + gco + 8 * it < g.Cout) dst[(int64_t)(8 * it) * HWo] = rg[it];
+        }
+        if (icol < IW) {
+#pragma unroll
+            for (int r = 0; r < IH; ++r)
+#pragma unroll
+                for (int k = 0; k < CPR; ++k) sIn[(irow + k * TROWS) * PS + r * IWS + icol] = split_word(ri[r * CPR + k]);
+        }
+    };
+
+    __syncthreads();                       // zero fill done
+    prefetch(blockIdx.x);
+    commit(blockIdx.x, 0);
+    __syncthreads();
+    int cur = 0;
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        prefetch(tile + gridDim.x);        // past the end: zero-record descriptors, nothing is read
+        __builtin_amdgcn_sched_barrier(0); // keep the loads above the matrix block
+        const unsigned *sA = smw + cur * BUF + aoff;
+        const unsigned *sB = smw + cur * BUF;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {   // 16 pixel slots per step: row kk>>1, slots (kk&1)*16 + 8h .. +7
+            const int row = kk >> 1, px0 = (kk & 1) * 16;
+            unsigned aw[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) aw[j] = sA[row * 32 + px0 + j];
+            bf16x8 ah, al;
+            peel(aw, ah, al);
+#pragma unroll
+            for (int q = 0; q < NTW; ++q) {
+                unsigned bw[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bw[j] = sB[boff[q] + row * IWS + px0 + j];
+                bf16x8 bh, bl;
+                peel(bw, bh, bl);
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[q], 0, 0, 0);
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[q], 0, 0, 0);
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[q], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        commit(tile + gridDim.x, cur ^ 1); // the other buffer was last read before the previous barrier
+        __syncthreads();
+        cur ^= 1;
+    }
+    // ---- write this workgroup's partial slab
+    const int64_t wsz = (int64_t)g.Cout * g.Cin * KK;
+    float *my = slab + (int64_t)blockIdx.x * (wsz + g.Cout);
+#pragma unroll
+    for (int q = 0; q < NTW; ++q) {
+        const int n = (nq + 4 * q) * 32 + (lane & 31);
+        if (n >= ncols) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (co < g.Cout) my[((int64_t)co * g.Cin + ci_base) * KK + n] = acc[q][r];
+        }
+    }
+    if (need_bias && blockIdx.z == 0) {    // lanes of a wave hold the 64 slots of channels gco + 8*it: fixed-order butterfly
+#pragma unroll
+        for (int it = 0; it < NG; ++it) {
+            float v = bacc[it];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+            if (lane == 0 && co_base + gco + 8 * it < g.Cout) my[wsz + co_base + gco + 8 * it] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // bf16 matrix-core weight gradient (KS in {1,3}, stride 1): M = out channels, N = (tap, ci), K = pixels.
 // MFMA wants 8 consecutive k = 8 consecutive PIXELS per lane.  NCHW gives exactly that for grad_out
 // ([co][2 rows x 32 slots], pitch 72 = 9*16 B).  For the input operand the 8 pixels start at x + kx, which
@@ -1127,6 +1327,51 @@ int launch_wgrad(hipStream_t st, const float *x, const float *gout, const float 
     return launch_wgrad_t<KS, S, 0>(st, x, gout, yact, slab, gpre_out, g, dact, dslope, nsplit, need_bias);
 }
 
+int wgrad_x3_splits(const ConvGeom &g, int ks) {
+    const int wtx = wgrad_wtx_rt(g, ks, 1);
+    const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, wtx);
+    const int64_t blocks = ceil_div(g.Cout, 64) * ceil_div(g.Cin, 64);
+    int64_t s = blocks <= 256 ? 256 / blocks : 1;      // one 512-thread workgroup per CU: fill one round of 256
+    if (s > tiles) s = tiles;
+    return (int)(s < 1 ? 1 : s);
+}
+
+template <int KS, int WTXO, int DACT>
+int launch_wgrad_x3_d(hipStream_t st, const float *x, const float *gout, const float *yact, float *slab, float *gpre_out,
+                      const ConvGeom &g, float dslope, int nsplit, int need_bias) {
+    using C = WCfg<KS, 1, WTXO>;
+    const size_t lds = (size_t)2 * (64 * GS + (C::CIB + 1) * C::PS) * sizeof(unsigned);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_x3<KS, WTXO, DACT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, C::WTX);
+    dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, C::CIB));
+    ProfScope ps("conv_wgrad_bf16x3", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS);
+    hipLaunchKernelGGL((conv_wgrad_x3<KS, WTXO, DACT>), grid, dim3(WXT), lds, st, x, gout, yact, slab, gpre_out, g, dslope,
+                       (int)tiles, need_bias);
+    return check_launch("conv_wgrad_bf16x3");
+}
+
+template <int KS, int WTXO>
+int launch_wgrad_x3_t(hipStream_t st, const float *x, const float *gout, const float *yact, float *slab, float *gpre_out,
+                      const ConvGeom &g, int dact, float dslope, int nsplit, int need_bias) {
+    if (dact == ACT_LEAKY) return launch_wgrad_x3_d<KS, WTXO, ACT_LEAKY>(st, x, gout, yact, slab, gpre_out, g, dslope, nsplit, need_bias);
+    if (dact == ACT_SIGMOID) return launch_wgrad_x3_d<KS, WTXO, ACT_SIGMOID>(st, x, gout, yact, slab, gpre_out, g, dslope, nsplit, need_bias);
+    return launch_wgrad_x3_d<KS, WTXO, ACT_NONE>(st, x, gout, yact, slab, gpre_out, g, dslope, nsplit, need_bias);
+}
+
+int launch_wgrad_x3(hipStream_t st, const float *x, const float *gout, const float *yact, float *slab, float *gpre_out,
+                    const ConvGeom &g, int ks, int dact, float dslope, int nsplit, int need_bias) {
+    if (ks == 1) return launch_wgrad_x3_t<1, 0>(st, x, gout, yact, slab, gpre_out, g, dact, dslope, nsplit, need_bias);
+    const int w = pick_wtx(g.Wo);
+    if (w == 26) return launch_wgrad_x3_t<3, 26>(st, x, gout, yact, slab, gpre_out, g, dact, dslope, nsplit, need_bias);
+    if (w == 28) return launch_wgrad_x3_t<3, 28>(st, x, gout, yact, slab, gpre_out, g, dact, dslope, nsplit, need_bias);
+    return launch_wgrad_x3_t<3, 0>(st, x, gout, yact, slab, gpre_out, g, dact, dslope, nsplit, need_bias);
+}
+
 template <int KS, int DACT>
 int launch_wgrad_bf16_d(hipStream_t st, const float *x, const float *gout, const float *yact, float *slab, const ConvGeom &g,
                         float dslope, int nsplit, int need_bias) {
@@ -1380,7 +1625,8 @@ extern "C" int ebfi_conv2d_backward_weight_ex(const void *input, const void *gra
                                               void *workspace, size_t workspace_bytes, int dtype, void *stream) {
     if (!input || !grad_output || !grad_weight) return fail(EBFI_ERR_ARG, "conv2d_backward_weight: null argument");
     const bool bf16mma = dtype == EBFI_F32_BF16MMA && stride == 1 && (ksize == 1 || ksize == 3);
-    if (dtype != EBFI_F32 && dtype != EBFI_F32_BF16MMA)
+    const bool x3 = dtype == EBFI_F32_BF16X3MMA && stride == 1 && (ksize == 1 || ksize == 3);   // else: exact fp32 kernel
+    if (dtype != EBFI_F32 && dtype != EBFI_F32_BF16MMA && dtype != EBFI_F32_BF16X3MMA)
         return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_weight: dtype %d not implemented", dtype);
     if (act != ACT_NONE && !saved_output) return fail(EBFI_ERR_ARG, "conv2d_backward_weight: activation needs saved_output");
     ConvGeom g;
@@ -1399,6 +1645,7 @@ extern "C" int ebfi_conv2d_backward_weight_ex(const void *input, const void *gra
     const float *yo = static_cast<const float *>(saved_output);
     float *slab = static_cast<float *>(workspace);
     int nsplit = wgrad_splits(g, ksize, stride);
+    if (x3) nsplit = wgrad_x3_splits(g, ksize);       // never more than the fp32 count the workspace is sized for
     if (bf16mma) {   // half-size channel blocks and short tiles: fewer, longer-lived workgroups (workspace is sized for the fp32 count)
         const int64_t blocks = ceil_div(Cout, 64) * ceil_div(Cin, 32);
         const int64_t want = ceil_div(768, blocks);
@@ -1408,7 +1655,8 @@ extern "C" int ebfi_conv2d_backward_weight_ex(const void *input, const void *gra
     float *gpre = static_cast<float *>(grad_preact_out);
     if (gpre && bf16mma) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_weight_ex: grad_preact_out with bf16 operands");
     int rc;
-    if (bf16mma && ksize == 3) rc = launch_wgrad_bf16<3>(st, x, go, yo, slab, g, act, slope, nsplit, need_bias);
+    if (x3) rc = launch_wgrad_x3(st, x, go, yo, slab, gpre, g, ksize, act, slope, nsplit, need_bias);
+    else if (bf16mma && ksize == 3) rc = launch_wgrad_bf16<3>(st, x, go, yo, slab, g, act, slope, nsplit, need_bias);
     else if (bf16mma) rc = launch_wgrad_bf16<1>(st, x, go, yo, slab, g, act, slope, nsplit, need_bias);
     else if (ksize == 3 && stride == 1) rc = launch_wgrad<3, 1>(st, x, go, yo, slab, gpre, g, act, slope, nsplit, need_bias);
     else if (ksize == 3 && stride == 2) rc = launch_wgrad<3, 2>(st, x, go, yo, slab, gpre, g, act, slope, nsplit, need_bias);

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(PKG_ROOT, "lib", "libebfi_hip.so")
 HEADER = os.path.join(REPO_ROOT, "include", "ebfi_hip.h")
 BUILD_SCRIPT = os.path.join(PKG_ROOT, "csrc", "build.sh")
 
-EBFI_F32, EBFI_BF16, EBFI_F32_BF16MMA = 0, 1, 2
+EBFI_F32, EBFI_BF16, EBFI_F32_BF16MMA, EBFI_F32_BF16X3MMA = 0, 1, 2, 3
 
 
 class EbfiNativeError(RuntimeError):

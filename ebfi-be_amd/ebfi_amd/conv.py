@@ -18,8 +18,8 @@ ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
 
 # Matrix-core operand precision of the 3x3 / 1x1 stride-1 convs (everything else always runs the exact fp32 kernels):
 #   "fp32"    exact fp32 matrix cores everywhere
-#   "bf16x3"  forward and data gradient with split bf16 operands (hi + lo, three MFMAs per product: ~1e-5 of fp32);
-#             the weight gradient stays on the exact fp32 kernel (it also hands grad * act' to the data gradient)
+#   "bf16x3"  forward, data and weight gradient with split bf16 operands (hi + lo pairs, three MFMAs per product):
+#             ~1e-5 of fp32, the parity-grade fast mode
 #   "bf16"    single bf16 rounding of the operands for forward, data and weight gradient (~3e-3; parity bar 2e-2)
 # fp32 tensors in memory and fp32 accumulation in every mode.
 _COMPUTE = "fp32"
@@ -121,9 +121,9 @@ class ConvBiasAct(Function):
                 ws = torch.empty(max(need, 4), dtype=torch.uint8, device=x.device)
                 if need_x and act != ACT_NONE and not bf16:
                     gpre = torch.empty_like(gout)
+                wdt = N.EBFI_F32_BF16MMA if bf16 else (N.EBFI_F32_BF16X3MMA if _x3_ok(k, stride) else N.EBFI_F32)
                 rc = lib.ebfi_conv2d_backward_weight_ex(N.ptr(x), N.ptr(gout), N.ptr(y), N.ptr(gw), N.ptr(gb), N.ptr(gpre),
-                                                        *geo, act, slope, N.ptr(ws), need,
-                                                        N.EBFI_F32_BF16MMA if bf16 else N.EBFI_F32, st)
+                                                        *geo, act, slope, N.ptr(ws), need, wdt, st)
                 N.check(rc, "ebfi_conv2d_backward_weight")
             if need_x:
                 gx = torch.empty_like(x)

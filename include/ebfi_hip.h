@@ -51,7 +51,7 @@ typedef enum {
 
 /* EBFI_F32_BF16MMA: fp32 tensors, operands rounded to bf16 for the matrix cores, fp32 accumulation
  * (accepted by ebfi_conv2d_backward_weight; the forward / data-gradient have *_bf16mma entry points) */
-typedef enum { EBFI_F32 = 0, EBFI_BF16 = 1, EBFI_F32_BF16MMA = 2 } ebfi_dtype;
+typedef enum { EBFI_F32 = 0, EBFI_BF16 = 1, EBFI_F32_BF16MMA = 2, EBFI_F32_BF16X3MMA = 3 } ebfi_dtype;
 
 int ebfi_abi_version(void);
 const char *ebfi_last_error(void);

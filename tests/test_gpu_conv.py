@@ -147,8 +147,8 @@ def test_bf16_mma_mode_vs_fp32_reference(B, Cin, H, W, Cout, k, act):
                                                   (1, 70, 9, 130, 33, 3, 1)])
 def test_bf16x3_split_precision_mode_vs_fp32_reference(B, Cin, H, W, Cout, k, act):
     """Split-precision mode (bf16 hi + lo operand pairs, 3 MFMAs per product, fp32 accumulation) for forward and
-    data gradient; the weight gradient stays on the exact fp32 kernel.  Bar: 1e-4 of the fp32 CPU statement, ten
-    times inside the 1e-3 parity tolerance of the path."""
+    data and weight gradient.  Bar: 1e-4 of the fp32 CPU statement, ten times inside the 1e-3 parity tolerance of
+    the path."""
     from ebfi_amd import _native as N
     from ebfi_amd import conv
     torch.manual_seed(B + Cin + H + W + Cout + k)
@@ -168,11 +168,11 @@ def test_bf16x3_split_precision_mode_vs_fp32_reference(B, Cin, H, W, Cout, k, ac
     finally:
         conv.set_compute_dtype("fp32")
         N.prof_enable(False)
-    assert {"conv_fwd_bf16x3", "conv_dgrad_bf16x3", "conv_wgrad_f32"} <= set(N.prof_collect())
+    assert {"conv_fwd_bf16x3", "conv_dgrad_bf16x3", "conv_wgrad_bf16x3"} <= set(N.prof_collect())
     assert _rel(out.detach(), ref) < 1e-4
     # derivative mask from the op's own output (a pre-activation within 1e-5 of zero may flip slope w.r.t. the CPU run)
     y = out.detach().cpu()
     gpre = g if act == 0 else g * (torch.where(y > 0, torch.ones_like(y), torch.full_like(y, 0.01)) if act == 1 else y * (1 - y))
     assert _rel(xd.grad, torch.nn.grad.conv2d_input(x.shape, w, gpre, stride=1, padding=k // 2)) < 1e-4
-    assert _rel(wd.grad, torch.nn.grad.conv2d_weight(x, w.shape, gpre, stride=1, padding=k // 2)) < 5e-5
+    assert _rel(wd.grad, torch.nn.grad.conv2d_weight(x, w.shape, gpre, stride=1, padding=k // 2)) < 1e-4
     assert _rel(bd.grad, gpre.sum(dim=(0, 2, 3))) < 5e-5

@@ -95,7 +95,7 @@ def main():
         sfx = "bf16" if a.bf16 else "f32"
         convmod.set_compute_dtype("bf16" if a.bf16 else ("bf16x3" if a.x3 else "fp32"))
         names = {"conv_fwd_" + sfx, "conv_dgrad_" + sfx, "conv_wgrad_" + sfx, "conv_wgrad_reduce_f32", "conv_pack_w_bf16",
-                 "conv_fwd_bf16x3", "conv_dgrad_bf16x3"}
+                 "conv_fwd_bf16x3", "conv_dgrad_bf16x3", "conv_wgrad_bf16x3"}
         peak = 2500.0 if a.bf16 else F32_MFMA_PEAK
         for (cin, cout, hh, ww, tag) in [(64, 64, h, w, "ResidualControl 64->64"), (128, 64, h, w, "Conv5 128->64"),
                                          (128, 1600, h, w, "KernelConv 128->1600"), (64, 64, 2 * h, 2 * w, "Recon 64->64 @2x")]:
