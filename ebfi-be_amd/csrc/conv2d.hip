@@ -1205,6 +1205,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_f32(const float *__rest
     }
 }
 
+// algorithmic HBM bytes of one launch (every operand once, results once; workspaces and re-reads not counted)
+double conv_bytes_fwd(const ConvGeom &g, int kk, bool dact) {
+    return 4.0 * ((double)g.B * g.Cin * g.H * g.W * (dact ? 2 : 1) + (double)g.B * g.Cout * g.Ho * g.Wo + (double)g.Cout * g.Cin * kk);
+}
+double conv_bytes_wgrad(const ConvGeom &g, int kk, bool dact, bool side_out) {
+    return 4.0 * ((double)g.B * g.Cin * g.H * g.W + (double)g.B * g.Cout * g.Ho * g.Wo * (1 + (dact ? 1 : 0) + (side_out ? 1 : 0)) +
+                  (double)g.Cout * g.Cin * kk);
+}
+
 int make_geom(ConvGeom &g, int B, int Cin, int H, int W, int Cout, int ks, int stride, int pad) {
     if (B < 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return fail(EBFI_ERR_ARG, "conv2d: non-positive dimension");
     if (ks != 1 && ks != 3 && ks != 7) return fail(EBFI_ERR_UNSUPPORTED, "conv2d: kernel size %d (1, 3 and 7 implemented)", ks);
@@ -1230,12 +1239,12 @@ int launch_fwd_d(hipStream_t st, const float *x, const float *dact_y, const floa
     const double flops = 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS;   // dense, un-padded
     if (g.Cout <= 32) {
         dim3 grid((unsigned)tiles, (unsigned)ceil_div(g.Cout, 32));
-        ProfScope ps(name, st, flops);
+        ProfScope ps(name, st, flops, conv_bytes_fwd(g, KS * KS, DACT != 0));
         hipLaunchKernelGGL((conv_fwd_f32<KS, S, 1, CK, TR, DACT>), grid, dim3(256), 0, st, x, dact_y, w, bias, out, g, act,
                            slope, dslope);
     } else {
         dim3 grid((unsigned)tiles, (unsigned)ceil_div(g.Cout, 64));
-        ProfScope ps(name, st, flops);
+        ProfScope ps(name, st, flops, conv_bytes_fwd(g, KS * KS, DACT != 0));
         hipLaunchKernelGGL((conv_fwd_f32<KS, S, 2, CK, TR, DACT>), grid, dim3(256), 0, st, x, dact_y, w, bias, out, g, act,
                            slope, dslope);
     }
@@ -1302,7 +1311,8 @@ int launch_wgrad_d(hipStream_t st, const float *x, const float *gout, const floa
     }
     const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, C::WTX);
     dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, C::CIB));
-    ProfScope ps("conv_wgrad_f32", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS);
+    ProfScope ps("conv_wgrad_f32", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS,
+                 conv_bytes_wgrad(g, KS * KS, DACT != 0, gpre_out != nullptr));
     hipLaunchKernelGGL((conv_wgrad_f32<KS, S, WTXO, DACT>), grid, dim3(256), lds, st, x, gout, yact, slab, gpre_out, g, dslope,
                        (int)tiles, need_bias);
     return check_launch("conv_wgrad_f32");
@@ -1349,7 +1359,8 @@ int launch_wgrad_x3_d(hipStream_t st, const float *x, const float *gout, const f
     }
     const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, C::WTX);
     dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, C::CIB));
-    ProfScope ps("conv_wgrad_bf16x3", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS);
+    ProfScope ps("conv_wgrad_bf16x3", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS,
+                 conv_bytes_wgrad(g, KS * KS, DACT != 0, gpre_out != nullptr));
     hipLaunchKernelGGL((conv_wgrad_x3<KS, WTXO, DACT>), grid, dim3(WXT), lds, st, x, gout, yact, slab, gpre_out, g, dslope,
                        (int)tiles, need_bias);
     return check_launch("conv_wgrad_bf16x3");
@@ -1385,7 +1396,8 @@ int launch_wgrad_bf16_d(hipStream_t st, const float *x, const float *gout, const
     }
     const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, C::WTX);
     dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, C::CIB));
-    ProfScope ps("conv_wgrad_bf16", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS);
+    ProfScope ps("conv_wgrad_bf16", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS,
+                 conv_bytes_wgrad(g, KS * KS, DACT != 0, false));
     hipLaunchKernelGGL((conv_wgrad_bf16<KS, DACT>), grid, dim3(256), lds, st, x, gout, yact, slab, g, dslope, (int)tiles,
                        need_bias);
     return check_launch("conv_wgrad_bf16");
@@ -1428,7 +1440,7 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
     if (x3) {
         constexpr int PSX = (TYB - 1 + KS) * (TX - 1 + KS);
         const size_t lds = (size_t)(2 * PSX * PITCH + 2 * KS * KS * 32 * mt * PITCH) * sizeof(__bf16);
-        ProfScope ps(name, st, flops);
+        ProfScope ps(name, st, flops, conv_bytes_fwd(g, KS * KS, dact != 0));
 #define EBFI_LAUNCH_X3(MT_, DA_)                                                                                          \
     do {                                                                                                                 \
         static bool attr_done = false;                                                                                   \
@@ -1453,7 +1465,7 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
         return check_launch(name);
     }
     {
-        ProfScope ps(name, st, flops);
+        ProfScope ps(name, st, flops, conv_bytes_fwd(g, KS * KS, dact != 0));
 #define EBFI_LAUNCH_BF16(MT_, DA_)                                                                                     \
     hipLaunchKernelGGL((conv_fwd_bf16<KS, MT_, DA_>), grid, dim3(256), 0, st, x, dact_y, wp, bias, out, g, K16, act, slope, \
                        dslope)

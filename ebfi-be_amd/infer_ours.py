@@ -41,7 +41,11 @@ def main():
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--num_ts", type=int, default=16, help="latent timestamps per clip (NumI of the reference loop)")
     ap.add_argument("--seed", type=int, default=123)
+    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16"],
+                    help="matrix-core operands of the convs: bf16x3 = split bf16 pairs, fp32-grade accuracy (default); fp32 = exact")
     a = ap.parse_args()
+    from ebfi_amd import conv
+    conv.set_compute_dtype(a.precision)
     torch.manual_seed(a.seed)
     device = torch.device("cuda", 0)
     model, margs = load_model(a.model_path, device)

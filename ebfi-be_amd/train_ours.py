@@ -60,7 +60,8 @@ def main():
     ap.add_argument("-r", "--resume", default=None, help="checkpoint to resume from")
     ap.add_argument("-seed", "--seed", type=int, default=123)
     ap.add_argument("--iterations", type=int, default=None)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16"],
+                    help="matrix-core operands of the convs: bf16x3 = split bf16 pairs, fp32-grade accuracy (default); fp32 = exact")
     ap.add_argument("--graph", action="store_true", help="replay forward+loss+backward from a captured hipGraph")
     args = ap.parse_args()
     with open(args.config) as fh:
