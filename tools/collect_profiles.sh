@@ -1,0 +1,30 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): the measurements that profiles/<round>/ is built from.  Output: gpurun_out/final/.
+# One GPU step after the other; a failing step stops the script (no retries).
+set -eo pipefail
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+OUT=gpurun_out/final
+rm -rf "$OUT"; mkdir -p "$OUT"
+export TMPDIR=/tmp
+echo "[1] smoke"; timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
+echo "[2] bench (default, with cpu baseline)"; timeout -k 10 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cut -c1-160 $OUT/bench.json
+echo "[3] rocprofv3 kernel stats of the bench command"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs > $OUT/bench_prof.json 2> $OUT/bench_prof.err
+find $OUT/prof -name "*kernel_trace*" -delete; find $OUT/prof -name "*.csv" | head
+echo "[4] PMC passes (eager launches), FETCH_SIZE then WRITE_SIZE"
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 400 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs --no-graph > /dev/null 2> $OUT/pmc_$C.err
+done
+python3 tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE > $OUT/pmc_traffic_summary.json; cat $OUT/pmc_traffic_summary.json | head -30
+rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
+echo "[5] op microbenchmarks"
+timeout -k 10 300 python tools/opbench.py --ops fac,dcn,conv --x3 --iters 20 > $OUT/opbench_x3.jsonl 2> $OUT/opbench_x3.err
+timeout -k 10 300 python tools/opbench.py --ops conv --iters 20 > $OUT/opbench_fp32.jsonl 2> $OUT/opbench_fp32.err
+echo "[6] other BASELINE configs"
+timeout -k 10 300 python ebfi-be_amd/infer_ours.py --batch 1 --height 128 --width 128 > $OUT/config1.log 2>&1; tail -1 $OUT/config1.log
+timeout -k 10 300 python ebfi-be_amd/infer_ours.py --batch 4 --height 256 --width 256 --precision fp32 > $OUT/config2_fp32.log 2>&1; tail -1 $OUT/config2_fp32.log
+timeout -k 10 300 python ebfi-be_amd/infer_ours.py --batch 4 --height 256 --width 256 > $OUT/config2_x3.log 2>&1; tail -1 $OUT/config2_x3.log
+timeout -k 10 400 python ebfi-be_amd/infer_ours.py --batch 8 --height 720 --width 1280 --num_ts 4 > $OUT/config5.log 2>&1; tail -1 $OUT/config5.log
+echo "[7] two-rank rehearsal of the bench (both ranks on this GPU, gloo)"
+EBFI_BENCH_REHEARSAL=1 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs > $OUT/bench_2rank_rehearsal.json 2> $OUT/bench_2rank_rehearsal.err; cut -c1-160 $OUT/bench_2rank_rehearsal.json
+du -sh $OUT
