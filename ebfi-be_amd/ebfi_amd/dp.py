@@ -92,7 +92,14 @@ class FlatGradBucket:
     def reduce_mean_packed(self):
         """Average the already packed buffer over ranks in place (one collective; no-op on one rank)."""
         if is_distributed():
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            if self.flat.is_cuda and dist.get_backend() == "gloo":
+                # rehearsal / CPU-only fabrics: gloo reduces device tensors through tiny staged chunks (seconds for
+                # 22.8 MB); one explicit round trip through host memory is two copies and a host all-reduce
+                host = self.flat.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                self.flat.copy_(host)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.mul_(1.0 / dist.get_world_size())
         return self.flat
 
