@@ -158,7 +158,7 @@ __device__ __forceinline__ TapPos tap_pos(const Geom &g, const float *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256) void dcn_fwd_f32(const float *__restrict__ x, const float *__restrict__ wgt,
+__global__ __launch_bounds__(256, 4) void dcn_fwd_f32(const float *__restrict__ x, const float *__restrict__ wgt,
                                                    const float *__restrict__ bias, const float *__restrict__ off,
                                                    const float *__restrict__ msk, float *__restrict__ out, Geom g) {
     __shared__ float sW[(KC + 2) * WSTR];   // [kl][co]
