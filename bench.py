@@ -6,14 +6,17 @@ loss + backward + flat RCCL gradient all-reduce + Adam) at B=8 per GPU, 256x256,
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One process per GPU; weak scaling (B=8 per rank).  Rank 0 prints ONE JSON line.  Besides the
-contract fields the line carries
-  roofline      the dominant hand-written kernel of the step (by device time inside the timed
-                region, measured with hipEvent pairs the library records on the launch stream):
-                algorithmic bytes per launch / average launch duration vs the 8 TB/s HBM peak
-  kernels       the same figures for every hand-written kernel that ran in the timed region
-  cpu_baseline  the CPU oracle (oracle/model_ref.py + loss_ref.py, a port of the reference path)
-                timed on this box's host cores on a bounded sample (rank 0, N=1 only)
+One process per GPU; weak scaling (B=8 per rank).  Rank 0 prints ONE JSON line.  Default precision: bf16x3
+(split-precision conv operands, fp32-grade accuracy, parity-tested at 1e-3 like the exact fp32 mode); forward + loss +
+backward + gradient packing are replayed from one captured hipGraph (--no-graph launches eagerly).  Besides the contract
+fields the line carries
+  roofline         the dominant hand-written kernel of the step by device time: its bound (matrix cores or HBM, whichever
+                   floor is higher for the work it was given), achieved vs peak, PMC traffic per launch; measured with
+                   hipEvent pairs the library records on the launch stream during a second, eager pass of the same K steps
+  kernels          the same figures for every hand-written kernel of the step
+  fp32_exact_mode  the same step with every conv on the exact fp32 matrix cores (second leg of the same run)
+  cpu_baseline     the CPU oracle (oracle/model_ref.py + loss_ref.py, a port of the reference path) timed on this box's
+                   host cores on a bounded sample (rank 0, N=1 only)
 """
 import argparse
 import json

@@ -866,6 +866,7 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
         boff[q] = 64 * GS + ((n < ncols) ? ci * PS + ky * IWS + kx : CIB * PS) + 8 * (lane >> 5);
     }
     const int aoff = (mt * 32 + (lane & 31)) * GS + 8 * (lane >> 5);
+    const bool last_live = (nq + 4 * (NTW - 1)) * 32 < ncols;   // e.g. 18 n-tiles over 4 column groups: 5, 5, 4, 4
     // both buffers start as zero words (= +0.0 pairs): pad slots / pad columns / the zero plane are never written later
     for (int i = tid; i < 2 * BUF; i += WXT) smw[i] = 0u;
 
@@ -956,6 +957,7 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
             peel(aw, ah, al);
 #pragma unroll
             for (int q = 0; q < NTW; ++q) {
+                if (q == NTW - 1 && !last_live) continue;   // wave-uniform: this wave's last n-tile lies past the columns
                 unsigned bw[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) bw[j] = sB[boff[q] + row * IWS + px0 + j];
