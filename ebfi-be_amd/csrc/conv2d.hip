@@ -818,7 +818,9 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
                                                      float *__restrict__ gpre_out, ConvGeom g, float dslope, int total_tiles,
                                                      int need_bias) {
     using C = WCfg<KS, 1, WTXO>;
-    constexpr int KK = KS * KS, WTX = C::WTX, IH = C::IH, IW = C::IW, IWP = C::IWP;
+    constexpr int KK = KS * KS, WTX = C::WTX, IH = C::IH, IW = C::IW;
+    constexpr int IWP = 32;                // lanes per staged input row; a 32-px tile has IW = 34: columns 32, 33 go separately
+    constexpr int EXC = IW > IWP ? IW - IWP : 0;
     constexpr int CIB = C::CIB, PS = C::PS, IWS = C::IWS;
     constexpr int TROWS = WXT / IWP;       // thread rows walking (row, channel) of the input tile
     constexpr int CPR = CIB / TROWS;       // channel steps per input row
@@ -826,7 +828,7 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
     constexpr int NG = 64 / (WXT / 64);    // grad_out channels per thread per tile (8 thread rows of 64 slots)
     constexpr int NTW = (CIB * KK + 127) / 128;   // n-tiles (of 32 columns) per wave: 4 column groups
     constexpr int BUF = 64 * GS + (CIB + 1) * PS; // words per buffer: grad_out image, channel planes, zero plane
-    static_assert(IWP == 32 && CIB % TROWS == 0 && WTX <= 32, "tile configuration");
+    static_assert(CIB % TROWS == 0 && WTX <= 32 && EXC * IH * CIB <= WXT && IWS >= IW, "tile configuration");
     extern __shared__ __attribute__((aligned(16))) unsigned smw[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -862,6 +864,8 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
     const unsigned go_bytes = (unsigned)g.Cout * (unsigned)HWo * 4u, x_bytes = (unsigned)g.Cin * (unsigned)HW * 4u;
 
     float rg[NG], ry[NG], ri[NI];
+    float rex = 0.f;                       // 32-px tiles: one element of the two extra halo columns per thread
+    const int ex_ci = tid & (CIB - 1), ex_r = (tid / CIB) / (EXC ? EXC : 1), ex_c = IWP + (tid / CIB) % (EXC ? EXC : 1);
     float bacc[NG];                        // bias: this thread's slot of channels gco + 8*it, summed over its tiles
 #pragma unroll
     for (int it = 0; it < NG; ++it) bacc[it] = 0.f;
@@ -894,6 +898,11 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
 #pragma unroll
             for (int k = 0; k < CPR; ++k) ri[r * CPR + k] = buf_ld(rxi, base + (unsigned)(k * TROWS) * (unsigned)HW * 4u);
         }
+        if constexpr (EXC > 0) {
+            const int yy = iy0 + ex_r, xe = ix0 + ex_c;
+            const bool ok = tid < EXC * IH * CIB && yy >= 0 && yy < g.H && xe >= 0 && xe < g.W;
+            rex = buf_ld(rxi, ok ? (unsigned)((ci_base + ex_ci) * HW + yy * g.W + xe) * 4u : SENT);
+        }
     };
     auto commit = [&](int tile, int buf) {
         unsigned *sG = smw + buf * BUF, *sIn = sG + 64 * GS;
@@ -921,6 +930,9 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
             for (int r = 0; r < IH; ++r)
 #pragma unroll
                 for (int k = 0; k < CPR; ++k) sIn[(irow + k * TROWS) * PS + r * IWS + icol] = split_word(ri[r * CPR + k]);
+        }
+        if constexpr (EXC > 0) {
+            if (tid < EXC * IH * CIB) sIn[ex_ci * PS + ex_r * IWS + ex_c] = split_word(rex);
         }
     };
 
@@ -1325,8 +1337,12 @@ int launch_wgrad(hipStream_t st, const float *x, const float *gout, const float 
     return launch_wgrad_t<KS, S, 0>(st, x, gout, yact, slab, gpre_out, g, dact, dslope, nsplit, need_bias);
 }
 
+// The split-precision kernel uses full 32-px tiles (two extra halo columns staged separately): a tile costs its 64 k-slots
+// whatever its width, so the widest tile = the fewest tiles is always the cheapest.
+int pick_wtx_x3(int) { return 32; }
+
 int wgrad_x3_splits(const ConvGeom &g, int ks) {
-    const int wtx = wgrad_wtx_rt(g, ks, 1);
+    const int wtx = ks == 3 ? pick_wtx_x3(g.Wo) : wgrad_wtx_rt(g, ks, 1);
     const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, wtx);
     const int64_t blocks = ceil_div(g.Cout, 64) * ceil_div(g.Cin, 64);
     int64_t s = blocks <= 256 ? 256 / blocks : 1;      // one 512-thread workgroup per CU: fill one round of 256
@@ -1365,10 +1381,7 @@ int launch_wgrad_x3_t(hipStream_t st, const float *x, const float *gout, const f
 int launch_wgrad_x3(hipStream_t st, const float *x, const float *gout, const float *yact, float *slab, float *gpre_out,
                     const ConvGeom &g, int ks, int dact, float dslope, int nsplit, int need_bias) {
     if (ks == 1) return launch_wgrad_x3_t<1, 0>(st, x, gout, yact, slab, gpre_out, g, dact, dslope, nsplit, need_bias);
-    const int w = pick_wtx(g.Wo);
-    if (w == 26) return launch_wgrad_x3_t<3, 26>(st, x, gout, yact, slab, gpre_out, g, dact, dslope, nsplit, need_bias);
-    if (w == 28) return launch_wgrad_x3_t<3, 28>(st, x, gout, yact, slab, gpre_out, g, dact, dslope, nsplit, need_bias);
-    return launch_wgrad_x3_t<3, 0>(st, x, gout, yact, slab, gpre_out, g, dact, dslope, nsplit, need_bias);
+    return launch_wgrad_x3_t<3, 32>(st, x, gout, yact, slab, gpre_out, g, dact, dslope, nsplit, need_bias);
 }
 
 template <int KS, int DACT>
