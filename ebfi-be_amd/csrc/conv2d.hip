@@ -421,28 +421,35 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16(const float *__restrict__ x
 
 // ------------------------------------------------------------------------------------------------
 // Split-precision variant ("bf16x3"): every fp32 operand is carried as hi = bf16(v) and lo = bf16(v - hi), and a
-// product is accumulated as hi*hi + hi*lo + lo*hi on the bf16 matrix cores (fp32 accumulation).  The dropped lo*lo
+// product is accumulated as lo*hi + hi*lo + hi*hi on the bf16 matrix cores (fp32 accumulation).  The dropped lo*lo
 // term and the rounding of lo are ~2^-17 relative: results agree with the exact-fp32 kernels to ~1e-5, at 3/16 of
 // their MFMA time.  Both images cost the LDS bytes of fp32, so the tile is 8 rows x 64 px for 512 threads (one weight
-// slice per CU instead of two): 119 KB of LDS, one workgroup of 8 waves per CU.
+// slice per CU instead of two): one workgroup of 8 waves per CU.
 constexpr int TYB = 8, NTB = 512;
 
+// ------------------------------------------------------------------------------------------------
+// conv_fwd_bf16x3_db: forward / data gradient of the split-precision mode, double-buffered.  With one 512-thread
+// workgroup per CU nothing else can cover the commit phase, so the operand images of chunk c+1 are written into a second
+// LDS buffer BETWEEN the MFMAs of chunk c (one barrier per chunk; measured 1-4 % over the single-buffer form).  Two buffers only fit without padding: rows are 16 channels = 32 bytes, and a row's two 16-byte
+// halves are swapped when bit 3 of the row index is set.  ds_read_b128 is served in groups of 16 lanes
+// ({0-3,12-15,20-27}, ...): rows r..r+27 of such a group then hit 16 distinct 16-byte slots of the 256-byte LDS row,
+// the same conflict-free property the 48-byte pitch bought, in 2/3 of the space (158 KB for both buffers).
 template <int KS, int MT, int DACT>
-__global__ __launch_bounds__(NTB) void conv_fwd_bf16x3(const float *__restrict__ x, const float *__restrict__ dact_y,
-                                                       const __bf16 *__restrict__ wp, const float *__restrict__ bias,
-                                                       float *__restrict__ out, ConvGeom g, int K16, int act, float slope,
-                                                       float dslope) {
-    constexpr int S = 1;
+__global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_db(const float *__restrict__ x, const float *__restrict__ dact_y,
+                                                          const __bf16 *__restrict__ wp, const float *__restrict__ bias,
+                                                          float *__restrict__ out, ConvGeom g, int K16, int act, float slope,
+                                                          float dslope) {
     constexpr int KK = KS * KS;
-    constexpr int IH = S * (TYB - 1) + KS, IW = S * (TX - 1) + KS;
+    constexpr int IH = TYB - 1 + KS, IW = TX - 1 + KS;
     constexpr int PS = IH * IW;            // positions of the staged input tile
     constexpr int COS = 32 * MT;
     constexpr int NPOS = (PS + NTB - 1) / NTB;
     constexpr int WPIECES = KK * COS * 2;  // 16-byte pieces of ONE weight image (hi or lo)
     constexpr int NWB = (2 * WPIECES + NTB - 1) / NTB;
-    constexpr int INE = PS * PITCH, WE = KK * COS * PITCH;   // elements per image
-    extern __shared__ __attribute__((aligned(16))) __bf16 smx[];
-    __bf16 *sInH = smx, *sInL = smx + INE, *sWH = smx + 2 * INE, *sWL = smx + 2 * INE + WE;
+    constexpr int INB = PS * 32, WB = KK * COS * 32;   // bytes of one input / weight image
+    constexpr int BUFB = 2 * INB + 2 * WB;             // one buffer: input hi | input lo | weight hi | weight lo
+    constexpr int T1 = KK > 1 ? (2 * KK + 2) / 3 : 1;  // taps multiplied before the next chunk's commit is slotted in
+    extern __shared__ __attribute__((aligned(16))) char smd[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = (g.Wo + TX - 1) / TX, tiles_y = (g.Ho + TYB - 1) / TYB;
@@ -452,7 +459,7 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3(const float *__restrict__
     const int b = t / tiles_y;
     const int y0 = ty * TYB, x0 = tx * TX;
     const int co_base = blockIdx.y * COS;
-    const int iy0 = S * y0 - g.pad, ix0 = S * x0 - g.pad;
+    const int iy0 = y0 - g.pad, ix0 = x0 - g.pad;
     const int HW = g.H * g.W;
     const unsigned plane_bytes = (unsigned)HW * 4u, x_bytes = (unsigned)g.Cin * plane_bytes;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (int64_t)b * g.Cin * HW, x_bytes);
@@ -469,15 +476,17 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3(const float *__restrict__
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
     unsigned in_off[NPOS];
+    int in_dst[NPOS];                      // byte offset of the row's half 0 (half 1 sits at the other 16 bytes of the row)
 #pragma unroll
     for (int q = 0; q < NPOS; ++q) {
         const int pos = tid + q * NTB;
         const int r = pos / IW, c = pos - r * IW;
         const int yy = iy0 + r, xx = ix0 + c;
         in_off[q] = (pos < PS && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) ? (unsigned)(yy * g.W + xx) * 4u : SENT;
+        in_dst[q] = pos * 32 + (((pos >> 3) & 1) << 4);
     }
     unsigned w_off[NWB];                   // byte offset of the owned 16-byte weight pieces for chunk 0 (hi image, then lo)
-    int w_dst[NWB];                        // their element offset from sWH
+    int w_dst[NWB];                        // their byte offset inside a buffer
 #pragma unroll
     for (int it = 0; it < NWB; ++it) {
         const int i = tid + it * NTB;
@@ -486,8 +495,16 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3(const float *__restrict__
         const int tap = row / COS, co = row - tap * COS;
         w_off[it] = i < 2 * WPIECES ? (unsigned)sel * img_bytes + (unsigned)(((tap * g.Cout + co_base + co) * K16 + half * 8) * 2)
                                     : SENT;
-        w_dst[it] = sel * WE + row * PITCH + half * 8;
+        w_dst[it] = 2 * INB + sel * WB + row * 32 + ((half ^ ((row >> 3) & 1)) << 4);
     }
+    // reader side: lane = (column lane&31, channel half lane>>5)
+    const int hsel = lane >> 5, l31 = lane & 31;
+    const int a_lane = 2 * INB + l31 * 32 + ((hsel ^ ((l31 >> 3) & 1)) << 4);   // + (tap*COS + m*32)*32: multiples of 1 KB keep bit 3
+    const int pbase = wave * IW + l31;
+    unsigned fbits = 0;                    // bit tap: half-swap of this lane's row for that tap (x halves n = 0, 1 agree)
+#pragma unroll
+    for (int tap = 0; tap < KK; ++tap)
+        fbits |= (unsigned)((((pbase + (tap / KS) * IW + (tap % KS)) >> 3) & 1) ^ hsel) << tap;
 
     float rin[NPOS * CKB];
     u32x4 rw[NWB];
@@ -506,7 +523,8 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3(const float *__restrict__
 #pragma unroll
         for (int it = 0; it < NWB; ++it) rw[it] = __builtin_amdgcn_raw_buffer_load_b128(rwt, w_off[it] + wb, 0, 0);
     };
-    auto commit = [&]() {
+    auto commit = [&](int buf) {
+        char *base = smd + buf * BUFB;
 #pragma unroll
         for (int q = 0; q < NPOS; ++q)
             if (tid + q * NTB < PS) {
@@ -519,49 +537,58 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3(const float *__restrict__
                     const unsigned lp = pack_bf16(v0 - (float)a0, v1 - (float)a1);
                     if (j < 4) { h0[j] = hp; l0[j] = lp; } else { h1[j - 4] = hp; l1[j - 4] = lp; }
                 }
-                u32x4 *dh = reinterpret_cast<u32x4 *>(sInH + (tid + q * NTB) * PITCH);
-                u32x4 *dl = reinterpret_cast<u32x4 *>(sInL + (tid + q * NTB) * PITCH);
-                dh[0] = h0; dh[1] = h1;
-                dl[0] = l0; dl[1] = l1;
+                const int d0 = in_dst[q], d1 = in_dst[q] ^ 16;
+                *reinterpret_cast<u32x4 *>(base + d0) = h0;
+                *reinterpret_cast<u32x4 *>(base + d1) = h1;
+                *reinterpret_cast<u32x4 *>(base + INB + d0) = l0;
+                *reinterpret_cast<u32x4 *>(base + INB + d1) = l1;
             }
 #pragma unroll
         for (int it = 0; it < NWB; ++it)
-            if (tid + it * NTB < 2 * WPIECES) *reinterpret_cast<u32x4 *>(sWH + w_dst[it]) = rw[it];
+            if (tid + it * NTB < 2 * WPIECES) *reinterpret_cast<u32x4 *>(base + w_dst[it]) = rw[it];
     };
 
     const int nchunks = K16 / CKB;
     prefetch(0);
+    commit(0);
+    __syncthreads();
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        __syncthreads();
-        commit();
-        __syncthreads();
-        prefetch(chunk + 1);      // past the last chunk every offset is out of range: reads 0, never committed
-        // lane: column (pixel / out channel) lane&31, k-half lane>>5 (channels 8h..8h+7 of the chunk)
-        const int boff = ((S * wave) * IW + S * (lane & 31)) * PITCH + (lane >> 5) * 8;
-        const int aoff = (lane & 31) * PITCH + (lane >> 5) * 8;
+        const char *base = smd + (chunk & 1) * BUFB;
+        prefetch(chunk + 1);      // past the last chunk every offset is out of range: reads 0
+        __builtin_amdgcn_sched_barrier(0);
+        auto taps = [&](int t0, int t1) {
 #pragma unroll
-        for (int tap = 0; tap < KK; ++tap) {
-            const int ky = tap / KS, kx = tap - ky * KS;
-            bf16x8 ah[MT], al[MT], bh[2], bl[2];
+            for (int tap = t0; tap < t1; ++tap) {
+                const int ky = tap / KS, kx = tap - ky * KS;
+                const char *bp = base + pbase * 32 + (int)(((fbits >> tap) & 1u) << 4) + (ky * IW + kx) * 32;
+                const char *ap = base + a_lane + tap * COS * 32;
+                bf16x8 ah[MT], al[MT], bh[2], bl[2];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                ah[m] = *reinterpret_cast<const bf16x8 *>(sWH + aoff + (tap * COS + m * 32) * PITCH);
-                al[m] = *reinterpret_cast<const bf16x8 *>(sWL + aoff + (tap * COS + m * 32) * PITCH);
-            }
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                bh[n] = *reinterpret_cast<const bf16x8 *>(sInH + boff + (ky * IW + kx + n * 32 * S) * PITCH);
-                bl[n] = *reinterpret_cast<const bf16x8 *>(sInL + boff + (ky * IW + kx + n * 32 * S) * PITCH);
-            }
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
+                for (int m = 0; m < MT; ++m) {
+                    ah[m] = *reinterpret_cast<const bf16x8 *>(ap + m * 1024);
+                    al[m] = *reinterpret_cast<const bf16x8 *>(ap + m * 1024 + WB);
+                }
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+                    bh[n] = *reinterpret_cast<const bf16x8 *>(bp + n * 1024);
+                    bl[n] = *reinterpret_cast<const bf16x8 *>(bp + n * 1024 + INB);
                 }
-        }
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+                    }
+            }
+        };
+        taps(0, T1);
+        __builtin_amdgcn_sched_barrier(0);
+        commit((chunk & 1) ^ 1);  // unconditional (zeros after the last chunk); that buffer was last read before the previous barrier
+        __builtin_amdgcn_sched_barrier(0);
+        taps(T1, KK);
+        __syncthreads();
     }
     store_out_tile<MT>(out, bias, acc, g, b, co_base, y0 + wave, x0, lane, act, slope);
 }
@@ -1440,17 +1467,17 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
     dim3 grid((unsigned)tiles, (unsigned)ceil_div(g.Cout, 32 * mt));
     if (x3) {
         constexpr int PSX = (TYB - 1 + KS) * (TX - 1 + KS);
-        const size_t lds = (size_t)(2 * PSX * PITCH + 2 * KS * KS * 32 * mt * PITCH) * sizeof(__bf16);
+        const size_t lds = (size_t)2 * (2 * PSX * 32 + 2 * KS * KS * 32 * mt * 32);   // two buffers of unpadded hi/lo images
         ProfScope ps(name, st, flops, conv_bytes_fwd(g, KS * KS, dact != 0));
 #define EBFI_LAUNCH_X3(MT_, DA_)                                                                                          \
     do {                                                                                                                 \
         static bool attr_done = false;                                                                                   \
         if (!attr_done) {                                                                                                \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_fwd_bf16x3<KS, MT_, DA_>),                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_fwd_bf16x3_db<KS, MT_, DA_>),                 \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                           \
             attr_done = true;                                                                                            \
         }                                                                                                                \
-        hipLaunchKernelGGL((conv_fwd_bf16x3<KS, MT_, DA_>), grid, dim3(NTB), lds, st, x, dact_y, wp, bias, out, g, K16, act,  \
+        hipLaunchKernelGGL((conv_fwd_bf16x3_db<KS, MT_, DA_>), grid, dim3(NTB), lds, st, x, dact_y, wp, bias, out, g, K16, act,  \
                            slope, dslope);                                                                               \
     } while (0)
         if (mt == 1) {
