@@ -6,7 +6,8 @@ runs the stride-1 data gradient on the same kernel with the activation derivativ
 staging (`ebfi_conv2d_backward_data`) plus a deterministic weight/bias gradient
 (`ebfi_conv2d_backward_weight`).  Configurations the kernels do not cover (kernel sizes other than
 1/3, dilation, groups, feature maps smaller than one tile) stay on PyTorch-ROCm's conv; that is a
-GPU library path, never a CPU fallback.
+GPU library path, never a CPU fallback.  Feature maps of any size >= 2 pixels take the native kernels (partial tiles are
+masked): MIOpen would otherwise JIT-compile a kernel per small, unusual shape -- minutes on a fresh machine.
 """
 import torch
 import torch.nn.functional as F
@@ -68,7 +69,7 @@ def supported(x, weight, stride, padding, dilation=(1, 1), groups=1):
     return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and
             weight.shape[-2] == k and k in (1, 3, 7) and stride[0] == stride[1] and stride[0] in (1, 2) and
             not (k == 1 and stride[0] != 1) and padding[0] == padding[1] and 0 <= padding[0] <= k and
-            tuple(dilation) == (1, 1) and groups == 1 and x.shape[-1] * x.shape[-2] >= 256)
+            tuple(dilation) == (1, 1) and groups == 1 and x.shape[-1] * x.shape[-2] >= 2)
 
 
 def _geo(x, weight, stride, pad):

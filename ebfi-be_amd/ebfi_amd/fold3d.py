@@ -27,7 +27,7 @@ from . import conv
 
 def usable(x):
     return x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.shape[2] == 2 and \
-        not torch.is_autocast_enabled() and x.shape[-1] * x.shape[-2] >= 256
+        not torch.is_autocast_enabled() and x.shape[-1] * x.shape[-2] >= 2
 
 
 def fold_conv3d_weight(w):

@@ -36,6 +36,12 @@ CASES = [
     (1, 6, 40, 72, 32, 7, 2, 3, 1, False),      # detail-branch stem (folded 3x7x7): 7x7 stride 2
     (1, 16, 38, 70, 3, 7, 1, 0, 0, True),       # detail-branch outconv: 7x7 valid conv on a reflection-padded map
     (2, 12, 33, 47, 20, 3, 2, 1, 0, False),     # stride-2 data gradient through zero insertion, odd sizes
+    (2, 8, 4, 5, 8, 3, 1, 1, 1, True),          # maps far smaller than one tile (deep levels of the detail branch)
+    (1, 16, 8, 8, 12, 3, 1, 1, 0, False),
+    (2, 8, 2, 2, 8, 3, 1, 1, 1, True),
+    (1, 8, 3, 3, 4, 1, 1, 0, 1, True),
+    (1, 6, 9, 7, 8, 3, 2, 1, 1, True),          # small stride-2
+    (1, 6, 10, 12, 8, 7, 2, 3, 1, False),       # small 7x7 stride-2 stem
 ]
 
 
@@ -144,7 +150,8 @@ def test_bf16_mma_mode_vs_fp32_reference(B, Cin, H, W, Cout, k, act):
 
 @pytest.mark.parametrize("B,Cin,H,W,Cout,k,act", [(2, 64, 16, 64, 64, 3, 1), (1, 128, 13, 70, 200, 3, 1), (1, 20, 17, 33, 24, 3, 0),
                                                   (2, 64, 16, 32, 64, 1, 1), (1, 64, 17, 33, 3, 3, 2), (1, 4, 24, 40, 64, 3, 1),
-                                                  (1, 70, 9, 130, 33, 3, 1)])
+                                                  (1, 70, 9, 130, 33, 3, 1), (2, 8, 4, 5, 8, 3, 1), (1, 16, 8, 8, 12, 3, 0),
+                                                  (2, 8, 2, 2, 8, 1, 1)])
 def test_bf16x3_split_precision_mode_vs_fp32_reference(B, Cin, H, W, Cout, k, act):
     """Split-precision mode (bf16 hi + lo operand pairs, 3 MFMAs per product, fp32 accumulation) for forward and
     data and weight gradient.  Bar: 1e-4 of the fp32 CPU statement, ten times inside the 1e-3 parity tolerance of
