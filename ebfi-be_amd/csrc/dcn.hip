@@ -32,6 +32,27 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// split precision (see conv2d.hip): a value as the pair (bf16 hi << 16 | bf16 lo), lo = bf16(v - hi)
+__device__ __forceinline__ unsigned split_word(float v) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const __bf16 h = (__bf16)v;
+    const float hf = (float)h;
+    bf16x2 p = {(__bf16)(v - hf), h};
+    return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ void peel(const unsigned (&w)[8], bf16x8 &hi, bf16x8 &lo) {
+    u32x4 h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = __builtin_amdgcn_perm(w[2 * i + 1], w[2 * i], 0x07060302u);
+        l[i] = __builtin_amdgcn_perm(w[2 * i + 1], w[2 * i], 0x05040100u);
+    }
+    hi = __builtin_bit_cast(bf16x8, h);
+    lo = __builtin_bit_cast(bf16x8, l);
+}
 
 constexpr int NP = 64;     // pixels per workgroup tile
 constexpr int KC = 72;     // max contraction rows per chunk (one group's channels x taps)
@@ -107,7 +128,13 @@ __device__ __forceinline__ void corners(const float *__restrict__ plane, const T
 
 // Sample `n` consecutive channels of one (pixel, tap) into the LDS column image.  NCH > 0 unrolls exactly
 // NCH channels so that all 4*NCH corner gathers are in flight together; NCH == 0 is the generic loop.
-template <int NCH>
+// SPLIT: store the split-precision word of the sample (bit pattern in the float slot) instead of the float.
+template <bool SPLIT>
+__device__ __forceinline__ float col_word(float v) {
+    if constexpr (SPLIT) return __uint_as_float(split_word(v));
+    else return v;
+}
+template <int NCH, bool SPLIT = false>
 __device__ __forceinline__ void sample_cols(const float *__restrict__ plane, int64_t plane_stride, const Tap &t,
                                             float mask, float *col, int col_stride, int n) {
     if constexpr (NCH > 0) {
@@ -116,12 +143,12 @@ __device__ __forceinline__ void sample_cols(const float *__restrict__ plane, int
         for (int c = 0; c < NCH; ++c) corners(plane + c * plane_stride, t, v[c][0], v[c][1], v[c][2], v[c][3]);
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
-            col[c * col_stride] = (t.w1 * v[c][0] + t.w2 * v[c][1] + t.w3 * v[c][2] + t.w4 * v[c][3]) * mask;
+            col[c * col_stride] = col_word<SPLIT>((t.w1 * v[c][0] + t.w2 * v[c][1] + t.w3 * v[c][2] + t.w4 * v[c][3]) * mask);
     } else {
         for (int c = 0; c < n; ++c, plane += plane_stride) {
             float v1, v2, v3, v4;
             corners(plane, t, v1, v2, v3, v4);
-            col[c * col_stride] = (t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4) * mask;
+            col[c * col_stride] = col_word<SPLIT>((t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4) * mask);
         }
     }
 }
@@ -157,12 +184,61 @@ __device__ __forceinline__ TapPos tap_pos(const Geom &g, const float *__restrict
     return r;
 }
 
+// forward-kernel variants of tap_pos / sample_cols: the pixel's (ho, wo) are computed once per thread instead of per item,
+// and the corner pairs are fetched through a buffer descriptor of the sample (32-bit lane offsets, the channel offset in
+// a scalar register, rows outside the image as an out-of-range offset that reads 0) -- the sampling walk is VALU-bound
+// (9000 vector instructions per wave), not bandwidth-bound, so address arithmetic and per-load branches are what it pays for.
+__device__ __forceinline__ TapPos tap_pos_hw(const Geom &g, const float *__restrict__ off, const float *__restrict__ msk,
+                                             int b, int grp, int tap, int p, int ho, int wo) {
+    const int i = tap / g.kw, j = tap - i * g.kw;
+    const int64_t ob = ((int64_t)(b * g.dg + grp) * 2 * g.kk + 2 * tap) * g.HWo + p;
+    const float dy = off[ob], dx = off[ob + g.HWo];
+    TapPos r;
+    r.mask = msk[((int64_t)(b * g.dg + grp) * g.kk + tap) * g.HWo + p];
+    r.h = (float)(ho * g.sh - g.ph + i * g.dh) + dy;
+    r.w = (float)(wo * g.sw - g.pw + j * g.dw) + dx;
+    return r;
+}
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int NCH, bool SPLIT>
+__device__ __forceinline__ void sample_cols_buf(__amdgpu_buffer_rsrc_t rx, unsigned chan_byte, unsigned plane_bytes, const Tap &t,
+                                                float mask, float *col, int col_stride, int n) {
+    const unsigned o0 = t.q0 >= 0 ? (unsigned)t.q0 * 4u : 0x80000000u, o1 = t.q1 >= 0 ? (unsigned)t.q1 * 4u : 0x80000000u;
+    auto one = [&](unsigned cb, float &s) {
+        // (channel offset added per lane: as a scalar offset it would need a provably wave-uniform value)
+        const u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(rx, o0 + cb, 0, 0), bq = __builtin_amdgcn_raw_buffer_load_b64(rx, o1 + cb, 0, 0);
+        const float ax = __uint_as_float(a.x), ay = __uint_as_float(a.y), bx = __uint_as_float(bq.x), by = __uint_as_float(bq.y);
+        const float v1 = ax * t.mlx + ay * t.mly, v2 = ax * t.mhx + ay * t.mhy;
+        const float v3 = bx * t.mlx + by * t.mly, v4 = bx * t.mhx + by * t.mhy;
+        s = (t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4) * mask;
+    };
+    if constexpr (NCH > 0) {
+        float sv[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) one(chan_byte + (unsigned)c * plane_bytes, sv[c]);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) col[c * col_stride] = col_word<SPLIT>(sv[c]);
+    } else {
+        for (int c = 0; c < n; ++c) {
+            float sv;
+            one(chan_byte + (unsigned)c * plane_bytes, sv);
+            col[c * col_stride] = col_word<SPLIT>(sv);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256, 4) void dcn_fwd_f32(const float *__restrict__ x, const float *__restrict__ wgt,
-                                                   const float *__restrict__ bias, const float *__restrict__ off,
-                                                   const float *__restrict__ msk, float *__restrict__ out, Geom g) {
-    __shared__ float sW[(KC + 2) * WSTR];   // [kl][co]
-    __shared__ float sCol[(KC + 2) * NP];   // [kl][px]
+// X3: the 64 x (cb*kk) x 64 product on the bf16 matrix cores in split precision (operands as bf16 hi + lo pairs, three
+// MFMAs per product, ~1e-5 of the exact kernel; see conv2d.hip).  LDS then holds the pair words and 16-row k-steps need
+// the images padded to KCP rows.  The default (X3 = false) is the exact fp32 kernel the known-answer tests pin.
+template <bool X3>
+__global__ __launch_bounds__(256, X3 ? 3 : 4) void dcn_fwd_f32(const float *__restrict__ x, const float *__restrict__ wgt,
+                                                              const float *__restrict__ bias, const float *__restrict__ off,
+                                                              const float *__restrict__ msk, float *__restrict__ out, Geom g) {
+    constexpr int ROWS = X3 ? KCP : KC + 2;
+    __shared__ float sW[ROWS * WSTR];   // [kl][co]
+    __shared__ float sCol[ROWS * NP];   // [kl][px]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / g.tiles_per_img;
     const int p0 = (blockIdx.x - b * g.tiles_per_img) * NP;
@@ -191,7 +267,13 @@ __global__ __launch_bounds__(256, 4) void dcn_fwd_f32(const float *__restrict__ 
     }
     const int px = tid & (NP - 1), p = p0 + px;
     const bool p_ok = p < g.HWo;
-    const int64_t plane_stride = (int64_t)g.H * g.W;
+    const int ho = p / g.Wo, wo = p - ho * g.Wo;
+    const unsigned plane_bytes = (unsigned)(g.H * g.W) * 4u;
+    const __amdgpu_buffer_rsrc_t rxs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(x + (int64_t)b * g.C * g.H * g.W), 0, (unsigned)g.C * plane_bytes, 0x00020000);
+    if constexpr (X3) {   // weight rows past the staged slice are never written: they must read as zero pairs
+        for (int i = klmax * WSTR + tid; i < ROWS * WSTR; i += 256) sW[i] = 0.f;
+    }
 
     for (int chunk = 0; chunk < g.nchunks; ++chunk) {
         const Chunk ck = get_chunk(g, chunk);
@@ -208,34 +290,62 @@ __global__ __launch_bounds__(256, 4) void dcn_fwd_f32(const float *__restrict__ 
             const int half_n = (ck.cb + 1) >> 1;               // channels of the first half
             const int nitems = 2 * g.kk;
             TapPos tp = {0.f, 0.f, 0.f};
-            if (p_ok && wave < nitems) tp = tap_pos(g, off, msk, b, ck.grp, wave >> 1, p, g.pw);
+            if (p_ok && wave < nitems) tp = tap_pos_hw(g, off, msk, b, ck.grp, wave >> 1, p, ho, wo);
             for (int item = wave; item < nitems; item += 4) {
                 const int tap = item >> 1, c_lo = (item & 1) ? half_n : 0;
                 const int n = (item & 1) ? ck.cb - half_n : half_n;
                 TapPos tp_next = {0.f, 0.f, 0.f};
-                if (p_ok && item + 4 < nitems) tp_next = tap_pos(g, off, msk, b, ck.grp, (item + 4) >> 1, p, g.pw);
+                if (p_ok && item + 4 < nitems) tp_next = tap_pos_hw(g, off, msk, b, ck.grp, (item + 4) >> 1, p, ho, wo);
                 float *col = sCol + (c_lo * g.kk + tap) * NP + px;
                 if (p_ok && n > 0) {
                     const Tap t = make_tap(tp.h, tp.w, g.H, g.W);
-                    const float *plane = x + (int64_t)(b * g.C + ck.cbase + c_lo) * plane_stride;
-                    if (n == 4) sample_cols<4>(plane, plane_stride, t, tp.mask, col, g.kk * NP, 4);
-                    else sample_cols<0>(plane, plane_stride, t, tp.mask, col, g.kk * NP, n);
+                    const unsigned chan_byte = (unsigned)(ck.cbase + c_lo) * plane_bytes;
+                    if (n == 4) sample_cols_buf<4, X3>(rxs, chan_byte, plane_bytes, t, tp.mask, col, g.kk * NP, 4);
+                    else sample_cols_buf<0, X3>(rxs, chan_byte, plane_bytes, t, tp.mask, col, g.kk * NP, n);
                 } else {
                     for (int c = 0; c < n; ++c) col[c * g.kk * NP] = 0.f;
                 }
                 tp = tp_next;
             }
         }
-        if (KLp != ck.KL && tid < NP) sCol[ck.KL * NP + tid] = 0.f;
+        if constexpr (X3) {   // rows up to the next multiple of 16 take part in the last k-step
+            const int KL16 = (ck.KL + 15) & ~15;
+            for (int i = ck.KL * NP + tid; i < KL16 * NP; i += 256) sCol[i] = 0.f;
+        } else {
+            if (KLp != ck.KL && tid < NP) sCol[ck.KL * NP + tid] = 0.f;
+        }
 #pragma unroll
         for (int it = 0; it < NWT; ++it)
-            if (tid + it * 256 < 64 * klmax) sW[w_dst[it]] = rwv[it];
+            if (tid + it * 256 < 64 * klmax) sW[w_dst[it]] = col_word<X3>(rwv[it]);
         __syncthreads();
         if (tile_live) {
-            const float *ap = sW + (lane >> 5) * WSTR + mt * 32 + (lane & 31);
-            const float *bp = sCol + (lane >> 5) * NP + nt * 32 + (lane & 31);
-            for (int ks = 0; ks < KLp; ks += 2)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[ks * WSTR], bp[ks * NP], acc, 0, 0, 0);
+            if constexpr (X3) {
+                const int KL16 = (ck.KL + 15) & ~15;
+                const float *ap = sW + 8 * (lane >> 5) * WSTR + mt * 32 + (lane & 31);
+                const float *bp = sCol + 8 * (lane >> 5) * NP + nt * 32 + (lane & 31);
+#pragma unroll
+                for (int ks = 0; ks < KCP; ks += 16) {
+                    if (ks < KL16) {      // wave-uniform
+                        unsigned aw[8], bw[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            aw[j] = __float_as_uint(ap[(ks + j) * WSTR]);
+                            bw[j] = __float_as_uint(bp[(ks + j) * NP]);
+                        }
+                        bf16x8 ah, al, bh, bl;
+                        peel(aw, ah, al);
+                        peel(bw, bh, bl);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                    }
+                }
+            } else {
+                const float *ap = sW + (lane >> 5) * WSTR + mt * 32 + (lane & 31);
+                const float *bp = sCol + (lane >> 5) * NP + nt * 32 + (lane & 31);
+                for (int ks = 0; ks < KLp; ks += 2)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[ks * WSTR], bp[ks * NP], acc, 0, 0, 0);
+            }
         }
     }
     if (tile_live) {
@@ -585,17 +695,28 @@ extern "C" int ebfi_dcn_forward(const void *input, const void *weight, const voi
                                 int sh, int sw, int ph, int pw, int dh, int dw, int deformable_group, int dtype,
                                 void *stream) {
     if (!input || !weight || !bias || !offset || !mask || !output) return fail(EBFI_ERR_ARG, "dcn_forward: null argument");
-    if (dtype != EBFI_F32) return fail(EBFI_ERR_UNSUPPORTED, "dcn_forward: dtype %d not implemented (fp32 only)", dtype);
+    if (dtype != EBFI_F32 && dtype != EBFI_F32_BF16X3MMA)
+        return fail(EBFI_ERR_UNSUPPORTED, "dcn_forward: dtype %d not implemented (fp32 tensors; exact or bf16x3 matrix operands)", dtype);
     Geom g;
     if (int rc = make_geom(g, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, deformable_group)) return rc;
     if (B == 0) return EBFI_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid((unsigned)(B * g.tiles_per_img), (unsigned)((Co + 63) / 64));
+    if (dtype == EBFI_F32_BF16X3MMA) {
+        const double P = (double)B * g.HWo;
+        ProfScope ps("dcn_fwd_bf16x3", st, 2.0 * P * C * g.kk * (4 + Co),
+                     4.0 * (P * (C + 3.0 * deformable_group * g.kk + Co) + (double)Co * C * g.kk));
+        hipLaunchKernelGGL(dcn_fwd_f32<true>, grid, dim3(256), 0, st, static_cast<const float *>(input),
+                           static_cast<const float *>(weight), static_cast<const float *>(bias),
+                           static_cast<const float *>(offset), static_cast<const float *>(mask),
+                           static_cast<float *>(output), g);
+        return check_launch("dcn_fwd_bf16x3");
+    }
     {
         const double P = (double)B * g.HWo;
         ProfScope ps("dcn_fwd_f32", st, 2.0 * P * C * g.kk * (4 + Co),
                      4.0 * (P * (C + 3.0 * deformable_group * g.kk + Co) + (double)Co * C * g.kk));
-        hipLaunchKernelGGL(dcn_fwd_f32, grid, dim3(256), 0, st, static_cast<const float *>(input),
+        hipLaunchKernelGGL(dcn_fwd_f32<false>, grid, dim3(256), 0, st, static_cast<const float *>(input),
                            static_cast<const float *>(weight), static_cast<const float *>(bias),
                            static_cast<const float *>(offset), static_cast<const float *>(mask),
                            static_cast<float *>(output), g);

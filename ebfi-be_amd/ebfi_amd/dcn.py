@@ -57,9 +57,15 @@ def dcn_v2_forward(input, weight, bias, offset, mask, stride, padding, dilation,
     offset, mask = offset.contiguous(), mask.contiguous()
     Ho, Wo = _out_hw(geo)
     out = torch.empty((geo[0], geo[4], Ho, Wo), dtype=input.dtype, device=input.device)
+    # matrix-core operand mode of the product (tensors are fp32 either way): exact fp32 unless the conv layers of the
+    # process run in split precision (ebfi_amd.conv.set_compute_dtype("bf16x3"))
+    from . import conv
+    code = N.dtype_code(input)
+    if code == N.EBFI_F32 and conv.get_compute_dtype() == "bf16x3":
+        code = N.EBFI_F32_BF16X3MMA
     with torch.cuda.device_of(input):
         rc = N.lib().ebfi_dcn_forward(N.ptr(input), N.ptr(weight), N.ptr(bias), N.ptr(offset), N.ptr(mask),
-                                      N.ptr(out), *geo, N.dtype_code(input), N.stream_ptr(input.device))
+                                      N.ptr(out), *geo, code, N.stream_ptr(input.device))
     N.check(rc, "ebfi_dcn_forward")
     return out
 

@@ -83,7 +83,10 @@ int ebfi_fac_backward(const void *input, const int64_t input_shape[4], const int
  *   offset [B, dg*2*kh*kw, Ho, Wo]  (channel 2*(i*kw+j) = dy, +1 = dx inside each group block)
  *   mask   [B, dg*kh*kw, Ho, Wo]    output [B,Co,Ho,Wo]
  *   Ho = (H + 2*ph - (dh*(kh-1)+1))/sh + 1, likewise Wo.
- * The column tensor of the reference never exists in memory. */
+ * The column tensor of the reference never exists in memory.
+ * ebfi_dcn_forward accepts dtype EBFI_F32 (exact fp32 matrix cores: the kernel the reference's known-answer tests pin)
+ * or EBFI_F32_BF16X3MMA (same fp32 tensors; the 64 x C*kh*kw x 64 product runs on the bf16 matrix cores in split
+ * precision, ~1e-5 of the exact result).  The backward is fp32 only. */
 int ebfi_dcn_forward(const void *input, const void *weight, const void *bias, const void *offset,
                      const void *mask, void *output,
                      int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw,

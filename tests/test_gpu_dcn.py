@@ -167,3 +167,29 @@ def test_argument_checks():
     with pytest.raises(RuntimeError):
         dcn_v2_conv(x, torch.zeros(1, 18, 6, 6).cuda(), torch.ones(1, 9, 6, 6).cuda(),
                     torch.randn(3, 5, 3, 3).cuda(), b, 1, 1, 1, 1)
+
+
+def test_dcn_forward_split_precision_product_vs_oracle():
+    """ebfi_dcn_forward with dtype EBFI_F32_BF16X3MMA (selected by the process-wide conv mode): the sampling is the exact
+    fp32 path, the product runs as bf16 hi/lo pairs -- within 1e-4 of the oracle (the exact kernel stays the default and
+    keeps the known-answer tests above)."""
+    from ebfi_amd import _native as N
+    from ebfi_amd import conv
+    from ebfi_amd.dcn import dcn_v2_forward
+    from oracle import ref_ops
+    torch.manual_seed(3)
+    for (B, C, H, W, Co, dg) in [(2, 64, 20, 36, 64, 8), (1, 16, 9, 13, 24, 2), (1, 64, 16, 64, 100, 8)]:
+        x, w, b = torch.randn(B, C, H, W), torch.randn(Co, C, 3, 3) / (C * 9) ** 0.5, torch.randn(Co)
+        off, msk = torch.randn(B, dg * 18, H, W) * 2, torch.sigmoid(torch.randn(B, dg * 9, H, W))
+        ref = ref_ops.dcn_forward(x, w, b, off, msk, 1, 1, 1, dg)
+        conv.set_compute_dtype("bf16x3")
+        N.prof_reset()
+        N.prof_enable(True)
+        try:
+            out = dcn_v2_forward(x.cuda(), w.cuda(), b.cuda(), off.cuda(), msk.cuda(), (1, 1), (1, 1), (1, 1), dg)
+            torch.cuda.synchronize()
+        finally:
+            conv.set_compute_dtype("fp32")
+            N.prof_enable(False)
+        assert "dcn_fwd_bf16x3" in N.prof_collect()
+        assert _rel(out.cpu(), ref) < 1e-4
