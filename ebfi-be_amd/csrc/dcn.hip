@@ -188,13 +188,16 @@ __device__ __forceinline__ TapPos tap_pos(const Geom &g, const float *__restrict
 // and the corner pairs are fetched through a buffer descriptor of the sample (32-bit lane offsets, the channel offset in
 // a scalar register, rows outside the image as an out-of-range offset that reads 0) -- the sampling walk is VALU-bound
 // (9000 vector instructions per wave), not bandwidth-bound, so address arithmetic and per-load branches are what it pays for.
-__device__ __forceinline__ TapPos tap_pos_hw(const Geom &g, const float *__restrict__ off, const float *__restrict__ msk,
-                                             int b, int grp, int tap, int p, int ho, int wo) {
+// roff / rmsk: descriptors of this sample's offset [dg*2*kk, HWo] and mask [dg*kk, HWo] planes; p4 = 4*p
+__device__ __forceinline__ TapPos tap_pos_hw(const Geom &g, __amdgpu_buffer_rsrc_t roff, __amdgpu_buffer_rsrc_t rmsk, int grp,
+                                             int tap, unsigned p4, int ho, int wo) {
     const int i = tap / g.kw, j = tap - i * g.kw;
-    const int64_t ob = ((int64_t)(b * g.dg + grp) * 2 * g.kk + 2 * tap) * g.HWo + p;
-    const float dy = off[ob], dx = off[ob + g.HWo];
+    const unsigned plane = (unsigned)g.HWo * 4u;
+    const unsigned ob = (unsigned)(grp * 2 * g.kk + 2 * tap) * plane + p4;
+    const float dy = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(roff, ob, 0, 0));
+    const float dx = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(roff, ob + plane, 0, 0));
     TapPos r;
-    r.mask = msk[((int64_t)(b * g.dg + grp) * g.kk + tap) * g.HWo + p];
+    r.mask = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rmsk, (unsigned)(grp * g.kk + tap) * plane + p4, 0, 0));
     r.h = (float)(ho * g.sh - g.ph + i * g.dh) + dy;
     r.w = (float)(wo * g.sw - g.pw + j * g.dw) + dx;
     return r;
@@ -271,6 +274,11 @@ __global__ __launch_bounds__(256, X3 ? 3 : 4) void dcn_fwd_f32(const float *__re
     const unsigned plane_bytes = (unsigned)(g.H * g.W) * 4u;
     const __amdgpu_buffer_rsrc_t rxs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(x + (int64_t)b * g.C * g.H * g.W), 0, (unsigned)g.C * plane_bytes, 0x00020000);
+    const unsigned p4 = (unsigned)p * 4u;
+    const __amdgpu_buffer_rsrc_t roff = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(off + (int64_t)b * g.dg * 2 * g.kk * g.HWo), 0, (unsigned)(g.dg * 2 * g.kk) * (unsigned)g.HWo * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rmsk = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(msk + (int64_t)b * g.dg * g.kk * g.HWo), 0, (unsigned)(g.dg * g.kk) * (unsigned)g.HWo * 4u, 0x00020000);
     if constexpr (X3) {   // weight rows past the staged slice are never written: they must read as zero pairs
         for (int i = klmax * WSTR + tid; i < ROWS * WSTR; i += 256) sW[i] = 0.f;
     }
@@ -290,12 +298,12 @@ __global__ __launch_bounds__(256, X3 ? 3 : 4) void dcn_fwd_f32(const float *__re
             const int half_n = (ck.cb + 1) >> 1;               // channels of the first half
             const int nitems = 2 * g.kk;
             TapPos tp = {0.f, 0.f, 0.f};
-            if (p_ok && wave < nitems) tp = tap_pos_hw(g, off, msk, b, ck.grp, wave >> 1, p, ho, wo);
+            if (p_ok && wave < nitems) tp = tap_pos_hw(g, roff, rmsk, ck.grp, wave >> 1, p4, ho, wo);
             for (int item = wave; item < nitems; item += 4) {
                 const int tap = item >> 1, c_lo = (item & 1) ? half_n : 0;
                 const int n = (item & 1) ? ck.cb - half_n : half_n;
                 TapPos tp_next = {0.f, 0.f, 0.f};
-                if (p_ok && item + 4 < nitems) tp_next = tap_pos_hw(g, off, msk, b, ck.grp, (item + 4) >> 1, p, ho, wo);
+                if (p_ok && item + 4 < nitems) tp_next = tap_pos_hw(g, roff, rmsk, ck.grp, (item + 4) >> 1, p4, ho, wo);
                 float *col = sCol + (c_lo * g.kk + tap) * NP + px;
                 if (p_ok && n > 0) {
                     const Tap t = make_tap(tp.h, tp.w, g.H, g.W);
