@@ -20,6 +20,7 @@ rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
 echo "[5] op microbenchmarks"
 timeout -k 10 300 python tools/opbench.py --ops fac,dcn,conv --x3 --iters 20 > $OUT/opbench_x3.jsonl 2> $OUT/opbench_x3.err
 timeout -k 10 300 python tools/opbench.py --ops conv --iters 20 > $OUT/opbench_fp32.jsonl 2> $OUT/opbench_fp32.err
+timeout -k 10 300 python tools/opbench.py --ops fac,dcn --iters 40 > $OUT/opbench_dcn_fac.jsonl 2> $OUT/opbench_dcn_fac.err; tail -1 $OUT/opbench_dcn_fac.jsonl | cut -c1-220
 echo "[6] other BASELINE configs"
 timeout -k 10 300 python ebfi-be_amd/infer_ours.py --batch 1 --height 128 --width 128 > $OUT/config1.log 2>&1; tail -1 $OUT/config1.log
 timeout -k 10 300 python ebfi-be_amd/infer_ours.py --batch 4 --height 256 --width 256 --precision fp32 > $OUT/config2_fp32.log 2>&1; tail -1 $OUT/config2_fp32.log
