@@ -109,9 +109,20 @@ class Engine:
             torch.cuda.current_stream(self.device).wait_stream(side)
             self.bucket.zero()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                loss = self._fwd_bwd(*static_in)
-                flat = self.bucket.gather()
+            try:
+                # thread_local: another thread of the process (the RCCL watchdog polling its events) must not
+                # invalidate the capture
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    loss = self._fwd_bwd(*static_in)
+                    flat = self.bucket.gather()
+            except RuntimeError as err:
+                # a capture that cannot be taken must not cost the run: say so and continue with eager launches
+                import sys
+                print("ebfi_amd.engine: hipGraph capture failed (%s); continuing with eager launches" % str(err).splitlines()[0],
+                      file=sys.stderr, flush=True)
+                self.use_graph = False
+                torch.cuda.synchronize(self.device)
+                return self.train_step(frame, event, t, gtex, target)
             entry = (graph, static_in, loss, flat, [p.grad for p in self.bucket.params])
             self._graphs[key] = entry
         graph, static_in, loss, flat, grads = entry

@@ -63,7 +63,7 @@ def main():
             model(frame, event, t_static, gtex)
         torch.cuda.current_stream(device).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             out_static = model(frame, event, t_static, gtex)[-1]
 
         def run():
