@@ -259,7 +259,7 @@ def main():
                                      "bf16x3": "fp32 tensors and accumulation; conv operands split into bf16 hi+lo pairs, 3 MFMAs "
                                                "per product (~1e-5 of fp32, parity-tested at 1e-3 like the fp32 mode)",
                                      "bf16": "fp32 tensors and accumulation; conv operands rounded once to bf16"}[args.precision],
-                       "launch": "eager" if args.no_graph else "hipGraph replay of fwd+loss+bwd+grad packing; all-reduce and Adam eager",
+                       "launch": "hipGraph replay of fwd+loss+bwd+grad packing; all-reduce and Adam eager" if eng.use_graph else "eager",
                        "rehearsal_single_device_gloo": rehearsal},
             "roofline": roofline,
             "kernels": per_kernel,
