@@ -407,6 +407,14 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
     const unsigned go_bytes = (unsigned)g.Co * (unsigned)g.HWo * 4u;
     const __amdgpu_buffer_rsrc_t rgo =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(gout + (int64_t)b * g.Co * g.HWo), 0, go_bytes, 0x00020000);
+    // the sampling walk fetches through descriptors like the forward kernel (32-bit lane offsets, no per-load branches)
+    const unsigned plane_bytes = (unsigned)(g.H * g.W) * 4u;
+    const __amdgpu_buffer_rsrc_t rxs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(x + (int64_t)b * g.C * g.H * g.W), 0, (unsigned)g.C * plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t roff = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(off + (int64_t)b * g.dg * 2 * g.kk * g.HWo), 0, (unsigned)(g.dg * 2 * g.kk) * (unsigned)g.HWo * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rmsk = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(msk + (int64_t)b * g.dg * g.kk * g.HWo), 0, (unsigned)(g.dg * g.kk) * (unsigned)g.HWo * 4u, 0x00020000);
 
     for (int chunk = 0; chunk < g.nchunks; ++chunk) {
         const Chunk ck = get_chunk(g, chunk);
@@ -469,7 +477,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
                 const int ho = y0 + band * 4 + (px >> 4), wo = x0 + (px & 15);
                 if (ho >= g.Ho || wo >= g.Wo) continue;
                 const int p = ho * g.Wo + wo;
-                const TapPos tp = tap_pos(g, off, msk, b, ck.grp, tap, p, g.pw);
+                const TapPos tp = tap_pos_hw(g, roff, rmsk, ck.grp, tap, (unsigned)p * 4u, ho, wo);
                 const Tap t = make_tap(tp.h, tp.w, g.H, g.W);
                 // grad_input positions follow the quirk; identical to `t` whenever pad_h == pad_w
                 Tap tq = t;
@@ -484,15 +492,19 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
                     if (r0 >= 0 && r0 + 1 < bx.BH && c0 >= 0 && c0 + 1 < bx.BW) cell = r0 * bx.BW + c0;
                 }
                 float val_h = 0.f, val_w = 0.f, mval = 0.f;
-                const float *plane = x + (int64_t)(b * g.C + ck.cbase) * g.H * g.W;
                 float *gplane = gx + (int64_t)(b * g.C + ck.cbase) * g.H * g.W;
                 float *bplane = sBox;
-                for (int cl = 0; cl < ck.cb; ++cl, plane += (int64_t)g.H * g.W, gplane += (int64_t)g.H * g.W,
-                         bplane += bx.BH * bx.BW) {
+                const unsigned o0 = t.q0 >= 0 ? (unsigned)t.q0 * 4u : 0x80000000u, o1 = t.q1 >= 0 ? (unsigned)t.q1 * 4u : 0x80000000u;
+                unsigned chan_byte = (unsigned)ck.cbase * plane_bytes;
+                for (int cl = 0; cl < ck.cb; ++cl, chan_byte += plane_bytes, gplane += (int64_t)g.H * g.W, bplane += bx.BH * bx.BW) {
                     const float cg = sCG[(cl * g.kk + tap) * NP + px];
                     if (t.valid) {
-                        float v1, v2, v3, v4;
-                        corners(plane, t, v1, v2, v3, v4);
+                        const u32x2 pa = __builtin_amdgcn_raw_buffer_load_b64(rxs, o0 + chan_byte, 0, 0);
+                        const u32x2 pb = __builtin_amdgcn_raw_buffer_load_b64(rxs, o1 + chan_byte, 0, 0);
+                        const float ax = __uint_as_float(pa.x), ay = __uint_as_float(pa.y);
+                        const float bxv = __uint_as_float(pb.x), byv = __uint_as_float(pb.y);
+                        const float v1 = ax * t.mlx + ay * t.mly, v2 = ax * t.mhx + ay * t.mhy;
+                        const float v3 = bxv * t.mlx + byv * t.mly, v4 = bxv * t.mhx + byv * t.mhy;
                         mval += cg * (t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4);
                         // d(sample)/dh and d(sample)/dw  (dmcn_get_coordinate_weight_cuda, :82-123)
                         const float wh = -(1.f - t.lw) * v1 - t.lw * v2 + (1.f - t.lw) * v3 + t.lw * v4;
@@ -502,11 +514,11 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
                     }
                     if (tq.valid) {
                         const float top = cg * tp.mask;
-                        if (cell >= 0) {   // whole 2x2 footprint inside the LDS box
-                            if (tq.o1 >= 0) atomicAdd(bplane + cell, tq.w1 * top);
-                            if (tq.o2 >= 0) atomicAdd(bplane + cell + 1, tq.w2 * top);
-                            if (tq.o3 >= 0) atomicAdd(bplane + cell + bx.BW, tq.w3 * top);
-                            if (tq.o4 >= 0) atomicAdd(bplane + cell + bx.BW + 1, tq.w4 * top);
+                        if (cell >= 0) {   // whole 2x2 footprint inside the LDS box; cells outside the image are dropped by the flush
+                            atomicAdd(bplane + cell, tq.w1 * top);
+                            atomicAdd(bplane + cell + 1, tq.w2 * top);
+                            atomicAdd(bplane + cell + bx.BW, tq.w3 * top);
+                            atomicAdd(bplane + cell + bx.BW + 1, tq.w4 * top);
                         } else {
                             if (tq.o1 >= 0) atomicAdd(gplane + tq.o1, tq.w1 * top);
                             if (tq.o2 >= 0) atomicAdd(gplane + tq.o2, tq.w2 * top);
