@@ -418,7 +418,6 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
 
     for (int chunk = 0; chunk < g.nchunks; ++chunk) {
         const Chunk ck = get_chunk(g, chunk);
-        const int mtiles = (ck.KL + 15) >> 4;
         const bool box_on = bx.use && ck.cb <= BOX_CH;
         __syncthreads();                   // previous chunk's flush has read the box
         if (box_on)
@@ -454,22 +453,22 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
                 }
                 // colgrad[kl][px] += sum_co W[co][kl] * gout[co][px]
                 const float *ap = sWt + (lane >> 4) * S80 + (lane & 15);
+                // all KCP/16 row tiles unconditionally (rows >= KL of the slice are zero): a per-MFMA `if (m < mtiles)`
+                // made the compiler shuffle the accumulators between register files around every instruction
 #pragma unroll
                 for (int ks = 0; ks < 16; ++ks) {
 #pragma unroll
                     for (int m = 0; m < KCP / 16; ++m)
-                        if (m < mtiles)
-                            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[ks * 4 * S80 + m * 16], bv[ks], acc[m], 0, 0, 0);
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[ks * 4 * S80 + m * 16], bv[ks], acc[m], 0, 0, 0);
                 }
             }
             __syncthreads();               // previous band's sampling has read sCG
 #pragma unroll
-            for (int m = 0; m < KCP / 16; ++m)
-                if (m < mtiles) {
+            for (int m = 0; m < KCP / 16; ++m) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        sCG[(m * 16 + (lane >> 4) * 4 + r) * NP + wave * 16 + (lane & 15)] = acc[m][r];
-                }
+                for (int r = 0; r < 4; ++r)
+                    sCG[(m * 16 + (lane >> 4) * 4 + r) * NP + wave * 16 + (lane & 15)] = acc[m][r];
+            }
             __syncthreads();
 
             for (int it = tid; it < g.kk * NP; it += 256) {
@@ -622,10 +621,11 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restric
             const float *bp = sCt + (lane >> 4) * S81 + (lane & 15);
             for (int ks = 0; ks < NP; ks += 4) {
                 const float av = ap[ks * S81];
+                // every column tile unconditionally (tiles >= ntiles are never stored): a per-MFMA condition makes the
+                // compiler shuffle the accumulators between register files around every instruction
 #pragma unroll
                 for (int n = 0; n < KCP / 16; ++n)
-                    if (n < ntiles)
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[ks * S81 + n * 16], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[ks * S81 + n * 16], acc[n], 0, 0, 0);
             }
         }
 #pragma unroll
