@@ -109,8 +109,8 @@ def lib():
                 raise EbfiNativeError("%s does not export %s" % (LIB_PATH, name)) from e
             fn.restype = res
             fn.argtypes = args
-        if h.ebfi_abi_version() != 1:
-            raise EbfiNativeError("ABI version mismatch: library %d, binding 1" % h.ebfi_abi_version())
+        if h.ebfi_abi_version() != 2:
+            raise EbfiNativeError("ABI version mismatch: library %d, binding 2" % h.ebfi_abi_version())
         _lib = h
     return _lib
 

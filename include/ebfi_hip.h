@@ -26,6 +26,7 @@
  *   ebfi_groupnorm_*            nn.GroupNorm of ExposureDecision (models/Ours/model_singleframe.py:36,66-67)
  *   ebfi_census_*               Ternary census loss (loss/restore.py:108-145)
  *   ebfi_gauss5_*               GaussianConv of the Laplacian-pyramid loss (loss/restore.py:149-163)
+ *   ebfi_gather_sum             weight re-layouts of the depth-2 Conv3d / ConvTranspose3d (models/model_misc/resnet_3D.py)
  *   ebfi_events_to_stack        dataloader/encodings.py:307-350 (events_to_stack)
  *   ebfi_frame2lap / _frame2dcp myutils/utils.py:34-49 / :15-31
  */
@@ -39,7 +40,7 @@
 extern "C" {
 #endif
 
-#define EBFI_ABI_VERSION 1
+#define EBFI_ABI_VERSION 2
 
 typedef enum {
     EBFI_OK = 0,
