@@ -32,6 +32,24 @@ def synthetic_batch(B, H, W, TB=16, device="cuda", seed=123, rank=0):
     return tuple(v.to(device) for v in (frame, event, t, gtex, target))
 
 
+def synthetic_batch_from_raw_events(B, H, W, TB=16, device="cuda", seed=123, rank=0, rate=0.35):
+    """Same batch statistics as `synthetic_batch`, but the event tensor comes the way the reference produces it
+    (h5dataset.py:327-352): a sorted raw event list per sample (N ~ rate*H*W*TB events uniform in x, y, sorted uniform t in
+    [0,1), polarity +-1) binned by the device `events_to_stack` kernel and transposed to [TB, 2, H, W]."""
+    from .encodings import events_to_stack
+    frame, _, t, gtex, target = synthetic_batch(B, H, W, TB, device=device, seed=seed, rank=rank)
+    g = torch.Generator(device="cpu").manual_seed(seed + rank + 7919)
+    n = int(rate * H * W * TB)
+    stacks = []
+    for _ in range(B):
+        xs = torch.randint(0, W, (n,), generator=g).to(device)
+        ys = torch.randint(0, H, (n,), generator=g).to(device)
+        ts = torch.sort(torch.rand(n, generator=g, dtype=torch.float64))[0].to(device)
+        ps = (torch.randint(0, 2, (n,), generator=g) * 2 - 1).float().to(device)
+        stacks.append(events_to_stack(xs, ys, ts, ps, TB, sensor_size=(H, W)).transpose(0, 1))   # [TB, 2, H, W]
+    return frame, torch.stack(stacks).contiguous(), t, gtex, target
+
+
 class Engine:
     def __init__(self, model_args=None, device="cuda", precision="fp32", lr=1e-4, seed=None, train=True, graph=False):
         if precision not in ("fp32", "bf16x3", "bf16"):

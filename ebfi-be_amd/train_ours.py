@@ -26,7 +26,7 @@ import yaml
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from ebfi_amd.dp import reduce_tensor  # noqa: E402
-from ebfi_amd.engine import Engine, synthetic_batch  # noqa: E402
+from ebfi_amd.engine import Engine, synthetic_batch, synthetic_batch_from_raw_events  # noqa: E402
 
 
 def init_distributed_mode():
@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16"],
                     help="matrix-core operands of the convs: bf16x3 = split bf16 pairs, fp32-grade accuracy (default); fp32 = exact")
     ap.add_argument("--graph", action="store_true", help="replay forward+loss+backward from a captured hipGraph")
+    ap.add_argument("--raw-events", action="store_true",
+                    help="build the event tensor from synthetic raw event lists with the device events_to_stack kernel "
+                         "(the reference's data path, h5dataset.py:327-352) instead of drawing voxel counts directly")
     args = ap.parse_args()
     with open(args.config) as fh:
         config = yaml.safe_load(fh)
@@ -89,7 +92,8 @@ def main():
     t0, frames = time.perf_counter(), 0
     for it in range(start, iterations):
         # one fresh synthetic batch per iteration, different on every rank (seed + rank, like the reference)
-        batch = synthetic_batch(B, H, W, TB, device=device, seed=args.seed + 1000 * it, rank=rank)
+        make = synthetic_batch_from_raw_events if args.raw_events else synthetic_batch
+        batch = make(B, H, W, TB, device=device, seed=args.seed + 1000 * it, rank=rank)
         loss = reduce_tensor(eng.train_step(*batch).clone())
         frames += B * world
         if rank == 0 and (it % 10 == 0 or it == iterations - 1):

@@ -30,7 +30,7 @@ def test_train_resume_infer(tmp_path):
     assert set(cpt) >= {"model", "optimizer", "config", "trainer"} and cpt["model"]["name"] == "EVFIAutoEx"
     assert "ResidualControl.Conv3.0.0.conv2d.weight" in cpt["model"]["states"]
     r = subprocess.run([sys.executable, os.path.join(PKG, "train_ours.py"), "-c", str(cfg_path), "-id", "t2",
-                        "--resume", str(ckpt), "--iterations", "5", "--graph"], capture_output=True, text=True, env=env, timeout=600)
+                        "--resume", str(ckpt), "--iterations", "5", "--graph", "--raw-events"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "Iteration: 4/5" in r.stdout, r.stderr[-2000:] + r.stdout[-500:]
     r = subprocess.run([sys.executable, os.path.join(PKG, "infer_ours.py"), "--model_path", str(ckpt), "--batch", "2",
                         "--height", "64", "--width", "64", "--num_ts", "3"], capture_output=True, text=True, env=env, timeout=600)

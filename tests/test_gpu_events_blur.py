@@ -66,3 +66,22 @@ def test_frame2lap_frame2dcp_vs_oracle():
         dcp = Frame2DCP(f.cuda()).cpu().numpy()
         assert np.array_equal(dcp, blur_ref.frame2dcp(f.numpy()))
     assert np.abs(lap).max() > 50       # unnormalised Laplacian of uint8 grey levels
+
+
+def test_raw_event_batch_matches_oracle_binning():
+    """Engine helper that builds the Event tensor of a batch from raw event lists with the device kernel: same counts
+    as the oracle's events_to_stack on the same lists, total = number of events (none fall out of range here)."""
+    from ebfi_amd.engine import synthetic_batch_from_raw_events
+    from oracle import events_ref
+    B, H, W, TB = 2, 24, 40, 4
+    frame, event, t, gtex, target = synthetic_batch_from_raw_events(B, H, W, TB, device="cuda", seed=5)
+    assert event.shape == (B, TB, 2, H, W) and frame.shape == (B, 3, H, W)
+    g = torch.Generator(device="cpu").manual_seed(5 + 7919)
+    n = int(0.35 * H * W * TB)
+    for b in range(B):
+        xs = torch.randint(0, W, (n,), generator=g)
+        ys = torch.randint(0, H, (n,), generator=g)
+        ts = torch.sort(torch.rand(n, generator=g, dtype=torch.float64))[0]
+        ps = (torch.randint(0, 2, (n,), generator=g) * 2 - 1).float()
+        ref = events_ref.events_to_stack(xs.numpy(), ys.numpy(), ts.numpy(), ps.numpy(), TB, (H, W))
+        assert torch.equal(event[b].cpu(), torch.as_tensor(ref).transpose(0, 1).float())
