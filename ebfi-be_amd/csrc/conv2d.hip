@@ -839,6 +839,8 @@ __device__ __forceinline__ void peel(const unsigned (&w)[8], bf16x8 &hi, bf16x8 
     lo = __builtin_bit_cast(bf16x8, l);
 }
 
+template <int KS> struct X3CIB { static constexpr int value = KS == 7 ? 16 : 64; };   // input channels per workgroup
+
 template <int KS, int WTXO, int DACT>
 __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x, const float *__restrict__ gout,
                                                      const float *__restrict__ yact, float *__restrict__ slab,
@@ -848,14 +850,15 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
     constexpr int KK = KS * KS, WTX = C::WTX, IH = C::IH, IW = C::IW;
     constexpr int IWP = 32;                // lanes per staged input row; a 32-px tile has IW = 34: columns 32, 33 go separately
     constexpr int EXC = IW > IWP ? IW - IWP : 0;
-    constexpr int CIB = C::CIB, PS = C::PS, IWS = C::IWS;
+    constexpr int CIB = X3CIB<KS>::value, PS = C::PS, IWS = C::IWS;   // 7x7: 16 input channels (784 columns) per workgroup
     constexpr int TROWS = WXT / IWP;       // thread rows walking (row, channel) of the input tile
     constexpr int CPR = CIB / TROWS;       // channel steps per input row
     constexpr int NI = IH * CPR;           // input elements per thread per tile
     constexpr int NG = 64 / (WXT / 64);    // grad_out channels per thread per tile (8 thread rows of 64 slots)
     constexpr int NTW = (CIB * KK + 127) / 128;   // n-tiles (of 32 columns) per wave: 4 column groups
     constexpr int BUF = 64 * GS + (CIB + 1) * PS; // words per buffer: grad_out image, channel planes, zero plane
-    static_assert(CIB % TROWS == 0 && WTX <= 32 && EXC * IH * CIB <= WXT && IWS >= IW, "tile configuration");
+    constexpr int NEX = (EXC * IH * CIB + WXT - 1) / WXT;   // extra-column elements per thread
+    static_assert(CIB % TROWS == 0 && WTX <= 32 && IWS >= IW, "tile configuration");
     extern __shared__ __attribute__((aligned(16))) unsigned smw[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -891,8 +894,8 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
     const unsigned go_bytes = (unsigned)g.Cout * (unsigned)HWo * 4u, x_bytes = (unsigned)g.Cin * (unsigned)HW * 4u;
 
     float rg[NG], ry[NG], ri[NI];
-    float rex = 0.f;                       // 32-px tiles: one element of the two extra halo columns per thread
-    const int ex_ci = tid & (CIB - 1), ex_r = (tid / CIB) / (EXC ? EXC : 1), ex_c = IWP + (tid / CIB) % (EXC ? EXC : 1);
+    float rex[NEX > 0 ? NEX : 1];          // 32-px tiles: the IW - 32 extra halo columns, element e = tid + i*WXT ->
+                                           // (channel e % CIB, row (e / CIB) / EXC, column 32 + (e / CIB) % EXC)
     float bacc[NG];                        // bias: this thread's slot of channels gco + 8*it, summed over its tiles
 #pragma unroll
     for (int it = 0; it < NG; ++it) bacc[it] = 0.f;
@@ -926,9 +929,13 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
             for (int k = 0; k < CPR; ++k) ri[r * CPR + k] = buf_ld(rxi, base + (unsigned)(k * TROWS) * (unsigned)HW * 4u);
         }
         if constexpr (EXC > 0) {
-            const int yy = iy0 + ex_r, xe = ix0 + ex_c;
-            const bool ok = tid < EXC * IH * CIB && yy >= 0 && yy < g.H && xe >= 0 && xe < g.W;
-            rex = buf_ld(rxi, ok ? (unsigned)((ci_base + ex_ci) * HW + yy * g.W + xe) * 4u : SENT);
+#pragma unroll
+            for (int i = 0; i < NEX; ++i) {
+                const int e = tid + i * WXT, rc = e / CIB;
+                const int yy = iy0 + rc / EXC, xe = ix0 + IWP + rc % EXC;
+                const bool ok = e < EXC * IH * CIB && yy >= 0 && yy < g.H && xe >= 0 && xe < g.W;
+                rex[i] = buf_ld(rxi, ok ? (unsigned)((ci_base + (e & (CIB - 1))) * HW + yy * g.W + xe) * 4u : SENT);
+            }
         }
     };
     auto commit = [&](int tile, int buf) {
@@ -959,7 +966,11 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
                 for (int k = 0; k < CPR; ++k) sIn[(irow + k * TROWS) * PS + r * IWS + icol] = split_word(ri[r * CPR + k]);
         }
         if constexpr (EXC > 0) {
-            if (tid < EXC * IH * CIB) sIn[ex_ci * PS + ex_r * IWS + ex_c] = split_word(rex);
+#pragma unroll
+            for (int i = 0; i < NEX; ++i) {
+                const int e = tid + i * WXT, rc = e / CIB;
+                if (e < EXC * IH * CIB) sIn[(e & (CIB - 1)) * PS + (rc / EXC) * IWS + IWP + rc % EXC] = split_word(rex[i]);
+            }
         }
     };
 
@@ -1369,9 +1380,9 @@ int launch_wgrad(hipStream_t st, const float *x, const float *gout, const float 
 int pick_wtx_x3(int) { return 32; }
 
 int wgrad_x3_splits(const ConvGeom &g, int ks) {
-    const int wtx = ks == 3 ? pick_wtx_x3(g.Wo) : wgrad_wtx_rt(g, ks, 1);
+    const int wtx = ks == 1 ? wgrad_wtx_rt(g, ks, 1) : pick_wtx_x3(g.Wo);
     const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, wtx);
-    const int64_t blocks = ceil_div(g.Cout, 64) * ceil_div(g.Cin, 64);
+    const int64_t blocks = ceil_div(g.Cout, 64) * ceil_div(g.Cin, ks == 7 ? 16 : 64);
     int64_t s = blocks <= 256 ? 256 / blocks : 1;      // one 512-thread workgroup per CU: fill one round of 256
     if (s > tiles) s = tiles;
     return (int)(s < 1 ? 1 : s);
@@ -1381,7 +1392,8 @@ template <int KS, int WTXO, int DACT>
 int launch_wgrad_x3_d(hipStream_t st, const float *x, const float *gout, const float *yact, float *slab, float *gpre_out,
                       const ConvGeom &g, float dslope, int nsplit, int need_bias) {
     using C = WCfg<KS, 1, WTXO>;
-    const size_t lds = (size_t)2 * (64 * GS + (C::CIB + 1) * C::PS) * sizeof(unsigned);
+    constexpr int CIB = X3CIB<KS>::value;
+    const size_t lds = (size_t)2 * (64 * GS + (CIB + 1) * C::PS) * sizeof(unsigned);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_x3<KS, WTXO, DACT>),
@@ -1389,7 +1401,7 @@ int launch_wgrad_x3_d(hipStream_t st, const float *x, const float *gout, const f
         attr_done = true;
     }
     const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, C::WTX);
-    dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, C::CIB));
+    dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, CIB));
     ProfScope ps("conv_wgrad_bf16x3", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS,
                  conv_bytes_wgrad(g, KS * KS, DACT != 0, gpre_out != nullptr));
     hipLaunchKernelGGL((conv_wgrad_x3<KS, WTXO, DACT>), grid, dim3(WXT), lds, st, x, gout, yact, slab, gpre_out, g, dslope,
@@ -1408,6 +1420,7 @@ int launch_wgrad_x3_t(hipStream_t st, const float *x, const float *gout, const f
 int launch_wgrad_x3(hipStream_t st, const float *x, const float *gout, const float *yact, float *slab, float *gpre_out,
                     const ConvGeom &g, int ks, int dact, float dslope, int nsplit, int need_bias) {
     if (ks == 1) return launch_wgrad_x3_t<1, 0>(st, x, gout, yact, slab, gpre_out, g, dact, dslope, nsplit, need_bias);
+    if (ks == 7) return launch_wgrad_x3_t<7, 32>(st, x, gout, yact, slab, gpre_out, g, dact, dslope, nsplit, need_bias);
     return launch_wgrad_x3_t<3, 32>(st, x, gout, yact, slab, gpre_out, g, dact, dslope, nsplit, need_bias);
 }
 
@@ -1665,7 +1678,7 @@ extern "C" int ebfi_conv2d_backward_weight_ex(const void *input, const void *gra
                                               void *workspace, size_t workspace_bytes, int dtype, void *stream) {
     if (!input || !grad_output || !grad_weight) return fail(EBFI_ERR_ARG, "conv2d_backward_weight: null argument");
     const bool bf16mma = dtype == EBFI_F32_BF16MMA && stride == 1 && (ksize == 1 || ksize == 3);
-    const bool x3 = dtype == EBFI_F32_BF16X3MMA && stride == 1 && (ksize == 1 || ksize == 3);   // else: exact fp32 kernel
+    const bool x3 = dtype == EBFI_F32_BF16X3MMA && stride == 1 && (ksize == 1 || ksize == 3 || ksize == 7);   // else: exact fp32 kernel
     if (dtype != EBFI_F32 && dtype != EBFI_F32_BF16MMA && dtype != EBFI_F32_BF16X3MMA)
         return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_weight: dtype %d not implemented", dtype);
     if (act != ACT_NONE && !saved_output) return fail(EBFI_ERR_ARG, "conv2d_backward_weight: activation needs saved_output");

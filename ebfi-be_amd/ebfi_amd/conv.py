@@ -122,7 +122,9 @@ class ConvBiasAct(Function):
                 ws = torch.empty(max(need, 4), dtype=torch.uint8, device=x.device)
                 if need_x and act != ACT_NONE and not bf16:
                     gpre = torch.empty_like(gout)
-                wdt = N.EBFI_F32_BF16MMA if bf16 else (N.EBFI_F32_BF16X3MMA if _x3_ok(k, stride) else N.EBFI_F32)
+                # (the split-precision weight gradient also covers 7x7 stride 1: the detail branch's output conv)
+                x3w = _COMPUTE == "bf16x3" and k in (1, 3, 7) and stride == 1
+                wdt = N.EBFI_F32_BF16MMA if bf16 else (N.EBFI_F32_BF16X3MMA if x3w else N.EBFI_F32)
                 rc = lib.ebfi_conv2d_backward_weight_ex(N.ptr(x), N.ptr(gout), N.ptr(y), N.ptr(gw), N.ptr(gb), N.ptr(gpre),
                                                         *geo, act, slope, N.ptr(ws), need, wdt, st)
                 N.check(rc, "ebfi_conv2d_backward_weight")

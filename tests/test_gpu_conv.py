@@ -151,7 +151,7 @@ def test_bf16_mma_mode_vs_fp32_reference(B, Cin, H, W, Cout, k, act):
 @pytest.mark.parametrize("B,Cin,H,W,Cout,k,act", [(2, 64, 16, 64, 64, 3, 1), (1, 128, 13, 70, 200, 3, 1), (1, 20, 17, 33, 24, 3, 0),
                                                   (2, 64, 16, 32, 64, 1, 1), (1, 64, 17, 33, 3, 3, 2), (1, 4, 24, 40, 64, 3, 1),
                                                   (1, 70, 9, 130, 33, 3, 1), (2, 8, 4, 5, 8, 3, 1), (1, 16, 8, 8, 12, 3, 0),
-                                                  (2, 8, 2, 2, 8, 1, 1)])
+                                                  (2, 8, 2, 2, 8, 1, 1), (1, 16, 38, 70, 3, 7, 0), (2, 20, 9, 33, 5, 7, 1)])
 def test_bf16x3_split_precision_mode_vs_fp32_reference(B, Cin, H, W, Cout, k, act):
     """Split-precision mode (bf16 hi + lo operand pairs, 3 MFMAs per product, fp32 accumulation) for forward and
     data and weight gradient.  Bar: 1e-4 of the fp32 CPU statement, ten times inside the 1e-3 parity tolerance of
@@ -175,7 +175,8 @@ def test_bf16x3_split_precision_mode_vs_fp32_reference(B, Cin, H, W, Cout, k, ac
     finally:
         conv.set_compute_dtype("fp32")
         N.prof_enable(False)
-    assert {"conv_fwd_bf16x3", "conv_dgrad_bf16x3", "conv_wgrad_bf16x3"} <= set(N.prof_collect())
+    want = {"conv_wgrad_bf16x3"} if k == 7 else {"conv_fwd_bf16x3", "conv_dgrad_bf16x3", "conv_wgrad_bf16x3"}   # 7x7: wgrad only
+    assert want <= set(N.prof_collect())
     assert _rel(out.detach(), ref) < 1e-4
     # derivative mask from the op's own output (a pre-activation within 1e-5 of zero may flip slope w.r.t. the CPU run)
     y = out.detach().cpu()

@@ -18,8 +18,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--precision", default="bf16x3")
+    ap.add_argument("--no-detail", action="store_true", help="DetailEnabled=False (what the detail branch costs)")
+    ap.add_argument("--gtex", action="store_true", help="UseGTEx=True (what the exposure-decision head costs)")
+    ap.add_argument("--rc-steps", type=int, default=12, help="ResidualControl rounds")
     a = ap.parse_args()
-    eng = Engine(device="cuda", seed=1, precision=a.precision, graph=True)
+    over = dict(step=a.rc_steps)
+    if a.no_detail:
+        over["DetailEnabled"] = False
+    if a.gtex:
+        over["UseGTEx"] = True
+    eng = Engine(over, device="cuda", seed=1, precision=a.precision, graph=True)
     batch = synthetic_batch(8, 256, 256)
     eng.train_step(*batch)
     torch.cuda.synchronize()
