@@ -20,9 +20,10 @@ __global__ __launch_bounds__(256) void src_fwd_kernel(const float *__restrict__ 
     if (i >= total4) return;
     const int64_t bc = i / HW4, r = i - bc * HW4;
     const int64_t b = bc / C, c = bc - b * C;
-    const f4 xv = reinterpret_cast<const f4 *>(x)[i];
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f4 xv = x ? reinterpret_cast<const f4 *>(x)[i] : zero;          // x == NULL: no residual
     const f4 v0 = reinterpret_cast<const f4 *>(a0)[i], v1 = reinterpret_cast<const f4 *>(a1)[i];
-    const float k0 = s0[bc], k1 = s1[bc];
+    const float k0 = s0[bc], k1 = s1 ? s1[bc] : 1.f;                     // s1 == NULL: second half unscaled
     f4 *o = reinterpret_cast<f4 *>(out);
     o[(b * 2 * C + c) * HW4 + r] = v0 * k0 + xv;
     o[(b * 2 * C + C + c) * HW4 + r] = v1 * k1 + xv;
@@ -43,15 +44,18 @@ __global__ __launch_bounds__(256) void src_bwd_kernel(const float *__restrict__ 
     const f4 *p0 = reinterpret_cast<const f4 *>(a0) + bc * HW4, *p1 = reinterpret_cast<const f4 *>(a1) + bc * HW4;
     f4 *o0 = reinterpret_cast<f4 *>(ga0) + bc * HW4, *o1 = reinterpret_cast<f4 *>(ga1) + bc * HW4;
     f4 *ox = reinterpret_cast<f4 *>(gx) + bc * HW4;
-    const float k0 = s0[bc], k1 = s1[bc];
+    const float k0 = s0[bc], k1 = s1 ? s1[bc] : 1.f;
     float d0 = 0.f, d1 = 0.f;
     for (int64_t i = threadIdx.x; i < HW4; i += 256) {
-        const f4 u0 = g0[i], u1 = g1[i], v0 = p0[i], v1 = p1[i];
+        const f4 u0 = g0[i], u1 = g1[i], v0 = p0[i];
         o0[i] = u0 * k0;
         o1[i] = u1 * k1;
-        ox[i] = u0 + u1;
+        if (gx) ox[i] = u0 + u1;
         d0 += (u0.x * v0.x + u0.y * v0.y) + (u0.z * v0.z + u0.w * v0.w);
-        d1 += (u1.x * v1.x + u1.y * v1.y) + (u1.z * v1.z + u1.w * v1.w);
+        if (gs1) {
+            const f4 v1 = p1[i];
+            d1 += (u1.x * v1.x + u1.y * v1.y) + (u1.z * v1.z + u1.w * v1.w);
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(256) void src_bwd_kernel(const float *__restrict__ 
     __syncthreads();
     if (threadIdx.x == 0) {
         gs0[bc] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-        gs1[bc] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        if (gs1) gs1[bc] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     }
 }
 
@@ -92,10 +96,10 @@ int check_planes(const char *who, int B, int C, int64_t HW) {
 
 }  // namespace
 
-// out [B,2C,H,W]: out[:, :C] = s0[b,c]*a0 + x, out[:, C:] = s1[b,c]*a1 + x
+// out [B,2C,H,W]: out[:, :C] = s0[b,c]*a0 + x, out[:, C:] = s1[b,c]*a1 + x   (x == NULL: no residual; s1 == NULL: s1 = 1)
 extern "C" int ebfi_scale_residual_cat_forward(const float *a0, const float *s0, const float *a1, const float *s1,
                                                const float *x, float *out, int B, int C, int64_t HW, void *stream) {
-    if (!a0 || !s0 || !a1 || !s1 || !x || !out) return fail(EBFI_ERR_ARG, "scale_residual_cat_forward: null argument");
+    if (!a0 || !s0 || !a1 || !out) return fail(EBFI_ERR_ARG, "scale_residual_cat_forward: null argument");
     if (int rc = check_planes("scale_residual_cat_forward", B, C, HW)) return rc;
     if (B == 0) return EBFI_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -109,10 +113,11 @@ extern "C" int ebfi_scale_residual_cat_forward(const float *a0, const float *s0,
 }
 
 // adjoint of the above for grad_out [B,2C,H,W]: grad_a0, grad_a1, grad_x [B,C,H,W]; grad_s0, grad_s1 [B,C]
+// (grad_x == NULL when there was no residual; s1 == NULL: a1 and grad_s1 are not touched)
 extern "C" int ebfi_scale_residual_cat_backward(const float *grad_out, const float *a0, const float *s0, const float *a1,
                                                 const float *s1, float *grad_a0, float *grad_a1, float *grad_x,
                                                 float *grad_s0, float *grad_s1, int B, int C, int64_t HW, void *stream) {
-    if (!grad_out || !a0 || !s0 || !a1 || !s1 || !grad_a0 || !grad_a1 || !grad_x || !grad_s0 || !grad_s1)
+    if (!grad_out || !a0 || !s0 || !grad_a0 || !grad_a1 || !grad_s0 || (s1 && (!a1 || !grad_s1)))
         return fail(EBFI_ERR_ARG, "scale_residual_cat_backward: null argument");
     if (int rc = check_planes("scale_residual_cat_backward", B, C, HW)) return rc;
     if (B == 0) return EBFI_OK;

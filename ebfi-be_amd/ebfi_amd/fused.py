@@ -5,41 +5,58 @@ from . import _native as N
 
 
 class _ScaleResidualCat(torch.autograd.Function):
+    """s1 / x may be None: unit scale on the second half / no residual."""
+
     @staticmethod
     def forward(ctx, a0, s0, a1, s1, x):
-        a0, a1, x = a0.contiguous(), a1.contiguous(), x.contiguous()
-        B, C = x.shape[0], x.shape[1]
-        HW = x.numel() // max(B * C, 1)
-        s0c, s1c = s0.reshape(B, C).contiguous(), s1.reshape(B, C).contiguous()
-        out = torch.empty((B, 2 * C) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
-        with torch.cuda.device_of(x):
+        a0, a1 = a0.contiguous(), a1.contiguous()
+        x = x.contiguous() if x is not None else None
+        B, C = a0.shape[0], a0.shape[1]
+        HW = a0.numel() // max(B * C, 1)
+        s0c = s0.reshape(B, C).contiguous()
+        s1c = s1.reshape(B, C).contiguous() if s1 is not None else None
+        out = torch.empty((B, 2 * C) + tuple(a0.shape[2:]), dtype=a0.dtype, device=a0.device)
+        with torch.cuda.device_of(a0):
             rc = N.lib().ebfi_scale_residual_cat_forward(N.ptr(a0), N.ptr(s0c), N.ptr(a1), N.ptr(s1c), N.ptr(x), N.ptr(out), B, C, HW,
-                                                         N.stream_ptr(x.device))
+                                                         N.stream_ptr(a0.device))
         N.check(rc, "ebfi_scale_residual_cat_forward")
-        ctx.save_for_backward(a0, s0c, a1, s1c)
-        ctx.s_shapes = (s0.shape, s1.shape)
+        ctx.save_for_backward(a0, s0c, a1 if s1 is not None else None, s1c)
+        ctx.meta = (s0.shape, s1.shape if s1 is not None else None, x is not None)
         return out
 
     @staticmethod
     def backward(ctx, g):
         a0, s0c, a1, s1c = ctx.saved_tensors
+        s0_shape, s1_shape, has_x = ctx.meta
         g = g.contiguous()
         B, C = a0.shape[0], a0.shape[1]
         HW = a0.numel() // max(B * C, 1)
-        ga0, ga1, gx = torch.empty_like(a0), torch.empty_like(a0), torch.empty_like(a0)
-        gs0, gs1 = torch.empty_like(s0c), torch.empty_like(s1c)
+        ga0, ga1 = torch.empty_like(a0), torch.empty_like(a0)
+        gx = torch.empty_like(a0) if has_x else None
+        gs0 = torch.empty_like(s0c)
+        gs1 = torch.empty_like(s1c) if s1c is not None else None
         with torch.cuda.device_of(g):
             rc = N.lib().ebfi_scale_residual_cat_backward(N.ptr(g), N.ptr(a0), N.ptr(s0c), N.ptr(a1), N.ptr(s1c), N.ptr(ga0),
                                                           N.ptr(ga1), N.ptr(gx), N.ptr(gs0), N.ptr(gs1), B, C, HW,
                                                           N.stream_ptr(g.device))
         N.check(rc, "ebfi_scale_residual_cat_backward")
-        return ga0, gs0.view(ctx.s_shapes[0]), ga1, gs1.view(ctx.s_shapes[1]), gx
+        return ga0, gs0.view(s0_shape), ga1, (gs1.view(s1_shape) if gs1 is not None else None), gx
+
+
+def _fusable(a0, a1, s0):
+    return (a0.is_cuda and a0.dtype == torch.float32 and a1.dtype == torch.float32 and a0.dim() == 4 and a0.shape == a1.shape and
+            (a0.shape[2] * a0.shape[3]) % 4 == 0 and s0.numel() == a0.shape[0] * a0.shape[1] and not torch.is_autocast_enabled())
 
 
 def scale_residual_cat(a0, s0, a1, s1, x):
     """cat([s0*a0 + x, s1*a1 + x], 1) for [B,C,H,W] maps and per-(sample, channel) scales s* [B,C,1,1]."""
-    if x.is_cuda and x.dtype == torch.float32 and a0.dtype == torch.float32 and a1.dtype == torch.float32 and x.dim() == 4 and \
-            (x.shape[2] * x.shape[3]) % 4 == 0 and s0.numel() == x.shape[0] * x.shape[1] == s1.numel() and \
-            a0.shape == x.shape == a1.shape and not torch.is_autocast_enabled():
+    if _fusable(a0, a1, s0) and s1.numel() == s0.numel() and x.shape == a0.shape and x.dtype == torch.float32:
         return _ScaleResidualCat.apply(a0, s0.float(), a1, s1.float(), x)
     return torch.cat([s0 * a0 + x, s1 * a1 + x], dim=1)
+
+
+def scale_cat(a0, s0, a1):
+    """cat([s0*a0, a1], 1): the channel-attention + concat stage of ExposureDecision (model_singleframe.py:68-72)."""
+    if _fusable(a0, a1, s0):
+        return _ScaleResidualCat.apply(a0, s0.float(), a1, None, None)
+    return torch.cat([s0 * a0, a1], dim=1)

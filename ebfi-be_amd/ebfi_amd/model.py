@@ -128,7 +128,7 @@ class ExposureDecision(BaseModel):
         ev = self.EventFeatExtract(Event)
         bl = self.BLFeatExtract(BlurryLevel)
         atten = torch.sigmoid(self.AVGPool(norm.group_norm(ev, self.GroupNorm) * norm.group_norm(bl, self.GroupNorm)))
-        ex = self.Conv1(torch.cat([ev * atten, bl], dim=1))
+        ex = self.Conv1(fused.scale_cat(ev, atten, bl))          # cat([ev * atten, bl], 1) as one fused stage
         return torch.sigmoid(self.AVGPool(ex).view(-1, 1))
 
 

@@ -190,7 +190,9 @@ int ebfi_frame2dcp(const float *frame, float *out, float *scratch /* [B,H,W] */,
 /* ------------------------------------------------------------------ fused stages between the convolutions
  * One round of ResidualControl (models/Ours/model_singleframe.py:124-134):
  *   out[:, :C] = s0[b,c] * a0 + x,  out[:, C:] = s1[b,c] * a1 + x      (a0/a1/x [B,C,H,W], s0/s1 [B,C], out [B,2C,H,W])
- * backward is its adjoint (grad_s* reduced per plane in fixed order).  HW = H*W, a multiple of 4. */
+ * backward is its adjoint (grad_s* reduced per plane in fixed order).  HW = H*W, a multiple of 4.
+ * x == NULL drops the residual (then grad_x == NULL), s1 == NULL means s1 = 1 (then a1 / grad_s1 are not read / written
+ * by the backward): cat([atten * ev, bl]) of ExposureDecision (model_singleframe.py:68-72) is the same stage. */
 int ebfi_scale_residual_cat_forward(const float *a0, const float *s0, const float *a1, const float *s1, const float *x,
                                     float *out, int B, int C, int64_t HW, void *stream);
 int ebfi_scale_residual_cat_backward(const float *grad_out, const float *a0, const float *s0, const float *a1,

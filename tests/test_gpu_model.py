@@ -247,3 +247,20 @@ def test_full_size_modes_agree_and_batch_is_independent():
     finally:
         conv.set_compute_dtype("fp32")
     assert _rel(s1, b[0][3:4]) < 1e-5 and _rel(f1, b[1][3:4]) < 1e-5
+
+
+def test_scale_cat_stage_of_exposure_decision():
+    from ebfi_amd.fused import scale_cat
+    torch.manual_seed(12)
+    for (B, C, H, W) in [(2, 4, 8, 8), (1, 64, 16, 32)]:
+        cpu = [torch.randn(B, C, H, W), torch.randn(B, C, 1, 1), torch.randn(B, C, H, W)]
+        ref_in = [t.clone().requires_grad_() for t in cpu]
+        ref = torch.cat([ref_in[1] * ref_in[0], ref_in[2]], dim=1)
+        g = torch.randn_like(ref)
+        ref.backward(g)
+        dev_in = [t.cuda().requires_grad_() for t in cpu]
+        out = scale_cat(*dev_in)
+        out.backward(g.cuda())
+        assert _rel(out.detach(), ref.detach()) < 1e-6
+        for d, r in zip(dev_in, ref_in):
+            assert d.grad.shape == r.grad.shape and _rel(d.grad, r.grad) < 1e-5
