@@ -87,6 +87,37 @@ __global__ void gather_sum_kernel(const float *__restrict__ src, const int *__re
     out[i] = acc;
 }
 
+// product-mean: out[plane] = mean_i a[plane][i] * b[plane][i]   (AdaptiveAvgPool2d(1) of a product of two maps:
+// ExposureDecision's correlation of the normalised event / blur features, model_singleframe.py:66-68) and its adjoint
+// ga = (g[plane] / n) * b, gb = (g[plane] / n) * a.  One workgroup per plane, fixed-order reduction.
+__global__ __launch_bounds__(256) void prodmean_fwd_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                           float *__restrict__ out, int64_t HW4) {
+    __shared__ float red[4];
+    const f4 *pa = reinterpret_cast<const f4 *>(a) + (int64_t)blockIdx.x * HW4;
+    const f4 *pb = reinterpret_cast<const f4 *>(b) + (int64_t)blockIdx.x * HW4;
+    float d = 0.f;
+    for (int64_t i = threadIdx.x; i < HW4; i += 256) {
+        const f4 u = pa[i], v = pb[i];
+        d += (u.x * v.x + u.y * v.y) + (u.z * v.z + u.w * v.w);
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) d += __shfl_xor(d, s, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)(HW4 * 4);
+}
+
+__global__ __launch_bounds__(256) void prodmean_bwd_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                           const float *__restrict__ g, float *__restrict__ ga,
+                                                           float *__restrict__ gb, int64_t HW4, int64_t total4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const float k = g[i / HW4] / (float)(HW4 * 4);
+    const f4 u = reinterpret_cast<const f4 *>(a)[i], v = reinterpret_cast<const f4 *>(b)[i];
+    reinterpret_cast<f4 *>(ga)[i] = v * k;
+    reinterpret_cast<f4 *>(gb)[i] = u * k;
+}
+
 int check_planes(const char *who, int B, int C, int64_t HW) {
     if (B < 0 || C <= 0 || HW <= 0) return fail(EBFI_ERR_ARG, "%s: bad dimensions", who);
     if (HW % 4 != 0) return fail(EBFI_ERR_UNSUPPORTED, "%s: H*W must be a multiple of 4 (got %lld)", who, (long long)HW);
@@ -138,4 +169,35 @@ extern "C" int ebfi_gather_sum(const float *src, const int32_t *idx, float *out,
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(gather_sum_kernel, dim3((unsigned)ceil_div(n_out, 256)), dim3(256), 0, st, src, idx, out, n_out, R);
     return check_launch("gather_sum");
+}
+
+// out[planes] = mean over HW of a*b (a, b [planes, HW] contiguous); HW a multiple of 4
+extern "C" int ebfi_prodmean_forward(const float *a, const float *b, float *out, int64_t planes, int64_t HW, void *stream) {
+    if (!a || !b || !out) return fail(EBFI_ERR_ARG, "prodmean_forward: null argument");
+    if (planes < 0 || planes > 2147483647LL || HW <= 0) return fail(EBFI_ERR_ARG, "prodmean_forward: bad dimensions");
+    if (HW % 4 != 0) return fail(EBFI_ERR_UNSUPPORTED, "prodmean_forward: H*W must be a multiple of 4");
+    if (planes == 0) return EBFI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    {
+        ProfScope ps("prodmean_fwd", st, 0.0, 8.0 * planes * (double)HW);
+        hipLaunchKernelGGL(prodmean_fwd_kernel, dim3((unsigned)planes), dim3(256), 0, st, a, b, out, HW / 4);
+    }
+    return check_launch("prodmean_fwd");
+}
+
+// grad_a = (grad_out[plane] / HW) * b, grad_b = (grad_out[plane] / HW) * a
+extern "C" int ebfi_prodmean_backward(const float *a, const float *b, const float *grad_out, float *grad_a, float *grad_b,
+                                      int64_t planes, int64_t HW, void *stream) {
+    if (!a || !b || !grad_out || !grad_a || !grad_b) return fail(EBFI_ERR_ARG, "prodmean_backward: null argument");
+    if (planes < 0 || HW <= 0) return fail(EBFI_ERR_ARG, "prodmean_backward: bad dimensions");
+    if (HW % 4 != 0) return fail(EBFI_ERR_UNSUPPORTED, "prodmean_backward: H*W must be a multiple of 4");
+    if (planes == 0) return EBFI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t total4 = planes * HW / 4;
+    {
+        ProfScope ps("prodmean_bwd", st, 0.0, 16.0 * planes * (double)HW);
+        hipLaunchKernelGGL(prodmean_bwd_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, a, b, grad_out, grad_a, grad_b,
+                           HW / 4, total4);
+    }
+    return check_launch("prodmean_bwd");
 }

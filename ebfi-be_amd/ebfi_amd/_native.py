@@ -55,6 +55,8 @@ SIGNATURES = {
     "ebfi_frame2dcp": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ebfi_scale_residual_cat_forward": (_i, [_vp] * 6 + [_i, _i, _i64, _vp]),
     "ebfi_scale_residual_cat_backward": (_i, [_vp] * 10 + [_i, _i, _i64, _vp]),
+    "ebfi_prodmean_forward": (_i, [_vp, _vp, _vp, _i64, _i64, _vp]),
+    "ebfi_prodmean_backward": (_i, [_vp] * 5 + [_i64, _i64, _vp]),
     "ebfi_gather_sum": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "ebfi_groupnorm_workspace": (_sz, [_i, _i]),
     "ebfi_groupnorm_forward": (_i, [_vp] * 6 + [_i, _i, _i64, _i, _c.c_float, _vp, _sz, _vp]),

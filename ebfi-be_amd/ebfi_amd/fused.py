@@ -60,3 +60,37 @@ def scale_cat(a0, s0, a1):
     if _fusable(a0, a1, s0):
         return _ScaleResidualCat.apply(a0, s0.float(), a1, None, None)
     return torch.cat([s0 * a0, a1], dim=1)
+
+
+class _ProdMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        B, C = a.shape[0], a.shape[1]
+        HW = a.numel() // max(B * C, 1)
+        out = torch.empty((B, C, 1, 1), dtype=a.dtype, device=a.device)
+        with torch.cuda.device_of(a):
+            rc = N.lib().ebfi_prodmean_forward(N.ptr(a), N.ptr(b), N.ptr(out), B * C, HW, N.stream_ptr(a.device))
+        N.check(rc, "ebfi_prodmean_forward")
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        B, C = a.shape[0], a.shape[1]
+        HW = a.numel() // max(B * C, 1)
+        ga, gb = torch.empty_like(a), torch.empty_like(b)
+        with torch.cuda.device_of(a):
+            rc = N.lib().ebfi_prodmean_backward(N.ptr(a), N.ptr(b), N.ptr(g), N.ptr(ga), N.ptr(gb), B * C, HW, N.stream_ptr(a.device))
+        N.check(rc, "ebfi_prodmean_backward")
+        return ga, gb
+
+
+def product_mean(a, b):
+    """AdaptiveAvgPool2d(1)(a * b) -> [B,C,1,1] without materialising the product."""
+    if a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 4 and a.shape == b.shape and \
+            (a.shape[2] * a.shape[3]) % 4 == 0 and not torch.is_autocast_enabled():
+        return _ProdMean.apply(a, b)
+    return (a * b).mean(dim=(2, 3), keepdim=True)

@@ -127,7 +127,8 @@ class ExposureDecision(BaseModel):
     def forward(self, Event, BlurryLevel):
         ev = self.EventFeatExtract(Event)
         bl = self.BLFeatExtract(BlurryLevel)
-        atten = torch.sigmoid(self.AVGPool(norm.group_norm(ev, self.GroupNorm) * norm.group_norm(bl, self.GroupNorm)))
+        # sigmoid(AVGPool(GN(ev) * GN(bl))): the pooled product as one reduction (the product map is never written)
+        atten = torch.sigmoid(fused.product_mean(norm.group_norm(ev, self.GroupNorm), norm.group_norm(bl, self.GroupNorm)))
         ex = self.Conv1(fused.scale_cat(ev, atten, bl))          # cat([ev * atten, bl], 1) as one fused stage
         return torch.sigmoid(self.AVGPool(ex).view(-1, 1))
 

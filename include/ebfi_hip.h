@@ -23,6 +23,7 @@
  *       src/cuda/dcn_v2_im2col_cuda.cu:125-402
  *   ebfi_conv2d_*               nn.Conv2d + activation inside ConvLayer (models/model_misc/submodules.py:159-200)
  *   ebfi_scale_residual_cat_*   exposure/time-scaled residual + concat of ResidualControl (model_singleframe.py:124-134)
+ *   ebfi_prodmean_*             AdaptiveAvgPool2d(1) of a product of two maps (ExposureDecision, model_singleframe.py:66-68)
  *   ebfi_groupnorm_*            nn.GroupNorm of ExposureDecision (models/Ours/model_singleframe.py:36,66-67)
  *   ebfi_census_*               Ternary census loss (loss/restore.py:108-145)
  *   ebfi_gauss5_*               GaussianConv of the Laplacian-pyramid loss (loss/restore.py:149-163)
@@ -198,6 +199,12 @@ int ebfi_scale_residual_cat_forward(const float *a0, const float *s0, const floa
 int ebfi_scale_residual_cat_backward(const float *grad_out, const float *a0, const float *s0, const float *a1,
                                      const float *s1, float *grad_a0, float *grad_a1, float *grad_x,
                                      float *grad_s0, float *grad_s1, int B, int C, int64_t HW, void *stream);
+
+/* out[plane] = mean over HW of a*b for contiguous [planes, HW] maps (AdaptiveAvgPool2d(1) of a product: the event / blur
+ * correlation of ExposureDecision, model_singleframe.py:66-68) and its adjoint.  HW a multiple of 4. */
+int ebfi_prodmean_forward(const float *a, const float *b, float *out, int64_t planes, int64_t HW, void *stream);
+int ebfi_prodmean_backward(const float *a, const float *b, const float *grad_out, float *grad_a, float *grad_b,
+                           int64_t planes, int64_t HW, void *stream);
 
 /* Sparse 0/1 linear map: out[i] = sum_{r<R} src[idx[i*R+r]], negative indices skipped.  Carries the weight
  * re-layouts that turn the depth-2 Conv3d / ConvTranspose3d of the detail branch (models/model_misc/resnet_3D.py,

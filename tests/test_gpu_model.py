@@ -264,3 +264,18 @@ def test_scale_cat_stage_of_exposure_decision():
         assert _rel(out.detach(), ref.detach()) < 1e-6
         for d, r in zip(dev_in, ref_in):
             assert d.grad.shape == r.grad.shape and _rel(d.grad, r.grad) < 1e-5
+
+
+def test_product_mean_stage():
+    from ebfi_amd.fused import product_mean
+    torch.manual_seed(13)
+    for (B, C, H, W) in [(2, 4, 8, 8), (1, 64, 16, 32), (3, 5, 6, 10)]:
+        a, b = torch.randn(B, C, H, W, requires_grad=True), torch.randn(B, C, H, W, requires_grad=True)
+        ref = (a * b).mean(dim=(2, 3), keepdim=True)
+        g = torch.randn_like(ref)
+        ref.backward(g)
+        ad, bd = a.detach().cuda().requires_grad_(), b.detach().cuda().requires_grad_()
+        out = product_mean(ad, bd)
+        out.backward(g.cuda())
+        assert out.shape == ref.shape and _rel(out.detach(), ref.detach()) < 1e-5
+        assert _rel(ad.grad, a.grad) < 1e-6 and _rel(bd.grad, b.grad) < 1e-6
