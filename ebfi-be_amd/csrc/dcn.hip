@@ -494,12 +494,26 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
                 float *gplane = gx + (int64_t)(b * g.C + ck.cbase) * g.H * g.W;
                 float *bplane = sBox;
                 const unsigned o0 = t.q0 >= 0 ? (unsigned)t.q0 * 4u : 0x80000000u, o1 = t.q1 >= 0 ? (unsigned)t.q1 * 4u : 0x80000000u;
-                unsigned chan_byte = (unsigned)ck.cbase * plane_bytes;
-                for (int cl = 0; cl < ck.cb; ++cl, chan_byte += plane_bytes, gplane += (int64_t)g.H * g.W, bplane += bx.BH * bx.BW) {
+                // the corner pairs of all channels of the chunk are fetched as ONE batch (a loop with a fetch per iteration
+                // is a chain of dependent memory round trips: the walk was bound by exactly that)
+                constexpr int CMAX = 8;                          // channels per batch (a 3x3 chunk has exactly 8)
+                const unsigned v0off = t.valid ? o0 : 0x80000000u, v1off = t.valid ? o1 : 0x80000000u;
+                for (int cg0 = 0; cg0 < ck.cb; cg0 += CMAX) {
+                u32x2 qa[CMAX], qb[CMAX];
+                const unsigned chan0 = (unsigned)(ck.cbase + cg0) * plane_bytes;
+#pragma unroll
+                for (int cj = 0; cj < CMAX; ++cj) {
+                    const unsigned cb_ = cg0 + cj < ck.cb ? chan0 + (unsigned)cj * plane_bytes : 0x80000000u;   // out of range: reads 0
+                    qa[cj] = __builtin_amdgcn_raw_buffer_load_b64(rxs, v0off + cb_, 0, 0);
+                    qb[cj] = __builtin_amdgcn_raw_buffer_load_b64(rxs, v1off + cb_, 0, 0);
+                }
+#pragma unroll
+                for (int cj = 0; cj < CMAX; ++cj, gplane += (int64_t)g.H * g.W, bplane += bx.BH * bx.BW) {
+                    const int cl = cg0 + cj;
+                    if (cl >= ck.cb) break;
                     const float cg = sCG[(cl * g.kk + tap) * NP + px];
                     if (t.valid) {
-                        const u32x2 pa = __builtin_amdgcn_raw_buffer_load_b64(rxs, o0 + chan_byte, 0, 0);
-                        const u32x2 pb = __builtin_amdgcn_raw_buffer_load_b64(rxs, o1 + chan_byte, 0, 0);
+                        const u32x2 pa = qa[cj], pb = qb[cj];
                         const float ax = __uint_as_float(pa.x), ay = __uint_as_float(pa.y);
                         const float bxv = __uint_as_float(pb.x), byv = __uint_as_float(pb.y);
                         const float v1 = ax * t.mlx + ay * t.mly, v2 = ax * t.mhx + ay * t.mhy;
@@ -526,6 +540,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
                         }
                     }
                 }
+                }   // channel batches
                 const int64_t ob = ((int64_t)(b * g.dg + ck.grp) * 2 * g.kk + 2 * tap) * g.HWo + p;
                 const int64_t mb = ((int64_t)(b * g.dg + ck.grp) * g.kk + tap) * g.HWo + p;
                 if (first_sub) {
@@ -604,12 +619,31 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restric
                 if (p < g.HWo) {
                     const TapPos tp = tap_pos(g, off, msk, b, ck.grp, tap, p, g.pw);
                     const Tap t = make_tap(tp.h, tp.w, g.H, g.W);
-                    const float *plane = x + (int64_t)(b * g.C + ck.cbase) * g.H * g.W;
-                    for (int cl = 0; cl < ck.cb; ++cl, plane += (int64_t)g.H * g.W) {
-                        float v1, v2, v3, v4;
-                        corners(plane, t, v1, v2, v3, v4);
-                        const float val = (t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4);
-                        sCt[px * S81 + cl * g.kk + tap] = val * tp.mask;
+                    // corner pairs of 8 channels per batch through the sample's descriptor (no dependent round trips)
+                    const __amdgpu_buffer_rsrc_t rxs = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<float *>(x + (int64_t)b * g.C * g.H * g.W), 0, (unsigned)g.C * (unsigned)(g.H * g.W) * 4u, 0x00020000);
+                    const unsigned plane_bytes = (unsigned)(g.H * g.W) * 4u;
+                    const unsigned o0 = t.q0 >= 0 ? (unsigned)t.q0 * 4u : 0x80000000u, o1 = t.q1 >= 0 ? (unsigned)t.q1 * 4u : 0x80000000u;
+                    for (int cg0 = 0; cg0 < ck.cb; cg0 += 8) {
+                        u32x2 qa[8], qb[8];
+                        const unsigned chan0 = (unsigned)(ck.cbase + cg0) * plane_bytes;
+#pragma unroll
+                        for (int cj = 0; cj < 8; ++cj) {
+                            const unsigned cb_ = cg0 + cj < ck.cb ? chan0 + (unsigned)cj * plane_bytes : 0x80000000u;
+                            qa[cj] = __builtin_amdgcn_raw_buffer_load_b64(rxs, o0 + cb_, 0, 0);
+                            qb[cj] = __builtin_amdgcn_raw_buffer_load_b64(rxs, o1 + cb_, 0, 0);
+                        }
+#pragma unroll
+                        for (int cj = 0; cj < 8; ++cj) {
+                            const int cl = cg0 + cj;
+                            if (cl >= ck.cb) break;
+                            const float ax = __uint_as_float(qa[cj].x), ay = __uint_as_float(qa[cj].y);
+                            const float bxv = __uint_as_float(qb[cj].x), byv = __uint_as_float(qb[cj].y);
+                            const float v1 = ax * t.mlx + ay * t.mly, v2 = ax * t.mhx + ay * t.mhy;
+                            const float v3 = bxv * t.mlx + byv * t.mly, v4 = bxv * t.mhx + byv * t.mhy;
+                            const float val = (t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4);
+                            sCt[px * S81 + cl * g.kk + tap] = val * tp.mask;
+                        }
                     }
                 } else {
                     for (int cl = 0; cl < ck.cb; ++cl) sCt[px * S81 + cl * g.kk + tap] = 0.f;
