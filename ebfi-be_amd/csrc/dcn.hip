@@ -442,12 +442,25 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
                         rgo, gbase + (unsigned)(4 * ks) * (unsigned)g.HWo * 4u, 0, 0));
                 if (band == 0 || nco > 1) {
                     __syncthreads();       // previous readers of sWt are done
-                    for (int i = tid; i < 64 * KCP; i += 256) {
-                        const int co = i / KCP, kl = i - co * KCP;
-                        float v = 0.f;
-                        if (kl < ck.KL && cob * 64 + co < g.Co)
-                            v = wgt[(int64_t)(cob * 64 + co) * g.Kd + (int64_t)ck.cbase * g.kk + kl];
-                        sWt[co * S80 + kl] = v;
+                    {   // the slice as ONE batch of loads (a load per loop iteration is a chain of dependent round trips)
+                        constexpr int NWS = (64 * KCP + 255) / 256;
+                        const __amdgpu_buffer_rsrc_t rwg = __builtin_amdgcn_make_buffer_rsrc(
+                            const_cast<float *>(wgt), 0, (unsigned)g.Co * (unsigned)g.Kd * 4u, 0x00020000);
+                        float wv[NWS];
+#pragma unroll
+                        for (int it = 0; it < NWS; ++it) {
+                            const int i = tid + it * 256;
+                            const int co = i / KCP, kl = i - co * KCP;
+                            const bool ok = i < 64 * KCP && kl < ck.KL && cob * 64 + co < g.Co;
+                            wv[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                                rwg, ok ? (unsigned)((cob * 64 + co) * g.Kd + ck.cbase * g.kk + kl) * 4u : 0x80000000u, 0, 0));
+                        }
+#pragma unroll
+                        for (int it = 0; it < NWS; ++it) {
+                            const int i = tid + it * 256;
+                            const int co = i / KCP, kl = i - co * KCP;
+                            if (i < 64 * KCP) sWt[co * S80 + kl] = wv[it];
+                        }
                     }
                     __syncthreads();
                 }
