@@ -156,3 +156,45 @@ def test_fold_index_tables_reproduce_the_tensor_folds():
         ref.backward(g)
         gw = torch.cat([g.flatten(), zero])[inv.long()].sum(-1).view(shape)
         assert inv.shape == (w.numel(), R) and torch.allclose(gw, w.grad, atol=1e-12), kind
+
+
+def test_flat_adam_matches_torch_adam_and_speaks_its_checkpoint_layout():
+    """FlatAdam (one fused update over a flat parameter buffer) against torch.optim.Adam on the same gradients, and
+    checkpoint interchange in both directions in torch's per-parameter layout (the reference's checkpoint format)."""
+    import copy
+    from ebfi_amd.dp import FlatAdam, FlatGradBucket
+    torch.manual_seed(3)
+    net_a = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.Conv2d(4, 2, 1))
+    net_b = copy.deepcopy(net_a)
+    names = [n for n, _ in net_a.named_parameters()]
+    opt_a = torch.optim.Adam(net_a.parameters(), lr=1e-2)
+    opt_b = FlatAdam(list(net_b.parameters()), lr=1e-2)
+    assert opt_b.views_intact() and [n for n, _ in net_b.named_parameters()] == names
+    bucket = FlatGradBucket(net_b)
+    x = torch.randn(2, 3, 8, 8)
+    for _ in range(3):
+        opt_a.zero_grad()
+        net_a(x).square().sum().backward()
+        opt_a.step()
+        bucket.zero()
+        net_b(x).square().sum().backward()
+        opt_b.step(bucket.gather())
+    for pa, pb in zip(net_a.parameters(), net_b.parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-6, atol=1e-7)
+    # FlatAdam -> torch.optim.Adam
+    sd = opt_b.state_dict()
+    assert set(sd) == {"state", "param_groups"} and len(sd["state"]) == 4 and sd["state"][0]["exp_avg"].shape == (4, 3, 3, 3)
+    opt_c = torch.optim.Adam(net_a.parameters(), lr=1e-2)
+    opt_c.load_state_dict(sd)
+    # torch.optim.Adam -> FlatAdam, then one more identical step on both sides
+    net_d = copy.deepcopy(net_a)
+    opt_d = FlatAdam(list(net_d.parameters()), lr=1e-2)
+    opt_d.load_state_dict(opt_a.state_dict())
+    bucket_d = FlatGradBucket(net_d)
+    opt_a.zero_grad()
+    net_a(x).square().sum().backward()
+    opt_a.step()
+    net_d(x).square().sum().backward()
+    opt_d.step(bucket_d.gather())
+    for pa, pd in zip(net_a.parameters(), net_d.parameters()):
+        assert torch.allclose(pa, pd, rtol=1e-6, atol=1e-7)
