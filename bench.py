@@ -15,6 +15,8 @@ fields the line carries
                    hipEvent pairs the library records on the launch stream during a second, eager pass of the same K steps
   kernels          the same figures for every hand-written kernel of the step
   fp32_exact_mode  the same step with every conv on the exact fp32 matrix cores (second leg of the same run)
+  ops              FAC fwd/bwd, DCNv2 fwd/bwd and the composite DCNv2+FAC forward (the north_star target, >= 0.30 of the HBM
+                   roofline) at B=8, 128x128 features, timed in the same process (N=1 only)
   cpu_baseline     the CPU oracle (oracle/model_ref.py + loss_ref.py, a port of the reference path) timed on this box's
                    host cores on a bounded sample (rank 0, N=1 only)
 """
@@ -97,26 +99,48 @@ def note(msg):
     print("[bench %7.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
 
 
+def symbol_of(label):
+    """Profiler labels are "<kernel symbol>" or "<kernel symbol>/<role>" (one kernel serving several ops, e.g. the
+    forward and the data gradient): device time is ranked per SYMBOL."""
+    return label.split("/")[0]
+
+
 def kernel_table(kernels, elapsed, steps):
-    """Per hand-written kernel: device time from the library's hipEvent pairs, algorithmic work from the
-    launchers (SURVEY.md 8(d) formulas, un-padded).  The bound of a kernel is whichever floor is higher for the work
-    it was given: matrix time (flops executed on the matrix cores / dense peak of the operand type; the split-precision
-    bf16x3 kernels execute 3 matrix flops per algorithmic flop) or HBM time (algorithmic bytes / 8 TB/s)."""
-    per_kernel = {}
-    for name, (launches, total_ms, flops, nbytes) in kernels.items():
-        if name.startswith("__") or launches == 0:
+    """Per hand-written kernel (grouped by kernel symbol): device time from the library's hipEvent pairs, algorithmic
+    work from the launchers (SURVEY.md 8(d) formulas, un-padded).  The bound of a kernel is whichever floor is higher for
+    the work it was given: matrix time (matrix flops EXECUTED / dense peak of the operand type; the split-precision x3
+    kernels execute 3 matrix flops per algorithmic flop) or HBM time (algorithmic bytes / 8 TB/s).  For matrix-bound
+    kernels `achieved` / `frac` are quoted in ALGORITHMIC flops (the useful work); the executed rate is given beside them
+    as `executed` / `frac_executed`."""
+    grouped = {}
+    for label, (launches, total_ms, flops, nbytes) in kernels.items():
+        if label.startswith("__") or launches == 0:
             continue
-        entry = {"launches": launches, "avg_ms": round(total_ms / launches, 5), "total_ms": round(total_ms, 3)}
+        e = grouped.setdefault(symbol_of(label), {"launches": 0, "total_ms": 0.0, "flops": 0.0, "bytes": 0.0, "roles": {}})
+        e["launches"] += launches
+        e["total_ms"] += total_ms
+        e["flops"] += flops
+        e["bytes"] += nbytes
+        if "/" in label:
+            e["roles"][label.split("/", 1)[1]] = {"launches": launches, "total_ms": round(total_ms, 3)}
+    per_kernel = {}
+    for name, e in grouped.items():
+        launches, total_ms, flops, nbytes = e["launches"], e["total_ms"], e["flops"], e["bytes"]
+        entry = {"launches": launches, "launches_per_step": launches / steps, "avg_ms": round(total_ms / launches, 5),
+                 "total_ms": round(total_ms, 3)}
+        if e["roles"]:
+            entry["roles"] = e["roles"]
         secs = total_ms * 1e-3
-        mult = 3 if "bf16x3" in name else 1
-        mfma_peak = BF16_MFMA_PEAK_TFS if "bf16" in name else F32_MFMA_PEAK_TFS
+        mult = 3 if "x3" in name else 1
+        mfma_peak = BF16_MFMA_PEAK_TFS if "bf16" in name or "x3" in name else F32_MFMA_PEAK_TFS
         t_mfma = mult * flops / (mfma_peak * 1e12)
         t_hbm = nbytes / (HBM_PEAK_GBS * 1e9)
         if flops > 0 and t_mfma >= t_hbm:
             entry.update(bound="mfma", algorithmic_flops_per_launch=flops / launches,
-                         achieved=round(mult * flops / secs / 1e12, 2), peak=mfma_peak, unit="TFLOP/s")
+                         achieved=round(flops / secs / 1e12, 2), peak=mfma_peak, unit="TFLOP/s")
             if mult != 1:
-                entry["matrix_flops_per_algorithmic_flop"] = mult
+                entry.update(matrix_flops_per_algorithmic_flop=mult, executed=round(mult * flops / secs / 1e12, 2),
+                             frac_executed=round(mult * flops / secs / 1e12 / mfma_peak, 4))
         elif nbytes > 0:
             entry.update(bound="hbm", algorithmic_bytes_per_launch=nbytes / launches,
                          achieved=round(nbytes / secs / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s")
@@ -136,9 +160,66 @@ def kernel_table(kernels, elapsed, steps):
         except (OSError, ValueError):
             pass
         roofline = {"kernel": ranked[0], "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
-                    "unit": d["unit"], "frac": d["frac"], "traffic": traffic, "launches_per_step": d["launches"] / steps,
+                    "unit": d["unit"], "frac": d["frac"], "traffic": traffic, "launches_per_step": d["launches_per_step"],
                     "avg_launch_ms": d["avg_ms"], "share_of_step": round(d["total_ms"] / (1e3 * elapsed), 4)}
+        for k in ("executed", "frac_executed", "matrix_flops_per_algorithmic_flop", "roles"):
+            if k in d:
+                roofline[k] = d[k]
     return per_kernel, roofline
+
+
+def ops_block(device, iters=20):
+    """The two extension ops of the path at the north_star size (B=8, 64 channels, 128x128 features: SURVEY.md 8(d)),
+    timed in THIS process with the library's hipEvent pairs: FAC forward / backward, DCNv2 forward / backward, and the
+    composite "DCNv2+FAC forward" the BASELINE target (>= 30 % of the HBM roofline) is stated on."""
+    from ebfi_amd import _native as N
+    from ebfi_amd.dcn import dcn_v2_backward, dcn_v2_forward
+    from ebfi_amd.fac import fac_backward, fac_forward
+    B, C, K, h, w, dg = B_PER_GPU, 64, 5, H // 2, W // 2, 8
+    P = B * h * w
+    g = torch.Generator(device="cpu").manual_seed(123)
+    rn = lambda *shape: torch.randn(*shape, generator=g).to(device)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(device)
+        N.prof_reset()
+        N.prof_enable(True)
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize(device)
+        N.prof_enable(False)
+        return {k: v[1] / v[0] for k, v in N.prof_collect().items() if v[0]}
+
+    out = {"shape": {"B": B, "C": C, "h": h, "w": w, "K": K, "deformable_groups": dg}, "iters": iters}
+    xp, kern, go = rn(B, C, h + 4, w + 4), rn(B, C * K * K, h, w), rn(B, C, h, w)
+    res = torch.empty(B, C, h, w, device=device)
+    t = timed(lambda: fac_forward(xp, kern, K, out=res))
+    fac_fwd_ms, fac_fwd_bytes = sum(t.values()), 4.0 * P * C * (1 + K * K + 1)
+    t = timed(lambda: fac_backward(xp, kern, K, go))
+    fac_bwd_ms, fac_bwd_bytes = sum(t.values()), 4.0 * P * C * (K * K + 1 + 1 + 1 + K * K)
+    del xp, kern, res
+    torch.cuda.empty_cache()
+    x, off = rn(B, C, h, w), rn(B, dg * 18, h, w) * 2
+    msk, wt, bias = torch.sigmoid(rn(B, dg * 9, h, w)), rn(C, C, 3, 3) / 24, rn(C)
+    cfg = ((1, 1), (1, 1), (1, 1), dg)
+    t = timed(lambda: dcn_v2_forward(x, wt, bias, off, msk, *cfg))
+    dcn_fwd_ms = sum(t.values())
+    dcn_fwd_bytes = 4.0 * (P * (C + 2 * dg * 9 + dg * 9 + C) + C * C * 9)
+    dcn_flops = 2.0 * P * C * 9 * (4 + C)
+    tb = timed(lambda: dcn_v2_backward(x, wt, bias, off, msk, go, *cfg))
+    hbm = lambda by, ms: {"ms": round(ms, 4), "algorithmic_bytes": by, "GBps": round(by / ms / 1e6, 1),
+                          "frac_hbm": round(by / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    out["fac_forward"] = hbm(fac_fwd_bytes, fac_fwd_ms)
+    out["fac_backward"] = hbm(fac_bwd_bytes, fac_bwd_ms)
+    out["dcn_forward"] = dict(hbm(dcn_fwd_bytes, dcn_fwd_ms), TFLOPs=round(dcn_flops / dcn_fwd_ms / 1e9, 2),
+                              frac_f32_mfma=round(dcn_flops / dcn_fwd_ms / 1e9 / F32_MFMA_PEAK_TFS, 4))
+    out["dcn_backward"] = {"ms": round(sum(tb.values()), 4), "kernels_ms": {k: round(v, 4) for k, v in sorted(tb.items())}}
+    out["dcn_fac_forward"] = dict(hbm(fac_fwd_bytes + dcn_fwd_bytes, fac_fwd_ms + dcn_fwd_ms),
+                                  target_frac_hbm=0.30, note="BASELINE.json north_star target: DCNv2+FAC forward at "
+                                  "B=8 256x256 (128x128 features), exact fp32 kernels, sum of the two launches")
+    return out
 
 
 def main():
@@ -152,6 +233,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel of the step eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ops", action="store_true", help="skip the FAC / DCNv2 op block (north_star target figure)")
     ap.add_argument("--no-bf16-leg", "--no-extra-legs", dest="no_extra_legs", action="store_true",
                     help="skip the secondary measurement of the same step in the exact-fp32 mode")
     args = ap.parse_args()
@@ -212,14 +294,16 @@ def main():
         sync()
         N.prof_reset()
         N.prof_enable(True)
-        t0 = time.perf_counter()
+        prof_elapsed = 0.0
         for _ in range(args.steps):
+            t0 = time.perf_counter()
             eng.train_step(*batch)
-        sync()
-        prof_elapsed = time.perf_counter() - t0
+            sync()
+            prof_elapsed += time.perf_counter() - t0
+            N.prof_fold()                           # once per step: the pending list never overflows
         N.prof_enable(False)
         eng.use_graph = graph_mode
-        kernels = N.prof_collect()
+        kernels = N.prof_collect()                  # raises if a single launch went untimed
         note("%s profiled eager pass: %d steps in %.3f s" % (tag, args.steps, prof_elapsed))
         return t_max.item(), kernels, loss_value, prof_elapsed
 
@@ -234,8 +318,20 @@ def main():
         extra_leg = {"note": "the same step with every conv on the exact fp32 matrix cores (v_mfma_f32_32x32x2_f32); informational",
                      "value": round(world * B_PER_GPU * args.steps / e2, 3), "unit": "frames/s",
                      "ms_per_step": round(1e3 * e2 / args.steps, 3), "loss": l2, "roofline": rf2,
-                     "kernels": {k: {f: v[f] for f in ("launches", "total_ms", "bound", "achieved", "unit", "frac") if f in v}
+                     "kernels": {k: {f: v[f] for f in ("launches", "launches_per_step", "total_ms", "bound", "achieved", "unit", "frac", "frac_executed") if f in v}
                                  for k, v in pk2.items()}}
+
+    # replicas must still be identical after the timed steps (same init, every rank applied the same averaged gradient):
+    # every rank contributes a checksum of its parameters, rank 0 compares them bit for bit
+    flat = eng.optimizer.flat.detach().double()
+    check = torch.stack([flat.sum(), flat.square().sum()]).to("cpu" if rehearsal or world == 1 else device)
+    checks = [check]
+    if world > 1:
+        checks = [torch.empty_like(check) for _ in range(world)]
+        dist.all_gather(checks, check)
+    checks = [tuple(c.cpu().tolist()) for c in checks]
+    if any(c != checks[0] for c in checks):
+        raise SystemExit("bench.py: replicas diverged, per-rank parameter checksums %r" % (checks,))
 
     if rank == 0:
         per_kernel, roofline = kernel_table(kernels, prof_elapsed, args.steps)
@@ -255,6 +351,8 @@ def main():
                                    "Lap/census loss + bwd + flat grad all-reduce + Adam; B=%d per GPU, %dx%d frames, "
                                    "TB=%d event bins, Poisson(0.35) event counts" % (B_PER_GPU, H, W, TB),
                        "global_batch": world * B_PER_GPU, "parallelism": "dp%d" % world, "loss": loss,
+                       "world_size": world, "collective_backend": (dist.get_backend() if world > 1 else None),
+                       "replica_param_checksum": {"sum": checks[0][0], "sum_sq": checks[0][1], "ranks_identical": True},
                        "precision": {"fp32": "fp32 tensors, exact fp32 matrix cores",
                                      "bf16x3": "fp32 tensors and accumulation; conv operands split into bf16 hi+lo pairs, 3 MFMAs "
                                                "per product (~1e-5 of fp32, parity-tested at 1e-3 like the fp32 mode)",
@@ -265,6 +363,12 @@ def main():
             "kernels": per_kernel,
             "fp32_exact_mode": extra_leg,
         }
+        if world == 1 and not args.no_ops:
+            note("op block: FAC / DCNv2 at B=8, 128x128 features ...")
+            del eng
+            torch.cuda.empty_cache()
+            out["ops"] = ops_block(device)
+            out["dcn_fac_forward_frac_hbm"] = out["ops"]["dcn_fac_forward"]["frac_hbm"]
         if world == 1 and not args.no_cpu_baseline:
             note("cpu baseline (oracle on host cores) ...")
             out["cpu_baseline"] = cpu_baseline(dict(DEFAULT_MODEL_ARGS))

@@ -16,6 +16,10 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 // hipGetLastError() after a launch -> EBFI_OK / EBFI_ERR_LAUNCH (with message)
 int check_launch(const char *what);
 
+// Raises a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) to at least `bytes` on the CURRENT
+// device, once per (kernel, device), thread-safe; EBFI_OK or EBFI_ERR_LAUNCH with the HIP error text.
+int ensure_dynamic_lds(const void *kernel, int bytes);
+
 // RAII hipEvent bracket around one kernel launch (no-op unless ebfi_prof_enable(1)).
 class ProfScope {
   public:

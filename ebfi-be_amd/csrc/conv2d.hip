@@ -1273,7 +1273,7 @@ int launch_fwd_d(hipStream_t st, const float *x, const float *dact_y, const floa
     constexpr int CK = KS == 7 ? 2 : 8;      // input channels staged per chunk (LDS budget of the weight slice)
     const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, TY) * ceil_div(g.Wo, TX);
     if (tiles > 2147483647LL) return fail(EBFI_ERR_ARG, "conv2d: too many tiles");
-    const char *name = TR ? "conv_dgrad_f32" : "conv_fwd_f32";
+    const char *name = TR ? "conv_fwd_f32/dgrad" : "conv_fwd_f32/fwd";   // one kernel, two roles
     const double flops = 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS;   // dense, un-padded
     if (g.Cout <= 32) {
         dim3 grid((unsigned)tiles, (unsigned)ceil_div(g.Cout, 32));
@@ -1341,12 +1341,7 @@ int launch_wgrad_d(hipStream_t st, const float *x, const float *gout, const floa
                    const ConvGeom &g, float dslope, int nsplit, int need_bias) {
     using C = WCfg<KS, S, WTXO>;
     const size_t lds = (size_t)(64 * GS + (C::CIB + 1) * C::PS + 64) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_f32<KS, S, WTXO, DACT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_wgrad_f32<KS, S, WTXO, DACT>), (int)lds)) return rc;
     const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, C::WTX);
     dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, C::CIB));
     ProfScope ps("conv_wgrad_f32", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS,
@@ -1394,19 +1389,14 @@ int launch_wgrad_x3_d(hipStream_t st, const float *x, const float *gout, const f
     using C = WCfg<KS, 1, WTXO>;
     constexpr int CIB = X3CIB<KS>::value;
     const size_t lds = (size_t)2 * (64 * GS + (CIB + 1) * C::PS) * sizeof(unsigned);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_x3<KS, WTXO, DACT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_wgrad_x3<KS, WTXO, DACT>), (int)lds)) return rc;
     const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, C::WTX);
     dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, CIB));
-    ProfScope ps("conv_wgrad_bf16x3", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS,
+    ProfScope ps("conv_wgrad_x3", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS,
                  conv_bytes_wgrad(g, KS * KS, DACT != 0, gpre_out != nullptr));
     hipLaunchKernelGGL((conv_wgrad_x3<KS, WTXO, DACT>), grid, dim3(WXT), lds, st, x, gout, yact, slab, gpre_out, g, dslope,
                        (int)tiles, need_bias);
-    return check_launch("conv_wgrad_bf16x3");
+    return check_launch("conv_wgrad_x3");
 }
 
 template <int KS, int WTXO>
@@ -1429,12 +1419,7 @@ int launch_wgrad_bf16_d(hipStream_t st, const float *x, const float *gout, const
                         float dslope, int nsplit, int need_bias) {
     using C = WCfgB<KS>;
     const size_t lds = (size_t)C::LDS_ELEMS * 2;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_bf16<KS, DACT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_wgrad_bf16<KS, DACT>), (int)lds)) return rc;
     const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, C::WTX);
     dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, C::CIB));
     ProfScope ps("conv_wgrad_bf16", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS,
@@ -1474,7 +1459,8 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
     const int ty = x3 ? TYB : TY;
     const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, ty) * ceil_div(g.Wo, TX);
     if (tiles > 2147483647LL) return fail(EBFI_ERR_ARG, "conv2d: too many tiles");
-    const char *name = x3 ? (transposed ? "conv_dgrad_bf16x3" : "conv_fwd_bf16x3") : (transposed ? "conv_dgrad_bf16" : "conv_fwd_bf16");
+    const char *name = x3 ? (transposed ? "conv_fwd_bf16x3_db/dgrad" : "conv_fwd_bf16x3_db/fwd")
+                          : (transposed ? "conv_fwd_bf16/dgrad" : "conv_fwd_bf16/fwd");   // label = kernel symbol / role
     const double flops = 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS;
     const int mt = g.Cout <= 32 ? 1 : 2;
     dim3 grid((unsigned)tiles, (unsigned)ceil_div(g.Cout, 32 * mt));
@@ -1484,12 +1470,8 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
         ProfScope ps(name, st, flops, conv_bytes_fwd(g, KS * KS, dact != 0));
 #define EBFI_LAUNCH_X3(MT_, DA_)                                                                                          \
     do {                                                                                                                 \
-        static bool attr_done = false;                                                                                   \
-        if (!attr_done) {                                                                                                \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_fwd_bf16x3_db<KS, MT_, DA_>),                 \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                           \
-            attr_done = true;                                                                                            \
-        }                                                                                                                \
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_bf16x3_db<KS, MT_, DA_>), 160 * 1024))   \
+            return rc_;                                                                                                  \
         hipLaunchKernelGGL((conv_fwd_bf16x3_db<KS, MT_, DA_>), grid, dim3(NTB), lds, st, x, dact_y, wp, bias, out, g, K16, act,  \
                            slope, dslope);                                                                               \
     } while (0)

@@ -836,12 +836,7 @@ extern "C" int ebfi_dcn_backward(const void *input, const void *weight, const vo
                 break;
             }
         const size_t lds = (size_t)(64 * S80 + KCP * NP + BOX_CH * BOX_CELLS) * sizeof(float);
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dcn_bwd_data_f32),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_done = true;
-        }
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&dcn_bwd_data_f32), (int)lds)) return rc;
         const int64_t tiles = (int64_t)B * ceil_div(g.Ho, BT) * ceil_div(g.Wo, BT);
         ProfScope ps("dcn_bwd_data_f32", st);
         hipLaunchKernelGGL(dcn_bwd_data_f32, dim3((unsigned)tiles), dim3(256), lds, st, x, wgt, off, msk, go,

@@ -1,6 +1,8 @@
 // ABI version, error text and the optional per-kernel hipEvent profiler.
+#include <map>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "common.hpp"
@@ -23,6 +25,23 @@ int check_launch(const char *what) {
     return EBFI_OK;
 }
 
+int ensure_dynamic_lds(const void *kernel, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, int> granted;   // (kernel, device) -> bytes already set
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(EBFI_ERR_LAUNCH, "hipGetDevice: %s", hipGetErrorString(e));
+    std::lock_guard<std::mutex> lock(mu);
+    int &have = granted[{kernel, dev}];
+    if (have >= bytes) return EBFI_OK;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess)
+        return fail(EBFI_ERR_LAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) on device %d: %s", bytes, dev,
+                    hipGetErrorString(e));
+    have = bytes;
+    return EBFI_OK;
+}
+
 namespace {
 struct Pending {
     int kernel;
@@ -42,6 +61,7 @@ struct Profiler {
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;  // recycled events
     int dropped = 0;
+    int capacity = EBFI_PROF_MAX_PENDING;   // pending pairs between two collects (ebfi_prof_set_capacity)
 
     int kernel_id(const char *name) {
         for (size_t i = 0; i < stats.size(); ++i)
@@ -71,7 +91,7 @@ ProfScope::ProfScope(const char *kernel_name, hipStream_t stream, double flops, 
     Profiler &p = prof();
     if (!p.enabled) return;  // racy read is fine: enable/disable happens between timed regions
     std::lock_guard<std::mutex> lock(p.mu);
-    if ((int)p.pending.size() >= EBFI_PROF_MAX_PENDING) {
+    if ((int)p.pending.size() >= p.capacity) {
         ++p.dropped;
         return;
     }
@@ -102,6 +122,14 @@ void ebfi_prof_enable(int on) {
     Profiler &p = prof();
     std::lock_guard<std::mutex> lock(p.mu);
     p.enabled = on != 0;
+}
+
+int ebfi_prof_set_capacity(int max_pending) {
+    Profiler &p = prof();
+    std::lock_guard<std::mutex> lock(p.mu);
+    if (max_pending < 1) return fail(EBFI_ERR_ARG, "prof capacity %d", max_pending);
+    p.capacity = max_pending;
+    return EBFI_OK;
 }
 
 void ebfi_prof_reset(void) {

@@ -67,6 +67,7 @@ SIGNATURES = {
     "ebfi_gauss5_forward": (_i, [_vp, _vp, _i64, _i, _i, _c.c_float, _vp]),
     "ebfi_gauss5_backward": (_i, [_vp, _vp, _i64, _i, _i, _c.c_float, _vp]),
     "ebfi_prof_enable": (None, [_i]),
+    "ebfi_prof_set_capacity": (_i, [_i]),
     "ebfi_prof_reset": (None, []),
     "ebfi_prof_collect": (_i, [_c.POINTER(_i)]),
     "ebfi_prof_num_kernels": (_i, []),
@@ -163,12 +164,23 @@ def prof_reset():
     lib().ebfi_prof_reset()
 
 
-def prof_collect():
-    """{kernel name: (launches, total_ms, algorithmic flops, algorithmic bytes)}; call after
-    torch.cuda.synchronize()."""
+def prof_fold():
+    """Fold the pending event pairs into the per-kernel totals (call after torch.cuda.synchronize(), e.g. once per
+    step, so that the bounded pending list never overflows).  Returns the number of launches dropped so far."""
+    dropped = _i(0)
+    lib().ebfi_prof_collect(ctypes.byref(dropped))
+    return dropped.value
+
+
+def prof_collect(strict=True):
+    """{label: (launches, total_ms, algorithmic flops, algorithmic bytes)}; call after torch.cuda.synchronize().
+    Raises when launches were dropped (pending list full): totals would be silently truncated otherwise."""
     h = lib()
     dropped = _i(0)
     h.ebfi_prof_collect(ctypes.byref(dropped))
+    if strict and dropped.value:
+        raise EbfiNativeError("profiler dropped %d launches (pending capacity exceeded): fold once per step with "
+                              "prof_fold() or raise ebfi_prof_set_capacity" % dropped.value)
     out = {}
     for k in range(h.ebfi_prof_num_kernels()):
         name, n, ms = _c.c_char_p(), _i64(0), _c.c_double(0)

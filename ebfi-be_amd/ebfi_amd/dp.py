@@ -165,28 +165,40 @@ class FlatAdam:
                 state[i] = {"step": st["step"].clone() if torch.is_tensor(st["step"]) else st["step"],
                             "exp_avg": st["exp_avg"][sl].view_as(p).clone(), "exp_avg_sq": st["exp_avg_sq"][sl].view_as(p).clone()}
         group = {k: v for k, v in self.inner.param_groups[0].items() if k != "params"}
+        group["lr"] = float(group["lr"])
         group["params"] = list(range(len(self.params)))
         return {"state": state, "param_groups": [group]}
 
+    # param_group entries that describe HOW this process runs the update, not the optimisation state: a checkpoint written
+    # by torch.optim.Adam (the reference's) carries fused=None / foreach=None, which would silently turn the single fused
+    # launch into the per-tensor path with a host sync per step
+    _LOCAL_KEYS = ("params", "fused", "foreach", "capturable", "differentiable")
+
     def load_state_dict(self, sd):
+        """Accepts torch's per-parameter Adam layout (what the reference's checkpoints hold, train_ours.py:621-671).
+        Parameters without an entry (never received a gradient before the save) start from zero moments.  All parameters
+        share ONE step counter here (the update is one launch over the flat buffer, missing gradients count as zero): it is
+        restored as the largest per-parameter step of the checkpoint -- identical to torch whenever every parameter had a
+        gradient on every step, which is the case for this model."""
         groups = sd["param_groups"]
         if len(groups) != 1 or len(groups[0]["params"]) != len(self.params):
             raise ValueError("optimizer state has %d parameters in %d group(s), this model trains %d"
                              % (sum(len(g["params"]) for g in groups), len(groups), len(self.params)))
         for k, v in groups[0].items():
-            if k != "params" and k in self.inner.param_groups[0]:
+            if k not in self._LOCAL_KEYS and k in self.inner.param_groups[0]:
                 self.inner.param_groups[0][k] = v
         if not sd["state"]:
             self.inner.state.pop(self.flat, None)
             return
         ids = groups[0]["params"]
         m, v = torch.zeros_like(self.flat.data), torch.zeros_like(self.flat.data)
-        step = None
+        step = 0.0
         for pid, p, off in zip(ids, self.params, self._offsets):
-            e = sd["state"][pid]
+            e = sd["state"].get(pid)
+            if e is None:
+                continue
             m[off:off + p.numel()] = e["exp_avg"].reshape(-1).to(m)
             v[off:off + p.numel()] = e["exp_avg_sq"].reshape(-1).to(v)
-            step = e["step"] if step is None else step
-        step = step.clone().to(dtype=torch.float32, device=self.flat.device if self.flat.is_cuda else "cpu") if torch.is_tensor(step) \
-            else torch.tensor(float(step), device=self.flat.device if self.flat.is_cuda else "cpu")
+            step = max(step, float(e["step"]))
+        step = torch.tensor(step, dtype=torch.float32, device=self.flat.device if self.flat.is_cuda else "cpu")
         self.inner.state[self.flat] = {"step": step, "exp_avg": m, "exp_avg_sq": v}

@@ -51,7 +51,8 @@ def synthetic_batch_from_raw_events(B, H, W, TB=16, device="cuda", seed=123, ran
 
 
 class Engine:
-    def __init__(self, model_args=None, device="cuda", precision="fp32", lr=1e-4, seed=None, train=True, graph=False):
+    def __init__(self, model_args=None, device="cuda", precision="fp32", lr=1e-4, seed=None, train=True, graph=False,
+                 accu_step=1, betas=(0.9, 0.999)):
         if precision not in ("fp32", "bf16x3", "bf16"):
             raise ValueError("precision must be 'fp32', 'bf16x3' or 'bf16'")
         self.device = torch.device(device)
@@ -61,7 +62,12 @@ class Engine:
         self.model_args = dict(DEFAULT_MODEL_ARGS, **(model_args or {}))
         self.model = EVFIAutoEx(**self.model_args).to(self.device)
         broadcast_parameters(self.model, 0)
-        self.iteration = 0
+        self.iteration = 0                                  # optimiser steps taken (the reference's train_iter_idx)
+        # gradient accumulation (trainer.accu_step, train_ours.py:206,259-277): every call of train_step is one
+        # forward+backward on loss / accu_step; the all-reduce and the optimiser step happen on every accu_step-th call
+        self.accu_step = max(1, int(accu_step))
+        self._micro = 0
+        self._accum = None
         # graph=True: forward + loss + backward + gradient packing are captured once into a hipGraph (per input shape,
         # precision and loss phase) and replayed; the all-reduce and the optimiser step stay eager (train_step_graph).
         self.use_graph = bool(graph) and self.device.type == "cuda"
@@ -73,7 +79,7 @@ class Engine:
             # one flat parameter buffer (parameters become views of it) updated by ONE fused Adam launch on the packed
             # gradient (0.4 ms per step less than the multi-tensor pass over 255 tensors); state_dict() keeps torch's
             # per-parameter layout for checkpoints
-            self.optimizer = FlatAdam(self.bucket.params, lr=lr, betas=(0.9, 0.999))
+            self.optimizer = FlatAdam(self.bucket.params, lr=lr, betas=tuple(betas))
         else:
             self.model.eval()
 
@@ -92,19 +98,36 @@ class Engine:
     def _fwd_bwd(self, frame, event, t, gtex, target):
         with self._autocast():
             sharp_pre, sharp = self.model(frame, event, t, gtex)
-            loss = self.loss(sharp_pre.float(), sharp.float(), target, self.iteration)
+            loss = self.loss(sharp_pre.float(), sharp.float(), target, self.iteration, self.accu_step)
             loss.backward()
         return loss.detach()
 
+    def _finish_micro_step(self, flat):
+        """`flat`: this call's packed gradient (of loss / accu_step).  Sums the calls of one accumulation window in place
+        and, on the window's last call, averages over ranks and takes the optimiser step.  True when a step was taken."""
+        if self.accu_step > 1:
+            if self._micro == 0:
+                self._accum = flat.clone() if self._accum is None else self._accum.copy_(flat)
+            else:
+                self._accum.add_(flat)
+            self._micro += 1
+            if self._micro < self.accu_step:
+                return False
+            self._micro = 0
+            self.bucket.flat = self._accum
+        self.bucket.reduce_mean_packed()
+        self.optimizer.step(self.bucket.flat)
+        self.iteration += 1
+        return True
+
     def train_step(self, frame, event, t, gtex, target):
-        """One optimiser step on this rank's batch; returns the (unreduced) loss tensor."""
+        """One forward+backward on this rank's batch (plus, every `accu_step`-th call, the gradient all-reduce and the
+        optimiser step); returns the (unreduced) loss tensor, already divided by accu_step like the reference's."""
         if self.use_graph:
             return self.train_step_graph(frame, event, t, gtex, target)
         self.bucket.zero()
         loss = self._fwd_bwd(frame, event, t, gtex, target)
-        self.bucket.all_reduce_mean()
-        self.optimizer.step(self.bucket.flat)
-        self.iteration += 1
+        self._finish_micro_step(self.bucket.gather())
         return loss
 
     def train_step_graph(self, frame, event, t, gtex, target):
@@ -113,7 +136,7 @@ class Engine:
         are views of the packed buffer, so the eager all-reduce / Adam that follow see ordinary tensors."""
         inputs = (frame, event, t, gtex, target)
         phase = self.iteration < 10e3                      # TrainLoss switches its weighting at 10k iterations
-        key = (self.precision, phase) + tuple((tuple(v.shape), v.dtype) for v in inputs)
+        key = (self.precision, phase, self.accu_step) + tuple((tuple(v.shape), v.dtype) for v in inputs)
         entry = self._graphs.get(key)
         if entry is None:
             static_in = [torch.empty_like(v) for v in inputs]
@@ -152,9 +175,7 @@ class Engine:
         self.bucket.flat = flat
         for p, g in zip(self.bucket.params, grads):        # (another shape's graph may have re-pointed them)
             p.grad = g
-        self.bucket.reduce_mean_packed()
-        self.optimizer.step(self.bucket.flat)
-        self.iteration += 1
+        self._finish_micro_step(flat)
         return loss.clone()
 
     @torch.no_grad()

@@ -12,8 +12,8 @@ What differs from the reference, on purpose:
   * the ``FixEx`` branch builds its tensor on the input's device instead of a hard ``.cuda()``
     (model_singleframe.py:309);
   * sub-modules are assembled from small builders rather than one class per block.
-2-D convolutions of ConvLayer run on the hand-written MFMA kernels (ebfi_amd.conv); the 3-D convs of
-the detail branch still go through PyTorch-ROCm (MIOpen), see DESIGN.md.
+2-D convolutions of ConvLayer run on the hand-written MFMA kernels (ebfi_amd.conv); the depth-2 3-D convs of the
+detail branch are folded onto the same 2-D kernels (ebfi_amd.fold3d) -- no MIOpen kernel is on the path, see DESIGN.md.
 """
 from math import ceil, floor
 

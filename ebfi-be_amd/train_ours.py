@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
 """train_ours.py -- MI355X counterpart of the reference entry point (train_ours.py:730-824).
 
-Keeps what the hot path needs from the reference trainer: YAML config with `model.name/args`,
-one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from torch.distributed.run), per-rank seeds
-(`seed + rank`, train_ours.py:737), the iteration body (forward -> Lap+census loss with the 0.1
-weighting that flips at 10k iterations -> backward -> Adam, train_ours.py:250-277), the loss
-all-reduce for logging (myutils/utils.py:80-92) and the checkpoint layout
-{model:{name,states}, optimizer, config, trainer} (train_ours.py:621-671) incl. --resume.
-Unlike the reference (whose fwd+bwd sits inside model.no_sync()) gradients ARE averaged across
-ranks every step (one flat RCCL all-reduce).  Data: synthetic batches; the HDF5
-pipeline, TensorBoard, validation and early stopping of the reference are out of scope.
+Keeps what the hot path needs from the reference trainer: YAML config with `model.name/args`, `optimizer`,
+`lr_scheduler`, `trainer.{accu_step, lr_min, iteration_based_train.*}`; one process per GPU (RANK / LOCAL_RANK /
+WORLD_SIZE from torch.distributed.run), per-rank seeds (`seed + rank`, train_ours.py:737); the iteration body of
+train_ours.py:250-347 in the reference's order -- forward -> Lap+census loss (0.1 weighting flips at 10k iterations,
+divided by accu_step) -> backward -> every accu_step-th pass: Adam step, loss all-reduce for logging
+(myutils/utils.py:80-92), periodic checkpoint, THEN lr_scheduler.step() (gated by lr_change_rate and lr_min, :335-338);
+and the checkpoint layout {model:{name,states}, lr_scheduler:{name,states}, optimizer:{name,states}, config,
+trainer:{training_mode, iteration, monitor_best}} (train_ours.py:621-671) with --resume / --reset as in
+_resume_checkpoint (:673-716): training continues at trainer.iteration + 1.
+Unlike the reference (whose fwd+bwd sits inside model.no_sync()) gradients ARE averaged across ranks every optimiser
+step (one flat RCCL all-reduce).  Data: synthetic batches; the HDF5 pipeline, TensorBoard, validation
+and early stopping of the reference are out of scope.
 
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train_ours.py -c config/train_ours.yml -id run
     python train_ours.py -c config/train_ours.yml -id run --iterations 20
@@ -28,6 +31,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from ebfi_amd.dp import reduce_tensor  # noqa: E402
 from ebfi_amd.engine import Engine, synthetic_batch, synthetic_batch_from_raw_events  # noqa: E402
 
+TRAINING_MODE = "iteration_based_train"
+CHECKPOINT_KEYS = ("model", "lr_scheduler", "optimizer", "config", "trainer")       # train_ours.py:628-644
+
 
 def init_distributed_mode():
     if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
@@ -43,14 +49,72 @@ def init_distributed_mode():
     return rank, world, gpu
 
 
-def save_checkpoint(path, eng, config, iteration):
-    """Same keys as the reference's _save_checkpoint so infer_ours.py / the reference can read it."""
-    state = {"model": {"name": config["model"]["name"], "states": eng.model.state_dict()},
-             "optimizer": {"name": "Adam", "states": eng.optimizer.state_dict()},
-             "config": config,
-             "trainer": {"training_mode": "iteration_based_train", "iteration": iteration, "monitor_best": None}}
+def build_lr_scheduler(config, optimizer):
+    """`eval(config['lr_scheduler']['name'])(optimizer, **args)` of the reference (train_ours.py:760-761) for the schedulers
+    of torch.optim.lr_scheduler; YAML floats such as `step_size: !!float 2e5` are made integral where torch expects it.
+    No `lr_scheduler` section -> None.  An unknown name fails loudly instead of training without a schedule."""
+    sec = config.get("lr_scheduler")
+    if not sec or not sec.get("name"):
+        return None
+    cls = getattr(torch.optim.lr_scheduler, sec["name"], None)
+    if cls is None:
+        raise ValueError("lr_scheduler '%s' is not a torch.optim.lr_scheduler class" % sec["name"])
+    args = dict(sec.get("args") or {})
+    if "step_size" in args:
+        args["step_size"] = int(args["step_size"])
+    return cls(optimizer, **args)
+
+
+def trainer_settings(config, cli_iterations=None):
+    """iterations / save_period / lr_change_rate from trainer.iteration_based_train (reference layout, train_ours.yml:79-98)
+    with the flat keys of this repo's small config as fallback; lr_min and accu_step from trainer."""
+    tr = config.get("trainer", {}) or {}
+    ib = tr.get("iteration_based_train", {}) or {}
+    get = lambda k, d: ib.get(k, tr.get(k, d))
+    return {"iterations": int(cli_iterations or float(get("iterations", 100))),
+            "save_period": int(get("save_period", 0)),
+            "lr_change_rate": max(1, int(get("lr_change_rate", 1))),
+            "lr_min": float(tr.get("lr_min", 1e-6)),
+            "accu_step": max(1, int(tr.get("accu_step", 1))),
+            "log_step": max(1, int(get("train_log_step", 10)))}
+
+
+def checkpoint_state(eng, scheduler, config, iteration, monitor_best=None):
+    """The reference's checkpoint dict (train_ours.py:628-655), key for key; `iteration` = index of the last completed
+    optimiser step, resumed at +1 (:695)."""
+    sched_name = (config.get("lr_scheduler") or {}).get("name")
+    return {"model": {"name": config["model"]["name"], "states": eng.model.state_dict()},
+            "lr_scheduler": {"name": sched_name, "states": scheduler.state_dict() if scheduler is not None else {}},
+            "optimizer": {"name": config["optimizer"]["name"], "states": eng.optimizer.state_dict()},
+            "config": config,
+            "trainer": {"training_mode": TRAINING_MODE, "iteration": int(iteration), "monitor_best": monitor_best}}
+
+
+def save_checkpoint(path, eng, scheduler, config, iteration):
     os.makedirs(os.path.dirname(path), exist_ok=True)
-    torch.save(state, path)
+    torch.save(checkpoint_state(eng, scheduler, config, iteration), path)
+
+
+def resume_checkpoint(path, eng, scheduler, config, reset=False, map_location="cpu"):
+    """Resumer + _resume_checkpoint of the reference (myutils/utils.py:178-215, train_ours.py:673-716): optimiser and
+    scheduler states are restored only without --reset and when the training mode matches, each only when the configured
+    name equals the checkpoint's; the model is always loaded (strict=False) when its name matches.  Returns the first
+    iteration to run."""
+    cpt = torch.load(path, map_location=map_location, weights_only=False)
+    start = 0
+    tr = cpt["trainer"]
+    if not reset and tr.get("training_mode") == TRAINING_MODE:
+        if config["optimizer"]["name"] == cpt["optimizer"]["name"]:
+            eng.optimizer.load_state_dict(cpt["optimizer"]["states"])
+        if scheduler is not None and (config.get("lr_scheduler") or {}).get("name") == cpt["lr_scheduler"]["name"]:
+            scheduler.load_state_dict(cpt["lr_scheduler"]["states"])
+            for group, lr in zip(eng.optimizer.param_groups, scheduler.get_last_lr()):
+                group["lr"] = lr
+        start = int(tr["iteration"]) + 1
+    if config["model"]["name"] == cpt["model"]["name"]:
+        eng.model.load_state_dict(cpt["model"]["states"], strict=False)
+    eng.iteration = start
+    return start
 
 
 def main():
@@ -58,6 +122,7 @@ def main():
     ap.add_argument("-c", "--config", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "config", "train_ours.yml"))
     ap.add_argument("-id", "--runid", default="run")
     ap.add_argument("-r", "--resume", default=None, help="checkpoint to resume from")
+    ap.add_argument("--reset", action="store_true", help="with --resume: load the model only, restart optimiser / schedule / count")
     ap.add_argument("-seed", "--seed", type=int, default=123)
     ap.add_argument("--iterations", type=int, default=None)
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16"],
@@ -69,44 +134,49 @@ def main():
     args = ap.parse_args()
     with open(args.config) as fh:
         config = yaml.safe_load(fh)
-    tr = config.get("trainer", {})
-    iterations = args.iterations or int(tr.get("iterations", 100))
+    tr = config.get("trainer", {}) or {}
+    st = trainer_settings(config, args.iterations)
     rank, world, gpu = init_distributed_mode()
     device = torch.device("cuda", gpu)
     assert config["model"]["name"] == "EVFIAutoEx", "only the EVFIAutoEx hot path is implemented"
+    assert config["optimizer"]["name"] == "Adam", "only Adam (config/train_ours.yml) is implemented"
+    oargs = config["optimizer"].get("args", {}) or {}
 
-    eng = Engine(config["model"]["args"], device=device, precision=args.precision,
-                 lr=float(config["optimizer"]["args"]["lr"]), seed=args.seed,      # same init on every rank
-                 graph=args.graph or bool(tr.get("graph", False)))
-    start = 0
-    if args.resume:
-        cpt = torch.load(args.resume, map_location=device)
-        eng.model.load_state_dict(cpt["model"]["states"], strict=False)
-        eng.optimizer.load_state_dict(cpt["optimizer"]["states"])
-        start = eng.iteration = int(cpt["trainer"]["iteration"])
+    eng = Engine(config["model"]["args"], device=device, precision=args.precision, lr=float(oargs.get("lr", 1e-4)),
+                 betas=tuple(oargs.get("betas", (0.9, 0.999))), seed=args.seed,      # same init on every rank
+                 graph=args.graph or bool(tr.get("graph", False)), accu_step=st["accu_step"])
+    scheduler = build_lr_scheduler(config, eng.optimizer.inner)
+    start = resume_checkpoint(args.resume, eng, scheduler, config, reset=args.reset, map_location=device) if args.resume else 0
     B, H, W = int(tr.get("batch_size", 8)), int(tr.get("height", 256)), int(tr.get("width", 256))
     TB = int(config["model"]["args"]["TB"])
     out_dir = os.path.join(tr.get("output_path", "./output"), "models", config.get("experiment", "Ours"), args.runid)
-    save_period = int(tr.get("save_period", 0))
 
-    t0, frames = time.perf_counter(), 0
-    for it in range(start, iterations):
-        # one fresh synthetic batch per iteration, different on every rank (seed + rank, like the reference)
-        make = synthetic_batch_from_raw_events if args.raw_events else synthetic_batch
-        batch = make(B, H, W, TB, device=device, seed=args.seed + 1000 * it, rank=rank)
-        loss = reduce_tensor(eng.train_step(*batch).clone())
-        frames += B * world
-        if rank == 0 and (it % 10 == 0 or it == iterations - 1):
+    t0, frames, it = time.perf_counter(), 0, start
+    make = synthetic_batch_from_raw_events if args.raw_events else synthetic_batch
+    while it < st["iterations"]:
+        for micro in range(st["accu_step"]):
+            # one fresh synthetic batch per pass, different on every rank (seed + rank, like the reference)
+            batch = make(B, H, W, TB, device=device, seed=args.seed + 1000 * (it * st["accu_step"] + micro), rank=rank)
+            loss = eng.train_step(*batch)
+            frames += B * world
+        loss = reduce_tensor(loss.clone())
+        lr_now = scheduler.get_last_lr()[0] if scheduler is not None else eng.optimizer.param_groups[0]["lr"]
+        if rank == 0 and (it % st["log_step"] == 0 or it == st["iterations"] - 1):
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            print("Iteration: %d/%d train_loss: %.4e  %.1f frames/s" % (it, iterations, loss.item(), frames / dt), flush=True)
-        if rank == 0 and save_period and it and it % save_period == 0:
-            save_checkpoint(os.path.join(out_dir, "checkpoint-iteration%d.pth" % it), eng, config, it)
+            print("Iteration: %d/%d train_loss: %.4e learning rate: %.4e  %.1f frames/s"
+                  % (it, st["iterations"], loss.item(), lr_now, frames / dt), flush=True)
+        # periodic checkpoints as train_ours.py:331-333 (saved BEFORE this iteration's scheduler step, like there), plus one
+        # after the last iteration
+        if rank == 0 and ((st["save_period"] and it % st["save_period"] == 0 and it != 0) or it == st["iterations"] - 1):
+            path = os.path.join(out_dir, "checkpoint-iteration%d.pth" % it)
+            save_checkpoint(path, eng, scheduler, config, it)
+            print("saved", path, flush=True)
+        if scheduler is not None and it % st["lr_change_rate"] == 0 and it != 0 and lr_now >= st["lr_min"]:   # :335-338
+            scheduler.step()
         if world > 1:
             dist.barrier()
-    if rank == 0:
-        save_checkpoint(os.path.join(out_dir, "checkpoint-iteration%d.pth" % iterations), eng, config, iterations)
-        print("saved", os.path.join(out_dir, "checkpoint-iteration%d.pth" % iterations))
+        it += 1
     if world > 1:
         dist.destroy_process_group()
 

@@ -245,10 +245,15 @@ int ebfi_census_backward(const float *x, const float *y, const float *grad_loss,
 /* ------------------------------------------------------------------ per-kernel device timing
  * When enabled, every launch made by this library is bracketed by a hipEvent pair recorded on the
  * launch stream.  ebfi_prof_collect() must be called after the stream(s) are synchronised; it
- * folds the pending pairs into per-kernel totals.  Slots are bounded (EBFI_PROF_MAX_PENDING);
- * launches beyond that are not timed (counted in *dropped). */
-#define EBFI_PROF_MAX_PENDING 8192
+ * folds the pending pairs into per-kernel totals and frees their slots (totals keep accumulating until
+ * ebfi_prof_reset), so a long run collects once per step.  Pending slots between two collects are bounded
+ * (default EBFI_PROF_MAX_PENDING, ebfi_prof_set_capacity changes it); launches beyond the bound are not
+ * timed and are counted in *dropped -- callers must treat dropped != 0 as a failed measurement.
+ * Labels are "<kernel symbol>" or "<kernel symbol>/<role>" when one kernel serves several ops
+ * (e.g. "conv_fwd_bf16x3_db/fwd" and "conv_fwd_bf16x3_db/dgrad"). */
+#define EBFI_PROF_MAX_PENDING 65536
 void ebfi_prof_enable(int on);
+int ebfi_prof_set_capacity(int max_pending);
 void ebfi_prof_reset(void);
 int ebfi_prof_collect(int *dropped);
 int ebfi_prof_num_kernels(void);

@@ -83,7 +83,7 @@ def test_convlayer_uses_native_kernels_and_matches():
     torch.cuda.synchronize()
     N.prof_enable(False)
     names = set(N.prof_collect())
-    assert {"conv_fwd_f32", "conv_wgrad_f32", "conv_wgrad_reduce_f32"} <= names
+    assert {"conv_fwd_f32/fwd", "conv_wgrad_f32", "conv_wgrad_reduce_f32"} <= names
     ref = F.leaky_relu(F.conv2d(x.cpu(), layer.conv2d.weight.detach().cpu(), layer.conv2d.bias.detach().cpu(), 1, 1), 0.01)
     assert _rel(y.detach(), ref) < 2e-5
 
@@ -175,7 +175,7 @@ def test_bf16x3_split_precision_mode_vs_fp32_reference(B, Cin, H, W, Cout, k, ac
     finally:
         conv.set_compute_dtype("fp32")
         N.prof_enable(False)
-    want = {"conv_wgrad_bf16x3"} if k == 7 else {"conv_fwd_bf16x3", "conv_dgrad_bf16x3", "conv_wgrad_bf16x3"}   # 7x7: wgrad only
+    want = {"conv_wgrad_x3"} if k == 7 else {"conv_fwd_bf16x3_db/fwd", "conv_fwd_bf16x3_db/dgrad", "conv_wgrad_x3"}   # 7x7: wgrad only
     assert want <= set(N.prof_collect())
     assert _rel(out.detach(), ref) < 1e-4
     # derivative mask from the op's own output (a pre-activation within 1e-5 of zero may flip slope w.r.t. the CPU run)
@@ -184,3 +184,35 @@ def test_bf16x3_split_precision_mode_vs_fp32_reference(B, Cin, H, W, Cout, k, ac
     assert _rel(xd.grad, torch.nn.grad.conv2d_input(x.shape, w, gpre, stride=1, padding=k // 2)) < 1e-4
     assert _rel(wd.grad, torch.nn.grad.conv2d_weight(x, w.shape, gpre, stride=1, padding=k // 2)) < 1e-4
     assert _rel(bd.grad, gpre.sum(dim=(0, 2, 3))) < 5e-5
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "fp32"])
+def test_hd_config5_kernelconv_128_to_1600(mode):
+    """BASELINE.json config 5 feature size: the 128 -> 1600 KernelConv at B=8, 360x640 (output 2.95e9 elements, 1.47 GB
+    per sample: the per-sample 32-bit descriptor reach).  Forward slices against the CPU conv on samples at both ends of
+    the batch, and the adjoint identities <conv(x), g> = <x, gx> = <w, gw> (+ bias) over the whole tensors tie the two
+    gradients to the checked forward."""
+    from ebfi_amd import conv
+    torch.manual_seed(17)
+    B, Cin, Cout, H, W = 8, 128, 1600, 360, 640
+    x = torch.randn(B, Cin, H, W, device="cuda").requires_grad_()
+    w = (torch.randn(Cout, Cin, 3, 3, device="cuda") / (Cin * 9) ** 0.5).requires_grad_()
+    b = torch.randn(Cout, device="cuda").requires_grad_()
+    conv.set_compute_dtype(mode)
+    try:
+        y = conv.conv_bias_act(x, w, b, 1, 1, conv.ACT_NONE, 0.0)
+        assert y.numel() > 2 ** 31
+        g = torch.randn(B, Cout, 8, 8, device="cuda").repeat_interleave(45, 2).repeat_interleave(80, 3)   # blocky: cheap to draw
+        y.backward(g)
+    finally:
+        conv.set_compute_dtype("fp32")
+    tol = 1e-4 if mode == "bf16x3" else 5e-5
+    for bi, co in ((0, 0), (7, 1550), (3, 777)):
+        ref = F.conv2d(x[bi:bi + 1].detach().cpu(), w[co:co + 50].detach().cpu(), b[co:co + 50].detach().cpu(), 1, 1)
+        assert _rel(y[bi:bi + 1, co:co + 50].detach(), ref) < tol, (bi, co)
+    ddot = lambda p, q: sum((p[i].double() * q[i].double()).sum() for i in range(p.shape[0]))
+    gsum = g.sum(dim=(0, 2, 3), dtype=torch.float64)
+    lin = ddot(y.detach(), g) - (b.detach().double() * gsum).sum()      # <conv(x) without bias, g>
+    assert abs((ddot(x.detach(), x.grad) - lin) / lin) < 1e-4
+    assert abs((ddot(w.detach(), w.grad) - lin) / lin) < 1e-4
+    assert _rel(b.grad, gsum.float().cpu()) < 1e-4

@@ -170,7 +170,8 @@ def test_argument_checks():
 
 
 def test_dcn_forward_split_precision_product_vs_oracle():
-    """ebfi_dcn_forward with dtype EBFI_F32_BF16X3MMA (selected by the process-wide conv mode): the sampling is the exact
+    """ebfi_dcn_forward with dtype EBFI_F32_BF16X3MMA (selected by the op's own `product` argument, never by the
+    process-wide conv mode): the sampling is the exact
     fp32 path, the product runs as bf16 hi/lo pairs -- within 1e-4 of the oracle (the exact kernel stays the default and
     keeps the known-answer tests above)."""
     from ebfi_amd import _native as N
@@ -182,14 +183,19 @@ def test_dcn_forward_split_precision_product_vs_oracle():
         x, w, b = torch.randn(B, C, H, W), torch.randn(Co, C, 3, 3) / (C * 9) ** 0.5, torch.randn(Co)
         off, msk = torch.randn(B, dg * 18, H, W) * 2, torch.sigmoid(torch.randn(B, dg * 9, H, W))
         ref = ref_ops.dcn_forward(x, w, b, off, msk, 1, 1, 1, dg)
-        conv.set_compute_dtype("bf16x3")
+        conv.set_compute_dtype("bf16x3")      # must NOT change what the DCN op runs: the product mode is its own argument
         N.prof_reset()
         N.prof_enable(True)
         try:
-            out = dcn_v2_forward(x.cuda(), w.cuda(), b.cuda(), off.cuda(), msk.cuda(), (1, 1), (1, 1), (1, 1), dg)
+            plain = dcn_v2_forward(x.cuda(), w.cuda(), b.cuda(), off.cuda(), msk.cuda(), (1, 1), (1, 1), (1, 1), dg)
+            torch.cuda.synchronize()
+            assert "dcn_fwd_bf16x3" not in N.prof_collect()
+            out = dcn_v2_forward(x.cuda(), w.cuda(), b.cuda(), off.cuda(), msk.cuda(), (1, 1), (1, 1), (1, 1), dg,
+                                 product="bf16x3")
             torch.cuda.synchronize()
         finally:
             conv.set_compute_dtype("fp32")
             N.prof_enable(False)
+        assert _rel(plain.cpu(), ref) < 1e-5
         assert "dcn_fwd_bf16x3" in N.prof_collect()
         assert _rel(out.cpu(), ref) < 1e-4

@@ -17,21 +17,31 @@ PKG = os.path.join(ROOT, "ebfi-be_amd")
 def test_train_resume_infer(tmp_path):
     cfg = yaml.safe_load(open(os.path.join(PKG, "config", "train_ours.yml")))
     cfg["model"]["args"].update(FrameBasech=16, EventBasech=16, InterCH=16, TB=4, step=2, channels=[4, 4, 8, 8])
-    cfg["trainer"].update(iterations=3, batch_size=2, height=64, width=64, output_path=str(tmp_path / "out"))
+    cfg["trainer"].update(batch_size=2, height=64, width=64, output_path=str(tmp_path / "out"))
+    cfg["trainer"]["iteration_based_train"].update(iterations=3, save_period=1)
+    cfg["lr_scheduler"]["args"].update(step_size=2.0, gamma=0.5)
     cfg_path = tmp_path / "cfg.yml"
     cfg_path.write_text(yaml.safe_dump(cfg))
     env = dict(os.environ, PYTHONPATH=PKG)
     r = subprocess.run([sys.executable, os.path.join(PKG, "train_ours.py"), "-c", str(cfg_path), "-id", "t"],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    ckpt = tmp_path / "out" / "models" / "Ours" / "t" / "checkpoint-iteration3.pth"
-    assert ckpt.exists()
-    cpt = torch.load(str(ckpt), map_location="cpu")
-    assert set(cpt) >= {"model", "optimizer", "config", "trainer"} and cpt["model"]["name"] == "EVFIAutoEx"
+    run_dir = tmp_path / "out" / "models" / "Ours" / "t"
+    assert (run_dir / "checkpoint-iteration1.pth").exists()        # periodic (save_period 1, never at iteration 0)
+    ckpt = run_dir / "checkpoint-iteration2.pth"                    # last completed iteration
+    assert ckpt.exists() and not (run_dir / "checkpoint-iteration0.pth").exists()
+    cpt = torch.load(str(ckpt), map_location="cpu", weights_only=False)
+    # exactly the reference's key set (train_ours.py:628-655): its Resumer reads model / optimizer / lr_scheduler / trainer
+    assert set(cpt) == {"model", "lr_scheduler", "optimizer", "config", "trainer"} and cpt["model"]["name"] == "EVFIAutoEx"
+    assert cpt["lr_scheduler"]["name"] == "StepLR" and cpt["trainer"]["iteration"] == 2
+    assert cpt["trainer"]["training_mode"] == "iteration_based_train"
+    assert "learning rate: 1.0000e-04" in r.stdout and "learning rate: 5.0000e-05" not in r.stdout   # decays after 2 counted steps
     assert "ResidualControl.Conv3.0.0.conv2d.weight" in cpt["model"]["states"]
     r = subprocess.run([sys.executable, os.path.join(PKG, "train_ours.py"), "-c", str(cfg_path), "-id", "t2",
                         "--resume", str(ckpt), "--iterations", "5", "--graph", "--raw-events"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "Iteration: 4/5" in r.stdout, r.stderr[-2000:] + r.stdout[-500:]
+    assert "Iteration: 2/5" not in r.stdout                         # resumes at trainer.iteration + 1 (train_ours.py:695)
+    assert "Iteration: 4/5" in r.stdout and "learning rate: 5.0000e-05" in r.stdout      # schedule restored and continued
     r = subprocess.run([sys.executable, os.path.join(PKG, "infer_ours.py"), "--model_path", str(ckpt), "--batch", "2",
                         "--height", "64", "--width", "64", "--num_ts", "3"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "interpolated 6 frames" in r.stdout, r.stderr[-2000:]
@@ -52,6 +62,11 @@ def test_bench_two_rank_rehearsal():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["cpu_baseline"] is None and d["roofline"]["kernel"].startswith("conv_")
+    assert d["config"]["world_size"] == 2 and d["config"]["collective_backend"] == "gloo"
+    assert d["config"]["replica_param_checksum"]["ranks_identical"] is True
+    # every launch of the profiled pass was timed: per-step launch counts are whole numbers
+    for name, k in d["kernels"].items():
+        assert float(k["launches_per_step"]).is_integer(), (name, k["launches_per_step"])
 
 
 def test_graph_replay_step_equals_eager_step():

@@ -109,6 +109,32 @@ def test_full_size_properties():
     assert _rel(gk[b:b + 1, 20 * 25:23 * 25].cpu(), gk_ref) < 1e-5
 
 
+def test_hd_config5_size_64bit_indexing():
+    """BASELINE.json config 5 feature size (B=8, 64 ch, 360x640, K=5): the filter tensor has 2.95e9 elements (11.8 GB),
+    past the 2^31 element count where the reference's own launcher overflows (`int n_grad_kernel`,
+    KernelConv2D_kernel.cu:166-167).  Adjoint identities over the whole tensors plus element-wise comparison with the
+    oracle on (b, c-slices) that lie BEYOND the 2^31-element mark."""
+    from ebfi_amd.fac import fac_backward, fac_forward
+    torch.manual_seed(321)
+    B, C, H, W, K = 8, 64, 360, 640, 5
+    x = torch.randn(B, C, H + 4, W + 4, device="cuda")
+    k = torch.randn(B, C * 25, H, W, device="cuda")
+    g = torch.randn(B, C, H, W, device="cuda")
+    assert k.numel() > 2 ** 31
+    out = fac_forward(x, k, K)
+    gx, gk = fac_backward(x, k, K, g)
+    ddot = lambda a, b: sum((a[i].double() * b[i].double()).sum() for i in range(B))     # per sample: bounded fp64 temporaries
+    dot = ddot(out, g)
+    assert abs((ddot(x, gx) - dot) / dot) < 1e-5
+    assert abs((ddot(k, gk) - dot) / dot) < 1e-5
+    for b, c0 in ((7, 61), (6, 0), (0, 30)):               # sample 7, channel 61: element offset 2.94e9
+        cs, ks = slice(c0, c0 + 2), slice(c0 * 25, (c0 + 2) * 25)
+        xs, kk, gs = x[b:b + 1, cs].cpu().contiguous(), k[b:b + 1, ks].cpu().contiguous(), g[b:b + 1, cs].cpu().contiguous()
+        assert _rel(out[b:b + 1, cs].cpu(), ref_ops.fac_forward(xs, kk, K)) < 1e-5
+        gx_ref, gk_ref = ref_ops.fac_backward(xs, kk, K, gs)
+        assert _rel(gx[b:b + 1, cs].cpu(), gx_ref) < 1e-5 and _rel(gk[b:b + 1, ks].cpu(), gk_ref) < 1e-5
+
+
 def test_empty_batch():
     from ebfi_amd.fac import fac_forward
     out = fac_forward(torch.zeros(0, 2, 8, 8).cuda(), torch.zeros(0, 18, 6, 6).cuda(), 3)

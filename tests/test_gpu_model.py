@@ -247,6 +247,12 @@ def test_full_size_modes_agree_and_batch_is_independent():
     finally:
         conv.set_compute_dtype("fp32")
     assert _rel(s1, b[0][3:4]) < 1e-5 and _rel(f1, b[1][3:4]) < 1e-5
+    # ... and that sample against the CPU oracle at the full 256x256 size (both modes, 1e-3)
+    sd = {k: v.detach().cpu().clone() for k, v in eng.model.state_dict().items()}
+    cpu = [v[3:4].cpu() for v in batch[:3]]
+    ref_s, ref_f = model_ref.evfi_forward(sd, DEFAULT_MODEL_ARGS, *cpu)
+    for mode in ("fp32", "bf16x3"):
+        assert _rel(res[mode][0][3:4], ref_s) < TOL and _rel(res[mode][1][3:4], ref_f) < TOL, mode
 
 
 def test_scale_cat_stage_of_exposure_decision():
@@ -279,3 +285,39 @@ def test_product_mean_stage():
         out.backward(g.cuda())
         assert out.shape == ref.shape and _rel(out.detach(), ref.detach()) < 1e-5
         assert _rel(ad.grad, a.grad) < 1e-6 and _rel(bd.grad, b.grad) < 1e-6
+
+
+def test_hd_config5_forward_vs_oracle_and_batch_independence():
+    """BASELINE.json config 5 (B=8, 720x1280 inference, default widths, default bf16x3 convs): one HD sample against the CPU
+    oracle with re-randomised weights (the x0.1 default init gives Sharp == 0.5: no signal), then the full B=8 batch
+    through the HIP path with that sample at index 5 -- it must come out as when run alone (the per-sample descriptors and
+    64-bit plane arithmetic hold across > 2^31-element tensors: the filter tensor is [8,1600,360,640] = 2.95e9 elements,
+    where the reference's own launcher overflows, KernelConv2D_kernel.cu:166-167)."""
+    from ebfi_amd import conv
+    from ebfi_amd.engine import DEFAULT_MODEL_ARGS, synthetic_batch
+    from ebfi_amd.model import EVFIAutoEx
+    torch.manual_seed(6)
+    net = EVFIAutoEx(**DEFAULT_MODEL_ARGS)
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() > 1:
+                p.copy_(torch.randn_like(p) * (1.2 / p[0].numel() ** 0.5))
+            else:
+                p.add_(0.05 * torch.randn_like(p))
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    frame, event, t, _, _ = synthetic_batch(8, 720, 1280, device="cpu", seed=55)
+    one = (frame[5:6], event[5:6], t[5:6])
+    ref_s, ref_f = model_ref.evfi_forward(sd, DEFAULT_MODEL_ARGS, *one)
+    assert ref_s.std() > 0.01
+    net = net.cuda().eval()
+    conv.set_compute_dtype("bf16x3")
+    try:
+        with torch.no_grad():
+            s1, f1 = net(*[v.cuda() for v in one])
+            assert _rel(s1, ref_s) < TOL and _rel(f1, ref_f) < TOL
+            s8, f8 = net(frame.cuda(), event.cuda(), t.cuda())
+    finally:
+        conv.set_compute_dtype("fp32")
+    assert s8.shape == (8, 3, 720, 1280) and torch.isfinite(f8).all()
+    assert _rel(s8[5:6], s1) < 1e-5 and _rel(f8[5:6], f1) < 1e-5
+    assert _rel(s8[5:6], ref_s) < TOL and _rel(f8[5:6], ref_f) < TOL

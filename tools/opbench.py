@@ -78,10 +78,8 @@ def main():
         bias = torch.randn(C, device=dev)
         g = torch.randn(B, C, h, w, device=dev)
         cfg = ((1, 1), (1, 1), (1, 1), dg)
-        from ebfi_amd import conv as convmode
-        convmode.set_compute_dtype("bf16x3" if a.x3 else "fp32")   # --x3: the product of the forward in split precision
-        t, _ = timed(lambda: dcn_v2_forward(x, wt, bias, off, msk, *cfg), a.iters, {"dcn_fwd_f32", "dcn_fwd_bf16x3"})
-        convmode.set_compute_dtype("fp32")
+        prod = "bf16x3" if a.x3 else "fp32"                         # --x3: the product of the forward in split precision
+        t, _ = timed(lambda: dcn_v2_forward(x, wt, bias, off, msk, *cfg, product=prod), a.iters, {"dcn_fwd_f32", "dcn_fwd_bf16x3"})
         by = 4 * (P * (C + 2 * dg * 9 + dg * 9 + C) + C * C * 9)
         fl = 2.0 * P * C * 9 * (4 + C)
         for n, ms in t.items():
@@ -97,8 +95,8 @@ def main():
         from ebfi_amd.conv import conv_bias_act
         sfx = "bf16" if a.bf16 else "f32"
         convmod.set_compute_dtype("bf16" if a.bf16 else ("bf16x3" if a.x3 else "fp32"))
-        names = {"conv_fwd_" + sfx, "conv_dgrad_" + sfx, "conv_wgrad_" + sfx, "conv_wgrad_reduce_f32", "conv_pack_w_bf16",
-                 "conv_fwd_bf16x3", "conv_dgrad_bf16x3", "conv_wgrad_bf16x3"}
+        names = {"conv_fwd_%s/fwd" % sfx, "conv_fwd_%s/dgrad" % sfx, "conv_wgrad_" + sfx, "conv_wgrad_reduce_f32", "conv_pack_w_bf16",
+                 "conv_fwd_bf16x3_db/fwd", "conv_fwd_bf16x3_db/dgrad", "conv_wgrad_x3"}
         peak = 2500.0 if a.bf16 else F32_MFMA_PEAK
         for (cin, cout, hh, ww, tag) in [(64, 64, h, w, "ResidualControl 64->64"), (128, 64, h, w, "Conv5 128->64"),
                                          (128, 1600, h, w, "KernelConv 128->1600"), (64, 64, 2 * h, 2 * w, "Recon 64->64 @2x")]:
