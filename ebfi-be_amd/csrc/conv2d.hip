@@ -427,6 +427,20 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16(const float *__restrict__ x
 // slice per CU instead of two): one workgroup of 8 waves per CU.
 constexpr int TYB = 8, NTB = 512;
 
+// In-kernel phase stamps: compiled in by tools/kbench.hip only (-DEBFI_KBENCH); the product build has no stamp code.
+#ifdef EBFI_KBENCH
+__device__ unsigned long long *g_kb_stamps = nullptr;      // [workgroup][2 waves][KB_NSTAMP]
+constexpr int KB_NSTAMP = 32;
+#define KB_STAMP(i)                                                                                                     \
+    do {                                                                                                                \
+        if (g_kb_stamps && (threadIdx.x == 0 || threadIdx.x == 256))                                                    \
+            g_kb_stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + (threadIdx.x >> 8)) * KB_NSTAMP + (i)] =  \
+                __builtin_amdgcn_s_memtime();                                                                           \
+    } while (0)
+#else
+#define KB_STAMP(i) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // conv_fwd_bf16x3_db: forward / data gradient of the split-precision mode, double-buffered.  With one 512-thread
 // workgroup per CU nothing else can cover the commit phase, so the operand images of chunk c+1 are written into a second
@@ -549,12 +563,16 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_db(const float *__restric
     };
 
     const int nchunks = K16 / CKB;
+    KB_STAMP(0);
     prefetch(0);
+    KB_STAMP(1);
     commit(0);
     __syncthreads();
+    KB_STAMP(2);
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const char *base = smd + (chunk & 1) * BUFB;
         prefetch(chunk + 1);      // past the last chunk every offset is out of range: reads 0
+        if (chunk < 6) KB_STAMP(3 + 4 * chunk);
         __builtin_amdgcn_sched_barrier(0);
         auto taps = [&](int t0, int t1) {
 #pragma unroll
@@ -584,13 +602,20 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_db(const float *__restric
             }
         };
         taps(0, T1);
+        if (chunk < 6) KB_STAMP(4 + 4 * chunk);
         __builtin_amdgcn_sched_barrier(0);
         commit((chunk & 1) ^ 1);  // unconditional (zeros after the last chunk); that buffer was last read before the previous barrier
+        if (chunk < 6) KB_STAMP(5 + 4 * chunk);
         __builtin_amdgcn_sched_barrier(0);
         taps(T1, KK);
         __syncthreads();
+        if (chunk < 6) KB_STAMP(6 + 4 * chunk);
     }
     store_out_tile<MT>(out, bias, acc, g, b, co_base, y0 + wave, x0, lane, act, slope);
+#ifdef EBFI_KBENCH
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    KB_STAMP(31);
 }
 
 // ------------------------------------------------------------------------------------------------
