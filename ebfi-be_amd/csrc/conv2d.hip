@@ -429,16 +429,28 @@ constexpr int TYB = 8, NTB = 512;
 
 // In-kernel phase stamps: compiled in by tools/kbench.hip only (-DEBFI_KBENCH); the product build has no stamp code.
 #ifdef EBFI_KBENCH
+// stamps go to a small LDS area behind the operand buffers (a global store per stamp would sit in the wave's vmcnt queue and
+// perturb exactly the waits being measured) and are copied out once at the end of the kernel
 __device__ unsigned long long *g_kb_stamps = nullptr;      // [workgroup][2 waves][KB_NSTAMP]
 constexpr int KB_NSTAMP = 32;
+#define KB_LDS_BYTES (2 * KB_NSTAMP * 8)
 #define KB_STAMP(i)                                                                                                     \
     do {                                                                                                                \
-        if (g_kb_stamps && (threadIdx.x == 0 || threadIdx.x == 256))                                                    \
-            g_kb_stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + (threadIdx.x >> 8)) * KB_NSTAMP + (i)] =  \
+        if (threadIdx.x == 0 || threadIdx.x == 256)                                                                     \
+            reinterpret_cast<unsigned long long *>(smd + KB_LDS_OFF)[(threadIdx.x >> 8) * KB_NSTAMP + (i)] =            \
                 __builtin_amdgcn_s_memtime();                                                                           \
     } while (0)
+#define KB_FLUSH()                                                                                                      \
+    do {                                                                                                                \
+        __syncthreads();                                                                                                \
+        if (g_kb_stamps && threadIdx.x < 2 * KB_NSTAMP)                                                                 \
+            g_kb_stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 * KB_NSTAMP + threadIdx.x] =                  \
+                reinterpret_cast<unsigned long long *>(smd + KB_LDS_OFF)[threadIdx.x];                                  \
+    } while (0)
 #else
+#define KB_LDS_BYTES 0
 #define KB_STAMP(i) do { } while (0)
+#define KB_FLUSH() do { } while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -448,11 +460,20 @@ constexpr int KB_NSTAMP = 32;
 // halves are swapped when bit 3 of the row index is set.  ds_read_b128 is served in groups of 16 lanes
 // ({0-3,12-15,20-27}, ...): rows r..r+27 of such a group then hit 16 distinct 16-byte slots of the 256-byte LDS row,
 // the same conflict-free property the 48-byte pitch bought, in 2/3 of the space (158 KB for both buffers).
-template <int KS, int MT, int DACT>
+// VEC = 4: the input tile is fetched as 16-byte quads of 4 consecutive pixels (a thread owns one quad position x 8 channels
+// = 8 loads instead of 32); needs W % 4 == 0 and padding KS/2.  Measured (tools/kbench, 64->64 at 128x128): equal to the
+// dword form without the activation derivative (39.1 vs 38.4 us), 16 % faster with it (46.8 vs 55.9 us: half the registers
+// held across the matrix block) -- so the launcher picks it for DACT != 0 only.  What the measurements of round 2 say about
+// this kernel (ablation builds of tools/kbench): its time is prologue 6.8 us (first input tile: 5-6 us from a cold start on
+// all 256 CUs at once) + 4 x 4.9 us per 16-channel chunk (matrix pipe 70 % busy; 3.45 us at 100 %) + 4.3 us of output
+// stores, i.e. fill and drain of the one tile a CU gets are a third of it; the memory side alone (no MFMA) takes 23 us, the
+// matrix side alone 29.6 us, the separate weight-packing launch another 5 us (now done once per step, ebfi_amd.weightbank).
+template <int KS, int MT, int DACT, int VEC>
 __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_db(const float *__restrict__ x, const float *__restrict__ dact_y,
                                                           const __bf16 *__restrict__ wp, const float *__restrict__ bias,
                                                           float *__restrict__ out, ConvGeom g, int K16, int act, float slope,
                                                           float dslope) {
+    constexpr bool QLD = VEC == 4;                     // input tile fetched as 16-byte quads
     constexpr int KK = KS * KS;
     constexpr int IH = TYB - 1 + KS, IW = TX - 1 + KS;
     constexpr int PS = IH * IW;            // positions of the staged input tile
@@ -462,8 +483,12 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_db(const float *__restric
     constexpr int NWB = (2 * WPIECES + NTB - 1) / NTB;
     constexpr int INB = PS * 32, WB = KK * COS * 32;   // bytes of one input / weight image
     constexpr int BUFB = 2 * INB + 2 * WB;             // one buffer: input hi | input lo | weight hi | weight lo
-    constexpr int T1 = KK > 1 ? (2 * KK + 2) / 3 : 1;  // taps multiplied before the next chunk's commit is slotted in
     extern __shared__ __attribute__((aligned(16))) char smd[];
+    [[maybe_unused]] constexpr int KB_LDS_OFF = 2 * BUFB;
+#ifdef EBFI_KBENCH
+    if (threadIdx.x < 2 * KB_NSTAMP) reinterpret_cast<unsigned long long *>(smd + KB_LDS_OFF)[threadIdx.x] = 0ull;
+    __syncthreads();
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = (g.Wo + TX - 1) / TX, tiles_y = (g.Ho + TYB - 1) / TYB;
@@ -491,6 +516,19 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_db(const float *__restric
 
     unsigned in_off[NPOS];
     int in_dst[NPOS];                      // byte offset of the row's half 0 (half 1 sits at the other 16 bytes of the row)
+    // VEC: quad (row qr, quad qq) of channel half qh; its pixel j sits in tile column 4*qq + j - SH (SH aligns the quads
+    // to 16 bytes in global memory: the tile starts `pad` pixels left of a multiple of 64)
+    constexpr int SH = (4 - (KS / 2) % 4) % 4;
+    constexpr int NQ = (IW + SH + 3) / 4;  // quads per tile row
+    constexpr int NITEM = IH * NQ * 2;
+    static_assert(!QLD || NITEM <= NTB, "one quad item per thread");
+    const int qh = tid & 1, qr = (tid >> 1) / NQ, qq = (tid >> 1) - qr * NQ;
+    unsigned q_off = SENT;
+    if constexpr (QLD) {
+        const int yy = iy0 + qr, xq = ix0 - SH + 4 * qq;
+        if (tid < NITEM && yy >= 0 && yy < g.H && xq >= 0 && xq + 3 < g.W)
+            q_off = (unsigned)(yy * g.W + xq) * 4u + (unsigned)(8 * qh) * plane_bytes;
+    }
 #pragma unroll
     for (int q = 0; q < NPOS; ++q) {
         const int pos = tid + q * NTB;
@@ -520,32 +558,82 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_db(const float *__restric
     for (int tap = 0; tap < KK; ++tap)
         fbits |= (unsigned)((((pbase + (tap / KS) * IW + (tap % KS)) >> 3) & 1) ^ hsel) << tap;
 
-    float rin[NPOS * CKB];
+    float rin[!QLD ? NPOS * CKB : 1];
+    float ryv[(!QLD && DACT != 0) ? NPOS * CKB : 1];
+    u32x4 rq[QLD ? 8 : 1], rqy[(QLD && DACT != 0) ? 8 : 1];     // VEC: 4 pixels of channels 8*qh + k
     u32x4 rw[NWB];
-    auto prefetch = [&](int chunk) {
+    // The vector-memory path takes one wave instruction every ~16 cycles whatever its width (address processing of 4 lanes
+    // per cycle): the 37+ loads of a chunk issued back to back stall all eight waves for ~5000 cycles in VMEM issue while the
+    // matrix cores idle (in-kernel stamps, tools/kbench).  The loads of chunk c+1 are therefore issued in NLG groups BETWEEN
+    // the taps of chunk c (load group g in front of the MFMAs of tap g) and committed after the last tap.
+    constexpr int NIN = QLD ? 8 : NPOS * CKB;          // input loads per thread and chunk
+    constexpr int NLOAD = NIN + NWB;                        // (activation-derivative loads ride along)
+    constexpr int NLG = KK >= 9 ? 6 : 1;                    // groups; the last taps carry none so that the data has landed
+    constexpr int LPG = (NLOAD + NLG - 1) / NLG;
+    auto prefetch_group = [&](int chunk, int grp) {
         const unsigned cb = (unsigned)chunk * (unsigned)CKB * plane_bytes;
-#pragma unroll
-        for (int q = 0; q < NPOS; ++q)
-#pragma unroll
-            for (int ci = 0; ci < CKB; ++ci) {
-                const unsigned o = in_off[q] + cb + (unsigned)ci * plane_bytes;
-                float v = buf_ld(rx, o);
-                if constexpr (DACT != 0) v *= act_grad_c<DACT>(buf_ld(ry, o), dslope);
-                rin[q * CKB + ci] = v;
-            }
         const unsigned wb = (unsigned)chunk * (unsigned)(CKB * 2);
 #pragma unroll
-        for (int it = 0; it < NWB; ++it) rw[it] = __builtin_amdgcn_raw_buffer_load_b128(rwt, w_off[it] + wb, 0, 0);
+        for (int i = 0; i < LPG; ++i) {
+            const int l = grp * LPG + i;
+            if (l < NIN) {
+                if constexpr (QLD) {
+                    const unsigned o = q_off + cb + (unsigned)l * plane_bytes;
+                    rq[l] = __builtin_amdgcn_raw_buffer_load_b128(rx, o, 0, 0);
+                    if constexpr (DACT != 0) rqy[l] = __builtin_amdgcn_raw_buffer_load_b128(ry, o, 0, 0);
+                } else {
+                    const int q = l / CKB, ci = l - q * CKB;
+                    const unsigned o = in_off[q] + cb + (unsigned)ci * plane_bytes;
+                    rin[l] = buf_ld(rx, o);
+                    if constexpr (DACT != 0) ryv[l] = buf_ld(ry, o);
+                }
+            } else if (l < NLOAD) {
+                rw[l - NIN] = __builtin_amdgcn_raw_buffer_load_b128(rwt, w_off[l - NIN] + wb, 0, 0);
+            }
+        }
+    };
+    auto prefetch = [&](int chunk) {
+#pragma unroll
+        for (int grp = 0; grp < NLG; ++grp) prefetch_group(chunk, grp);
     };
     auto commit = [&](int buf) {
         char *base = smd + buf * BUFB;
+        if constexpr (QLD) {
+            if (tid < NITEM) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = 4 * qq + j - SH;
+                    if (c < 0 || c >= IW) continue;
+                    u32x4 hv, lv;
+#pragma unroll
+                    for (int k = 0; k < 8; k += 2) {
+                        float v0 = __uint_as_float(rq[k][j]), v1 = __uint_as_float(rq[k + 1][j]);
+                        if constexpr (DACT != 0) {
+                            v0 *= act_grad_c<DACT>(__uint_as_float(rqy[k][j]), dslope);
+                            v1 *= act_grad_c<DACT>(__uint_as_float(rqy[k + 1][j]), dslope);
+                        }
+                        const __bf16 a0 = (__bf16)v0, a1 = (__bf16)v1;
+                        hv[k >> 1] = pack_bf16((float)a0, (float)a1);
+                        lv[k >> 1] = pack_bf16(v0 - (float)a0, v1 - (float)a1);
+                    }
+                    const int pos = qr * IW + c;
+                    const int d = pos * 32 + ((qh ^ ((pos >> 3) & 1)) << 4);
+                    *reinterpret_cast<u32x4 *>(base + d) = hv;
+                    *reinterpret_cast<u32x4 *>(base + INB + d) = lv;
+                }
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < NPOS; ++q)
             if (tid + q * NTB < PS) {
                 u32x4 h0, h1, l0, l1;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float v0 = rin[q * CKB + 2 * j], v1 = rin[q * CKB + 2 * j + 1];
+                    float v0 = rin[q * CKB + 2 * j], v1 = rin[q * CKB + 2 * j + 1];
+                    if constexpr (DACT != 0) {
+                        v0 *= act_grad_c<DACT>(ryv[q * CKB + 2 * j], dslope);
+                        v1 *= act_grad_c<DACT>(ryv[q * CKB + 2 * j + 1], dslope);
+                    }
                     const __bf16 a0 = (__bf16)v0, a1 = (__bf16)v1;
                     const unsigned hp = pack_bf16((float)a0, (float)a1);
                     const unsigned lp = pack_bf16(v0 - (float)a0, v1 - (float)a1);
@@ -557,6 +645,7 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_db(const float *__restric
                 *reinterpret_cast<u32x4 *>(base + INB + d0) = l0;
                 *reinterpret_cast<u32x4 *>(base + INB + d1) = l1;
             }
+        }
 #pragma unroll
         for (int it = 0; it < NWB; ++it)
             if (tid + it * NTB < 2 * WPIECES) *reinterpret_cast<u32x4 *>(base + w_dst[it]) = rw[it];
@@ -571,43 +660,56 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_db(const float *__restric
     KB_STAMP(2);
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const char *base = smd + (chunk & 1) * BUFB;
-        prefetch(chunk + 1);      // past the last chunk every offset is out of range: reads 0
         if (chunk < 6) KB_STAMP(3 + 4 * chunk);
-        __builtin_amdgcn_sched_barrier(0);
-        auto taps = [&](int t0, int t1) {
+        // operand fragments of tap t+1 are fetched from LDS before the MFMAs of tap t are issued (two register sets), and
+        // the global loads of the next chunk ride between the taps
+        bf16x8 ah[2][MT], al[2][MT], bh[2][2], bl[2][2];
+        auto tap_read = [&](int tap, int set) {
+            const int ky = tap / KS, kx = tap - ky * KS;
+            const char *bp = base + pbase * 32 + (int)(((fbits >> tap) & 1u) << 4) + (ky * IW + kx) * 32;
+            const char *ap = base + a_lane + tap * COS * 32;
 #pragma unroll
-            for (int tap = t0; tap < t1; ++tap) {
-                const int ky = tap / KS, kx = tap - ky * KS;
-                const char *bp = base + pbase * 32 + (int)(((fbits >> tap) & 1u) << 4) + (ky * IW + kx) * 32;
-                const char *ap = base + a_lane + tap * COS * 32;
-                bf16x8 ah[MT], al[MT], bh[2], bl[2];
+            for (int m = 0; m < MT; ++m) {
+                ah[set][m] = *reinterpret_cast<const bf16x8 *>(ap + m * 1024);
+                al[set][m] = *reinterpret_cast<const bf16x8 *>(ap + m * 1024 + WB);
+            }
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    ah[m] = *reinterpret_cast<const bf16x8 *>(ap + m * 1024);
-                    al[m] = *reinterpret_cast<const bf16x8 *>(ap + m * 1024 + WB);
-                }
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    bh[n] = *reinterpret_cast<const bf16x8 *>(bp + n * 1024);
-                    bl[n] = *reinterpret_cast<const bf16x8 *>(bp + n * 1024 + INB);
-                }
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
-                    }
+            for (int n = 0; n < 2; ++n) {
+                bh[set][n] = *reinterpret_cast<const bf16x8 *>(bp + n * 1024);
+                bl[set][n] = *reinterpret_cast<const bf16x8 *>(bp + n * 1024 + INB);
             }
         };
-        taps(0, T1);
+        auto tap_mfma = [&](int set) {
+#ifdef KB_NO_MFMA                         // ablation (harness only): keep the operand reads alive, issue no matrix work
+#pragma unroll
+            for (int m = 0; m < MT; ++m) { asm volatile("" ::"v"(ah[set][m]), "v"(al[set][m])); }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) { asm volatile("" ::"v"(bh[set][n]), "v"(bl[set][n])); }
+            return;
+#endif
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[set][m], bh[set][n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][m], bl[set][n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][m], bh[set][n], acc[m][n], 0, 0, 0);
+                }
+        };
+        tap_read(0, 0);
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap) {
+            if (tap + 1 < KK) tap_read(tap + 1, (tap + 1) & 1);
+#ifndef KB_NO_LOADS
+            if (tap < NLG) prefetch_group(chunk + 1, tap);     // past the last chunk every offset is out of range: reads 0
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            tap_mfma(tap & 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (chunk < 6) KB_STAMP(4 + 4 * chunk);
-        __builtin_amdgcn_sched_barrier(0);
         commit((chunk & 1) ^ 1);  // unconditional (zeros after the last chunk); that buffer was last read before the previous barrier
         if (chunk < 6) KB_STAMP(5 + 4 * chunk);
-        __builtin_amdgcn_sched_barrier(0);
-        taps(T1, KK);
         __syncthreads();
         if (chunk < 6) KB_STAMP(6 + 4 * chunk);
     }
@@ -616,6 +718,7 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_db(const float *__restric
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     KB_STAMP(31);
+    KB_FLUSH();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1229,6 +1332,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16(const float *__restric
     }
 }
 
+// Table-driven packing of MANY weights in one launch: entry e of `table` names the fp32 source element of packed bf16
+// element e (bits 0..29: index into `src`; bit 30: this element is the rounding remainder lo = bf16(v - float(bf16(v)))
+// instead of hi = bf16(v); negative: structural zero).  The host lays the entries out as the conv kernels expect them
+// ([hi image | lo image] per weight, forward and transposed layouts, channel padding, folded 3-D kernels, concatenated
+// convolutions): ebfi_amd/weightbank.py.
+__global__ __launch_bounds__(256) void pack_table_bf16_kernel(const float *__restrict__ src, const int32_t *__restrict__ table,
+                                                              int64_t n, __bf16 *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int32_t t = table[e];
+    float v = 0.f;
+    if (t >= 0) v = src[t & 0x3fffffff];
+    const __bf16 h = (__bf16)v;
+    out[e] = (t >= 0 && (t & 0x40000000)) ? (__bf16)(v - (float)h) : h;
+}
+
 // 64 consecutive elements per workgroup, 4 thread rows each summing every 4th slab (4 loads in
 // flight), then a fixed-order combine through LDS: deterministic, and short dependent chains.
 // perm_cin > 0: the slabs hold the weight part as [co][tap][ci] (bf16 kernel); gw is always [co][ci][tap].
@@ -1475,12 +1594,12 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
     if (!workspace || ws_bytes < need) return fail(EBFI_ERR_WORKSPACE, "conv2d bf16: workspace %zu bytes < required %zu", ws_bytes, need);
     __bf16 *wp = static_cast<__bf16 *>(workspace);
     const int64_t total = (int64_t)KS * KS * g.Cout * K16;
-    {
+    if (w != nullptr) {   // w == nullptr: `workspace` already holds the packed images (ebfi_conv2d_pack_bf16x3 / ebfi_pack_table_bf16)
         ProfScope ps("conv_pack_w_bf16", st);
         hipLaunchKernelGGL(conv_pack_w_bf16, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, w, wp, g.Cout, g.Cin, K16,
                            KS * KS, transposed, x3);
+        if (int rc = check_launch("conv_pack_w_bf16")) return rc;
     }
-    if (int rc = check_launch("conv_pack_w_bf16")) return rc;
     const int ty = x3 ? TYB : TY;
     const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, ty) * ceil_div(g.Wo, TX);
     if (tiles > 2147483647LL) return fail(EBFI_ERR_ARG, "conv2d: too many tiles");
@@ -1491,15 +1610,24 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
     dim3 grid((unsigned)tiles, (unsigned)ceil_div(g.Cout, 32 * mt));
     if (x3) {
         constexpr int PSX = (TYB - 1 + KS) * (TX - 1 + KS);
-        const size_t lds = (size_t)2 * (2 * PSX * 32 + 2 * KS * KS * 32 * mt * 32);   // two buffers of unpadded hi/lo images
+        const size_t lds = (size_t)2 * (2 * PSX * 32 + 2 * KS * KS * 32 * mt * 32) + KB_LDS_BYTES;   // two buffers of unpadded hi/lo images
         ProfScope ps(name, st, flops, conv_bytes_fwd(g, KS * KS, dact != 0));
+#define EBFI_LAUNCH_X3V(MT_, DA_, VEC_)                                                                                   \
+    do {                                                                                                                 \
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_bf16x3_db<KS, MT_, DA_, VEC_>), 160 * 1024)) \
+            return rc_;                                                                                                  \
+        hipLaunchKernelGGL((conv_fwd_bf16x3_db<KS, MT_, DA_, VEC_>), grid, dim3(NTB), lds, st, x, dact_y, wp, bias, out, g, K16, \
+                           act, slope, dslope);                                                                          \
+    } while (0)
 #define EBFI_LAUNCH_X3(MT_, DA_)                                                                                          \
     do {                                                                                                                 \
-        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_bf16x3_db<KS, MT_, DA_>), 160 * 1024))   \
-            return rc_;                                                                                                  \
-        hipLaunchKernelGGL((conv_fwd_bf16x3_db<KS, MT_, DA_>), grid, dim3(NTB), lds, st, x, dact_y, wp, bias, out, g, K16, act,  \
-                           slope, dslope);                                                                               \
+        if (vec == 4) EBFI_LAUNCH_X3V(MT_, DA_, 4);                                                                      \
+        else EBFI_LAUNCH_X3V(MT_, DA_, 1);                                                                               \
     } while (0)
+        // 16-byte input quads: rows must keep quads aligned, same-padding only; used where they pay (see the kernel's header)
+        const bool vec4 = g.W % 4 == 0 && g.pad == KS / 2 && aligned16(x) && (!dact_y || aligned16(dact_y));
+        const char *vec_env = getenv("EBFI_CONV_VEC");     // development switch (tools/kbench): 1 = dword loads, 4 = quad loads
+        const int vec = !vec4 ? 1 : (vec_env ? atoi(vec_env) : (dact != ACT_NONE ? 4 : 1));
         if (mt == 1) {
             if (dact == ACT_LEAKY) EBFI_LAUNCH_X3(1, ACT_LEAKY);
             else if (dact == ACT_SIGMOID) EBFI_LAUNCH_X3(1, ACT_SIGMOID);
@@ -1509,6 +1637,7 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
             else if (dact == ACT_SIGMOID) EBFI_LAUNCH_X3(2, ACT_SIGMOID);
             else EBFI_LAUNCH_X3(2, ACT_NONE);
         }
+#undef EBFI_LAUNCH_X3V
 #undef EBFI_LAUNCH_X3
         return check_launch(name);
     }
@@ -1542,7 +1671,7 @@ namespace {
 int conv_forward_bf16_impl(const char *who, int x3, const void *input, const void *weight, const void *bias, void *output, int B,
                            int Cin, int H, int W, int Cout, int ksize, int stride, int pad, int act, float slope,
                            void *workspace, size_t workspace_bytes, void *stream) {
-    if (!input || !weight || !output) return fail(EBFI_ERR_ARG, "%s: null argument", who);
+    if (!input || !output || (!weight && !(x3 && workspace))) return fail(EBFI_ERR_ARG, "%s: null argument", who);
     if (act < 0 || act > 2) return fail(EBFI_ERR_ARG, "%s: unknown activation %d", who, act);
     if (stride != 1 || (ksize != 1 && ksize != 3))
         return fail(EBFI_ERR_UNSUPPORTED, "%s: k=%d stride=%d (k in {1,3}, stride 1)", who, ksize, stride);
@@ -1560,7 +1689,7 @@ int conv_forward_bf16_impl(const char *who, int x3, const void *input, const voi
 int conv_backward_data_bf16_impl(const char *who, int x3, const void *grad_output, const void *saved_output, const void *weight,
                                  void *grad_input, int B, int Cin, int H, int W, int Cout, int ksize, int stride, int pad,
                                  int act, float slope, void *workspace, size_t workspace_bytes, void *stream) {
-    if (!grad_output || !weight || !grad_input) return fail(EBFI_ERR_ARG, "%s: null argument", who);
+    if (!grad_output || !grad_input || (!weight && !(x3 && workspace))) return fail(EBFI_ERR_ARG, "%s: null argument", who);
     if (act != ACT_NONE && !saved_output) return fail(EBFI_ERR_ARG, "%s: activation needs saved_output", who);
     if (stride != 1 || pad > ksize - 1 || (ksize != 1 && ksize != 3))
         return fail(EBFI_ERR_UNSUPPORTED, "%s: k=%d stride=%d pad=%d", who, ksize, stride, pad);
@@ -1577,6 +1706,36 @@ int conv_backward_data_bf16_impl(const char *who, int x3, const void *grad_outpu
     return launch_fwd_bf16<1>(st, go, yo, w, nullptr, gi, g, 1, ACT_NONE, 0.f, act, slope, workspace, workspace_bytes, x3);
 }
 }  // namespace
+
+extern "C" int ebfi_pack_table_bf16(const float *src, const int32_t *table, int64_t n, void *out, void *stream) {
+    if (!src || !table || !out || n < 0) return fail(EBFI_ERR_ARG, "pack_table_bf16: null argument");
+    if (n == 0) return EBFI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope ps("pack_table_bf16", st, 0.0, 10.0 * (double)n);
+    hipLaunchKernelGGL(pack_table_bf16_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, src, table, n,
+                       static_cast<__bf16 *>(out));
+    return check_launch("pack_table_bf16");
+}
+
+extern "C" size_t ebfi_conv2d_packed_bytes(int Cin, int Cout, int ksize, int transposed) {
+    return transposed ? 2 * bf16_pack_bytes(Cin, Cout, ksize) : 2 * bf16_pack_bytes(Cout, Cin, ksize);
+}
+
+extern "C" int ebfi_conv2d_pack_bf16x3(const void *weight, int Cin, int Cout, int ksize, int transposed, void *packed,
+                                       size_t packed_bytes, void *stream) {
+    if (!weight || !packed) return fail(EBFI_ERR_ARG, "conv2d_pack_bf16x3: null argument");
+    if (Cin <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3)) return fail(EBFI_ERR_ARG, "conv2d_pack_bf16x3: Cin %d Cout %d k %d", Cin, Cout, ksize);
+    const int M = transposed ? Cin : Cout, K = transposed ? Cout : Cin, K16 = (K + 15) / 16 * 16;
+    if (packed_bytes < ebfi_conv2d_packed_bytes(Cin, Cout, ksize, transposed))
+        return fail(EBFI_ERR_WORKSPACE, "conv2d_pack_bf16x3: %zu bytes < required %zu", packed_bytes,
+                    ebfi_conv2d_packed_bytes(Cin, Cout, ksize, transposed));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)ksize * ksize * M * K16;
+    ProfScope ps("conv_pack_w_bf16", st);
+    hipLaunchKernelGGL(conv_pack_w_bf16, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, static_cast<const float *>(weight),
+                       static_cast<__bf16 *>(packed), M, K, K16, ksize * ksize, transposed, 1);
+    return check_launch("conv_pack_w_bf16");
+}
 
 // fp32 tensors, bf16 matrix-core operands, fp32 accumulation; ksize in {1,3}, stride 1.
 extern "C" int ebfi_conv2d_forward_bf16mma(const void *input, const void *weight, const void *bias, void *output, int B,

@@ -49,6 +49,9 @@ SIGNATURES = {
     "ebfi_conv2d_backward_data_bf16mma": (_i, [_vp] * 4 + [_i] * 8 + [_i, _c.c_float, _vp, _sz, _vp]),
     "ebfi_conv2d_forward_bf16x3": (_i, [_vp] * 4 + [_i] * 8 + [_i, _c.c_float, _vp, _sz, _vp]),
     "ebfi_conv2d_backward_data_bf16x3": (_i, [_vp] * 4 + [_i] * 8 + [_i, _c.c_float, _vp, _sz, _vp]),
+    "ebfi_conv2d_packed_bytes": (_sz, [_i, _i, _i, _i]),
+    "ebfi_conv2d_pack_bf16x3": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "ebfi_pack_table_bf16": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "ebfi_events_workspace": (_sz, [_i]),
     "ebfi_events_to_stack": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ebfi_frame2lap": (_i, [_vp, _vp, _i, _i, _i, _vp]),

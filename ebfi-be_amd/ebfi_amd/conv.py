@@ -167,5 +167,99 @@ def _act_grad(y, act, slope):
     return y * (1 - y)
 
 
+class SiteConvBiasAct(Function):
+    """conv + bias + activation whose weight images live in the active WeightBank (ebfi_amd.weightbank): pre-split once
+    per optimiser step, possibly folded (depth-2 Conv3d / ConvTranspose3d) or concatenated from several parameters.
+    3x3 / 1x1, stride 1, split-precision kernels.  `params` = the site's source weights followed by its source biases:
+    they are inputs only so that autograd routes the gradients; their values are read from the bank."""
+
+    @staticmethod
+    def forward(ctx, x, site, pad, act, slope, *params):
+        x = x.contiguous()
+        B, Cin, H, W = (int(v) for v in x.shape)
+        if Cin != site.K:
+            raise RuntimeError("input has %d channels, the packed weight expects %d" % (Cin, site.K))
+        geo = [B, Cin, H, W, site.M, site.ks, 1, int(pad)]
+        Ho, Wo = H + 2 * pad - site.ks + 1, W + 2 * pad - site.ks + 1
+        out = torch.empty((B, site.M, Ho, Wo), dtype=x.dtype, device=x.device)
+        with torch.cuda.device_of(x):
+            rc = N.lib().ebfi_conv2d_forward_bf16x3(N.ptr(x), N.ptr(None), N.ptr(site.bias()), N.ptr(out), *geo, act, slope,
+                                                    site.fwd_ptr(), site.fwd_bytes, N.stream_ptr(x.device))
+        N.check(rc, "ebfi_conv2d_forward_bf16x3 (packed)")
+        ctx.site, ctx.cfg, ctx.geo = site, (act, slope), geo
+        ctx.save_for_backward(x, out if act != ACT_NONE else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, y = ctx.saved_tensors
+        site, (act, slope), geo = ctx.site, ctx.cfg, ctx.geo
+        gout = gout.contiguous()
+        lib = N.lib()
+        need_x = ctx.needs_input_grad[0]
+        need_p = any(ctx.needs_input_grad[5:])
+        gx, pgrads = None, [None] * (len(site.w_shapes) + len(site.b_shapes))
+        with torch.cuda.device_of(x):
+            st = N.stream_ptr(x.device)
+            gpre = None
+            if need_p:
+                gw2 = torch.empty((site.M, site.K, site.ks, site.ks), dtype=x.dtype, device=x.device)
+                gb2 = torch.empty(site.M, dtype=x.dtype, device=x.device) if site.has_bias else None
+                need = int(lib.ebfi_conv2d_backward_weight_workspace(*geo, N.EBFI_F32))
+                ws = torch.empty(max(need, 4), dtype=torch.uint8, device=x.device)
+                if need_x and act != ACT_NONE:
+                    gpre = torch.empty_like(gout)
+                rc = lib.ebfi_conv2d_backward_weight_ex(N.ptr(x), N.ptr(gout), N.ptr(y), N.ptr(gw2), N.ptr(gb2), N.ptr(gpre), *geo,
+                                                        act, slope, N.ptr(ws), need, N.EBFI_F32_BF16X3MMA, st)
+                N.check(rc, "ebfi_conv2d_backward_weight")
+                pgrads = _route_site_grads(site, gw2, gb2, st)
+            if need_x:
+                gx = torch.empty_like(x)
+                src, sy, a = (gpre, None, ACT_NONE) if gpre is not None else (gout, y, act)
+                rc = lib.ebfi_conv2d_backward_data_bf16x3(N.ptr(src), N.ptr(sy), N.ptr(None), N.ptr(gx), *geo, a,
+                                                          slope if a != ACT_NONE else 0.0, site.tr_ptr(), site.tr_bytes, st)
+                N.check(rc, "ebfi_conv2d_backward_data_bf16x3 (packed)")
+        return (gx, None, None, None, None) + tuple(pgrads)
+
+
+def _route_site_grads(site, gw2, gb2, st):
+    """Gradient of the folded / concatenated weight [M,K,ks,ks] (and bias [M]) -> gradients of the source parameters."""
+    lib = N.lib()
+    out = []
+    if site.kind == "id":                     # plain (or row-concatenated) Conv2d weights: the rows ARE the parameters
+        row = 0
+        for shp in site.w_shapes:
+            out.append(gw2[row:row + shp[0]].view(shp))
+            row += shp[0]
+        row = 0
+        for shp in site.b_shapes:
+            out.append(gb2[row:row + shp[0]].view(shp))
+            row += shp[0]
+        return out
+    for shp, inv, R in zip(site.w_shapes, site.w_inv, site.w_R):
+        g = torch.empty(shp, dtype=gw2.dtype, device=gw2.device)
+        N.check(lib.ebfi_gather_sum(N.ptr(gw2), N.ptr(inv), N.ptr(g), g.numel(), R, st), "ebfi_gather_sum")
+        out.append(g)
+    for shp, inv, R in zip(site.b_shapes, site.b_inv, site.b_R):
+        g = torch.empty(shp, dtype=gb2.dtype, device=gb2.device)
+        N.check(lib.ebfi_gather_sum(N.ptr(gb2), N.ptr(inv), N.ptr(g), g.numel(), R, st), "ebfi_gather_sum")
+        out.append(g)
+    return out
+
+
+def site_usable(site, x, stride=1):
+    return (site is not None and _COMPUTE == "bf16x3" and int(stride) == 1 and x.is_cuda and x.dtype == torch.float32 and
+            x.dim() == 4 and x.shape[1] == site.K)
+
+
+def conv_site(x, site, padding, act, slope, weights, biases):
+    """The convolution of bank site `site` (weights / biases: its source parameters, for gradient routing)."""
+    return SiteConvBiasAct.apply(x, site, int(padding), int(act), float(slope), *weights, *biases)
+
+
 def conv_bias_act(x, weight, bias, stride=1, padding=0, act=ACT_NONE, slope=0.0):
+    from . import weightbank
+    site = weightbank.lookup(weight, "id")
+    if site_usable(site, x, stride) and (bias is not None) == site.has_bias and len(site.w_shapes) == 1:
+        return conv_site(x, site, padding, act, slope, [weight], [bias] if bias is not None else [])
     return ConvBiasAct.apply(x, weight, bias, int(stride), int(padding), int(act), float(slope))

@@ -82,6 +82,13 @@ class Engine:
             self.optimizer = FlatAdam(self.bucket.params, lr=lr, betas=tuple(betas))
         else:
             self.model.eval()
+        # MFMA operand images of every conv weight, refreshed by one launch per step instead of one per conv call
+        # (ebfi_amd.weightbank); training reads the optimiser's flat parameter buffer, inference keeps its own copy
+        self.bank = None
+        if self.device.type == "cuda":
+            from . import weightbank
+            self.bank = weightbank.build_for(self.model, flat=self.optimizer.flat.data, params=self.optimizer.params) if train \
+                else weightbank.build_for(self.model)
 
     @contextlib.contextmanager
     def _autocast(self):
@@ -95,8 +102,16 @@ class Engine:
         finally:
             conv.set_compute_dtype(prev)
 
+    def _bank(self):
+        """Context of one pass: the weight bank refreshed (ONE pack launch, captured with the step's graph) and active
+        while the split-precision mode runs; a no-op otherwise."""
+        if self.bank is None or self.precision != "bf16x3":
+            return contextlib.nullcontext()
+        self.bank.refresh()
+        return self.bank.active()
+
     def _fwd_bwd(self, frame, event, t, gtex, target):
-        with self._autocast():
+        with self._autocast(), self._bank():
             sharp_pre, sharp = self.model(frame, event, t, gtex)
             loss = self.loss(sharp_pre.float(), sharp.float(), target, self.iteration, self.accu_step)
             loss.backward()
@@ -180,5 +195,5 @@ class Engine:
 
     @torch.no_grad()
     def infer(self, frame, event, t, gtex=None):
-        with self._autocast():
+        with self._autocast(), self._bank():
             return self.model(frame, event, t, gtex)[-1]

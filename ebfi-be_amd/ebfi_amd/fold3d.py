@@ -22,7 +22,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _native as N
-from . import conv
+from . import conv, weightbank
 
 
 def usable(x):
@@ -115,6 +115,10 @@ def conv3d_d2(x, m, act=conv.ACT_NONE, slope=0.0):
     if kh == 1 and s != 1:                               # 1x1 strided shortcut: subsample, then 1x1
         x2 = x2[:, :, ::s, ::s].contiguous()
         s = 1
+    site = weightbank.lookup(m.weight, "conv3d")         # folded images kept in the weight bank (one pack launch per step)
+    if conv.site_usable(site, x2, s):
+        y2 = conv.conv_site(x2, site, m.padding[1], act, slope, [m.weight], [m.bias] if m.bias is not None else [])
+        return y2.view(B, m.out_channels, 2, y2.shape[-2], y2.shape[-1])
     b2 = folded("rep2", _rep2, m.bias) if m.bias is not None else None
     y2 = conv.conv_bias_act(x2, folded("conv3d", fold_conv3d_weight, m.weight), b2, s, m.padding[1], act, slope)
     return y2.view(B, m.out_channels, 2, y2.shape[-2], y2.shape[-1])
@@ -148,6 +152,10 @@ def conv_transpose3d_d2(x, m):
     B, Ci, D, H, W = x.shape
     assert D == 2 and m.kernel_size == (3, 4, 4) and m.stride == (1, 2, 2) and m.padding == (1, 1, 1)
     assert m.output_padding == (0, 0, 0) and m.dilation == (1, 1, 1) and m.groups == 1
+    site = weightbank.lookup(m.weight, "convT3d")
+    if conv.site_usable(site, x.reshape(B, 2 * Ci, H, W)):
+        y = conv.conv_site(x.reshape(B, 2 * Ci, H, W), site, 1, conv.ACT_NONE, 0.0, [m.weight], [m.bias] if m.bias is not None else [])
+        return F.pixel_shuffle(y, 2).view(B, m.out_channels, 2, 2 * H, 2 * W)
     b8 = folded("rep8", _rep8, m.bias) if m.bias is not None else None
     y = conv.conv_bias_act(x.reshape(B, 2 * Ci, H, W), folded("convT3d", fold_conv_transpose3d_weight, m.weight), b8, 1, 1,
                            conv.ACT_NONE, 0.0)

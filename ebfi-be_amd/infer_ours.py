@@ -50,6 +50,13 @@ def main():
     torch.manual_seed(a.seed)
     device = torch.device("cuda", 0)
     model, margs = load_model(a.model_path, device)
+    import contextlib
+    from ebfi_amd import weightbank
+    stack = contextlib.ExitStack()
+    if a.precision == "bf16x3":        # conv weight images packed ONCE for the whole run instead of inside every conv call
+        bank = weightbank.build_for(model)
+        bank.refresh()
+        stack.enter_context(bank.active())
     frame, event, _, gtex, _ = synthetic_batch(a.batch, a.height, a.width, margs["TB"], device=device, seed=a.seed)
     t_static = torch.zeros(a.batch, 1, device=device)
     model(frame, event, t_static, gtex)           # untimed warm-up (module load, allocator)

@@ -172,6 +172,18 @@ int ebfi_conv2d_backward_data_bf16x3(const void *grad_output, const void *saved_
                                      int stride, int pad, int act, float slope,
                                      void *workspace, size_t workspace_bytes, void *stream);
 
+/* Weights packed ahead of the call.  ebfi_conv2d_forward_bf16x3 / ebfi_conv2d_backward_data_bf16x3 re-pack `weight` into
+ * `workspace` on every call; when `weight` is NULL they take `workspace` as ALREADY holding the packed images
+ * ([hi | lo], bf16 [tap][M][K16]: forward M = Cout, K = Cin; data gradient `transposed`: M = Cin, K = Cout, taps flipped;
+ * ebfi_conv2d_packed_bytes bytes) -- weights change once per optimiser step, not once per launch.
+ * ebfi_conv2d_pack_bf16x3 packs one weight; ebfi_pack_table_bf16 packs ANY number of weights in one launch from a host-built
+ * table: packed element e = bf16 of src[table[e] & 0x3fffffff] (its rounding remainder when bit 30 is set, 0 when
+ * table[e] < 0), which also carries folded / concatenated weight layouts (ebfi_amd/weightbank.py). */
+size_t ebfi_conv2d_packed_bytes(int Cin, int Cout, int ksize, int transposed);
+int ebfi_conv2d_pack_bf16x3(const void *weight, int Cin, int Cout, int ksize, int transposed, void *packed,
+                            size_t packed_bytes, void *stream);
+int ebfi_pack_table_bf16(const float *src, const int32_t *table, int64_t n, void *out, void *stream);
+
 /* ------------------------------------------------------------------ event voxel binning
  * xs, ys, ts: float64[n] device (ts sorted, normalised as h5dataset.py:334), ps: float32[n].
  * out: float32 [2, bins, H, W], fully overwritten (index 0 = positive, 1 = negative counts).

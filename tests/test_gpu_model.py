@@ -322,3 +322,51 @@ def test_hd_config5_forward_vs_oracle_and_batch_independence():
     # (global means over 921 600 pixels are reduced in a batch-dependent partition: 2e-5 measured)
     assert _rel(s8[5:6], s1) < 1e-4 and _rel(f8[5:6], f1) < 1e-4
     assert _rel(s8[5:6], ref_s) < TOL and _rel(f8[5:6], ref_f) < TOL
+
+
+def test_weight_bank_path_is_bit_identical_to_per_call_packing(fix):
+    """ebfi_amd.weightbank: one table-driven pack launch per step for all conv weights (plain, folded depth-2 3-D, biases)
+    instead of a pack launch inside every conv call.  Same kernels on the same images: forward outputs and every
+    parameter gradient must be bit-identical with and without the bank, and a parameter update must be picked up."""
+    from ebfi_amd import conv, weightbank
+    from ebfi_amd import _native as N
+    z, sd, cfg = fix
+    net, _ = _net(cfg, sd)
+    net.train()
+    c = lambda k: torch.from_numpy(z[k]).cuda()
+    inputs = (c("in.Frame"), c("in.Event"), c("in.T"))
+    conv.set_compute_dtype("bf16x3")
+    try:
+        def run(bank):
+            net.zero_grad(set_to_none=True)
+            N.prof_reset()
+            N.prof_enable(True)
+            if bank is not None:
+                bank.ensure_fresh()
+                with bank.active():
+                    s, f = net(*inputs)
+                    (s.square().sum() + f.sum()).backward()
+            else:
+                s, f = net(*inputs)
+                (s.square().sum() + f.sum()).backward()
+            torch.cuda.synchronize()
+            N.prof_enable(False)
+            prof = N.prof_collect()
+            return s.detach().clone(), f.detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters()}, prof
+        s0, f0, g0, prof0 = run(None)
+        bank = weightbank.build_for(net)
+        assert {k for _, k in bank.sites} == {"id", "conv3d", "convT3d"}
+        s1, f1, g1, prof1 = run(bank)
+        assert torch.equal(s0, s1) and torch.equal(f0, f1)
+        for n in g0:
+            assert torch.equal(g0[n], g1[n]), n
+        assert prof0["conv_pack_w_bf16"][0] > 50 and "conv_pack_w_bf16" not in prof1 and prof1["pack_table_bf16"][0] == 1
+        with torch.no_grad():                      # an in-place update (what the optimiser does) must invalidate the images
+            for p in net.parameters():
+                p.mul_(1.01)
+        s2, _, _, prof2 = run(bank)
+        assert prof2["pack_table_bf16"][0] == 1 and not torch.equal(s2, s1)
+        s3, _, _, _ = run(None)
+        assert torch.equal(s2, s3)
+    finally:
+        conv.set_compute_dtype("fp32")

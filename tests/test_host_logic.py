@@ -198,3 +198,77 @@ def test_flat_adam_matches_torch_adam_and_speaks_its_checkpoint_layout():
     opt_d.step(bucket_d.gather())
     for pa, pd in zip(net_a.parameters(), net_d.parameters()):
         assert torch.allclose(pa, pd, rtol=1e-6, atol=1e-7)
+
+
+def test_weight_bank_tables_reproduce_the_per_call_packing():
+    """ebfi_amd.weightbank on the host: emulate `ebfi_pack_table_bf16` (packed[e] = bf16 hi / lo of flat[table[e]], 0 for
+    structural zeros) and compare every site's four images with the layouts the conv kernels expect, computed directly from
+    the (folded / concatenated) fp32 weight: forward [tap][co][ci16], data gradient [tap][ci][co16] with flipped taps;
+    folded biases likewise; and the adjoint tables route a gradient of the folded weight back exactly like autograd."""
+    from ebfi_amd import fold3d, weightbank
+    torch.manual_seed(21)
+    net = EVFIAutoEx(**dict(DEFAULT_MODEL_ARGS, FrameBasech=8, EventBasech=8, InterCH=8, TB=4, step=2, channels=[4, 4, 8, 8]))
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_(torch.randn_like(p))
+    params = list(net.parameters())
+    bank = weightbank.build_for(net, params=params)
+    rc = net.ResidualControl
+    cat_site = bank.register([rc.Conv3[0][0].conv2d.weight, rc.Conv4[0][0].conv2d.weight],
+                             [rc.Conv3[0][0].conv2d.bias, rc.Conv4[0][0].conv2d.bias], kind="cat34")
+    bank._finalize()
+    flat = bank.flat.double()
+    table = bank.table.long()
+    idx = torch.where(table >= 0, table & (weightbank.LO_FLAG - 1), torch.zeros_like(table))
+    src = torch.where(table >= 0, flat[idx], torch.zeros((), dtype=torch.float64)).float()
+    hi = src.bfloat16()
+    packed = torch.where((table >= 0) & ((table & weightbank.LO_FLAG) != 0), (src - hi.float()).bfloat16(), hi)
+    bias_buf = torch.where(bank.bias_table >= 0, bank.flat[bank.bias_table.long().clamp_min(0)], torch.zeros(()))
+
+    def expect(W2):
+        M, K, ks, _ = W2.shape
+        K16, M16 = (K + 15) // 16 * 16, (M + 15) // 16 * 16
+        f = torch.zeros(ks * ks, M, K16)
+        f[:, :, :K] = W2.permute(2, 3, 0, 1).reshape(ks * ks, M, K)
+        t = torch.zeros(ks * ks, K, M16)
+        t[:, :, :M] = W2.flip((2, 3)).permute(2, 3, 1, 0).reshape(ks * ks, K, M)
+        split = lambda v: (v.bfloat16(), (v - v.bfloat16().float()).bfloat16())
+        return split(f.reshape(-1)), split(t.reshape(-1))
+
+    kinds = set()
+    by_ptr = {p.data_ptr(): p for p in params}
+    for (ptr, kind), s in bank.sites.items():
+        w = by_ptr[ptr].detach()
+        if kind == "conv3d":
+            W2, b2 = fold3d.fold_conv3d_weight(w), fold3d._rep2
+        elif kind == "convT3d":
+            W2, b2 = fold3d.fold_conv_transpose3d_weight(w), fold3d._rep8
+        elif kind == "cat34":
+            W2, b2 = torch.cat([rc.Conv3[0][0].conv2d.weight, rc.Conv4[0][0].conv2d.weight]).detach(), None
+        else:
+            W2, b2 = w, (lambda t: t)
+        assert tuple(W2.shape) == (s.M, s.K, s.ks, s.ks)
+        (fh, fl), (th, tl) = expect(W2)
+        n = fh.numel()
+        o = s.fwd_off // 2
+        assert torch.equal(packed[o:o + n], fh) and torch.equal(packed[o + n:o + 2 * n], fl), kind
+        assert s.fwd_bytes == 4 * n
+        n, o = th.numel(), s.tr_off // 2
+        assert torch.equal(packed[o:o + n], th) and torch.equal(packed[o + n:o + 2 * n], tl), kind
+        kinds.add(kind)
+        # adjoint of the fold: gradient of W2 routed back to the parameter
+        if kind in ("conv3d", "convT3d"):
+            wr = w.clone().requires_grad_()
+            fold = fold3d.fold_conv3d_weight if kind == "conv3d" else fold3d.fold_conv_transpose3d_weight
+            g2 = torch.randn(s.M, s.K, s.ks, s.ks)
+            fold(wr).backward(g2)
+            inv = s.w_inv[0].long()
+            routed = torch.cat([g2.flatten(), torch.zeros(1)])[inv].sum(-1).view(w.shape)
+            assert torch.allclose(routed, wr.grad, atol=1e-6), kind
+    assert kinds == {"id", "conv3d", "convT3d", "cat34"}
+    # folded biases: one Conv_3d of the decoder (bias=True) and the concatenated pair
+    dec = net.Detail.decoder[0].conv[0]
+    sb = bank.sites[(dec.weight.data_ptr(), "conv3d")]
+    assert sb.has_bias and torch.equal(bias_buf[sb.bias_off:sb.bias_off + sb.M], dec.bias.detach().repeat_interleave(2))
+    assert torch.equal(bias_buf[cat_site.bias_off:cat_site.bias_off + cat_site.M],
+                       torch.cat([rc.Conv3[0][0].conv2d.bias, rc.Conv4[0][0].conv2d.bias]).detach())

@@ -1,0 +1,189 @@
+// kbench: standalone A/B harness for the conv kernels of csrc/conv2d.hip (no Python, no torch).
+//
+// Built by tools/build_kbench.sh into tools/bin/kbench (git-ignored, travels to the GPU box with the snapshot):
+//     hipcc --offload-arch=gfx950 -O3 -DEBFI_KBENCH tools/kbench.hip ebfi-be_amd/csrc/runtime.hip -o tools/bin/kbench
+// It #includes conv2d.hip so that the kernels in its anonymous namespace can be launched directly, times every variant
+// with hipEvent pairs over interleaved rounds in ONE process (cdna_hip_programming.md rule 24), checks each variant's
+// output against the exact-fp32 kernel of the library, and -- with -DEBFI_KBENCH -- reads the in-kernel s_memtime
+// stamps (phase breakdown per workgroup).  Development tool only: nothing in the product path depends on it.
+//
+//   kbench fwd   [Cin Cout H W B]     forward variants (default 64 64 128 128 8)
+//   kbench wgrad [Cin Cout H W B]     weight-gradient variants
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../ebfi-be_amd/csrc/conv2d.hip"
+
+#define CK(x)                                                                                         \
+    do {                                                                                              \
+        hipError_t e_ = (x);                                                                          \
+        if (e_ != hipSuccess) {                                                                       \
+            fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_));         \
+            exit(2);                                                                                  \
+        }                                                                                             \
+    } while (0)
+
+static float *dev_random(size_t n, unsigned seed, float scale) {
+    std::vector<float> h(n);
+    unsigned s = seed * 2654435761u + 12345u;
+    for (size_t i = 0; i < n; ++i) {
+        s = s * 1664525u + 1013904223u;
+        const float u = (float)((s >> 8) & 0xffff) / 65536.f;
+        s = s * 1664525u + 1013904223u;
+        const float v = (float)((s >> 8) & 0xffff) / 65536.f;
+        h[i] = scale * (u + v - 1.f) * 2.4494897f;   // ~unit variance
+    }
+    float *d;
+    CK(hipMalloc(&d, n * sizeof(float)));
+    CK(hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    return d;
+}
+
+static double max_rel(const float *a_dev, const float *b_dev, size_t n) {
+    std::vector<float> a(n), b(n);
+    CK(hipMemcpy(a.data(), a_dev, n * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(b.data(), b_dev, n * 4, hipMemcpyDeviceToHost));
+    double md = 0, mb = 0;
+    for (size_t i = 0; i < n; ++i) {
+        md = std::max(md, (double)std::fabs(a[i] - b[i]));
+        mb = std::max(mb, (double)std::fabs(b[i]));
+    }
+    return md / std::max(mb, 1e-30);
+}
+
+struct Variant {
+    std::string name;
+    std::function<int()> run;
+    std::vector<float> us;
+};
+
+static void time_variants(std::vector<Variant> &vs, int rounds, int reps) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (auto &v : vs)
+        for (int i = 0; i < 3; ++i)
+            if (v.run()) { fprintf(stderr, "%s: launch failed: %s\n", v.name.c_str(), ebfi_last_error()); exit(3); }
+    CK(hipDeviceSynchronize());
+    for (int r = 0; r < rounds; ++r)
+        for (auto &v : vs) {
+            CK(hipEventRecord(e0, nullptr));
+            for (int i = 0; i < reps; ++i) v.run();
+            CK(hipEventRecord(e1, nullptr));
+            CK(hipEventSynchronize(e1));
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            v.us.push_back(1e3f * ms / reps);
+        }
+    for (auto &v : vs) {
+        std::sort(v.us.begin(), v.us.end());
+        printf("  %-34s median %8.2f us   min %8.2f us\n", v.name.c_str(), v.us[v.us.size() / 2], v.us[0]);
+    }
+}
+
+#ifdef EBFI_KBENCH
+static void report_stamps(unsigned long long *d_stamps, size_t nwg, const char *what) {
+    std::vector<unsigned long long> h(nwg * 2 * KB_NSTAMP);
+    CK(hipMemcpy(h.data(), d_stamps, h.size() * 8, hipMemcpyDeviceToHost));
+    printf("  phase stamps of %s (cycles of s_memtime, mean over %zu workgroups; wave 0 | wave 4)\n", what, nwg);
+    for (int i = 1; i < KB_NSTAMP; ++i) {
+        double d[2] = {0, 0}, s[2] = {0, 0};
+        size_t cnt = 0;
+        for (size_t w = 0; w < nwg; ++w) {
+            bool ok = true;
+            for (int k = 0; k < 2; ++k) ok = ok && h[(w * 2 + k) * KB_NSTAMP + i] && h[(w * 2 + k) * KB_NSTAMP];
+            if (!ok) continue;
+            ++cnt;
+            for (int k = 0; k < 2; ++k) {
+                int prev = i - 1;
+                while (prev > 0 && !h[(w * 2 + k) * KB_NSTAMP + prev]) --prev;
+                d[k] += (double)(h[(w * 2 + k) * KB_NSTAMP + i] - h[(w * 2 + k) * KB_NSTAMP + prev]);
+                s[k] += (double)(h[(w * 2 + k) * KB_NSTAMP + i] - h[(w * 2 + k) * KB_NSTAMP]);
+            }
+        }
+        if (!cnt) continue;
+        printf("    stamp %2d: +%8.0f | +%8.0f    since start %8.0f | %8.0f\n", i, d[0] / cnt, d[1] / cnt, s[0] / cnt, s[1] / cnt);
+    }
+}
+#endif
+
+int main(int argc, char **argv) {
+    const std::string mode = argc > 1 ? argv[1] : "fwd";
+    const int Cin = argc > 2 ? atoi(argv[2]) : 64, Cout = argc > 3 ? atoi(argv[3]) : 64;
+    const int H = argc > 4 ? atoi(argv[4]) : 128, W = argc > 5 ? atoi(argv[5]) : 128, B = argc > 6 ? atoi(argv[6]) : 8;
+    const size_t nx = (size_t)B * Cin * H * W, ny = (size_t)B * Cout * H * W, nw = (size_t)Cout * Cin * 9;
+    float *x = dev_random(nx, 1, 1.f), *w = dev_random(nw, 2, 1.f / std::sqrt((float)Cin * 9)), *bias = dev_random(Cout, 3, 0.1f);
+    float *g = dev_random(ny, 4, 1.f);
+    float *y_ref, *y, *gx, *gx_ref, *gw, *gw_ref, *gb;
+    CK(hipMalloc(&y_ref, ny * 4));
+    CK(hipMalloc(&y, ny * 4));
+    CK(hipMalloc(&gx, nx * 4));
+    CK(hipMalloc(&gx_ref, nx * 4));
+    CK(hipMalloc(&gw, nw * 4));
+    CK(hipMalloc(&gw_ref, nw * 4));
+    CK(hipMalloc(&gb, Cout * 4));
+    const size_t wsb = ebfi_conv2d_bf16_workspace(Cin, Cout, 3);
+    void *ws;
+    CK(hipMalloc(&ws, wsb));
+    const size_t wgb = ebfi_conv2d_backward_weight_workspace(B, Cin, H, W, Cout, 3, 1, 1, EBFI_F32);
+    void *wgs;
+    CK(hipMalloc(&wgs, wgb));
+    printf("kbench %s: Cin %d Cout %d %dx%d B %d   (algorithmic %.2f GFLOP, x3 = %.2f)\n", mode.c_str(), Cin, Cout, H, W, B,
+           2e-9 * B * H * W * (double)Cin * Cout * 9, 6e-9 * B * H * W * (double)Cin * Cout * 9);
+#ifdef EBFI_KBENCH
+    unsigned long long *d_stamps = nullptr;
+    const size_t nwg_max = 65536;
+    CK(hipMalloc(&d_stamps, nwg_max * 2 * KB_NSTAMP * 8));
+    CK(hipMemset(d_stamps, 0, nwg_max * 2 * KB_NSTAMP * 8));
+    unsigned long long *null_stamps = nullptr;
+#endif
+    if (mode == "fwd") {
+        if (ebfi_conv2d_forward(x, w, bias, y_ref, B, Cin, H, W, Cout, 3, 1, 1, 1, 0.01f, EBFI_F32, nullptr)) { fprintf(stderr, "%s\n", ebfi_last_error()); return 3; }
+        std::vector<Variant> vs;
+        vs.push_back({"fwd fp32 exact (library)", [&] { return ebfi_conv2d_forward(x, w, bias, y, B, Cin, H, W, Cout, 3, 1, 1, 1, 0.01f, EBFI_F32, nullptr); }, {}});
+        auto with_vec = [&](const char *v, std::function<int()> f) { return [=] { setenv("EBFI_CONV_VEC", v, 1); int rc = f(); unsetenv("EBFI_CONV_VEC"); return rc; }; };
+        auto fwd = [&] { return ebfi_conv2d_forward_bf16x3(x, w, bias, y, B, Cin, H, W, Cout, 3, 1, 1, 1, 0.01f, ws, wsb, nullptr); };
+        auto dg_act = [&] { return ebfi_conv2d_backward_data_bf16x3(g, y_ref, w, gx, B, Cin, H, W, Cout, 3, 1, 1, 1, 0.01f, ws, wsb, nullptr); };
+        auto dg = [&] { return ebfi_conv2d_backward_data_bf16x3(g, nullptr, w, gx, B, Cin, H, W, Cout, 3, 1, 1, 0, 0.f, ws, wsb, nullptr); };
+        vs.push_back({"fwd x3 dword ld / dword st", with_vec("1", fwd), {}});
+        vs.push_back({"fwd x3 quad ld / dword st", with_vec("4", fwd), {}});
+        vs.push_back({"dgrad x3 act' folded, dword", with_vec("1", dg_act), {}});
+        vs.push_back({"dgrad x3 act' folded, quad", with_vec("4", dg_act), {}});
+        vs.push_back({"dgrad x3 plain, quad", with_vec("4", dg), {}});
+        time_variants(vs, 7, 20);
+        ebfi_conv2d_forward_bf16x3(x, w, bias, y, B, Cin, H, W, Cout, 3, 1, 1, 1, 0.01f, ws, wsb, nullptr);
+        CK(hipDeviceSynchronize());
+        printf("  bf16x3 forward vs exact fp32: max rel %.3e\n", max_rel(y, y_ref, ny));
+        ebfi_conv2d_backward_data(g, y_ref, w, gx_ref, B, Cin, H, W, Cout, 3, 1, 1, 1, 0.01f, EBFI_F32, nullptr);
+        ebfi_conv2d_backward_data_bf16x3(g, y_ref, w, gx, B, Cin, H, W, Cout, 3, 1, 1, 1, 0.01f, ws, wsb, nullptr);
+        CK(hipDeviceSynchronize());
+        printf("  bf16x3 dgrad (act' folded) vs exact fp32: max rel %.3e\n", max_rel(gx, gx_ref, nx));
+#ifdef EBFI_KBENCH
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_kb_stamps), &d_stamps, sizeof(d_stamps)));
+        ebfi_conv2d_forward_bf16x3(x, w, bias, y, B, Cin, H, W, Cout, 3, 1, 1, 1, 0.01f, ws, wsb, nullptr);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_kb_stamps), &null_stamps, sizeof(null_stamps)));
+        const size_t nwg = (size_t)B * ((H + 7) / 8) * ((W + 63) / 64) * ((Cout + 63) / 64);
+        report_stamps(d_stamps, std::min(nwg, nwg_max), "conv_fwd_bf16x3_db forward");
+#endif
+    } else if (mode == "wgrad") {
+        if (ebfi_conv2d_backward_weight(x, g, y_ref, gw_ref, gb, B, Cin, H, W, Cout, 3, 1, 1, 0, 0.f, wgs, wgb, EBFI_F32, nullptr)) { fprintf(stderr, "%s\n", ebfi_last_error()); return 3; }
+        std::vector<Variant> vs;
+        vs.push_back({"wgrad fp32 exact (library)", [&] { return ebfi_conv2d_backward_weight(x, g, y_ref, gw, gb, B, Cin, H, W, Cout, 3, 1, 1, 0, 0.f, wgs, wgb, EBFI_F32, nullptr); }, {}});
+        vs.push_back({"wgrad bf16x3 (library)", [&] { return ebfi_conv2d_backward_weight(x, g, y_ref, gw, gb, B, Cin, H, W, Cout, 3, 1, 1, 0, 0.f, wgs, wgb, EBFI_F32_BF16X3MMA, nullptr); }, {}});
+        time_variants(vs, 7, 20);
+        ebfi_conv2d_backward_weight(x, g, y_ref, gw, gb, B, Cin, H, W, Cout, 3, 1, 1, 0, 0.f, wgs, wgb, EBFI_F32_BF16X3MMA, nullptr);
+        CK(hipDeviceSynchronize());
+        printf("  bf16x3 wgrad vs exact fp32: max rel %.3e\n", max_rel(gw, gw_ref, nw));
+    } else {
+        fprintf(stderr, "usage: kbench fwd|wgrad [Cin Cout H W B]\n");
+        return 1;
+    }
+    return 0;
+}
