@@ -33,6 +33,19 @@ enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_SIGMOID = 2 };
 
 struct ConvGeom {
     int B, Cin, H, W, Cout, Ho, Wo, pad;
+    int groups = 1;    // grouped convolution (split-precision kernels only): Cin = input channels PER GROUP, Cout = all output
+                       // channels; output channel co reads input channels [grp*Cin, (grp+1)*Cin), grp = co / (Cout/groups)
+};
+
+// Optional extras of the split-precision forward / data-gradient epilogue: out = act(acc + bias + addend) * act'(mask_y)
+// (addend, mask_y shaped like the output; NULL = absent).  They let a chain of layers hand PRE-activation gradients from
+// layer to layer: the data gradient of layer k adds the other gradient paths into its input and applies the derivative of
+// the activation that produced that input, so no layer's weight / data gradient has to re-read a saved activation.
+struct EpiExtra {
+    const float *addend;
+    const float *mask_y;
+    int mask_act;
+    float mask_slope;
 };
 
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
@@ -80,14 +93,19 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, unsigned byte_o
 // past the descriptor's extent, the bias is fetched as one batch (a missing bias reads zeros from an empty descriptor) and the
 // activation is selected outside the element loop.  The previous per-element `if` chain compiled to ~70 instructions and a
 // dependent bias load per element (4500 instructions per thread), several microseconds per workgroup.
-template <int MT>
+template <int MT, bool EXTRA = false>
 __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const float *__restrict__ bias, const f32x16 (&acc)[MT][2],
                                                const ConvGeom &g, int b, int co_base, int yo, int x0, int lane, int act,
-                                               float slope) {
+                                               float slope, EpiExtra ex = EpiExtra{nullptr, nullptr, 0, 0.f}) {
     const int HWo = g.Ho * g.Wo;
     const unsigned plane = (unsigned)HWo * 4u;
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(out + (int64_t)b * g.Cout * HWo, (unsigned)g.Cout * plane);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(bias ? bias : out, bias ? (unsigned)g.Cout * 4u : 0u);
+    // the extras: descriptors over the same sample of tensors shaped like the output (absent: empty descriptor, reads 0)
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc((EXTRA && ex.addend) ? ex.addend + (int64_t)b * g.Cout * HWo : out,
+                                                (EXTRA && ex.addend) ? (unsigned)g.Cout * plane : 0u);
+    const __amdgpu_buffer_rsrc_t rm = make_rsrc((EXTRA && ex.mask_y) ? ex.mask_y + (int64_t)b * g.Cout * HWo : out,
+                                                (EXTRA && ex.mask_y) ? (unsigned)g.Cout * plane : 0u);
     const int h = lane >> 5, l31 = lane & 31;
     float bv[MT][16];
 #pragma unroll
@@ -102,10 +120,27 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
                 const int xo = x0 + n * 32 + l31;
                 const unsigned base = (yo < g.Ho && xo < g.Wo && co_base + m * 32 + 4 * h < g.Cout)
                                           ? (unsigned)(co_base + m * 32 + 4 * h) * plane + (unsigned)(yo * g.Wo + xo) * 4u : SENT;
+                if constexpr (EXTRA) {
+                    float av[16], mv[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(actf(acc[m][n][r] + bv[m][r])), ro,
-                                                          base + (unsigned)((r & 3) + 8 * (r >> 2)) * plane, 0, 0);
+                    for (int r = 0; r < 16; ++r) {
+                        av[r] = buf_ld(ra, base + (unsigned)((r & 3) + 8 * (r >> 2)) * plane);
+                        mv[r] = buf_ld(rm, base + (unsigned)((r & 3) + 8 * (r >> 2)) * plane);
+                    }
+                    const bool leaky = ex.mask_act == ACT_LEAKY, sig = ex.mask_act == ACT_SIGMOID, has_m = ex.mask_y != nullptr;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = actf(acc[m][n][r] + bv[m][r] + av[r]);
+                        const float d = leaky ? (mv[r] > 0.f ? 1.f : ex.mask_slope) : (sig ? mv[r] * (1.f - mv[r]) : 1.f);
+                        v = has_m ? v * d : v;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, base + (unsigned)((r & 3) + 8 * (r >> 2)) * plane, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(actf(acc[m][n][r] + bv[m][r])), ro,
+                                                              base + (unsigned)((r & 3) + 8 * (r >> 2)) * plane, 0, 0);
+                }
             }
     };
     if (act == ACT_LEAKY) emit([slope](float v) { return v > 0.f ? v : v * slope; });
@@ -472,7 +507,7 @@ template <int KS, int MT, int DACT, int VEC>
 __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_db(const float *__restrict__ x, const float *__restrict__ dact_y,
                                                           const __bf16 *__restrict__ wp, const float *__restrict__ bias,
                                                           float *__restrict__ out, ConvGeom g, int K16, int act, float slope,
-                                                          float dslope) {
+                                                          float dslope, EpiExtra epi) {
     constexpr bool QLD = VEC == 4;                     // input tile fetched as 16-byte quads
     constexpr int KK = KS * KS;
     constexpr int IH = TYB - 1 + KS, IW = TX - 1 + KS;
@@ -501,8 +536,10 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_db(const float *__restric
     const int iy0 = y0 - g.pad, ix0 = x0 - g.pad;
     const int HW = g.H * g.W;
     const unsigned plane_bytes = (unsigned)HW * 4u, x_bytes = (unsigned)g.Cin * plane_bytes;
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (int64_t)b * g.Cin * HW, x_bytes);
-    const __amdgpu_buffer_rsrc_t ry = make_rsrc(DACT ? dact_y + (int64_t)b * g.Cin * HW : x, DACT ? x_bytes : 0u);
+    // grouped convolution: this block's output channels read the input channels of their group only
+    const int64_t in_base = ((int64_t)b * g.groups + co_base / (g.Cout / g.groups)) * g.Cin * HW;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + in_base, x_bytes);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(DACT ? dact_y + in_base : x, DACT ? x_bytes : 0u);
     const unsigned img_bytes = (unsigned)KK * (unsigned)g.Cout * (unsigned)K16 * 2u;   // one packed weight image
     const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(wp), 0, 2u * img_bytes, 0x00020000);
 
@@ -713,7 +750,10 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_db(const float *__restric
         __syncthreads();
         if (chunk < 6) KB_STAMP(6 + 4 * chunk);
     }
-    store_out_tile<MT>(out, bias, acc, g, b, co_base, y0 + wave, x0, lane, act, slope);
+    if (epi.addend != nullptr || epi.mask_y != nullptr)
+        store_out_tile<MT, true>(out, bias, acc, g, b, co_base, y0 + wave, x0, lane, act, slope, epi);
+    else
+        store_out_tile<MT, false>(out, bias, acc, g, b, co_base, y0 + wave, x0, lane, act, slope);
 #ifdef EBFI_KBENCH
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -990,7 +1030,8 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
     extern __shared__ __attribute__((aligned(16))) unsigned smw[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int co_base = blockIdx.y * 64, ci_base = blockIdx.z * CIB;
+    const int co_base = blockIdx.y * 64, ci_base = blockIdx.z * CIB;   // ci_base: inside the block's group
+    const int grp = co_base / (g.Cout / g.groups);                     // grouped convolution: input channels of this group
     const int ci_cnt = min(CIB, g.Cin - ci_base);
     const int ncols = ci_cnt * KK;
     const int mt = wave & 1, nq = wave >> 1;   // wave: co tile mt, n-tiles nq, nq+4, nq+8, ...
@@ -1038,7 +1079,7 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
         const __amdgpu_buffer_rsrc_t rgo = make_rsrc(gout + (int64_t)(live ? b : 0) * g.Cout * HWo, live ? go_bytes : 0u);
         const __amdgpu_buffer_rsrc_t rya = make_rsrc((DACT ? yact : gout) + (int64_t)(live ? b : 0) * g.Cout * HWo,
                                                      (live && DACT) ? go_bytes : 0u);
-        const __amdgpu_buffer_rsrc_t rxi = make_rsrc(x + (int64_t)(live ? b : 0) * g.Cin * HW, live ? x_bytes : 0u);
+        const __amdgpu_buffer_rsrc_t rxi = make_rsrc(x + ((int64_t)(live ? b : 0) * g.groups + grp) * g.Cin * HW, live ? x_bytes : 0u);
         const int gy = y0 + gpy, gx = x0 + gpx;
         const unsigned g0 = (gpx < WTX && gy < g.Ho && gx < g.Wo) ? (unsigned)((co_base + gco) * HWo + gy * g.Wo + gx) * 4u : SENT;
 #pragma unroll
@@ -1389,10 +1430,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_f32(const float *__rest
 
 // algorithmic HBM bytes of one launch (every operand once, results once; workspaces and re-reads not counted)
 double conv_bytes_fwd(const ConvGeom &g, int kk, bool dact) {
-    return 4.0 * ((double)g.B * g.Cin * g.H * g.W * (dact ? 2 : 1) + (double)g.B * g.Cout * g.Ho * g.Wo + (double)g.Cout * g.Cin * kk);
+    return 4.0 * ((double)g.B * g.groups * g.Cin * g.H * g.W * (dact ? 2 : 1) + (double)g.B * g.Cout * g.Ho * g.Wo + (double)g.Cout * g.Cin * kk);
 }
 double conv_bytes_wgrad(const ConvGeom &g, int kk, bool dact, bool side_out) {
-    return 4.0 * ((double)g.B * g.Cin * g.H * g.W + (double)g.B * g.Cout * g.Ho * g.Wo * (1 + (dact ? 1 : 0) + (side_out ? 1 : 0)) +
+    return 4.0 * ((double)g.B * g.groups * g.Cin * g.H * g.W + (double)g.B * g.Cout * g.Ho * g.Wo * (1 + (dact ? 1 : 0) + (side_out ? 1 : 0)) +
                   (double)g.Cout * g.Cin * kk);
 }
 
@@ -1588,7 +1629,7 @@ size_t bf16_pack_bytes(int M, int K, int ks) { return (size_t)ks * ks * M * (siz
 template <int KS>
 int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const float *w, const float *bias, float *out,
                     const ConvGeom &g, int transposed, int act, float slope, int dact, float dslope, void *workspace,
-                    size_t ws_bytes, int x3 = 0) {
+                    size_t ws_bytes, int x3 = 0, EpiExtra epi = EpiExtra{nullptr, nullptr, 0, 0.f}) {
     const int K16 = (g.Cin + 15) / 16 * 16;
     const size_t need = bf16_pack_bytes(g.Cout, g.Cin, KS) * (x3 ? 2 : 1);
     if (!workspace || ws_bytes < need) return fail(EBFI_ERR_WORKSPACE, "conv2d bf16: workspace %zu bytes < required %zu", ws_bytes, need);
@@ -1617,7 +1658,7 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
         if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_bf16x3_db<KS, MT_, DA_, VEC_>), 160 * 1024)) \
             return rc_;                                                                                                  \
         hipLaunchKernelGGL((conv_fwd_bf16x3_db<KS, MT_, DA_, VEC_>), grid, dim3(NTB), lds, st, x, dact_y, wp, bias, out, g, K16, \
-                           act, slope, dslope);                                                                          \
+                           act, slope, dslope, epi);                                                                     \
     } while (0)
 #define EBFI_LAUNCH_X3(MT_, DA_)                                                                                          \
     do {                                                                                                                 \
@@ -1889,6 +1930,68 @@ extern "C" int ebfi_conv2d_backward_weight_ex(const void *input, const void *gra
         hipLaunchKernelGGL(conv_wgrad_reduce_f32, dim3((unsigned)ceil_div(n_total, 64)), dim3(256), 0, st, slab, nsplit,
                            n_weight, n_total, static_cast<float *>(grad_weight), static_cast<float *>(grad_bias),
                            bf16mma ? Cin : 0, ksize * ksize);
+    }
+    return check_launch("conv_wgrad_reduce_f32");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Building blocks of hand-scheduled layer chains (ebfi_amd/rc_fused.py): a split-precision convolution on weights that
+// are ALREADY packed (weight bank), optionally grouped, with the epilogue extras of EpiExtra; and the matching grouped
+// weight gradient on pre-activation gradients.  The data gradient of a layer is this same forward convolution over its
+// gradient with the transposed images, so one entry point serves both directions.
+extern "C" int ebfi_conv2d_packed_x3(const void *input, const void *packed, size_t packed_bytes, const void *bias, void *output,
+                                     int B, int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups, int act,
+                                     float slope, const void *addend, const void *mask_y, int mask_act, float mask_slope,
+                                     void *stream) {
+    if (!input || !packed || !output) return fail(EBFI_ERR_ARG, "conv2d_packed_x3: null argument");
+    if (act < 0 || act > 2 || mask_act < 0 || mask_act > 2) return fail(EBFI_ERR_ARG, "conv2d_packed_x3: unknown activation");
+    if (ksize != 1 && ksize != 3) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_x3: k=%d", ksize);
+    if (groups < 1 || Cout % groups != 0 || (groups > 1 && (Cout / groups) % 64 != 0))
+        return fail(EBFI_ERR_ARG, "conv2d_packed_x3: %d output channels in %d groups (groups need multiples of 64 channels)", Cout, groups);
+    ConvGeom g;
+    if (int rc = make_geom(g, B, Cin_per_group, H, W, Cout, ksize, 1, pad)) return rc;
+    if ((int64_t)groups * (Cin_per_group + 64) * H * W * 4 >= (1LL << 31) - (1LL << 26))
+        return fail(EBFI_ERR_ARG, "conv2d_packed_x3: one sample exceeds the 2 GiB reach of 32-bit buffer offsets");
+    g.groups = groups;
+    if (B == 0) return EBFI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const EpiExtra epi{static_cast<const float *>(addend), static_cast<const float *>(mask_y), mask_act, mask_slope};
+    const float *x = static_cast<const float *>(input), *bs = static_cast<const float *>(bias);
+    float *o = static_cast<float *>(output);
+    void *ws = const_cast<void *>(packed);
+    if (ksize == 3) return launch_fwd_bf16<3>(st, x, nullptr, nullptr, bs, o, g, 0, act, slope, 0, 0.f, ws, packed_bytes, 1, epi);
+    return launch_fwd_bf16<1>(st, x, nullptr, nullptr, bs, o, g, 0, act, slope, 0, 0.f, ws, packed_bytes, 1, epi);
+}
+
+extern "C" int ebfi_conv2d_backward_weight_x3g(const void *input, const void *grad_output, void *grad_weight, void *grad_bias,
+                                               int B, int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups,
+                                               void *workspace, size_t workspace_bytes, void *stream) {
+    if (!input || !grad_output || !grad_weight) return fail(EBFI_ERR_ARG, "conv2d_backward_weight_x3g: null argument");
+    if (ksize != 1 && ksize != 3) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_weight_x3g: k=%d", ksize);
+    if (groups < 1 || Cout % groups != 0 || (groups > 1 && (Cout / groups) % 64 != 0))
+        return fail(EBFI_ERR_ARG, "conv2d_backward_weight_x3g: %d output channels in %d groups", Cout, groups);
+    ConvGeom g;
+    if (int rc = make_geom(g, B, Cin_per_group, H, W, Cout, ksize, 1, pad)) return rc;
+    g.groups = groups;
+    const size_t need = ebfi_conv2d_backward_weight_workspace(B, Cin_per_group, H, W, Cout, ksize, 1, pad, EBFI_F32);
+    if (!workspace || workspace_bytes < need)
+        return fail(EBFI_ERR_WORKSPACE, "conv2d_backward_weight_x3g: workspace %zu bytes < required %zu", workspace_bytes, need);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t n_weight = (int64_t)Cout * Cin_per_group * ksize * ksize, n_total = n_weight + Cout;
+    if (B == 0) {
+        (void)hipMemsetAsync(grad_weight, 0, (size_t)n_weight * sizeof(float), st);
+        if (grad_bias) (void)hipMemsetAsync(grad_bias, 0, (size_t)Cout * sizeof(float), st);
+        return EBFI_OK;
+    }
+    float *slab = static_cast<float *>(workspace);
+    const int nsplit = wgrad_x3_splits(g, ksize);
+    if (int rc = launch_wgrad_x3(st, static_cast<const float *>(input), static_cast<const float *>(grad_output), nullptr, slab, nullptr,
+                                 g, ksize, ACT_NONE, 0.f, nsplit, grad_bias != nullptr))
+        return rc;
+    {
+        ProfScope ps("conv_wgrad_reduce_f32", st);
+        hipLaunchKernelGGL(conv_wgrad_reduce_f32, dim3((unsigned)ceil_div(n_total, 64)), dim3(256), 0, st, slab, nsplit, n_weight,
+                           n_total, static_cast<float *>(grad_weight), static_cast<float *>(grad_bias), 0, ksize * ksize);
     }
     return check_launch("conv_wgrad_reduce_f32");
 }

@@ -15,14 +15,15 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void src_fwd_kernel(const float *__restrict__ a0, const float *__restrict__ s0,
                                                       const float *__restrict__ a1, const float *__restrict__ s1,
                                                       const float *__restrict__ x, float *__restrict__ out, int C, int64_t HW4,
-                                                      int64_t total4) {
+                                                      int64_t total4, int64_t a_bs4) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total4) return;
     const int64_t bc = i / HW4, r = i - bc * HW4;
     const int64_t b = bc / C, c = bc - b * C;
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
     const f4 xv = x ? reinterpret_cast<const f4 *>(x)[i] : zero;          // x == NULL: no residual
-    const f4 v0 = reinterpret_cast<const f4 *>(a0)[i], v1 = reinterpret_cast<const f4 *>(a1)[i];
+    const int64_t ia = b * a_bs4 + c * HW4 + r;                          // a0 / a1 may be channel slices of a wider tensor
+    const f4 v0 = reinterpret_cast<const f4 *>(a0)[ia], v1 = reinterpret_cast<const f4 *>(a1)[ia];
     const float k0 = s0[bc], k1 = s1 ? s1[bc] : 1.f;                     // s1 == NULL: second half unscaled
     f4 *o = reinterpret_cast<f4 *>(out);
     o[(b * 2 * C + c) * HW4 + r] = v0 * k0 + xv;
@@ -35,21 +36,35 @@ __global__ __launch_bounds__(256) void src_bwd_kernel(const float *__restrict__ 
                                                       const float *__restrict__ s0, const float *__restrict__ a1,
                                                       const float *__restrict__ s1, float *__restrict__ ga0,
                                                       float *__restrict__ ga1, float *__restrict__ gx, float *__restrict__ gs0,
-                                                      float *__restrict__ gs1, int C, int64_t HW4) {
+                                                      float *__restrict__ gs1, int C, int64_t HW4, int64_t a_bs4, int64_t ga_bs4,
+                                                      int mask_leaky, float mask_slope) {
     __shared__ float red[2][4];
     const int64_t bc = blockIdx.x;
     const int64_t b = bc / C, c = bc - b * C;
     const f4 *g0 = reinterpret_cast<const f4 *>(gout) + (b * 2 * C + c) * HW4;
     const f4 *g1 = reinterpret_cast<const f4 *>(gout) + (b * 2 * C + C + c) * HW4;
-    const f4 *p0 = reinterpret_cast<const f4 *>(a0) + bc * HW4, *p1 = reinterpret_cast<const f4 *>(a1) + bc * HW4;
-    f4 *o0 = reinterpret_cast<f4 *>(ga0) + bc * HW4, *o1 = reinterpret_cast<f4 *>(ga1) + bc * HW4;
+    // a0 / a1 and grad_a0 / grad_a1 may be channel slices of wider tensors (batch strides a_bs4 / ga_bs4)
+    const f4 *p0 = reinterpret_cast<const f4 *>(a0) + b * a_bs4 + c * HW4, *p1 = reinterpret_cast<const f4 *>(a1) + b * a_bs4 + c * HW4;
+    f4 *o0 = reinterpret_cast<f4 *>(ga0) + b * ga_bs4 + c * HW4, *o1 = reinterpret_cast<f4 *>(ga1) + b * ga_bs4 + c * HW4;
     f4 *ox = reinterpret_cast<f4 *>(gx) + bc * HW4;
     const float k0 = s0[bc], k1 = s1 ? s1[bc] : 1.f;
     float d0 = 0.f, d1 = 0.f;
+    // mask_leaky: a0 / a1 are outputs of LeakyReLU(mask_slope) layers and the gradients leave as PRE-activation gradients
+    auto dm = [&](const f4 &v) {
+        f4 m;
+        m.x = v.x > 0.f ? 1.f : mask_slope; m.y = v.y > 0.f ? 1.f : mask_slope;
+        m.z = v.z > 0.f ? 1.f : mask_slope; m.w = v.w > 0.f ? 1.f : mask_slope;
+        return m;
+    };
     for (int64_t i = threadIdx.x; i < HW4; i += 256) {
         const f4 u0 = g0[i], u1 = g1[i], v0 = p0[i];
-        o0[i] = u0 * k0;
-        o1[i] = u1 * k1;
+        if (mask_leaky) {
+            o0[i] = u0 * k0 * dm(v0);
+            o1[i] = u1 * k1 * dm(p1[i]);
+        } else {
+            o0[i] = u0 * k0;
+            o1[i] = u1 * k1;
+        }
         if (gx) ox[i] = u0 + u1;
         d0 += (u0.x * v0.x + u0.y * v0.y) + (u0.z * v0.z + u0.w * v0.w);
         if (gs1) {
@@ -128,9 +143,20 @@ int check_planes(const char *who, int B, int C, int64_t HW) {
 }  // namespace
 
 // out [B,2C,H,W]: out[:, :C] = s0[b,c]*a0 + x, out[:, C:] = s1[b,c]*a1 + x   (x == NULL: no residual; s1 == NULL: s1 = 1)
+extern "C" int ebfi_scale_residual_cat_forward_ex(const float *a0, const float *s0, const float *a1, const float *s1,
+                                                  const float *x, float *out, int B, int C, int64_t HW, int64_t a_batch_stride,
+                                                  void *stream);
 extern "C" int ebfi_scale_residual_cat_forward(const float *a0, const float *s0, const float *a1, const float *s1,
                                                const float *x, float *out, int B, int C, int64_t HW, void *stream) {
+    return ebfi_scale_residual_cat_forward_ex(a0, s0, a1, s1, x, out, B, C, HW, (int64_t)C * HW, stream);
+}
+
+// same with a0 / a1 given as channel slices of wider [B, *, H, W] tensors: a_batch_stride elements between samples
+extern "C" int ebfi_scale_residual_cat_forward_ex(const float *a0, const float *s0, const float *a1, const float *s1,
+                                                  const float *x, float *out, int B, int C, int64_t HW, int64_t a_batch_stride,
+                                                  void *stream) {
     if (!a0 || !s0 || !a1 || !out) return fail(EBFI_ERR_ARG, "scale_residual_cat_forward: null argument");
+    if (a_batch_stride % 4 != 0 || a_batch_stride < (int64_t)C * HW) return fail(EBFI_ERR_ARG, "scale_residual_cat_forward: batch stride");
     if (int rc = check_planes("scale_residual_cat_forward", B, C, HW)) return rc;
     if (B == 0) return EBFI_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -138,16 +164,35 @@ extern "C" int ebfi_scale_residual_cat_forward(const float *a0, const float *s0,
     {
         ProfScope ps("scale_residual_cat_fwd", st, 0.0, 20.0 * B * C * (double)HW);
         hipLaunchKernelGGL(src_fwd_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, a0, s0, a1, s1, x, out, C, HW / 4,
-                           total4);
+                           total4, a_batch_stride / 4);
     }
     return check_launch("scale_residual_cat_fwd");
 }
 
 // adjoint of the above for grad_out [B,2C,H,W]: grad_a0, grad_a1, grad_x [B,C,H,W]; grad_s0, grad_s1 [B,C]
 // (grad_x == NULL when there was no residual; s1 == NULL: a1 and grad_s1 are not touched)
+extern "C" int ebfi_scale_residual_cat_backward_ex(const float *grad_out, const float *a0, const float *s0, const float *a1,
+                                                   const float *s1, float *grad_a0, float *grad_a1, float *grad_x,
+                                                   float *grad_s0, float *grad_s1, int B, int C, int64_t HW,
+                                                   int64_t a_batch_stride, int64_t grad_a_batch_stride, int mask_leaky,
+                                                   float mask_slope, void *stream);
 extern "C" int ebfi_scale_residual_cat_backward(const float *grad_out, const float *a0, const float *s0, const float *a1,
                                                 const float *s1, float *grad_a0, float *grad_a1, float *grad_x,
                                                 float *grad_s0, float *grad_s1, int B, int C, int64_t HW, void *stream) {
+    return ebfi_scale_residual_cat_backward_ex(grad_out, a0, s0, a1, s1, grad_a0, grad_a1, grad_x, grad_s0, grad_s1, B, C, HW,
+                                               (int64_t)C * HW, (int64_t)C * HW, 0, 0.f, stream);
+}
+
+// same with a0 / a1 and grad_a0 / grad_a1 as channel slices of wider tensors (batch strides in elements); mask_leaky != 0:
+// a0 / a1 came out of LeakyReLU(mask_slope) layers and grad_a* leave multiplied by that derivative (pre-activation gradients)
+extern "C" int ebfi_scale_residual_cat_backward_ex(const float *grad_out, const float *a0, const float *s0, const float *a1,
+                                                   const float *s1, float *grad_a0, float *grad_a1, float *grad_x,
+                                                   float *grad_s0, float *grad_s1, int B, int C, int64_t HW,
+                                                   int64_t a_batch_stride, int64_t grad_a_batch_stride, int mask_leaky,
+                                                   float mask_slope, void *stream) {
+    if (a_batch_stride % 4 != 0 || grad_a_batch_stride % 4 != 0 || a_batch_stride < (int64_t)C * HW ||
+        grad_a_batch_stride < (int64_t)C * HW || (mask_leaky && !a1))
+        return fail(EBFI_ERR_ARG, "scale_residual_cat_backward: batch stride / mask");
     if (!grad_out || !a0 || !s0 || !grad_a0 || !grad_a1 || !grad_s0 || (s1 && (!a1 || !grad_s1)))
         return fail(EBFI_ERR_ARG, "scale_residual_cat_backward: null argument");
     if (int rc = check_planes("scale_residual_cat_backward", B, C, HW)) return rc;
@@ -156,7 +201,7 @@ extern "C" int ebfi_scale_residual_cat_backward(const float *grad_out, const flo
     {
         ProfScope ps("scale_residual_cat_bwd", st, 0.0, 28.0 * B * C * (double)HW);
         hipLaunchKernelGGL(src_bwd_kernel, dim3((unsigned)(B * C)), dim3(256), 0, st, grad_out, a0, s0, a1, s1, grad_a0, grad_a1,
-                           grad_x, grad_s0, grad_s1, C, HW / 4);
+                           grad_x, grad_s0, grad_s1, C, HW / 4, a_batch_stride / 4, grad_a_batch_stride / 4, mask_leaky, mask_slope);
     }
     return check_launch("scale_residual_cat_bwd");
 }

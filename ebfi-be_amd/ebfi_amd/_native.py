@@ -12,7 +12,8 @@ import threading
 
 PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # .../ebfi-be_amd
 REPO_ROOT = os.path.dirname(PKG_ROOT)
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libebfi_hip.so")
+# EBFI_LIB_PATH: development switch for same-box A/B runs of two builds of the library
+LIB_PATH = os.environ.get("EBFI_LIB_PATH") or os.path.join(PKG_ROOT, "lib", "libebfi_hip.so")
 HEADER = os.path.join(REPO_ROOT, "include", "ebfi_hip.h")
 BUILD_SCRIPT = os.path.join(PKG_ROOT, "csrc", "build.sh")
 
@@ -52,6 +53,10 @@ SIGNATURES = {
     "ebfi_conv2d_packed_bytes": (_sz, [_i, _i, _i, _i]),
     "ebfi_conv2d_pack_bf16x3": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ebfi_pack_table_bf16": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "ebfi_conv2d_packed_x3": (_i, [_vp, _vp, _sz, _vp, _vp] + [_i] * 8 + [_i, _c.c_float, _vp, _vp, _i, _c.c_float, _vp]),
+    "ebfi_conv2d_backward_weight_x3g": (_i, [_vp] * 4 + [_i] * 8 + [_vp, _sz, _vp]),
+    "ebfi_scale_residual_cat_forward_ex": (_i, [_vp] * 6 + [_i, _i, _i64, _i64, _vp]),
+    "ebfi_scale_residual_cat_backward_ex": (_i, [_vp] * 10 + [_i, _i, _i64, _i64, _i64, _i, _c.c_float, _vp]),
     "ebfi_events_workspace": (_sz, [_i]),
     "ebfi_events_to_stack": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ebfi_frame2lap": (_i, [_vp, _vp, _i, _i, _i, _vp]),
@@ -112,6 +117,8 @@ def lib():
             try:
                 fn = getattr(h, name)
             except AttributeError as e:
+                if os.environ.get("EBFI_LIB_PATH"):     # an older build under A/B: newer entry points simply stay unbound
+                    continue
                 raise EbfiNativeError("%s does not export %s" % (LIB_PATH, name)) from e
             fn.restype = res
             fn.argtypes = args

@@ -85,7 +85,8 @@ class Engine:
         # MFMA operand images of every conv weight, refreshed by one launch per step instead of one per conv call
         # (ebfi_amd.weightbank); training reads the optimiser's flat parameter buffer, inference keeps its own copy
         self.bank = None
-        if self.device.type == "cuda":
+        import os
+        if self.device.type == "cuda" and os.environ.get("EBFI_NO_BANK", "0") != "1":     # (switch for A/B measurements)
             from . import weightbank
             self.bank = weightbank.build_for(self.model, flat=self.optimizer.flat.data, params=self.optimizer.params) if train \
                 else weightbank.build_for(self.model)

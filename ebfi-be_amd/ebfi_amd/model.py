@@ -151,7 +151,16 @@ class ResidualControl(BaseModel):
         self.Conv5 = bank(lambda: [c3(2 * Basech)])
         initialize_weights([self.Conv1, self.Conv2, self.Conv3, self.Conv4, self.Conv5], 0.1)
 
+    def _ebfi_bank_register(self, bank):
+        from . import rc_fused
+        rc_fused.register(bank, self)
+
     def forward(self, data, Ex, T):
+        from . import rc_fused
+        if rc_fused.usable(self, data):       # split-precision mode with an active weight bank: one hand-scheduled node
+            out = rc_fused.residual_control(self, data, Ex, T)
+            if out is not None:
+                return out
         ex, t = Ex[:, :, None, None], T[:, :, None, None]
         x = data
         for i in range(self.step):

@@ -1,0 +1,173 @@
+"""ResidualControl as ONE hand-scheduled autograd node (reference models/Ours/model_singleframe.py:79-136).
+
+The module is 48 % of the model's FLOPs in 60 small 3x3 convolutions.  Run layer by layer through autograd it costs, per
+round, 5 forward + 5 data-gradient + 5 weight-gradient convolutions, two gradient-accumulation adds for the three
+consumers of x, a saved-activation read in every weight / data gradient, and a side output of grad*act' per layer.  Here
+one round is
+
+    forward   ya = lrelu(conv(x; [W3a | W4a]))        one convolution to 128 channels (Conv3[i][0] and Conv4[i][0] share x)
+              a  = lrelu(gconv(ya; [W3b | W4b]))      one grouped convolution (groups = 2) for Conv3[i][1] / Conv4[i][1]
+              c  = cat(s_ex*a[:, :64] + x, s_t*a[:, 64:] + x)      fused stage, reads the halves of `a` in place
+              x' = lrelu(conv(c; W5))
+    backward  everything flows as PRE-activation gradients: the data gradient of each layer applies, in its epilogue, the
+              derivative of the activation that produced its input (and adds the residual path), so no kernel re-reads a
+              saved output for act', none writes a grad*act' side tensor, and no add kernel runs
+
+on the weight images of the active weight bank (split-precision mode).  The per-round scales s_ex = Conv1[i](Ex),
+s_t = Conv2[i](T) stay ordinary autograd tensors (computed for all rounds at once by the module).
+Not active (fp32 / bf16 modes, no bank, CPU tensors): the module falls back to its layer-by-layer form.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _native as N
+from . import conv, weightbank
+
+ACT = conv.ACT_LEAKY
+
+
+def register(bank, rc):
+    """Sites of one ResidualControl module: concatenated first layers, grouped second layers (Conv5 is a plain site)."""
+    for i in range(rc.step):
+        a3, a4 = rc.Conv3[i][0].conv2d, rc.Conv4[i][0].conv2d
+        b3, b4 = rc.Conv3[i][1].conv2d, rc.Conv4[i][1].conv2d
+        bank.register([a3.weight, a4.weight], [a3.bias, a4.bias], kind="rcA")
+        bank.register([b3.weight, b4.weight], [b3.bias, b4.bias], kind="rcB", groups=2)
+
+
+def sites_of(rc):
+    """[(siteA, siteB, siteC)] per round under the active bank, or None when any is missing."""
+    out = []
+    for i in range(rc.step):
+        sa = weightbank.lookup(rc.Conv3[i][0].conv2d.weight, "rcA")
+        sb = weightbank.lookup(rc.Conv3[i][1].conv2d.weight, "rcB")
+        sc = weightbank.lookup(rc.Conv5[i][0].conv2d.weight, "id")
+        if sa is None or sb is None or sc is None or not sc.has_bias:
+            return None
+        out.append((sa, sb, sc))
+    return out
+
+
+def usable(rc, x):
+    if conv.get_compute_dtype() != "bf16x3" or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
+        return False
+    if (x.shape[2] * x.shape[3]) % 4 != 0 or torch.is_autocast_enabled():
+        return False
+    if x.shape[1] % 64 != 0:          # a workgroup's 64 output channels must lie inside one group of the grouped layers
+        return False
+    acts = {type(m.activation) for bank in (rc.Conv3, rc.Conv4, rc.Conv5) for seq in bank for m in seq}
+    return acts == {torch.nn.LeakyReLU} and weightbank.active_bank() is not None
+
+
+def _conv(lib, st, x, packed, nbytes, bias, out, B, cin_g, H, W, cout, groups, act, slope, addend=None, mask=None):
+    rc = lib.ebfi_conv2d_packed_x3(N.ptr(x), packed, nbytes, N.ptr(bias), N.ptr(out), B, cin_g, H, W, cout, 3, 1, groups, act, slope,
+                                   N.ptr(addend), N.ptr(mask), ACT if mask is not None else 0, slope if mask is not None else 0.0, st)
+    N.check(rc, "ebfi_conv2d_packed_x3")
+
+
+def _wgrad(lib, st, x, g, B, cin_g, H, W, cout, groups, ws_cache):
+    gw = torch.empty((cout, cin_g, 3, 3), dtype=x.dtype, device=x.device)
+    gb = torch.empty(cout, dtype=x.dtype, device=x.device)
+    key = (cin_g, cout)
+    if key not in ws_cache:
+        need = int(lib.ebfi_conv2d_backward_weight_workspace(B, cin_g, H, W, cout, 3, 1, 1, N.EBFI_F32))
+        ws_cache[key] = (torch.empty(max(need, 4), dtype=torch.uint8, device=x.device), need)
+    ws, need = ws_cache[key]
+    rc = lib.ebfi_conv2d_backward_weight_x3g(N.ptr(x), N.ptr(g), N.ptr(gw), N.ptr(gb), B, cin_g, H, W, cout, 3, 1, groups,
+                                             N.ptr(ws), need, st)
+    N.check(rc, "ebfi_conv2d_backward_weight_x3g")
+    return gw, gb
+
+
+class ResidualControlFn(Function):
+    """apply(data, s_ex [step,B,C], s_t [step,B,C], sites, slope, *params) -> x_step.
+    params per round: W3a, b3a, W4a, b4a, W3b, b3b, W4b, b4b, W5, b5 (inputs only so that autograd routes their gradients)."""
+
+    @staticmethod
+    def forward(ctx, data, s_ex, s_t, sites, slope, *params):
+        x = data.contiguous()
+        B, C, H, W = (int(v) for v in x.shape)
+        HW = H * W
+        s_ex, s_t = s_ex.contiguous(), s_t.contiguous()
+        lib = N.lib()
+        saved = []
+        with torch.cuda.device_of(x):
+            st = N.stream_ptr(x.device)
+            new = lambda ch: torch.empty((B, ch, H, W), dtype=x.dtype, device=x.device)
+            for i, (sa, sb, sc) in enumerate(sites):
+                ya, a, c, xn = new(2 * C), new(2 * C), new(2 * C), new(C)
+                _conv(lib, st, x, sa.fwd_ptr(), sa.fwd_bytes, sa.bias(), ya, B, C, H, W, 2 * C, 1, ACT, slope)
+                _conv(lib, st, ya, sb.fwd_ptr(), sb.fwd_bytes, sb.bias(), a, B, C, H, W, 2 * C, 2, ACT, slope)
+                rc = lib.ebfi_scale_residual_cat_forward_ex(N.ptr(a), N.ptr(s_ex[i]), N._vp(a.data_ptr() + 4 * C * HW), N.ptr(s_t[i]),
+                                                            N.ptr(x), N.ptr(c), B, C, HW, 2 * C * HW, st)
+                N.check(rc, "ebfi_scale_residual_cat_forward_ex")
+                _conv(lib, st, c, sc.fwd_ptr(), sc.fwd_bytes, sc.bias(), xn, B, 2 * C, H, W, C, 1, ACT, slope)
+                saved += [x, ya, a, c]
+                x = xn
+        ctx.sites, ctx.slope, ctx.dims = sites, slope, (B, C, H, W)
+        ctx.save_for_backward(s_ex, s_t, x, *saved)
+        return x
+
+    @staticmethod
+    def backward(ctx, gout):
+        s_ex, s_t, xlast, *saved = ctx.saved_tensors
+        sites, slope, (B, C, H, W) = ctx.sites, ctx.slope, ctx.dims
+        HW = H * W
+        lib = N.lib()
+        nstep = len(sites)
+        gs_ex, gs_t = torch.empty_like(s_ex), torch.empty_like(s_t)
+        pgrads = [None] * (10 * nstep)
+        ws_cache = {}
+        with torch.cuda.device_of(gout):
+            st = N.stream_ptr(gout.device)
+            new = lambda ch: torch.empty((B, ch, H, W), dtype=gout.dtype, device=gout.device)
+            # gradient of the last round's pre-activation (later rounds get theirs from the epilogue below)
+            gpre5 = torch.where(xlast > 0, gout, gout * slope)
+            gdata = None
+            for i in range(nstep - 1, -1, -1):
+                sa, sb, sc = sites[i]
+                x, ya, a, c = saved[4 * i:4 * i + 4]
+                gw5, gb5 = _wgrad(lib, st, c, gpre5, B, 2 * C, H, W, C, 1, ws_cache)
+                gc = new(2 * C)
+                _conv(lib, st, gpre5, sc.tr_ptr(), sc.tr_bytes, None, gc, B, C, H, W, 2 * C, 1, 0, 0.0)
+                gpre_b, gxres = new(2 * C), new(C)
+                rc = lib.ebfi_scale_residual_cat_backward_ex(
+                    N.ptr(gc), N.ptr(a), N.ptr(s_ex[i]), N._vp(a.data_ptr() + 4 * C * HW), N.ptr(s_t[i]), N.ptr(gpre_b),
+                    N._vp(gpre_b.data_ptr() + 4 * C * HW), N.ptr(gxres), N.ptr(gs_ex[i]), N.ptr(gs_t[i]), B, C, HW, 2 * C * HW,
+                    2 * C * HW, 1, slope, st)
+                N.check(rc, "ebfi_scale_residual_cat_backward_ex")
+                gwb, gbb = _wgrad(lib, st, ya, gpre_b, B, C, H, W, 2 * C, 2, ws_cache)
+                gpre_a = new(2 * C)
+                _conv(lib, st, gpre_b, sb.tr_ptr(), sb.tr_bytes, None, gpre_a, B, C, H, W, 2 * C, 2, 0, slope, None, ya)
+                gwa, gba = _wgrad(lib, st, x, gpre_a, B, C, H, W, 2 * C, 1, ws_cache)
+                gx = new(C)
+                # grad wrt x of this round = data gradient of the merged first layers + the residual path; for i > 0 it
+                # leaves as the pre-activation gradient of the previous round's Conv5 (x is that layer's LeakyReLU output)
+                _conv(lib, st, gpre_a, sa.tr_ptr(), sa.tr_bytes, None, gx, B, 2 * C, H, W, C, 1, 0, slope, gxres, x if i > 0 else None)
+                if i > 0:
+                    gpre5 = gx
+                else:
+                    gdata = gx
+                pgrads[10 * i:10 * i + 10] = [gwa[:C], gba[:C], gwa[C:], gba[C:], gwb[:C], gbb[:C], gwb[C:], gbb[C:], gw5, gb5]
+        need = ctx.needs_input_grad
+        return (gdata if need[0] else None, gs_ex if need[1] else None, gs_t if need[2] else None, None, None) + tuple(pgrads)
+
+
+def residual_control(rc, data, Ex, T):
+    """Fused ResidualControl.forward; the caller checked `usable` and found the sites."""
+    sites = sites_of(rc)
+    if sites is None:
+        return None
+    slope = float(rc.Conv5[0][0].activation.negative_slope)
+    # per-round channel scales Conv1[i](Ex), Conv2[i](T) for all rounds at once: [step, B, C]
+    def scales(bank_modules, v):
+        w = torch.stack([m[0].conv2d.weight.flatten(1) for m in bank_modules])          # [step, C, Cin]
+        b = torch.stack([m[0].conv2d.bias for m in bank_modules])                        # [step, C]
+        s = torch.einsum("bk,sck->sbc", v, w) + b[:, None, :]
+        return torch.nn.functional.leaky_relu(s, float(bank_modules[0][0].activation.negative_slope))
+    s_ex, s_t = scales(rc.Conv1, Ex), scales(rc.Conv2, T)
+    params = []
+    for i in range(rc.step):
+        for m in (rc.Conv3[i][0], rc.Conv4[i][0], rc.Conv3[i][1], rc.Conv4[i][1], rc.Conv5[i][0]):
+            params += [m.conv2d.weight, m.conv2d.bias]
+    return ResidualControlFn.apply(data, s_ex, s_t, sites, slope, *params)

@@ -40,7 +40,7 @@ def lookup(param, kind="id"):
 
 class Site:
     """Packed images of one (possibly folded / concatenated) conv weight [M = Cout, K = Cin, ks, ks]."""
-    __slots__ = ("bank", "kind", "M", "K", "ks", "fwd_off", "tr_off", "fwd_bytes", "tr_bytes", "bias_off", "has_bias",
+    __slots__ = ("bank", "kind", "M", "K", "ks", "groups", "fwd_off", "tr_off", "fwd_bytes", "tr_bytes", "bias_off", "has_bias",
                  "w_inv", "w_R", "b_inv", "b_R", "w_shapes", "b_shapes")
 
     def fwd_ptr(self):
@@ -106,9 +106,11 @@ class WeightBank:
             raise KeyError("parameter is not part of this bank")
         return ent[0]
 
-    def register(self, weights, biases=None, kind="id", fold_w=None, fold_b=None):
+    def register(self, weights, biases=None, kind="id", fold_w=None, fold_b=None, groups=1):
         """`weights`: one parameter, or a list concatenated along the (folded) output-channel axis.  `fold_w` / `fold_b`:
-        0/1 linear maps from the parameter's shape to [M, K, ks, ks] / [M] (None = identity).  Keyed by the FIRST weight."""
+        0/1 linear maps from the parameter's shape to [M, K, ks, ks] / [M] (None = identity).  Keyed by the FIRST weight.
+        `groups` > 1: the M rows form that many groups, each convolving its own K input channels (a grouped convolution:
+        the data-gradient image is then [tap][(group, ci)][co within the group])."""
         weights = list(weights) if isinstance(weights, (list, tuple)) else [weights]
         biases = list(biases) if isinstance(biases, (list, tuple)) else ([biases] if biases is not None else [])
         key = (weights[0].data_ptr(), kind)
@@ -123,9 +125,13 @@ class WeightBank:
         KK, K16, M16 = ks * ks, (K + 15) // 16 * 16, (M + 15) // 16 * 16
         pad = lambda t, n: torch.cat([t, t.new_full(t.shape[:-1] + (n - t.shape[-1],), -1)], dim=-1)
         fwd = pad(ids.permute(2, 3, 0, 1).reshape(KK, M, K), K16).reshape(-1)                    # [tap][co][ci16]
-        tr = pad(ids.flip((2, 3)).permute(2, 3, 1, 0).reshape(KK, K, M), M16).reshape(-1)        # [tap][ci][co16], taps flipped
+        if M % groups != 0:
+            raise ValueError("%d output channels do not split into %d groups" % (M, groups))
+        Mg = M // groups
+        tr = pad(ids.flip((2, 3)).view(groups, Mg, K, ks, ks).permute(3, 4, 0, 2, 1).reshape(KK, groups * K, Mg),
+                 (Mg + 15) // 16 * 16).reshape(-1)                                               # [tap][(g, ci)][co16], taps flipped
         s = Site()
-        s.bank, s.kind, s.M, s.K, s.ks = self, kind, int(M), int(K), int(ks)
+        s.bank, s.kind, s.M, s.K, s.ks, s.groups = self, kind, int(M), int(K), int(ks), int(groups)
         for name, img in (("fwd", fwd), ("tr", tr)):
             lo = torch.where(img >= 0, img | LO_FLAG, img)
             setattr(s, name + "_off", 2 * self._n_packed)

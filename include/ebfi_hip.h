@@ -184,6 +184,23 @@ int ebfi_conv2d_pack_bf16x3(const void *weight, int Cin, int Cout, int ksize, in
                             size_t packed_bytes, void *stream);
 int ebfi_pack_table_bf16(const float *src, const int32_t *table, int64_t n, void *out, void *stream);
 
+/* Split-precision convolution on packed weight images with the options hand-scheduled layer chains need
+ * (ebfi_amd/rc_fused.py; ResidualControl, reference models/Ours/model_singleframe.py:115-136):
+ *   groups      grouped convolution: input [B, groups*Cin_per_group, H, W], output channel co reads the input channels
+ *               of group co / (Cout/groups); Cout/groups a multiple of 64 when groups > 1
+ *   addend      [B,Cout,Ho,Wo] added before the activation (NULL: none)
+ *   mask_y      [B,Cout,Ho,Wo]: the result is multiplied by act'(mask_y) for activation mask_act / mask_slope (NULL: none)
+ * out = act(conv(input) + bias + addend) * act'(mask_y); stride 1.  With transposed images it is the data gradient of a
+ * layer; addend + mask then turn its output into the PRE-activation gradient of the layer below. */
+int ebfi_conv2d_packed_x3(const void *input, const void *packed, size_t packed_bytes, const void *bias, void *output,
+                          int B, int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups, int act,
+                          float slope, const void *addend, const void *mask_y, int mask_act, float mask_slope, void *stream);
+/* weight / bias gradient of such a (grouped) convolution from a pre-activation gradient: grad_weight
+ * [Cout, Cin_per_group, k, k]; workspace as ebfi_conv2d_backward_weight_workspace(B, Cin_per_group, H, W, Cout, k, 1, pad) */
+int ebfi_conv2d_backward_weight_x3g(const void *input, const void *grad_output, void *grad_weight, void *grad_bias,
+                                    int B, int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups,
+                                    void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------ event voxel binning
  * xs, ys, ts: float64[n] device (ts sorted, normalised as h5dataset.py:334), ps: float32[n].
  * out: float32 [2, bins, H, W], fully overwritten (index 0 = positive, 1 = negative counts).
@@ -211,6 +228,16 @@ int ebfi_scale_residual_cat_forward(const float *a0, const float *s0, const floa
 int ebfi_scale_residual_cat_backward(const float *grad_out, const float *a0, const float *s0, const float *a1,
                                      const float *s1, float *grad_a0, float *grad_a1, float *grad_x,
                                      float *grad_s0, float *grad_s1, int B, int C, int64_t HW, void *stream);
+
+/* The same stage with a0 / a1 (and grad_a0 / grad_a1) given as channel slices of wider [B, *, H, W] tensors (batch strides
+ * in elements, multiples of 4).  mask_leaky != 0: a0 / a1 are LeakyReLU(mask_slope) outputs and grad_a0 / grad_a1 leave
+ * multiplied by that activation's derivative, i.e. as gradients of the PRE-activations. */
+int ebfi_scale_residual_cat_forward_ex(const float *a0, const float *s0, const float *a1, const float *s1, const float *x,
+                                       float *out, int B, int C, int64_t HW, int64_t a_batch_stride, void *stream);
+int ebfi_scale_residual_cat_backward_ex(const float *grad_out, const float *a0, const float *s0, const float *a1,
+                                        const float *s1, float *grad_a0, float *grad_a1, float *grad_x, float *grad_s0,
+                                        float *grad_s1, int B, int C, int64_t HW, int64_t a_batch_stride,
+                                        int64_t grad_a_batch_stride, int mask_leaky, float mask_slope, void *stream);
 
 /* out[plane] = mean over HW of a*b for contiguous [planes, HW] maps (AdaptiveAvgPool2d(1) of a product: the event / blur
  * correlation of ExposureDecision, model_singleframe.py:66-68) and its adjoint.  HW a multiple of 4. */

@@ -324,10 +324,10 @@ def test_hd_config5_forward_vs_oracle_and_batch_independence():
     assert _rel(s8[5:6], ref_s) < TOL and _rel(f8[5:6], ref_f) < TOL
 
 
-def test_weight_bank_path_is_bit_identical_to_per_call_packing(fix):
+def test_weight_bank_path_equals_per_call_packing(fix):
     """ebfi_amd.weightbank: one table-driven pack launch per step for all conv weights (plain, folded depth-2 3-D, biases)
-    instead of a pack launch inside every conv call.  Same kernels on the same images: forward outputs and every
-    parameter gradient must be bit-identical with and without the bank, and a parameter update must be picked up."""
+    instead of a pack launch inside every conv call.  Same kernels on the same images: forward outputs must be
+    bit-identical with and without the bank, parameter gradients equal, and a parameter update must be picked up."""
     from ebfi_amd import conv, weightbank
     from ebfi_amd import _native as N
     z, sd, cfg = fix
@@ -355,11 +355,11 @@ def test_weight_bank_path_is_bit_identical_to_per_call_packing(fix):
             return s.detach().clone(), f.detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters()}, prof
         s0, f0, g0, prof0 = run(None)
         bank = weightbank.build_for(net)
-        assert {k for _, k in bank.sites} == {"id", "conv3d", "convT3d"}
+        assert {k for _, k in bank.sites} == {"id", "conv3d", "convT3d", "rcA", "rcB"}
         s1, f1, g1, prof1 = run(bank)
         assert torch.equal(s0, s1) and torch.equal(f0, f1)
-        for n in g0:
-            assert torch.equal(g0[n], g1[n]), n
+        for n in g0:     # (PyTorch's replication / reflection pad backward accumulate with atomics: last-bit run-to-run noise)
+            assert _rel(g1[n], g0[n]) < 1e-5, n
         assert prof0["conv_pack_w_bf16"][0] > 50 and "conv_pack_w_bf16" not in prof1 and prof1["pack_table_bf16"][0] == 1
         with torch.no_grad():                      # an in-place update (what the optimiser does) must invalidate the images
             for p in net.parameters():
@@ -368,5 +368,57 @@ def test_weight_bank_path_is_bit_identical_to_per_call_packing(fix):
         assert prof2["pack_table_bf16"][0] == 1 and not torch.equal(s2, s1)
         s3, _, _, _ = run(None)
         assert torch.equal(s2, s3)
+    finally:
+        conv.set_compute_dtype("fp32")
+
+
+def test_fused_residual_control_equals_layerwise():
+    """ebfi_amd.rc_fused: ResidualControl as one hand-scheduled node (merged first layers, grouped second layers, gradients
+    handed down as pre-activation gradients through the data-gradient epilogues) against the layer-by-layer autograd form
+    of the same module on the same split-precision kernels (default width 64, ragged 20x36 maps): output, input gradient,
+    scalar-input gradients and every parameter gradient; the layer-by-layer form against the CPU oracle."""
+    from ebfi_amd import conv, rc_fused, weightbank
+    from ebfi_amd import _native as N
+    from ebfi_amd.model import ResidualControl
+    torch.manual_seed(31)
+    step = 3
+    rc = ResidualControl(BLinch=1, Tinch=1, Basech=64, step=step)
+    with torch.no_grad():
+        for p in rc.parameters():
+            p.copy_(torch.randn_like(p) * (1.0 / p[0].numel() ** 0.5) if p.dim() > 1 else 0.1 * torch.randn_like(p))
+    x0, ex0, t0 = torch.randn(2, 64, 20, 36), torch.rand(2, 1), torch.rand(2, 1)
+    sd = {"ResidualControl." + k: v.detach().clone() for k, v in rc.state_dict().items()}
+    ref = model_ref.residual_control(sd, "ResidualControl", x0, ex0, t0, step)
+    rc = rc.cuda().train()
+    gout = torch.randn(2, 64, 20, 36).cuda()
+    conv.set_compute_dtype("bf16x3")
+    try:
+        def run(bank):
+            rc.zero_grad(set_to_none=True)
+            x, ex, t = x0.cuda().requires_grad_(), ex0.cuda().requires_grad_(), t0.cuda().requires_grad_()
+            N.prof_reset()
+            N.prof_enable(True)
+            if bank is not None:
+                bank.ensure_fresh()
+                with bank.active():
+                    assert rc_fused.usable(rc, x) and rc_fused.sites_of(rc) is not None
+                    y = rc(x, ex, t)
+                    y.backward(gout)
+            else:
+                y = rc(x, ex, t)
+                y.backward(gout)
+            torch.cuda.synchronize()
+            N.prof_enable(False)
+            return y.detach(), x.grad, ex.grad, t.grad, {n: p.grad.clone() for n, p in rc.named_parameters()}, N.prof_collect()
+        y0, gx0, ge0, gt0, gp0, prof0 = run(None)
+        assert _rel(y0, ref) < TOL
+        y1, gx1, ge1, gt1, gp1, prof1 = run(weightbank.build_for(rc))
+        assert y0.abs().max() > 1e-3 and _rel(y1, y0) < 1e-5
+        assert _rel(gx1, gx0) < 3e-5 and _rel(ge1, ge0) < 3e-5 and _rel(gt1, gt0) < 3e-5
+        for n in gp0:
+            assert _rel(gp1[n], gp0[n]) < 5e-5, n
+        # 3 convolutions forward and 3 data gradients per round on one kernel, 3 weight gradients per round
+        assert prof1["conv_fwd_bf16x3_db/fwd"][0] == 6 * step and prof1["conv_wgrad_x3"][0] == 3 * step
+        assert prof0["conv_fwd_bf16x3_db/fwd"][0] == 5 * step and prof0["conv_wgrad_x3"][0] == 5 * step
     finally:
         conv.set_compute_dtype("fp32")
