@@ -1062,13 +1062,27 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
     const int icol = tid & (IWP - 1), irow = tid / IWP;                              // input: column, thread row (0..15)
     const unsigned go_bytes = (unsigned)g.Cout * (unsigned)HWo * 4u, x_bytes = (unsigned)g.Cin * (unsigned)HW * 4u;
 
-    float rg[NG], ry[NG], ri[NI];
-    float rex[NEX > 0 ? NEX : 1];          // 32-px tiles: the IW - 32 extra halo columns, element e = tid + i*WXT ->
+    // registers of one tile in flight between its global loads and its commit to LDS
+    struct Stage {
+        float rg[NG], ry[DACT != 0 ? NG : 1], ri[NI];
+        float rex[NEX > 0 ? NEX : 1];      // 32-px tiles: the IW - 32 extra halo columns, element e = tid + i*WXT ->
                                            // (channel e % CIB, row (e / CIB) / EXC, column 32 + (e / CIB) % EXC)
+    };
+    // The tile loop is paced by the LATENCY of its staging loads (ablations in tools/kbench at 64->64, 128x128, B=8: without
+    // any matrix work or LDS operand read the kernel still takes 43 of its 46 us; without the loads 37; with neither 27 --
+    // one tile = 51 KB per CU in flight against ~3 us of load latency under load).  PF2 keeps TWO tiles in flight in
+    // registers; measured SLOWER (69 vs 53 us: the second register set pushes the kernel to 256 VGPRs + 15 spills), as the
+    // round-1 attempt was -- left selectable for the day the matrix block is restructured to need fewer registers.
+    constexpr bool PF2 = false;
+    Stage sa, sb;
     float bacc[NG];                        // bias: this thread's slot of channels gco + 8*it, summed over its tiles
 #pragma unroll
     for (int it = 0; it < NG; ++it) bacc[it] = 0.f;
-    auto prefetch = [&](int tile) {
+    auto prefetch = [&](int tile, Stage &s) {
+        float (&rg)[NG] = s.rg;
+        float (&ri)[NI] = s.ri;
+        auto &ry = s.ry;
+        auto &rex = s.rex;
         int t = tile;
         const int tx = t % tiles_x; t /= tiles_x;
         const int ty = t % tiles_y;
@@ -1107,7 +1121,11 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
             }
         }
     };
-    auto commit = [&](int tile, int buf) {
+    auto commit = [&](int tile, int buf, Stage &s) {
+        float (&rg)[NG] = s.rg;
+        float (&ri)[NI] = s.ri;
+        auto &ry = s.ry;
+        auto &rex = s.rex;
         unsigned *sG = smw + buf * BUF, *sIn = sG + 64 * GS;
 #pragma unroll
         for (int it = 0; it < NG; ++it) {
@@ -1144,15 +1162,12 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
     };
 
     __syncthreads();                       // zero fill done
-    prefetch(blockIdx.x);
-    commit(blockIdx.x, 0);
-    __syncthreads();
-    int cur = 0;
-    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-        prefetch(tile + gridDim.x);        // past the end: zero-record descriptors, nothing is read
-        __builtin_amdgcn_sched_barrier(0); // keep the loads above the matrix block
+    auto matrix_block = [&](int cur) {
         const unsigned *sA = smw + cur * BUF + aoff;
         const unsigned *sB = smw + cur * BUF;
+#ifdef KB_NO_LDSREAD
+        if (g.pad != 12345) { } else
+#endif
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {   // 16 pixel slots per step: row kk>>1, slots (kk&1)*16 + 8h .. +7
             const int row = kk >> 1, px0 = (kk & 1) * 16;
@@ -1169,15 +1184,59 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
                 for (int j = 0; j < 8; ++j) bw[j] = sB[boff[q] + row * IWS + px0 + j];
                 bf16x8 bh, bl;
                 peel(bw, bh, bl);
+#ifdef KB_NO_MFMA        // ablation (tools/kbench only): operand reads and peels stay alive, no matrix work
+                asm volatile("" ::"v"(al), "v"(ah), "v"(bl), "v"(bh));
+#else
                 acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[q], 0, 0, 0);
                 acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[q], 0, 0, 0);
                 acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[q], 0, 0, 0);
+#endif
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        commit(tile + gridDim.x, cur ^ 1); // the other buffer was last read before the previous barrier
-        __syncthreads();
-        cur ^= 1;
+    };
+    const int G = gridDim.x;
+    prefetch(blockIdx.x, sa);
+    commit(blockIdx.x, 0, sa);
+    __syncthreads();
+    int cur = 0;
+    if constexpr (PF2) {
+        // two tiles in flight: while tile t is multiplied, the loads of t+G (issued one iteration ago) and t+2G are
+        // outstanding; t+G is committed after the matrix block and its registers take the loads of t+3G
+        prefetch(blockIdx.x + G, sa);
+        prefetch(blockIdx.x + 2 * G, sb);
+        for (int tile = blockIdx.x; tile < total_tiles; tile += 2 * G) {
+            __builtin_amdgcn_sched_barrier(0);
+            matrix_block(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            commit(tile + G, cur ^ 1, sa);          // the other buffer was last read before the previous barrier
+#ifndef KB_NO_LOADS
+            prefetch(tile + 3 * G, sa);             // past the end: zero-record descriptors, nothing is read
+#endif
+            __syncthreads();
+            cur ^= 1;
+            if (tile + G >= total_tiles) break;
+            __builtin_amdgcn_sched_barrier(0);
+            matrix_block(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            commit(tile + 2 * G, cur ^ 1, sb);
+#ifndef KB_NO_LOADS
+            prefetch(tile + 4 * G, sb);
+#endif
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+        for (int tile = blockIdx.x; tile < total_tiles; tile += G) {
+#ifndef KB_NO_LOADS
+            prefetch(tile + G, sa);            // past the end: zero-record descriptors, nothing is read
+#endif
+            __builtin_amdgcn_sched_barrier(0); // keep the loads above the matrix block
+            matrix_block(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            commit(tile + G, cur ^ 1, sa);     // the other buffer was last read before the previous barrier
+            __syncthreads();
+            cur ^= 1;
+        }
     }
     // ---- write this workgroup's partial slab
     const int64_t wsz = (int64_t)g.Cout * g.Cin * KK;
@@ -1188,6 +1247,9 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
     for (int q = 0; q < NTW; ++q) {
         const int n = (nq + 4 * q) * 32 + (lane & 31);
         const unsigned o0 = n < ncols ? (unsigned)(((co_base + mt * 32 + 4 * (lane >> 5)) * g.Cin + ci_base) * KK + n) * 4u : SENT;
+#ifdef KB_NO_SLAB
+        if (g.pad == 12345)
+#endif
 #pragma unroll
         for (int r = 0; r < 16; ++r) buf_st(rsl, o0 + (unsigned)((r & 3) + 8 * (r >> 2)) * co_row, acc[q][r]);
     }

@@ -177,6 +177,7 @@ int main(int argc, char **argv) {
         std::vector<Variant> vs;
         vs.push_back({"wgrad fp32 exact (library)", [&] { return ebfi_conv2d_backward_weight(x, g, y_ref, gw, gb, B, Cin, H, W, Cout, 3, 1, 1, 0, 0.f, wgs, wgb, EBFI_F32, nullptr); }, {}});
         vs.push_back({"wgrad bf16x3 (library)", [&] { return ebfi_conv2d_backward_weight(x, g, y_ref, gw, gb, B, Cin, H, W, Cout, 3, 1, 1, 0, 0.f, wgs, wgb, EBFI_F32_BF16X3MMA, nullptr); }, {}});
+        vs.push_back({"wgrad bf16x3 act' folded + side out", [&] { return ebfi_conv2d_backward_weight_ex(x, g, y_ref, gw, gb, y, B, Cin, H, W, Cout, 3, 1, 1, 1, 0.01f, wgs, wgb, EBFI_F32_BF16X3MMA, nullptr); }, {}});
         time_variants(vs, 7, 20);
         ebfi_conv2d_backward_weight(x, g, y_ref, gw, gb, B, Cin, H, W, Cout, 3, 1, 1, 0, 0.f, wgs, wgb, EBFI_F32_BF16X3MMA, nullptr);
         CK(hipDeviceSynchronize());
