@@ -225,21 +225,33 @@ def test_weight_bank_tables_reproduce_the_per_call_packing():
     packed = torch.where((table >= 0) & ((table & weightbank.LO_FLAG) != 0), (src - hi.float()).bfloat16(), hi)
     bias_buf = torch.where(bank.bias_table >= 0, bank.flat[bank.bias_table.long().clamp_min(0)], torch.zeros(()))
 
-    def expect(W2):
+    def expect(W2, groups=1):
         M, K, ks, _ = W2.shape
-        K16, M16 = (K + 15) // 16 * 16, (M + 15) // 16 * 16
+        Mg = M // groups
+        K16, M16 = (K + 15) // 16 * 16, (Mg + 15) // 16 * 16
         f = torch.zeros(ks * ks, M, K16)
         f[:, :, :K] = W2.permute(2, 3, 0, 1).reshape(ks * ks, M, K)
-        t = torch.zeros(ks * ks, K, M16)
-        t[:, :, :M] = W2.flip((2, 3)).permute(2, 3, 1, 0).reshape(ks * ks, K, M)
+        t = torch.zeros(ks * ks, groups * K, M16)      # rows (group, ci), columns = output channels inside the group
+        for gi in range(groups):
+            t[:, gi * K:(gi + 1) * K, :Mg] = W2[gi * Mg:(gi + 1) * Mg].flip((2, 3)).permute(2, 3, 1, 0).reshape(ks * ks, K, Mg)
         split = lambda v: (v.bfloat16(), (v - v.bfloat16().float()).bfloat16())
         return split(f.reshape(-1)), split(t.reshape(-1))
 
     kinds = set()
     by_ptr = {p.data_ptr(): p for p in params}
+    pair = {}                                    # first weight of a ResidualControl pair -> (Conv3 layer, Conv4 layer)
+    for i in range(rc.step):
+        for j in (0, 1):
+            pair[rc.Conv3[i][j].conv2d.weight.data_ptr()] = (rc.Conv3[i][j].conv2d, rc.Conv4[i][j].conv2d)
     for (ptr, kind), s in bank.sites.items():
         w = by_ptr[ptr].detach()
-        if kind == "conv3d":
+        groups = 1
+        if kind in ("rcA", "rcB"):               # declared by ResidualControl._ebfi_bank_register
+            W2, b2 = torch.cat([pair[ptr][0].weight, pair[ptr][1].weight]).detach(), None
+            groups = 2 if kind == "rcB" else 1
+            assert s.groups == groups
+            assert torch.equal(bias_buf[s.bias_off:s.bias_off + s.M], torch.cat([pair[ptr][0].bias, pair[ptr][1].bias]).detach())
+        elif kind == "conv3d":
             W2, b2 = fold3d.fold_conv3d_weight(w), fold3d._rep2
         elif kind == "convT3d":
             W2, b2 = fold3d.fold_conv_transpose3d_weight(w), fold3d._rep8
@@ -248,7 +260,7 @@ def test_weight_bank_tables_reproduce_the_per_call_packing():
         else:
             W2, b2 = w, (lambda t: t)
         assert tuple(W2.shape) == (s.M, s.K, s.ks, s.ks)
-        (fh, fl), (th, tl) = expect(W2)
+        (fh, fl), (th, tl) = expect(W2, groups)
         n = fh.numel()
         o = s.fwd_off // 2
         assert torch.equal(packed[o:o + n], fh) and torch.equal(packed[o + n:o + 2 * n], fl), kind
@@ -265,7 +277,7 @@ def test_weight_bank_tables_reproduce_the_per_call_packing():
             inv = s.w_inv[0].long()
             routed = torch.cat([g2.flatten(), torch.zeros(1)])[inv].sum(-1).view(w.shape)
             assert torch.allclose(routed, wr.grad, atol=1e-6), kind
-    assert kinds == {"id", "conv3d", "convT3d", "cat34"}
+    assert kinds == {"id", "conv3d", "convT3d", "cat34", "rcA", "rcB"}
     # folded biases: one Conv_3d of the decoder (bias=True) and the concatenated pair
     dec = net.Detail.decoder[0].conv[0]
     sb = bank.sites[(dec.weight.data_ptr(), "conv3d")]
