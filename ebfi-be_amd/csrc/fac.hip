@@ -131,7 +131,9 @@ __global__ __launch_bounds__(256) void fac_bwd_rows_f32(const float *__restrict_
                                                         const float *__restrict__ gout, Str4 gs,
                                                         float *__restrict__ gin, Str4 gis,
                                                         float *__restrict__ gkern, Str4 gks, int C, int Ho,
-                                                        int Wo) {
+                                                        int Wo, float kslope) {
+    // kslope: grad_kernel leaves multiplied by (kernel > 0 ? 1 : kslope) -- the derivative of the LeakyReLU that produced the
+    // filters, so that the layer below receives the gradient of its PRE-activation (1.0 = plain grad_kernel, bit for bit)
     static_assert(K == 1 || K == 3 || K == 5, "carry scheme needs K-1 <= 4");
     constexpr int RPW = 64 / TPR;          // rows per wave
     constexpr int ROWS = 4 * RPW;          // rows per 256-thread workgroup
@@ -179,7 +181,8 @@ __global__ __launch_bounds__(256) void fac_bwd_rows_f32(const float *__restrict_
                     const int t = ky * K + kx;
                     const f32x4 w = ld_stream4(kbase + (int64_t)t * ks.s1 + (int64_t)y * ks.s2 + x);
                     if (gkbase != nullptr) {
-                        const f32x4 p = {inr[kx + 0] * g.x, inr[kx + 1] * g.y, inr[kx + 2] * g.z, inr[kx + 3] * g.w};
+                        const f32x4 p = {inr[kx + 0] * g.x * (w.x > 0.f ? 1.f : kslope), inr[kx + 1] * g.y * (w.y > 0.f ? 1.f : kslope),
+                                         inr[kx + 2] * g.z * (w.z > 0.f ? 1.f : kslope), inr[kx + 3] * g.w * (w.w > 0.f ? 1.f : kslope)};
                         st_stream4(gkbase + (int64_t)t * gks.s1 + (int64_t)y * gks.s2 + x, p);
                     }
                     s[kx + 0] = fmaf(w.x, g.x, s[kx + 0]);
@@ -233,7 +236,8 @@ __global__ void fac_bwd_input_generic_f32(const float *__restrict__ kern, Str4 k
 
 __global__ void fac_bwd_kernel_generic_f32(const float *__restrict__ in, Str4 is,
                                            const float *__restrict__ gout, Str4 gs, float *__restrict__ gkern,
-                                           Str4 gks, int64_t total, int C, int Ho, int Wo, int K) {
+                                           Str4 gks, int64_t total, int C, int Ho, int Wo, int K,
+                                           const float *__restrict__ kern, Str4 ks, float kslope) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int x = (int)(idx % Wo);
@@ -242,8 +246,10 @@ __global__ void fac_bwd_kernel_generic_f32(const float *__restrict__ in, Str4 is
     const int ky = (int)((idx / ((int64_t)Wo * Ho * K)) % K);
     const int c = (int)((idx / ((int64_t)Wo * Ho * K * K)) % C);
     const int64_t b = idx / ((int64_t)Wo * Ho * K * K * C);
-    const float v = in[b * is.s0 + (int64_t)c * is.s1 + (int64_t)(y + ky) * is.s2 + (int64_t)(x + kx) * is.s3] *
-                    gout[b * gs.s0 + (int64_t)c * gs.s1 + (int64_t)y * gs.s2 + (int64_t)x * gs.s3];
+    float v = in[b * is.s0 + (int64_t)c * is.s1 + (int64_t)(y + ky) * is.s2 + (int64_t)(x + kx) * is.s3] *
+              gout[b * gs.s0 + (int64_t)c * gs.s1 + (int64_t)y * gs.s2 + (int64_t)x * gs.s3];
+    if (kslope != 1.f && kern[b * ks.s0 + ((int64_t)c * K * K + ky * K + kx) * ks.s1 + (int64_t)y * ks.s2 + (int64_t)x * ks.s3] <= 0.f)
+        v *= kslope;
     gkern[b * gks.s0 + ((int64_t)c * K * K + ky * K + kx) * gks.s1 + (int64_t)y * gks.s2 + (int64_t)x * gks.s3] = v;
 }
 
@@ -283,23 +289,23 @@ void launch_fwd_tile(hipStream_t st, const float *in, Str4 is, const float *kern
 
 template <int K, int TPR>
 void launch_bwd_rows_t(hipStream_t st, const float *in, Str4 is, const float *kern, Str4 ks, const float *go,
-                       Str4 gs, float *gin, Str4 gis, float *gk, Str4 gks, int B, int C, int Ho, int Wo) {
+                       Str4 gs, float *gin, Str4 gis, float *gk, Str4 gks, int B, int C, int Ho, int Wo, float kslope) {
     constexpr int ROWS = 4 * (64 / TPR);
     dim3 grid((unsigned)ceil_div(Ho + K - 1, ROWS), (unsigned)(B * C));
     const double px = (double)B * C * Ho * Wo;     // filters + gout + in read, grad_in + grad_kernel written
     ProfScope ps("fac_bwd_rows_f32", st, 4.0 * px * K * K, 4.0 * px * (K * K + 1 + 1 + (gin ? 1 : 0) + (gk ? K * K : 0)));
     hipLaunchKernelGGL((fac_bwd_rows_f32<K, TPR>), grid, dim3(256), 0, st, in, is, kern, ks, go, gs, gin, gis, gk, gks,
-                       C, Ho, Wo);
+                       C, Ho, Wo, kslope);
 }
 
 template <int K>
 void launch_bwd_rows(hipStream_t st, const float *in, Str4 is, const float *kern, Str4 ks, const float *go, Str4 gs,
-                     float *gin, Str4 gis, float *gk, Str4 gks, int B, int C, int Ho, int Wo) {
+                     float *gin, Str4 gis, float *gk, Str4 gks, int B, int C, int Ho, int Wo, float kslope) {
     const int nx4 = Wo / 4;
-    if (nx4 <= 8) launch_bwd_rows_t<K, 8>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo);
-    else if (nx4 <= 16) launch_bwd_rows_t<K, 16>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo);
-    else if (nx4 <= 32) launch_bwd_rows_t<K, 32>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo);
-    else launch_bwd_rows_t<K, 64>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo);
+    if (nx4 <= 8) launch_bwd_rows_t<K, 8>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo, kslope);
+    else if (nx4 <= 16) launch_bwd_rows_t<K, 16>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo, kslope);
+    else if (nx4 <= 32) launch_bwd_rows_t<K, 32>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo, kslope);
+    else launch_bwd_rows_t<K, 64>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo, kslope);
 }
 
 }  // namespace
@@ -342,11 +348,31 @@ extern "C" int ebfi_fac_forward(const void *input, const int64_t input_shape[4],
     return check_launch("fac_fwd_generic_f32");
 }
 
+extern "C" int ebfi_fac_backward_ex(const void *input, const int64_t input_shape[4], const int64_t input_stride[4],
+                                    const void *kernel, const int64_t kernel_shape[4], const int64_t kernel_stride[4],
+                                    int kernel_size, const void *grad_output, const int64_t grad_output_stride[4],
+                                    void *grad_input, const int64_t grad_input_stride[4], void *grad_kernel,
+                                    const int64_t grad_kernel_stride[4], float kernel_leaky_slope, int dtype, void *stream);
+
 extern "C" int ebfi_fac_backward(const void *input, const int64_t input_shape[4], const int64_t input_stride[4],
                                  const void *kernel, const int64_t kernel_shape[4], const int64_t kernel_stride[4],
                                  int kernel_size, const void *grad_output, const int64_t grad_output_stride[4],
                                  void *grad_input, const int64_t grad_input_stride[4], void *grad_kernel,
                                  const int64_t grad_kernel_stride[4], int dtype, void *stream) {
+    return ebfi_fac_backward_ex(input, input_shape, input_stride, kernel, kernel_shape, kernel_stride, kernel_size, grad_output,
+                                grad_output_stride, grad_input, grad_input_stride, grad_kernel, grad_kernel_stride, 1.f, dtype,
+                                stream);
+}
+
+// kernel_leaky_slope != 1: the filters are the output of a LeakyReLU(kernel_leaky_slope) layer and grad_kernel leaves as the
+// gradient of that layer's PRE-activation (multiplied by 1 where kernel > 0, by the slope elsewhere) -- the conv that
+// produced the filters then needs neither its saved output nor a grad*act' side tensor in its own backward
+extern "C" int ebfi_fac_backward_ex(const void *input, const int64_t input_shape[4], const int64_t input_stride[4],
+                                    const void *kernel, const int64_t kernel_shape[4], const int64_t kernel_stride[4],
+                                    int kernel_size, const void *grad_output, const int64_t grad_output_stride[4],
+                                    void *grad_input, const int64_t grad_input_stride[4], void *grad_kernel,
+                                    const int64_t grad_kernel_stride[4], float kernel_leaky_slope, int dtype, void *stream) {
+    const float kslope = kernel_leaky_slope;
     if (!input || !kernel || !grad_output || !input_shape || !input_stride || !kernel_shape || !kernel_stride ||
         !grad_output_stride)
         return fail(EBFI_ERR_ARG, "fac_backward: null argument");
@@ -371,9 +397,9 @@ extern "C" int ebfi_fac_backward(const void *input, const int64_t input_shape[4]
     const bool fast = (K == 1 || K == 3 || K == 5) && (Wo % 4 == 0) && is.s3 == 1 && vec4_ok(kern, ks) &&
                       vec4_ok(go, gs) && (!gk || vec4_ok(gk, gks)) && (!gin || gis.s3 == 1) && B * C <= 65535;
     if (fast) {
-        if (K == 5) launch_bwd_rows<5>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, (int)B, (int)C, (int)Ho, (int)Wo);
-        else if (K == 3) launch_bwd_rows<3>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, (int)B, (int)C, (int)Ho, (int)Wo);
-        else launch_bwd_rows<1>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, (int)B, (int)C, (int)Ho, (int)Wo);
+        if (K == 5) launch_bwd_rows<5>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, (int)B, (int)C, (int)Ho, (int)Wo, kslope);
+        else if (K == 3) launch_bwd_rows<3>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, (int)B, (int)C, (int)Ho, (int)Wo, kslope);
+        else launch_bwd_rows<1>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, (int)B, (int)C, (int)Ho, (int)Wo, kslope);
         return check_launch("fac_bwd_rows_f32");
     }
     if (gin) {
@@ -387,7 +413,7 @@ extern "C" int ebfi_fac_backward(const void *input, const int64_t input_shape[4]
         const int64_t total = B * C * K * K * Ho * Wo;
         ProfScope ps("fac_bwd_kernel_generic_f32", st);
         hipLaunchKernelGGL(fac_bwd_kernel_generic_f32, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, in, is,
-                           go, gs, gk, gks, total, (int)C, (int)Ho, (int)Wo, K);
+                           go, gs, gk, gks, total, (int)C, (int)Ho, (int)Wo, K, kern, ks, kslope);
     }
     return check_launch("fac_bwd_kernel_generic_f32");
 }

@@ -37,6 +37,7 @@ SIGNATURES = {
     "ebfi_last_error": (_c.c_char_p, []),
     "ebfi_fac_forward": (_i, [_vp, _p64, _p64, _vp, _p64, _p64, _i, _vp, _p64, _p64, _i, _vp]),
     "ebfi_fac_backward": (_i, [_vp, _p64, _p64, _vp, _p64, _p64, _i, _vp, _p64, _vp, _p64, _vp, _p64, _i, _vp]),
+    "ebfi_fac_backward_ex": (_i, [_vp, _p64, _p64, _vp, _p64, _p64, _i, _vp, _p64, _vp, _p64, _vp, _p64, _c.c_float, _i, _vp]),
     "ebfi_dcn_forward": (_i, [_vp] * 6 + [_i] * 14 + [_i, _vp]),
     "ebfi_dcn_backward_workspace": (_sz, [_i] * 14 + [_i]),
     "ebfi_dcn_backward": (_i, [_vp] * 11 + [_i] * 14 + [_vp, _sz, _i, _vp]),

@@ -79,7 +79,9 @@ def _geo(x, weight, stride, pad):
 
 class ConvBiasAct(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, act, slope):
+    def forward(ctx, x, weight, bias, stride, pad, act, slope, grad_preact=False):
+        """grad_preact: the gradient that will arrive in backward is already the gradient of the PRE-activation (its producer
+        applied act' -- e.g. the FAC backward with kernel_leaky_slope): backward then runs as for act = none."""
         x, weight = x.contiguous(), weight.contiguous()
         geo = _geo(x, weight, stride, pad)
         k = geo[5]
@@ -96,6 +98,8 @@ class ConvBiasAct(Function):
                 rc = lib.ebfi_conv2d_forward(N.ptr(x), N.ptr(weight), bptr, N.ptr(out), *geo, act, slope, N.EBFI_F32,
                                              N.stream_ptr(x.device))
         N.check(rc, "ebfi_conv2d_forward")
+        if grad_preact:
+            act, slope = ACT_NONE, 0.0
         ctx.cfg = (stride, pad, act, slope, bias is not None)
         ctx.save_for_backward(x, weight, out if act != ACT_NONE else None)
         return out
@@ -158,7 +162,7 @@ class ConvBiasAct(Function):
                     rc = lib.ebfi_conv2d_backward_data(N.ptr(up), N.ptr(None), N.ptr(weight), N.ptr(gx), *geo1, ACT_NONE, 0.0,
                                                        N.EBFI_F32, st)
                 N.check(rc, "ebfi_conv2d_backward_data")
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None
 
 
 def _act_grad(y, act, slope):
@@ -174,7 +178,7 @@ class SiteConvBiasAct(Function):
     they are inputs only so that autograd routes the gradients; their values are read from the bank."""
 
     @staticmethod
-    def forward(ctx, x, site, pad, act, slope, *params):
+    def forward(ctx, x, site, pad, act, slope, grad_preact, *params):
         x = x.contiguous()
         B, Cin, H, W = (int(v) for v in x.shape)
         if Cin != site.K:
@@ -186,6 +190,8 @@ class SiteConvBiasAct(Function):
             rc = N.lib().ebfi_conv2d_forward_bf16x3(N.ptr(x), N.ptr(None), N.ptr(site.bias()), N.ptr(out), *geo, act, slope,
                                                     site.fwd_ptr(), site.fwd_bytes, N.stream_ptr(x.device))
         N.check(rc, "ebfi_conv2d_forward_bf16x3 (packed)")
+        if grad_preact:                      # the incoming gradient is already that of the pre-activation
+            act, slope = ACT_NONE, 0.0
         ctx.site, ctx.cfg, ctx.geo = site, (act, slope), geo
         ctx.save_for_backward(x, out if act != ACT_NONE else None)
         return out
@@ -197,7 +203,7 @@ class SiteConvBiasAct(Function):
         gout = gout.contiguous()
         lib = N.lib()
         need_x = ctx.needs_input_grad[0]
-        need_p = any(ctx.needs_input_grad[5:])
+        need_p = any(ctx.needs_input_grad[6:])
         gx, pgrads = None, [None] * (len(site.w_shapes) + len(site.b_shapes))
         with torch.cuda.device_of(x):
             st = N.stream_ptr(x.device)
@@ -219,7 +225,7 @@ class SiteConvBiasAct(Function):
                 rc = lib.ebfi_conv2d_backward_data_bf16x3(N.ptr(src), N.ptr(sy), N.ptr(None), N.ptr(gx), *geo, a,
                                                           slope if a != ACT_NONE else 0.0, site.tr_ptr(), site.tr_bytes, st)
                 N.check(rc, "ebfi_conv2d_backward_data_bf16x3 (packed)")
-        return (gx, None, None, None, None) + tuple(pgrads)
+        return (gx, None, None, None, None, None) + tuple(pgrads)
 
 
 def _route_site_grads(site, gw2, gb2, st):
@@ -252,14 +258,14 @@ def site_usable(site, x, stride=1):
             x.dim() == 4 and x.shape[1] == site.K)
 
 
-def conv_site(x, site, padding, act, slope, weights, biases):
+def conv_site(x, site, padding, act, slope, weights, biases, grad_preact=False):
     """The convolution of bank site `site` (weights / biases: its source parameters, for gradient routing)."""
-    return SiteConvBiasAct.apply(x, site, int(padding), int(act), float(slope), *weights, *biases)
+    return SiteConvBiasAct.apply(x, site, int(padding), int(act), float(slope), bool(grad_preact), *weights, *biases)
 
 
-def conv_bias_act(x, weight, bias, stride=1, padding=0, act=ACT_NONE, slope=0.0):
+def conv_bias_act(x, weight, bias, stride=1, padding=0, act=ACT_NONE, slope=0.0, grad_preact=False):
     from . import weightbank
     site = weightbank.lookup(weight, "id")
     if site_usable(site, x, stride) and (bias is not None) == site.has_bias and len(site.w_shapes) == 1:
-        return conv_site(x, site, padding, act, slope, [weight], [bias] if bias is not None else [])
-    return ConvBiasAct.apply(x, weight, bias, int(stride), int(padding), int(act), float(slope))
+        return conv_site(x, site, padding, act, slope, [weight], [bias] if bias is not None else [], grad_preact)
+    return ConvBiasAct.apply(x, weight, bias, int(stride), int(padding), int(act), float(slope), bool(grad_preact))

@@ -32,7 +32,9 @@ def fac_forward(input_pad, kernel, kernel_size, out=None):
     return out
 
 
-def fac_backward(input_pad, kernel, kernel_size, grad_output, need_input=True, need_kernel=True):
+def fac_backward(input_pad, kernel, kernel_size, grad_output, need_input=True, need_kernel=True, kernel_leaky_slope=None):
+    """`kernel_leaky_slope`: the filters came out of a LeakyReLU(slope) layer and grad_kernel is wanted as the gradient of
+    that layer's pre-activation (None = plain grad_kernel)."""
     N.require_gpu(input_pad, kernel, grad_output)
     gin = torch.empty_like(input_pad, memory_format=torch.contiguous_format) if need_input else None
     gk = torch.empty_like(kernel, memory_format=torch.contiguous_format) if need_kernel else None
@@ -40,12 +42,13 @@ def fac_backward(input_pad, kernel, kernel_size, grad_output, need_input=True, n
     if kernel.numel() == 0:
         return gin, gk
     with torch.cuda.device_of(input_pad):
-        rc = N.lib().ebfi_fac_backward(
+        rc = N.lib().ebfi_fac_backward_ex(
             N.ptr(input_pad), N.i64x4(input_pad.shape), N.i64x4(input_pad.stride()),
             N.ptr(kernel), N.i64x4(kernel.shape), N.i64x4(kernel.stride()), int(kernel_size),
             N.ptr(grad_output), N.i64x4(grad_output.stride()),
             N.ptr(gin), N.i64x4(gin.stride()) if gin is not None else unit,
             N.ptr(gk), N.i64x4(gk.stride()) if gk is not None else unit,
+            1.0 if kernel_leaky_slope is None else float(kernel_leaky_slope),
             N.dtype_code(input_pad), N.stream_ptr(input_pad.device))
     N.check(rc, "ebfi_fac_backward")
     return gin, gk
@@ -53,8 +56,12 @@ def fac_backward(input_pad, kernel, kernel_size, grad_output, need_input=True, n
 
 class KernelConv2DFunction(Function):
     @staticmethod
-    def forward(ctx, input, kernel, kernel_size):
+    def forward(ctx, input, kernel, kernel_size, kernel_leaky_slope=None):
+        """`kernel_leaky_slope` (extension of the reference signature, default None = reference behaviour): see fac_backward;
+        only for a `kernel` whose ONLY consumer is this op and whose producer runs with conv.conv_bias_act(...,
+        grad_is_preact=True)."""
         ctx.kernel_size = kernel_size
+        ctx.kernel_leaky_slope = kernel_leaky_slope
         assert input.is_contiguous()
         assert kernel.is_contiguous()
         assert ctx.kernel_size == int((kernel.size(1) / input.size(1)) ** 0.5)
@@ -72,8 +79,8 @@ class KernelConv2DFunction(Function):
         if not grad_output.is_cuda:
             raise NotImplementedError()
         gin, gk = fac_backward(input, kernel, ctx.kernel_size, grad_output,
-                               ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        return gin, gk, None
+                               ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.kernel_leaky_slope)
+        return gin, gk, None, None
 
 
 class KernelConv2D(nn.Module):
@@ -84,5 +91,5 @@ class KernelConv2D(nn.Module):
         r = (kernel_size - 1) // 2
         self.pad = nn.ReplicationPad2d([r, r, r, r])
 
-    def forward(self, input, kernel):
-        return KernelConv2DFunction.apply(self.pad(input), kernel, self.kernel_size)
+    def forward(self, input, kernel, kernel_leaky_slope=None):
+        return KernelConv2DFunction.apply(self.pad(input), kernel, self.kernel_size, kernel_leaky_slope)

@@ -50,12 +50,24 @@ class ConvLayer(nn.Module):
         elif norm == "IN":
             self.norm_layer = nn.InstanceNorm2d(out_channels, track_running_stats=True)
 
-    def forward(self, x):
+    def native(self, x):
+        """(act code, slope) when this layer runs as ONE fused native kernel on `x`, else None."""
         c = self.conv2d
         fuse = conv.activation_code(self.activation) if self.norm not in ("BN", "IN") else None
         if fuse is not None and not torch.is_autocast_enabled() and \
                 conv.supported(x, c.weight, c.stride, c.padding, c.dilation, c.groups):
-            return conv.conv_bias_act(x, c.weight, c.bias, c.stride[0], c.padding[0], fuse[0], fuse[1])
+            return fuse
+        return None
+
+    def forward(self, x, grad_is_preact=False):
+        """grad_is_preact (native path only): the consumer of the output hands back the gradient of the PRE-activation
+        (see fac.KernelConv2DFunction kernel_leaky_slope), so backward needs no saved output."""
+        c = self.conv2d
+        fuse = self.native(x)
+        if fuse is not None:
+            return conv.conv_bias_act(x, c.weight, c.bias, c.stride[0], c.padding[0], fuse[0], fuse[1], grad_is_preact)
+        if grad_is_preact:
+            raise RuntimeError("grad_is_preact needs the fused native conv kernel")
         if x.shape[-2:] == (1, 1) and c.kernel_size == (1, 1) and c.groups == 1:
             y = F.linear(x.flatten(1), c.weight.flatten(1), c.bias)[:, :, None, None]   # scalar-conditioned scales
         else:
@@ -184,8 +196,17 @@ class Modification(BaseModel):
 
     def forward(self, FrameTensor, EventTensor):
         ev = self.Conv1(EventTensor)
-        filters = self.KernelConv(torch.cat([ev, FrameTensor], dim=1))
-        ev1 = self.Conv3(self.KPN(ev, filters))
+        cat = torch.cat([ev, FrameTensor], dim=1)
+        fuse = self.KernelConv.native(cat)
+        import os
+        if fuse is not None and fuse[0] == conv.ACT_LEAKY and ev.is_cuda and os.environ.get("EBFI_NO_PREACT", "0") != "1":
+            # the 1600-channel filter tensor has one consumer, the FAC op: its backward returns the gradient of the filters'
+            # PRE-activation (kernel > 0 ? g : slope*g), so the 128 -> 1600 conv's weight / data gradient neither re-read the
+            # 839 MB saved output for act' nor write / read a grad*act' side tensor of that size
+            filters = self.KernelConv(cat, grad_is_preact=True)
+            ev1 = self.Conv3(self.KPN(ev, filters, kernel_leaky_slope=fuse[1]))
+        else:
+            ev1 = self.Conv3(self.KPN(ev, self.KernelConv(cat)))
         return FrameTensor * ev1 + self.Conv2(ev1)
 
 

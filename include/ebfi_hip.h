@@ -79,6 +79,17 @@ int ebfi_fac_backward(const void *input, const int64_t input_shape[4], const int
                       void *grad_kernel, const int64_t grad_kernel_stride[4],
                       int dtype, void *stream);
 
+/* Same, with grad_kernel leaving as the gradient of the PRE-activation of the LeakyReLU(kernel_leaky_slope) layer that produced
+ * the filters (KernelConv + FAC in Modification, reference models/Ours/model_singleframe.py:161-162): grad_kernel is
+ * multiplied by 1 where kernel > 0 and by the slope elsewhere.  kernel_leaky_slope = 1 is ebfi_fac_backward exactly. */
+int ebfi_fac_backward_ex(const void *input, const int64_t input_shape[4], const int64_t input_stride[4],
+                         const void *kernel, const int64_t kernel_shape[4], const int64_t kernel_stride[4],
+                         int kernel_size,
+                         const void *grad_output, const int64_t grad_output_stride[4],
+                         void *grad_input, const int64_t grad_input_stride[4],
+                         void *grad_kernel, const int64_t grad_kernel_stride[4],
+                         float kernel_leaky_slope, int dtype, void *stream);
+
 /* ------------------------------------------------------------------ DCNv2 (modulated deformable conv)
  * All tensors contiguous NCHW:
  *   input [B,C,H,W]  weight [Co,C,kh,kw]  bias [Co]

@@ -135,6 +135,19 @@ def test_hd_config5_size_64bit_indexing():
         assert _rel(gx[b:b + 1, cs].cpu(), gx_ref) < 1e-5 and _rel(gk[b:b + 1, ks].cpu(), gk_ref) < 1e-5
 
 
+def test_backward_with_filter_activation_mask():
+    """ebfi_fac_backward_ex: grad_kernel as the gradient of the LeakyReLU pre-activation that produced the filters (fast row
+    kernel and generic kernel), against masking the oracle's grad_kernel; grad_input unchanged."""
+    from ebfi_amd.fac import fac_backward
+    torch.manual_seed(17)
+    for (B, C, H, W, K) in [(2, 4, 12, 16, 5), (1, 3, 9, 10, 3), (1, 2, 7, 9, 5)]:      # last two: generic path (W % 4 != 0)
+        x, k, g = torch.randn(B, C, H + K - 1, W + K - 1), torch.randn(B, C * K * K, H, W), torch.randn(B, C, H, W)
+        gx_ref, gk_ref = ref_ops.fac_backward(x, k, K, g)
+        gx, gk = fac_backward(x.cuda(), k.cuda(), K, g.cuda(), kernel_leaky_slope=0.01)
+        assert _rel(gx.cpu(), gx_ref) < 1e-5
+        assert _rel(gk.cpu(), gk_ref * torch.where(k > 0, torch.ones_like(k), torch.full_like(k, 0.01))) < 1e-5
+
+
 def test_empty_batch():
     from ebfi_amd.fac import fac_forward
     out = fac_forward(torch.zeros(0, 2, 8, 8).cuda(), torch.zeros(0, 18, 6, 6).cuda(), 3)
