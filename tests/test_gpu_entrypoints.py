@@ -84,3 +84,21 @@ def test_graph_replay_step_equals_eager_step():
     assert len(engines[1]._graphs) == 1 and engines[1].bucket.views_intact()
     for (n, a), b in zip(engines[0].model.named_parameters(), engines[1].model.parameters()):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), n
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs on the node (the round's GPU box has one)")
+def test_bench_two_gpus_rccl():
+    """bench.py with 2 ranks on 2 GPUs over RCCL (backend 'nccl'): the hipGraph capture of forward + loss + backward happens
+    with the RCCL communicator (and its watchdog thread) alive -- Engine captures with capture_error_mode='thread_local' --
+    and the replicas must stay bit-identical after the timed steps (bench.py compares per-rank parameter checksums)."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29641", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-extra-legs"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["config"]["collective_backend"] == "nccl"
+    assert d["config"]["replica_param_checksum"]["ranks_identical"] is True
+    assert "hipGraph replay" in d["config"]["launch"]
