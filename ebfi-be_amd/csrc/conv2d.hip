@@ -689,6 +689,120 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_db(const float *__restric
     };
 
     const int nchunks = K16 / CKB;
+    // operand fragments of tap t+1 are fetched from LDS before the MFMAs of tap t are issued (two register sets)
+    bf16x8 ah[2][MT], al[2][MT], bh[2][2], bl[2][2];
+    auto tap_read = [&](const char *base, int tap, int set) {
+        const int ky = tap / KS, kx = tap - ky * KS;
+        const char *bp = base + pbase * 32 + (int)(((fbits >> tap) & 1u) << 4) + (ky * IW + kx) * 32;
+        const char *ap = base + a_lane + tap * COS * 32;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            ah[set][m] = *reinterpret_cast<const bf16x8 *>(ap + m * 1024);
+            al[set][m] = *reinterpret_cast<const bf16x8 *>(ap + m * 1024 + WB);
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            bh[set][n] = *reinterpret_cast<const bf16x8 *>(bp + n * 1024);
+            bl[set][n] = *reinterpret_cast<const bf16x8 *>(bp + n * 1024 + INB);
+        }
+    };
+    auto tap_mfma = [&](int set) {
+#ifdef KB_NO_MFMA                         // ablation (harness only): keep the operand reads alive, issue no matrix work
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { asm volatile("" ::"v"(ah[set][m]), "v"(al[set][m])); }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) { asm volatile("" ::"v"(bh[set][n]), "v"(bl[set][n])); }
+        return;
+#endif
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[set][m], bh[set][n], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][m], bl[set][n], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][m], bh[set][n], acc[m][n], 0, 0, 0);
+            }
+    };
+    // P15: the commit of chunk c+1 hidden behind the matrix work of chunk c (3x3, dword loads, no activation derivative).  In
+    // the plain form a chunk costs 4.9 us against 3.45 us of matrix work (in-kernel stamps): ~0.9 us of it is the commit
+    // (conversion + LDS writes, with the load latency in front) and the barrier skew it causes, during which no wave of the
+    // CU has matrix work.  Here the inputs of chunk c+1 are loaded in front of taps 0..3 of chunk c and converted / written
+    // to the other LDS buffer in four slices behind taps 5..8 (each slice waits only for ITS loads, issued >= 4 taps
+    // earlier); only the five weight pieces are committed at the chunk's end.  (A second register set for a two-chunk
+    // distance does not fit: 256 VGPRs + 123 spills, 3.5x slower -- measured.)
+    constexpr bool P15 = !QLD && DACT == 0 && KS == 3 && NPOS == 2;
+    if constexpr (P15) {
+        auto load_inputs = [&](int chunk, int l0, int l1) {
+            const unsigned cb = (unsigned)chunk * (unsigned)CKB * plane_bytes;
+#pragma unroll
+            for (int l = l0; l < l1; ++l) {
+                const int q = l / CKB, ci = l - q * CKB;
+                rin[l] = buf_ld(rx, in_off[q] + cb + (unsigned)ci * plane_bytes);
+            }
+        };
+        auto load_weights = [&](int chunk, int i0, int i1) {
+            const unsigned wb = (unsigned)chunk * (unsigned)(CKB * 2);
+#pragma unroll
+            for (int it = i0; it < i1; ++it)
+                if (it < NWB) rw[it] = __builtin_amdgcn_raw_buffer_load_b128(rwt, w_off[it] + wb, 0, 0);
+        };
+        // slice sl in 0..3: position sl >> 1, channel half sl & 1 -> the hi and the lo 16-byte piece of that half
+        // (loads 8*sl .. 8*sl+7 in issue order)
+        auto commit_slice = [&](int buf, int sl) {
+            const int q = sl >> 1, hf = sl & 1;
+            if (tid + q * NTB < PS) {
+                u32x4 hv, lv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v0 = rin[q * CKB + 8 * hf + 2 * j], v1 = rin[q * CKB + 8 * hf + 2 * j + 1];
+                    const __bf16 a0 = (__bf16)v0, a1 = (__bf16)v1;
+                    hv[j] = pack_bf16((float)a0, (float)a1);
+                    lv[j] = pack_bf16(v0 - (float)a0, v1 - (float)a1);
+                }
+                char *dst = smd + buf * BUFB + (hf ? (in_dst[q] ^ 16) : in_dst[q]);
+                *reinterpret_cast<u32x4 *>(dst) = hv;
+                *reinterpret_cast<u32x4 *>(dst + INB) = lv;
+            }
+        };
+        auto commit_weights = [&](int buf) {
+            char *base = smd + buf * BUFB;
+#pragma unroll
+            for (int it = 0; it < NWB; ++it)
+                if (tid + it * NTB < 2 * WPIECES) *reinterpret_cast<u32x4 *>(base + w_dst[it]) = rw[it];
+        };
+        KB_STAMP(0);
+        load_inputs(0, 0, NPOS * CKB);
+        load_weights(0, 0, NWB);
+        KB_STAMP(1);
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) commit_slice(0, sl);
+        commit_weights(0);
+        __syncthreads();
+        KB_STAMP(2);
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const char *base = smd + (chunk & 1) * BUFB;
+            const int nb = (chunk & 1) ^ 1;
+            if (chunk < 6) KB_STAMP(3 + 4 * chunk);
+            tap_read(base, 0, 0);
+#pragma unroll
+            for (int tap = 0; tap < KK; ++tap) {
+                if (tap + 1 < KK) tap_read(base, tap + 1, (tap + 1) & 1);
+#ifndef KB_NO_LOADS
+                if (tap < 4) load_inputs(chunk + 1, 8 * tap, 8 * tap + 8);   // past the last chunk: out of range, reads 0
+                if (tap == 4) load_weights(chunk + 1, 0, NWB);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                tap_mfma(tap & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (tap >= 5) commit_slice(nb, tap - 5);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (chunk < 6) KB_STAMP(5 + 4 * chunk);
+            commit_weights(nb);
+            __syncthreads();
+            if (chunk < 6) KB_STAMP(6 + 4 * chunk);
+        }
+    } else {
     KB_STAMP(0);
     prefetch(0);
     KB_STAMP(1);
@@ -698,45 +812,10 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_db(const float *__restric
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const char *base = smd + (chunk & 1) * BUFB;
         if (chunk < 6) KB_STAMP(3 + 4 * chunk);
-        // operand fragments of tap t+1 are fetched from LDS before the MFMAs of tap t are issued (two register sets), and
-        // the global loads of the next chunk ride between the taps
-        bf16x8 ah[2][MT], al[2][MT], bh[2][2], bl[2][2];
-        auto tap_read = [&](int tap, int set) {
-            const int ky = tap / KS, kx = tap - ky * KS;
-            const char *bp = base + pbase * 32 + (int)(((fbits >> tap) & 1u) << 4) + (ky * IW + kx) * 32;
-            const char *ap = base + a_lane + tap * COS * 32;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                ah[set][m] = *reinterpret_cast<const bf16x8 *>(ap + m * 1024);
-                al[set][m] = *reinterpret_cast<const bf16x8 *>(ap + m * 1024 + WB);
-            }
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                bh[set][n] = *reinterpret_cast<const bf16x8 *>(bp + n * 1024);
-                bl[set][n] = *reinterpret_cast<const bf16x8 *>(bp + n * 1024 + INB);
-            }
-        };
-        auto tap_mfma = [&](int set) {
-#ifdef KB_NO_MFMA                         // ablation (harness only): keep the operand reads alive, issue no matrix work
-#pragma unroll
-            for (int m = 0; m < MT; ++m) { asm volatile("" ::"v"(ah[set][m]), "v"(al[set][m])); }
-#pragma unroll
-            for (int n = 0; n < 2; ++n) { asm volatile("" ::"v"(bh[set][n]), "v"(bl[set][n])); }
-            return;
-#endif
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[set][m], bh[set][n], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][m], bl[set][n], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][m], bh[set][n], acc[m][n], 0, 0, 0);
-                }
-        };
-        tap_read(0, 0);
+        tap_read(base, 0, 0);
 #pragma unroll
         for (int tap = 0; tap < KK; ++tap) {
-            if (tap + 1 < KK) tap_read(tap + 1, (tap + 1) & 1);
+            if (tap + 1 < KK) tap_read(base, tap + 1, (tap + 1) & 1);
 #ifndef KB_NO_LOADS
             if (tap < NLG) prefetch_group(chunk + 1, tap);     // past the last chunk every offset is out of range: reads 0
 #endif
@@ -749,6 +828,7 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_db(const float *__restric
         if (chunk < 6) KB_STAMP(5 + 4 * chunk);
         __syncthreads();
         if (chunk < 6) KB_STAMP(6 + 4 * chunk);
+    }
     }
     if (epi.addend != nullptr || epi.mask_y != nullptr)
         store_out_tile<MT, true>(out, bias, acc, g, b, co_base, y0 + wave, x0, lane, act, slope, epi);
