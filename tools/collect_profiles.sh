@@ -3,7 +3,7 @@
 # One GPU step after the other; a failing step stops the script (no retries).
 set -eo pipefail
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
-OUT=gpurun_out/final
+OUT=gpurun_out/${1:-final}
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 echo "[1] smoke"; timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
@@ -11,6 +11,9 @@ echo "[2] bench (default, with cpu baseline)"; timeout -k 10 600 python bench.py
 echo "[3] rocprofv3 kernel stats of the bench command"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs > $OUT/bench_prof.json 2> $OUT/bench_prof.err
 find $OUT/prof -name "*kernel_trace*" -delete; find $OUT/prof -name "*.csv" | head
+echo "[3b] timeline of graph-replayed steps"
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o g -- python3 tools/graphprof.py --steps 12 > $OUT/graphprof.log 2>&1
+f=$(find $OUT/trace -name "*kernel_trace.csv" | head -1); python3 tools/trace_summary.py $f 0.5 > $OUT/graph_replay_timeline.txt; rm -rf $OUT/trace; head -5 $OUT/graph_replay_timeline.txt
 echo "[4] PMC passes (eager launches), FETCH_SIZE then WRITE_SIZE"
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs --no-graph > /dev/null 2> $OUT/pmc_$C.err
@@ -19,6 +22,8 @@ python3 tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE > $OUT/pmc_
 rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
 echo "[5] op microbenchmarks"
 timeout -k 10 300 python tools/opbench.py --ops fac,dcn,conv --x3 --iters 20 > $OUT/opbench_x3.jsonl 2> $OUT/opbench_x3.err
+echo "[5b] kernel harness (in-kernel stamps of the forward kernel, weight gradient)"
+( for a in "64 64" "128 64" "64 128" "128 1600"; do timeout -k 5 60 tools/bin/kbench fwd $a 128 128 8; timeout -k 5 60 tools/bin/kbench wgrad $a 128 128 8; done ) > $OUT/kbench.log 2>&1 || true
 timeout -k 10 300 python tools/opbench.py --ops conv --iters 20 > $OUT/opbench_fp32.jsonl 2> $OUT/opbench_fp32.err
 timeout -k 10 300 python tools/opbench.py --ops fac,dcn --iters 40 > $OUT/opbench_dcn_fac.jsonl 2> $OUT/opbench_dcn_fac.err; tail -1 $OUT/opbench_dcn_fac.jsonl | cut -c1-220
 echo "[6] other BASELINE configs"
