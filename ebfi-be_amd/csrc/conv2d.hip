@@ -1089,8 +1089,13 @@ __device__ __forceinline__ void peel(const unsigned (&w)[8], bf16x8 &hi, bf16x8 
 
 template <int KS> struct X3CIB { static constexpr int value = KS == 7 ? 16 : 64; };   // input channels per workgroup
 
-template <int KS, int WTXO, int DACT>
-__global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x, const float *__restrict__ gout,
+// WX = threads per workgroup, CIBT = input channels per workgroup (0: the default of X3CIB).  <512, 64>: one workgroup
+// of 8 waves per CU (121 KB of LDS).  <256, 32>: 78 KB, TWO workgroups per CU -- each keeps its own tile in flight and
+// they run out of phase, so one's staging loads / commit overlap the other's matrix block (the tile loop of the
+// one-per-CU form is paced by load latency: see the note at `Stage`); the grad_out tile is then fetched once per
+// 32-channel block instead of once per 64.
+template <int KS, int WTXO, int DACT, int WX, int CIBT>
+__global__ __launch_bounds__(WX) void conv_wgrad_x3(const float *__restrict__ x, const float *__restrict__ gout,
                                                      const float *__restrict__ yact, float *__restrict__ slab,
                                                      float *__restrict__ gpre_out, ConvGeom g, float dslope, int total_tiles,
                                                      int need_bias) {
@@ -1098,12 +1103,13 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
     constexpr int KK = KS * KS, WTX = C::WTX, IH = C::IH, IW = C::IW;
     constexpr int IWP = 32;                // lanes per staged input row; a 32-px tile has IW = 34: columns 32, 33 go separately
     constexpr int EXC = IW > IWP ? IW - IWP : 0;
-    constexpr int CIB = X3CIB<KS>::value, PS = C::PS, IWS = C::IWS;   // 7x7: 16 input channels (784 columns) per workgroup
+    constexpr int CIB = CIBT ? CIBT : X3CIB<KS>::value, PS = C::PS, IWS = C::IWS;   // 7x7: 16 input channels (784 columns) per workgroup
+    constexpr int WXT = WX, NW64 = WX / 64, NQ = WX / 128;   // thread rows of 64 slots; column groups of the waves
     constexpr int TROWS = WXT / IWP;       // thread rows walking (row, channel) of the input tile
     constexpr int CPR = CIB / TROWS;       // channel steps per input row
     constexpr int NI = IH * CPR;           // input elements per thread per tile
     constexpr int NG = 64 / (WXT / 64);    // grad_out channels per thread per tile (8 thread rows of 64 slots)
-    constexpr int NTW = (CIB * KK + 127) / 128;   // n-tiles (of 32 columns) per wave: 4 column groups
+    constexpr int NTW = (CIB * KK + 32 * NQ - 1) / (32 * NQ);   // n-tiles (of 32 columns) per wave: NQ column groups
     constexpr int BUF = 64 * GS + (CIB + 1) * PS; // words per buffer: grad_out image, channel planes, zero plane
     constexpr int NEX = (EXC * IH * CIB + WXT - 1) / WXT;   // extra-column elements per thread
     static_assert(CIB % TROWS == 0 && WTX <= 32 && IWS >= IW, "tile configuration");
@@ -1114,7 +1120,7 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
     const int grp = co_base / (g.Cout / g.groups);                     // grouped convolution: input channels of this group
     const int ci_cnt = min(CIB, g.Cin - ci_base);
     const int ncols = ci_cnt * KK;
-    const int mt = wave & 1, nq = wave >> 1;   // wave: co tile mt, n-tiles nq, nq+4, nq+8, ...
+    const int mt = wave & 1, nq = wave >> 1;   // wave: co tile mt, n-tiles nq, nq+NQ, nq+2*NQ, ...
     const int tiles_x = (g.Wo + WTX - 1) / WTX, tiles_y = (g.Ho + WTY - 1) / WTY;
     const int HW = g.H * g.W, HWo = g.Ho * g.Wo;
 
@@ -1127,13 +1133,13 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
     int boff[NTW];
 #pragma unroll
     for (int q = 0; q < NTW; ++q) {
-        const int n = (nq + 4 * q) * 32 + (lane & 31);
+        const int n = (nq + NQ * q) * 32 + (lane & 31);
         const int ci = n / KK, tap = n - ci * KK;
         const int ky = tap / KS, kx = tap - ky * KS;
         boff[q] = 64 * GS + ((n < ncols) ? ci * PS + ky * IWS + kx : CIB * PS) + 8 * (lane >> 5);
     }
     const int aoff = (mt * 32 + (lane & 31)) * GS + 8 * (lane >> 5);
-    const bool last_live = (nq + 4 * (NTW - 1)) * 32 < ncols;   // e.g. 18 n-tiles over 4 column groups: 5, 5, 4, 4
+    const bool last_live = (nq + NQ * (NTW - 1)) * 32 < ncols;   // e.g. 18 n-tiles over 4 column groups: 5, 5, 4, 4
     // both buffers start as zero words (= +0.0 pairs): pad slots / pad columns / the zero plane are never written later
     for (int i = tid; i < 2 * BUF; i += WXT) smw[i] = 0u;
 
@@ -1178,7 +1184,7 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
         const unsigned g0 = (gpx < WTX && gy < g.Ho && gx < g.Wo) ? (unsigned)((co_base + gco) * HWo + gy * g.Wo + gx) * 4u : SENT;
 #pragma unroll
         for (int it = 0; it < NG; ++it) {
-            const unsigned o = g0 + (unsigned)(8 * it) * (unsigned)HWo * 4u;   // channels >= Cout fall out of range
+            const unsigned o = g0 + (unsigned)(NW64 * it) * (unsigned)HWo * 4u;   // channels >= Cout fall out of range
             rg[it] = buf_ld(rgo, o);
             if constexpr (DACT != 0) ry[it] = buf_ld(rya, o);
         }
@@ -1211,7 +1217,7 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
         for (int it = 0; it < NG; ++it) {
             if constexpr (DACT != 0) rg[it] *= act_grad_c<DACT>(ry[it], dslope);
             bacc[it] += rg[it];
-            sG[(gco + 8 * it) * GS + gslot] = split_word(rg[it]);
+            sG[(gco + NW64 * it) * GS + gslot] = split_word(rg[it]);
         }
         if (gpre_out != nullptr && blockIdx.z == 0) {   // side output: grad_out * act'(y), consumed by the data gradient
             int t = tile;
@@ -1224,7 +1230,7 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
             const __amdgpu_buffer_rsrc_t rgp = make_rsrc(gpre_out + (int64_t)(live ? b : 0) * g.Cout * HWo, live ? go_bytes : 0u);
             const unsigned o0 = (gpx < WTX && gy < g.Ho && gx < g.Wo) ? (unsigned)((co_base + gco) * HWo + gy * g.Wo + gx) * 4u : SENT;
 #pragma unroll
-            for (int it = 0; it < NG; ++it) buf_st(rgp, o0 + (unsigned)(8 * it) * (unsigned)HWo * 4u, rg[it]);
+            for (int it = 0; it < NG; ++it) buf_st(rgp, o0 + (unsigned)(NW64 * it) * (unsigned)HWo * 4u, rg[it]);
         }
         if (icol < IW) {
 #pragma unroll
@@ -1325,7 +1331,7 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
     const unsigned co_row = (unsigned)(g.Cin * KK) * 4u;
 #pragma unroll
     for (int q = 0; q < NTW; ++q) {
-        const int n = (nq + 4 * q) * 32 + (lane & 31);
+        const int n = (nq + NQ * q) * 32 + (lane & 31);
         const unsigned o0 = n < ncols ? (unsigned)(((co_base + mt * 32 + 4 * (lane >> 5)) * g.Cin + ci_base) * KK + n) * 4u : SENT;
 #ifdef KB_NO_SLAB
         if (g.pad == 12345)
@@ -1339,7 +1345,7 @@ __global__ __launch_bounds__(WXT) void conv_wgrad_x3(const float *__restrict__ x
             float v = bacc[it];
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-            if (lane == 0 && co_base + gco + 8 * it < g.Cout) my[wsz + co_base + gco + 8 * it] = v;
+            if (lane == 0 && co_base + gco + NW64 * it < g.Cout) my[wsz + co_base + gco + NW64 * it] = v;
         }
     }
 }
@@ -1701,29 +1707,51 @@ int launch_wgrad(hipStream_t st, const float *x, const float *gout, const float 
 // whatever its width, so the widest tile = the fewest tiles is always the cheapest.
 int pick_wtx_x3(int) { return 32; }
 
+// Workgroup shape of the split-precision weight gradient: 256 threads x 32 input channels at two workgroups per CU for
+// the 3x3 layers with multiples of 32 input channels and few output-channel blocks, 512 threads x 64 (16 for 7x7) channels
+// otherwise.  Measured (tools/kbench, 128x128, B=8): 64->64 54.5 vs 58.1 us, 128->64 87.1 vs 89.5, 64->128 85.9 vs 86.8,
+// 128->1600 1765 vs 1671 (the grad_out tile is fetched once per 32-channel block: with 25 output blocks that costs more
+// than the second resident workgroup hides).
+bool wgrad_x3_small_wg(const ConvGeom &g, int ks) {
+    const bool off = getenv("EBFI_WGRAD_BIGWG") != nullptr;            // development switch (A/B runs)
+    return !off && ks == 3 && g.Cin % 32 == 0 && g.Cout <= 256;
+}
+
 int wgrad_x3_splits(const ConvGeom &g, int ks) {
     const int wtx = ks == 1 ? wgrad_wtx_rt(g, ks, 1) : pick_wtx_x3(g.Wo);
     const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, wtx);
-    const int64_t blocks = ceil_div(g.Cout, 64) * ceil_div(g.Cin, ks == 7 ? 16 : 64);
-    int64_t s = blocks <= 256 ? 256 / blocks : 1;      // one 512-thread workgroup per CU: fill one round of 256
+    const bool small = wgrad_x3_small_wg(g, ks);
+    const int64_t blocks = ceil_div(g.Cout, 64) * ceil_div(g.Cin, small ? 32 : (ks == 7 ? 16 : 64));
+    const int64_t slots = small ? 512 : 256;           // resident workgroups of the chip: fill one round of them
+    int64_t s = blocks <= slots ? slots / blocks : 1;
     if (s > tiles) s = tiles;
     return (int)(s < 1 ? 1 : s);
+}
+
+template <int KS, int WTXO, int DACT, int WX, int CIBT>
+int launch_wgrad_x3_w(hipStream_t st, const float *x, const float *gout, const float *yact, float *slab, float *gpre_out,
+                      const ConvGeom &g, float dslope, int nsplit, int need_bias) {
+    using C = WCfg<KS, 1, WTXO>;
+    constexpr int CIB = CIBT ? CIBT : X3CIB<KS>::value;
+    const size_t lds = (size_t)2 * (64 * GS + (CIB + 1) * C::PS) * sizeof(unsigned);
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_wgrad_x3<KS, WTXO, DACT, WX, CIBT>), (int)lds)) return rc;
+    const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, C::WTX);
+    dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, CIB));
+    ProfScope ps("conv_wgrad_x3", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS,
+                 conv_bytes_wgrad(g, KS * KS, DACT != 0, gpre_out != nullptr));
+    hipLaunchKernelGGL((conv_wgrad_x3<KS, WTXO, DACT, WX, CIBT>), grid, dim3(WX), lds, st, x, gout, yact, slab, gpre_out, g, dslope,
+                       (int)tiles, need_bias);
+    return check_launch("conv_wgrad_x3");
 }
 
 template <int KS, int WTXO, int DACT>
 int launch_wgrad_x3_d(hipStream_t st, const float *x, const float *gout, const float *yact, float *slab, float *gpre_out,
                       const ConvGeom &g, float dslope, int nsplit, int need_bias) {
-    using C = WCfg<KS, 1, WTXO>;
-    constexpr int CIB = X3CIB<KS>::value;
-    const size_t lds = (size_t)2 * (64 * GS + (CIB + 1) * C::PS) * sizeof(unsigned);
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_wgrad_x3<KS, WTXO, DACT>), (int)lds)) return rc;
-    const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, C::WTX);
-    dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, CIB));
-    ProfScope ps("conv_wgrad_x3", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS,
-                 conv_bytes_wgrad(g, KS * KS, DACT != 0, gpre_out != nullptr));
-    hipLaunchKernelGGL((conv_wgrad_x3<KS, WTXO, DACT>), grid, dim3(WXT), lds, st, x, gout, yact, slab, gpre_out, g, dslope,
-                       (int)tiles, need_bias);
-    return check_launch("conv_wgrad_x3");
+    if constexpr (KS == 3) {
+        if (wgrad_x3_small_wg(g, KS))
+            return launch_wgrad_x3_w<KS, WTXO, DACT, 256, 32>(st, x, gout, yact, slab, gpre_out, g, dslope, nsplit, need_bias);
+    }
+    return launch_wgrad_x3_w<KS, WTXO, DACT, WXT, 0>(st, x, gout, yact, slab, gpre_out, g, dslope, nsplit, need_bias);
 }
 
 template <int KS, int WTXO>

@@ -176,7 +176,8 @@ int main(int argc, char **argv) {
         if (ebfi_conv2d_backward_weight(x, g, y_ref, gw_ref, gb, B, Cin, H, W, Cout, 3, 1, 1, 0, 0.f, wgs, wgb, EBFI_F32, nullptr)) { fprintf(stderr, "%s\n", ebfi_last_error()); return 3; }
         std::vector<Variant> vs;
         vs.push_back({"wgrad fp32 exact (library)", [&] { return ebfi_conv2d_backward_weight(x, g, y_ref, gw, gb, B, Cin, H, W, Cout, 3, 1, 1, 0, 0.f, wgs, wgb, EBFI_F32, nullptr); }, {}});
-        vs.push_back({"wgrad bf16x3 (library)", [&] { return ebfi_conv2d_backward_weight(x, g, y_ref, gw, gb, B, Cin, H, W, Cout, 3, 1, 1, 0, 0.f, wgs, wgb, EBFI_F32_BF16X3MMA, nullptr); }, {}});
+        vs.push_back({"wgrad x3 512 thr x 64 ch, 1 WG/CU", [&] { setenv("EBFI_WGRAD_BIGWG", "1", 1); int rc = ebfi_conv2d_backward_weight(x, g, y_ref, gw, gb, B, Cin, H, W, Cout, 3, 1, 1, 0, 0.f, wgs, wgb, EBFI_F32_BF16X3MMA, nullptr); unsetenv("EBFI_WGRAD_BIGWG"); return rc; }, {}});
+        vs.push_back({"wgrad x3 256 thr x 32 ch, 2 WG/CU", [&] { return ebfi_conv2d_backward_weight(x, g, y_ref, gw, gb, B, Cin, H, W, Cout, 3, 1, 1, 0, 0.f, wgs, wgb, EBFI_F32_BF16X3MMA, nullptr); }, {}});
         vs.push_back({"wgrad bf16x3 act' folded + side out", [&] { return ebfi_conv2d_backward_weight_ex(x, g, y_ref, gw, gb, y, B, Cin, H, W, Cout, 3, 1, 1, 1, 0.01f, wgs, wgb, EBFI_F32_BF16X3MMA, nullptr); }, {}});
         time_variants(vs, 7, 20);
         ebfi_conv2d_backward_weight(x, g, y_ref, gw, gb, B, Cin, H, W, Cout, 3, 1, 1, 0, 0.f, wgs, wgb, EBFI_F32_BF16X3MMA, nullptr);
