@@ -507,7 +507,7 @@ template <int KS, int MT, int DACT, int VEC>
 __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_db(const float *__restrict__ x, const float *__restrict__ dact_y,
                                                           const __bf16 *__restrict__ wp, const float *__restrict__ bias,
                                                           float *__restrict__ out, ConvGeom g, int K16, int act, float slope,
-                                                          float dslope, EpiExtra epi) {
+                                                          float dslope, EpiExtra epi, int tiles_total) {
     constexpr bool QLD = VEC == 4;                     // input tile fetched as 16-byte quads
     constexpr int KK = KS * KS;
     constexpr int IH = TYB - 1 + KS, IW = TX - 1 + KS;
@@ -732,12 +732,34 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_db(const float *__restric
     // distance does not fit: 256 VGPRs + 123 spills, 3.5x slower -- measured.)
     constexpr bool P15 = !QLD && DACT == 0 && KS == 3 && NPOS == 2;
     if constexpr (P15) {
-        auto load_inputs = [&](int chunk, int l0, int l1) {
+        // PERSISTENT over pixel tiles: this workgroup walks tiles blockIdx.x, + gridDim.x, ... of its output-channel
+        // block.  The chunk pipeline runs across the tile boundary: during the LAST chunk of a tile the loads / commit
+        // slices are those of the NEXT tile's first chunk, so a new tile starts its matrix work right after the stores of
+        // the finished one have been issued -- the 6.8 us prologue and most of the 4.3 us store drain of a tile (a third of
+        // a 4-chunk tile) are paid once per workgroup instead of once per tile.
+        const int grp = co_base / (g.Cout / g.groups);
+        auto tile_coords = [&](int tt, int &tb, int &ty0, int &tx0) {
+            int u = tt;
+            const int txi = u % tiles_x; u /= tiles_x;
+            const int tyi = u % tiles_y;
+            tb = u / tiles_y; ty0 = tyi * TYB; tx0 = txi * TX;
+        };
+        auto tile_offsets = [&](int ty0, int tx0, bool live, unsigned (&o)[NPOS]) {
+#pragma unroll
+            for (int q = 0; q < NPOS; ++q) {
+                const int pos = tid + q * NTB;
+                const int r = pos / IW, c = pos - r * IW;
+                const int yy = ty0 - g.pad + r, xx = tx0 - g.pad + c;
+                o[q] = (live && pos < PS && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) ? (unsigned)(yy * g.W + xx) * 4u : SENT;
+            }
+        };
+        auto load_inputs = [&](const float *src, unsigned nbytes, const unsigned (&offs)[NPOS], int chunk, int l0, int l1) {
+            const __amdgpu_buffer_rsrc_t r = make_rsrc(src, nbytes);
             const unsigned cb = (unsigned)chunk * (unsigned)CKB * plane_bytes;
 #pragma unroll
             for (int l = l0; l < l1; ++l) {
                 const int q = l / CKB, ci = l - q * CKB;
-                rin[l] = buf_ld(rx, in_off[q] + cb + (unsigned)ci * plane_bytes);
+                rin[l] = buf_ld(r, offs[q] + cb + (unsigned)ci * plane_bytes);
             }
         };
         auto load_weights = [&](int chunk, int i0, int i1) {
@@ -770,8 +792,10 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_db(const float *__restric
             for (int it = 0; it < NWB; ++it)
                 if (tid + it * NTB < 2 * WPIECES) *reinterpret_cast<u32x4 *>(base + w_dst[it]) = rw[it];
         };
+        int tcur = blockIdx.x, cb_ = b, cy0 = y0, cx0 = x0;
+        const float *xcur = x + in_base;
         KB_STAMP(0);
-        load_inputs(0, 0, NPOS * CKB);
+        load_inputs(xcur, x_bytes, in_off, 0, 0, NPOS * CKB);
         load_weights(0, 0, NWB);
         KB_STAMP(1);
 #pragma unroll
@@ -779,29 +803,68 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_db(const float *__restric
         commit_weights(0);
         __syncthreads();
         KB_STAMP(2);
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
-            const char *base = smd + (chunk & 1) * BUFB;
-            const int nb = (chunk & 1) ^ 1;
-            if (chunk < 6) KB_STAMP(3 + 4 * chunk);
-            tap_read(base, 0, 0);
+        int item = 0;
+        for (;;) {
+            const int tn = tcur + (int)gridDim.x;
+            const bool nlive = tn < tiles_total;
+            int nb_, ny0, nx0;
+            tile_coords(nlive ? tn : 0, nb_, ny0, nx0);
+            unsigned noff[NPOS];
+            tile_offsets(ny0, nx0, nlive, noff);
+            const float *xnext = x + ((int64_t)nb_ * g.groups + grp) * g.Cin * HW;
+            for (int chunk = 0; chunk < nchunks; ++chunk, ++item) {
+                const char *base = smd + (item & 1) * BUFB;
+                const int nb = (item & 1) ^ 1;
+                // what is staged during this chunk: the tile's next chunk, or the first chunk of the next tile
+                const bool last = chunk == nchunks - 1;
+                const float *lsrc = last ? xnext : xcur;
+                const unsigned lbytes = (last && !nlive) ? 0u : x_bytes;      // past the last tile: empty descriptor, reads 0
+                const int lchunk = last ? 0 : chunk + 1;
+                unsigned loff[NPOS];
 #pragma unroll
-            for (int tap = 0; tap < KK; ++tap) {
-                if (tap + 1 < KK) tap_read(base, tap + 1, (tap + 1) & 1);
+                for (int q = 0; q < NPOS; ++q) loff[q] = last ? noff[q] : in_off[q];
+                if (item < 6) KB_STAMP(3 + 4 * item);
+                tap_read(base, 0, 0);
+#pragma unroll
+                for (int tap = 0; tap < KK; ++tap) {
+                    if (tap + 1 < KK) tap_read(base, tap + 1, (tap + 1) & 1);
 #ifndef KB_NO_LOADS
-                if (tap < 4) load_inputs(chunk + 1, 8 * tap, 8 * tap + 8);   // past the last chunk: out of range, reads 0
-                if (tap == 4) load_weights(chunk + 1, 0, NWB);
+                    if (tap < 4) load_inputs(lsrc, lbytes, loff, lchunk, 8 * tap, 8 * tap + 8);
+                    if (tap == 4) load_weights(lchunk, 0, NWB);
 #endif
-                __builtin_amdgcn_sched_barrier(0);
-                tap_mfma(tap & 1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (tap >= 5) commit_slice(nb, tap - 5);
-                __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    tap_mfma(tap & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (tap >= 5) commit_slice(nb, tap - 5);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (item < 6) KB_STAMP(5 + 4 * item);
+                commit_weights(nb);
+                __syncthreads();
+                if (item < 6) KB_STAMP(6 + 4 * item);
             }
-            if (chunk < 6) KB_STAMP(5 + 4 * chunk);
-            commit_weights(nb);
-            __syncthreads();
-            if (chunk < 6) KB_STAMP(6 + 4 * chunk);
+            // the finished tile leaves (stores are asynchronous), the accumulators restart for the next one
+            if (epi.addend != nullptr || epi.mask_y != nullptr)
+                store_out_tile<MT, true>(out, bias, acc, g, cb_, co_base, cy0 + wave, cx0, lane, act, slope, epi);
+            else
+                store_out_tile<MT, false>(out, bias, acc, g, cb_, co_base, cy0 + wave, cx0, lane, act, slope);
+            if (!nlive) break;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+            tcur = tn; cb_ = nb_; cy0 = ny0; cx0 = nx0; xcur = xnext;
+#pragma unroll
+            for (int q = 0; q < NPOS; ++q) in_off[q] = noff[q];
         }
+#ifdef EBFI_KBENCH
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        KB_STAMP(31);
+        KB_FLUSH();
+        return;
     } else {
     KB_STAMP(0);
     prefetch(0);
@@ -1827,8 +1890,8 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
     do {                                                                                                                 \
         if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_bf16x3_db<KS, MT_, DA_, VEC_>), 160 * 1024)) \
             return rc_;                                                                                                  \
-        hipLaunchKernelGGL((conv_fwd_bf16x3_db<KS, MT_, DA_, VEC_>), grid, dim3(NTB), lds, st, x, dact_y, wp, bias, out, g, K16, \
-                           act, slope, dslope, epi);                                                                     \
+        hipLaunchKernelGGL((conv_fwd_bf16x3_db<KS, MT_, DA_, VEC_>), (VEC_ == 1 && DA_ == 0 && KS == 3) ? pgrid : grid,    \
+                           dim3(NTB), lds, st, x, dact_y, wp, bias, out, g, K16, act, slope, dslope, epi, (int)tiles);   \
     } while (0)
 #define EBFI_LAUNCH_X3(MT_, DA_)                                                                                          \
     do {                                                                                                                 \
@@ -1839,6 +1902,13 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
         const bool vec4 = g.W % 4 == 0 && g.pad == KS / 2 && aligned16(x) && (!dact_y || aligned16(dact_y));
         const char *vec_env = getenv("EBFI_CONV_VEC");     // development switch (tools/kbench): 1 = dword loads, 4 = quad loads
         const int vec = !vec4 ? 1 : (vec_env ? atoi(vec_env) : (dact != ACT_NONE ? 4 : 1));
+        // the persistent form (3x3, dword loads, no folded derivative): one round of workgroups, each walking
+        // ceil(tiles / gx) pixel tiles of its output-channel block
+        const int64_t co_blocks = ceil_div(g.Cout, 32 * mt);
+        int64_t gx = 256 / co_blocks;
+        if (gx < 1) gx = 1;
+        if (gx > tiles || getenv("EBFI_CONV_NOPERSIST")) gx = tiles;
+        const dim3 pgrid((unsigned)gx, (unsigned)co_blocks);
         if (mt == 1) {
             if (dact == ACT_LEAKY) EBFI_LAUNCH_X3(1, ACT_LEAKY);
             else if (dact == ACT_SIGMOID) EBFI_LAUNCH_X3(1, ACT_SIGMOID);

@@ -151,7 +151,8 @@ int main(int argc, char **argv) {
         auto fwd = [&] { return ebfi_conv2d_forward_bf16x3(x, w, bias, y, B, Cin, H, W, Cout, 3, 1, 1, 1, 0.01f, ws, wsb, nullptr); };
         auto dg_act = [&] { return ebfi_conv2d_backward_data_bf16x3(g, y_ref, w, gx, B, Cin, H, W, Cout, 3, 1, 1, 1, 0.01f, ws, wsb, nullptr); };
         auto dg = [&] { return ebfi_conv2d_backward_data_bf16x3(g, nullptr, w, gx, B, Cin, H, W, Cout, 3, 1, 1, 0, 0.f, ws, wsb, nullptr); };
-        vs.push_back({"fwd x3 dword ld / dword st", with_vec("1", fwd), {}});
+        vs.push_back({"fwd x3 one tile per workgroup", [&] { setenv("EBFI_CONV_NOPERSIST", "1", 1); int rc = fwd(); unsetenv("EBFI_CONV_NOPERSIST"); return rc; }, {}});
+        vs.push_back({"fwd x3 persistent over tiles", with_vec("1", fwd), {}});
         vs.push_back({"fwd x3 quad ld / dword st", with_vec("4", fwd), {}});
         vs.push_back({"dgrad x3 act' folded, dword", with_vec("1", dg_act), {}});
         vs.push_back({"dgrad x3 act' folded, quad", with_vec("4", dg_act), {}});
