@@ -67,6 +67,8 @@ SIGNATURES = {
     "ebfi_prodmean_forward": (_i, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "ebfi_prodmean_backward": (_i, [_vp] * 5 + [_i64, _i64, _vp]),
     "ebfi_gather_sum": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
+    "ebfi_se_gate_forward": (_i, [_vp] * 7 + [_i, _i, _i64, _i, _c.c_float, _vp]),
+    "ebfi_se_gate_backward": (_i, [_vp] * 11 + [_i, _i, _i64, _i, _c.c_float, _vp]),
     "ebfi_groupnorm_workspace": (_sz, [_i, _i]),
     "ebfi_groupnorm_forward": (_i, [_vp] * 6 + [_i, _i, _i64, _i, _c.c_float, _vp, _sz, _vp]),
     "ebfi_groupnorm_backward": (_i, [_vp] * 8 + [_i, _i, _i64, _i, _vp, _sz, _vp]),

@@ -162,9 +162,59 @@ def conv_transpose3d_d2(x, m):
     return F.pixel_shuffle(y, 2).view(B, m.out_channels, 2, 2 * H, 2 * W)
 
 
-def se_gate(x, attn_conv):
-    """SEGating (resnet_3D.py:89-105): x * sigmoid(W @ mean(x) + b) with the 1x1x1 conv as a matmul."""
+class _SEGate(torch.autograd.Function):
+    """act(x * sigmoid(W mean(x) + b) (+ res)) as two launches forward, three backward (csrc/segate.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, res, act, slope):
+        x = x.contiguous()
+        res = res.contiguous() if res is not None else None
+        B, C = int(x.shape[0]), int(x.shape[1])
+        n = x.numel() // (B * C)
+        w2 = weight.reshape(C, C).contiguous()
+        out = torch.empty_like(x)
+        mean = torch.empty(B * C, dtype=x.dtype, device=x.device)
+        gate = torch.empty(B * C, dtype=x.dtype, device=x.device)
+        with torch.cuda.device_of(x):
+            rc = N.lib().ebfi_se_gate_forward(N.ptr(x), N.ptr(w2), N.ptr(bias), N.ptr(res), N.ptr(out), N.ptr(mean), N.ptr(gate), B, C,
+                                              n, act, slope, N.stream_ptr(x.device))
+        N.check(rc, "ebfi_se_gate_forward")
+        ctx.cfg = (B, C, n, act, slope, res is not None, bias is not None, weight.shape)
+        ctx.save_for_backward(x, w2, gate, mean, out if act != 0 else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w2, gate, mean, out = ctx.saved_tensors
+        B, C, n, act, slope, has_res, has_bias, wshape = ctx.cfg
+        g = g.contiguous()
+        gx = torch.empty_like(x)
+        gres = torch.empty_like(x) if has_res else None
+        gw = torch.empty_like(w2)
+        gb = torch.empty(C, dtype=x.dtype, device=x.device) if has_bias else None
+        ws = torch.empty(2 * B * C, dtype=x.dtype, device=x.device)
+        with torch.cuda.device_of(x):
+            rc = N.lib().ebfi_se_gate_backward(N.ptr(g), N.ptr(out), N.ptr(x), N.ptr(w2), N.ptr(gate), N.ptr(mean), N.ptr(gx), N.ptr(gres),
+                                               N.ptr(gw), N.ptr(gb), N.ptr(ws), B, C, n, act, slope, N.stream_ptr(x.device))
+        N.check(rc, "ebfi_se_gate_backward")
+        return gx, gw.view(wshape), gb, gres, None, None
+
+
+def se_gate(x, attn_conv, res=None, act=0, slope=0.0):
+    """SEGating (resnet_3D.py:89-105) x * sigmoid(W @ mean(x) + b), optionally followed by `+ res` and an activation
+    (act 1 = LeakyReLU(slope), slope 0 = ReLU): what BasicBlock (:137-141) and the decoder stages of UNet3d_18
+    (model_singleframe.py:213-221) do right after the gate."""
+    B, C = x.shape[0], x.shape[1]
+    n = x.numel() // max(B * C, 1)
+    import os
+    if os.environ.get("EBFI_NO_SEGATE", "0") != "1" and \
+            x.is_cuda and x.dtype == torch.float32 and n % 4 == 0 and B * C <= 4096 and attn_conv.in_channels == attn_conv.out_channels == C \
+            and (res is None or res.shape == x.shape) and not torch.is_autocast_enabled():
+        return _SEGate.apply(x, attn_conv.weight, attn_conv.bias, res, int(act), float(slope))
     pooled = x.mean(dim=(2, 3, 4))
     w = attn_conv.weight.view(attn_conv.out_channels, attn_conv.in_channels)
     gate = torch.sigmoid(F.linear(pooled, w, attn_conv.bias))
-    return x * gate[:, :, None, None, None]
+    y = x * gate[:, :, None, None, None]
+    if res is not None:
+        y = y + res
+    return F.leaky_relu(y, slope) if act == 1 else y

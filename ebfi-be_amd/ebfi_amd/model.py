@@ -227,10 +227,15 @@ class SEGating(nn.Module):
         self.pool = nn.AdaptiveAvgPool3d(1)
         self.attn_layer = nn.Sequential(nn.Conv3d(inplanes, inplanes, kernel_size=1, stride=1, bias=True), nn.Sigmoid())
 
-    def forward(self, x):
+    def forward(self, x, res=None, post_act=None):
+        """res / post_act (extensions used by this package's own blocks): add `res` and apply ReLU (post_act = 0.0) or
+        LeakyReLU(post_act) after the gate, fused into the gate's kernels."""
         if fold3d.usable(x):
-            return fold3d.se_gate(x, self.attn_layer[0])
-        return x * self.attn_layer(self.pool(x))
+            return fold3d.se_gate(x, self.attn_layer[0], res, 0 if post_act is None else 1, post_act or 0.0)
+        y = x * self.attn_layer(self.pool(x))
+        if res is not None:
+            y = y + res
+        return y if post_act is None else F.leaky_relu(y, post_act)
 
 
 def _norm3d(bn, ch):
@@ -253,9 +258,8 @@ class BasicBlock(nn.Module):
     def forward(self, x):
         if fold3d.usable(x) and isinstance(self.conv1[1], identity):
             out = fold3d.conv3d_d2(x, self.conv1[0], conv.ACT_LEAKY, 0.0)        # conv + ReLU fused
-            out = self.fg(fold3d.conv3d_d2(out, self.conv2[0]))
             res = x if self.downsample is None else fold3d.conv3d_d2(x, self.downsample[0])
-            return torch.relu(out + res)
+            return self.fg(fold3d.conv3d_d2(out, self.conv2[0]), res, 0.0)      # gate, + residual, ReLU in one stage
         out = self.fg(self.conv2(self.conv1(x)))
         res = x if self.downsample is None else self.downsample(x)
         return self.relu(out + res)
@@ -313,10 +317,12 @@ class Conv_3d(nn.Module):
         self.conv = nn.Sequential(nn.Conv3d(in_ch, out_ch, kernel_size=kernel_size, stride=stride, padding=padding, bias=bias),
                                   SEGating(out_ch), _norm3d(bn, out_ch))
 
-    def forward(self, x):
+    def forward(self, x, post_act=None):
+        """post_act: LeakyReLU slope applied after the block (UNet3d_18 does, model_singleframe.py:213-221), fused into the gate."""
         if fold3d.usable(x) and isinstance(self.conv[2], identity):
-            return self.conv[1](fold3d.conv3d_d2(x, self.conv[0]))
-        return self.conv(x)
+            return self.conv[1](fold3d.conv3d_d2(x, self.conv[0]), None, post_act)
+        y = self.conv(x)
+        return y if post_act is None else F.leaky_relu(y, post_act)
 
 
 class upConv3D(nn.Module):
@@ -330,10 +336,11 @@ class upConv3D(nn.Module):
                     nn.Conv3d(in_ch, out_ch, kernel_size=1, stride=1)]
         self.upconv = nn.Sequential(*head, SEGating(out_ch), _norm3d(bn, out_ch))
 
-    def forward(self, x):
+    def forward(self, x, post_act=None):
         if fold3d.usable(x) and self.upmode == "transpose" and isinstance(self.upconv[2], identity):
-            return self.upconv[1](fold3d.conv_transpose3d_d2(x, self.upconv[0]))
-        return self.upconv(x)
+            return self.upconv[1](fold3d.conv_transpose3d_d2(x, self.upconv[0]), None, post_act)
+        y = self.upconv(x)
+        return y if post_act is None else F.leaky_relu(y, post_act)
 
 
 class UNet3d_18(nn.Module):
@@ -359,9 +366,10 @@ class UNet3d_18(nn.Module):
     def forward(self, img0, img1):
         skips = self.encoder(torch.stack((img0, img1), dim=2))
         y = skips[4]
+        slope = self.lrelu.negative_slope
         for stage, skip in zip(self.decoder[:4], (skips[3], skips[2], skips[1], skips[0])):
-            y = torch.cat([self.lrelu(stage(y)), skip], dim=1)
-        y = self.lrelu(self.decoder[4](y))
+            y = torch.cat([stage(y, slope), skip], dim=1)          # LeakyReLU(0.2) fused into the stage's gate
+        y = self.decoder[4](y, slope)
         y = torch.cat(torch.unbind(y, 2), 1)
         ff, oc = self.feature_fuse[0], self.outconv[1]
         if isinstance(self.feature_fuse[1], identity) and conv.supported(y, ff.weight, ff.stride, ff.padding) and \

@@ -24,6 +24,7 @@
  *   ebfi_conv2d_*               nn.Conv2d + activation inside ConvLayer (models/model_misc/submodules.py:159-200)
  *   ebfi_scale_residual_cat_*   exposure/time-scaled residual + concat of ResidualControl (model_singleframe.py:124-134)
  *   ebfi_prodmean_*             AdaptiveAvgPool2d(1) of a product of two maps (ExposureDecision, model_singleframe.py:66-68)
+ *   ebfi_se_gate_*              SEGating (+ residual + ReLU / LeakyReLU) of the detail branch (models/model_misc/resnet_3D.py:89-141)
  *   ebfi_groupnorm_*            nn.GroupNorm of ExposureDecision (models/Ours/model_singleframe.py:36,66-67)
  *   ebfi_census_*               Ternary census loss (loss/restore.py:108-145)
  *   ebfi_gauss5_*               GaussianConv of the Laplacian-pyramid loss (loss/restore.py:149-163)
@@ -260,6 +261,18 @@ int ebfi_prodmean_backward(const float *a, const float *b, const float *grad_out
  * re-layouts that turn the depth-2 Conv3d / ConvTranspose3d of the detail branch (models/model_misc/resnet_3D.py,
  * model_singleframe.py:170-223) into 2-D convolutions, and their adjoints. */
 int ebfi_gather_sum(const float *src, const int32_t *idx, float *out, int64_t n_out, int R, void *stream);
+
+/* ------------------------------------------------------------------ squeeze-excite gate of the detail branch
+ * SEGating (models/model_misc/resnet_3D.py:89-105) fused with what follows it: out = act(x * sigmoid(W mean(x) + b) (+ res)).
+ * x, res, out: [B*C planes][N] contiguous fp32 (a [B,C,D,H,W] tensor as it stands), N % 4 == 0, B*C <= 4096;
+ * weight [C,C] (the 1x1x1 conv), bias [C] or NULL; act: 0 none, 1 LeakyReLU(slope) (slope 0 = ReLU).
+ * forward writes mean [B*C] and gate [B*C] for the backward; backward workspace: 2*B*C floats; grad_res / grad_bias may
+ * be NULL; `out` may be NULL when act == 0.  Deterministic (fixed-order reductions). */
+int ebfi_se_gate_forward(const float *x, const float *weight, const float *bias, const float *res, float *out, float *mean,
+                         float *gate, int B, int C, int64_t N, int act, float slope, void *stream);
+int ebfi_se_gate_backward(const float *grad_out, const float *out, const float *x, const float *weight, const float *gate,
+                          const float *mean, float *grad_x, float *grad_res, float *grad_weight, float *grad_bias,
+                          float *workspace, int B, int C, int64_t N, int act, float slope, void *stream);
 
 /* ------------------------------------------------------------------ GroupNorm (exposure-decision head)
  * nn.GroupNorm(groups, C) on contiguous NCHW fp32 (reference models/Ours/model_singleframe.py:36,66-67).

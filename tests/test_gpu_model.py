@@ -422,3 +422,38 @@ def test_fused_residual_control_equals_layerwise():
         assert prof0["conv_fwd_bf16x3_db/fwd"][0] == 5 * step and prof0["conv_wgrad_x3"][0] == 5 * step
     finally:
         conv.set_compute_dtype("fp32")
+
+
+def test_se_gate_kernels_vs_torch_cpu():
+    """csrc/segate.hip: SEGating (+ residual + ReLU / LeakyReLU) against the reference formulation
+    x * sigmoid(Conv3d_1x1x1(AdaptiveAvgPool3d(1)(x))) on the CPU (resnet_3D.py:89-105,:137-141): output and all gradients."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from ebfi_amd.model import SEGating
+    torch.manual_seed(23)
+    for (B, C, H, W, res, act) in [(2, 16, 8, 12, True, 0.0), (3, 24, 6, 10, False, 0.2), (1, 8, 5, 8, False, None), (2, 64, 4, 4, True, 0.0)]:
+        gate = SEGating(C)
+        with torch.no_grad():
+            gate.attn_layer[0].weight.copy_(torch.randn_like(gate.attn_layer[0].weight) * 0.5)
+            gate.attn_layer[0].bias.copy_(torch.randn(C) * 0.3)
+        x = torch.randn(B, C, 2, H, W, requires_grad=True)
+        r = torch.randn(B, C, 2, H, W, requires_grad=True) if res else None
+        y = x * torch.sigmoid(gate.attn_layer[0](gate.pool(x)))
+        if r is not None:
+            y = y + r
+        if act is not None:
+            y = F.leaky_relu(y, act)
+        g = torch.randn_like(y)
+        y.backward(g)
+        gd = SEGating(C).cuda()
+        gd.load_state_dict(gate.state_dict())
+        xd = x.detach().cuda().requires_grad_()
+        rd = r.detach().cuda().requires_grad_() if r is not None else None
+        yd = gd(xd, rd, act)
+        yd.backward(g.cuda())
+        assert _rel(yd.detach(), y.detach()) < 1e-5
+        assert _rel(xd.grad, x.grad) < 2e-5
+        if r is not None:
+            assert _rel(rd.grad, r.grad) < 1e-5
+        assert _rel(gd.attn_layer[0].weight.grad, gate.attn_layer[0].weight.grad) < 5e-5
+        assert _rel(gd.attn_layer[0].bias.grad, gate.attn_layer[0].bias.grad) < 5e-5
