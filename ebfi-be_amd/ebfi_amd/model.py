@@ -416,6 +416,20 @@ class EVFIAutoEx(BaseModel):
             self.Detail = UNet3d_18(channels=channels, bn=False)
         initialize_weights([self.FrameFeatExtract, self.EventFeatExtract, self.Reconstruction], 0.1)
 
+    def _reconstruct(self, x):
+        """self.Reconstruction(x) (model_singleframe.py:257-266) with the LeakyReLU that follows the PixelShuffle applied in the
+        epilogue of the 64 -> 256 conv instead (an elementwise activation commutes with the shuffle): two passes over the
+        [B,64,H,W] map less in each direction."""
+        head = self.Reconstruction[0]
+        up = head[0]
+        if isinstance(up, ConvLayer) and up.activation is None and isinstance(head[1], nn.PixelShuffle) and \
+                isinstance(head[2], nn.LeakyReLU) and up.native(x) is not None:
+            c = up.conv2d
+            y = conv.conv_bias_act(x, c.weight, c.bias, c.stride[0], c.padding[0], conv.ACT_LEAKY, float(head[2].negative_slope))
+            y = F.pixel_shuffle(y, head[1].upscale_factor)
+            return self.Reconstruction[2](self.Reconstruction[1](y))
+        return self.Reconstruction(x)
+
     def LoadExposureDecision(self):
         self.ExposureDecision.load_pretrain()
 
@@ -454,7 +468,7 @@ class EVFIAutoEx(BaseModel):
         event_feat = self.EventFeatExtract(Event)
         ex = self._exposure(Frame, Event, GTEx)
         event_feat = self.ResidualControl(event_feat, ex, T)
-        Sharp = self.Reconstruction(self.Modification(frame_feat, event_feat))
+        Sharp = self._reconstruct(self.Modification(frame_feat, event_feat))
         Final = Sharp + self.Detail(img0=Frame, img1=Sharp) if self.DetailEnabled else Sharp
 
         if cropper is not None:

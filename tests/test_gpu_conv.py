@@ -35,6 +35,8 @@ CASES = [
     (1, 70, 16, 32, 64, 3, 1, 1, 1, True),      # Cin spills into a second 64-channel block
     (1, 6, 40, 72, 32, 7, 2, 3, 1, False),      # detail-branch stem (folded 3x7x7): 7x7 stride 2
     (1, 16, 38, 70, 3, 7, 1, 0, 0, True),       # detail-branch outconv: 7x7 valid conv on a reflection-padded map
+    (1, 16, 11, 268, 3, 7, 1, 0, 0, True),      # ... 262 output columns: the 5-pixel-per-lane tiles of the direct kernel
+    (2, 5, 9, 41, 4, 7, 1, 3, 0, False),        # direct kernel: same padding, 4 output channels, odd channel count
     (2, 12, 33, 47, 20, 3, 2, 1, 0, False),     # stride-2 data gradient through zero insertion, odd sizes
     (2, 8, 4, 5, 8, 3, 1, 1, 1, True),          # maps far smaller than one tile (deep levels of the detail branch)
     (1, 16, 8, 8, 12, 3, 1, 1, 0, False),

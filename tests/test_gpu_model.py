@@ -359,7 +359,7 @@ def test_weight_bank_path_equals_per_call_packing(fix):
         s1, f1, g1, prof1 = run(bank)
         assert torch.equal(s0, s1) and torch.equal(f0, f1)
         for n in g0:     # (PyTorch's replication / reflection pad backward accumulate with atomics: last-bit run-to-run noise)
-            assert _rel(g1[n], g0[n]) < 1e-5, n
+            assert _rel(g1[n], g0[n]) < 5e-5, n
         assert prof0["conv_pack_w_bf16"][0] > 50 and "conv_pack_w_bf16" not in prof1 and prof1["pack_table_bf16"][0] == 1
         with torch.no_grad():                      # an in-place update (what the optimiser does) must invalidate the images
             for p in net.parameters():
