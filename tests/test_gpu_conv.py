@@ -153,7 +153,10 @@ def test_bf16_mma_mode_vs_fp32_reference(B, Cin, H, W, Cout, k, act):
 @pytest.mark.parametrize("B,Cin,H,W,Cout,k,act", [(2, 64, 16, 64, 64, 3, 1), (1, 128, 13, 70, 200, 3, 1), (1, 20, 17, 33, 24, 3, 0),
                                                   (2, 64, 16, 32, 64, 1, 1), (1, 64, 17, 33, 3, 3, 2), (1, 4, 24, 40, 64, 3, 1),
                                                   (1, 70, 9, 130, 33, 3, 1), (2, 8, 4, 5, 8, 3, 1), (1, 16, 8, 8, 12, 3, 0),
-                                                  (2, 8, 2, 2, 8, 1, 1), (1, 16, 38, 70, 3, 7, 0), (2, 20, 9, 33, 5, 7, 1)])
+                                                  (2, 8, 2, 2, 8, 1, 1), (1, 16, 38, 70, 3, 7, 0), (2, 20, 9, 33, 5, 7, 1),
+                                                  # persistent forward workgroups walking SEVERAL pixel tiles each (ragged last
+                                                  # round, 5 output-channel blocks) and weight-gradient workgroups of both shapes
+                                                  (5, 64, 100, 130, 300, 3, 1), (3, 32, 70, 200, 64, 3, 0)])
 def test_bf16x3_split_precision_mode_vs_fp32_reference(B, Cin, H, W, Cout, k, act):
     """Split-precision mode (bf16 hi + lo operand pairs, 3 MFMAs per product, fp32 accumulation) for forward and
     data and weight gradient.  Bar: 1e-4 of the fp32 CPU statement, ten times inside the 1e-3 parity tolerance of
@@ -218,3 +221,54 @@ def test_hd_config5_kernelconv_128_to_1600(mode):
     assert abs((ddot(x.detach(), x.grad) - lin) / lin) < 1e-4
     assert abs((ddot(w.detach(), w.grad) - lin) / lin) < 1e-4
     assert _rel(b.grad, gsum.float().cpu()) < 1e-4
+
+
+def test_packed_grouped_conv_with_epilogue_extras_vs_cpu():
+    """ebfi_conv2d_packed_x3 / ebfi_conv2d_backward_weight_x3g, the building blocks of the hand-scheduled ResidualControl
+    node: a GROUPED 3x3 convolution (groups = 2) on pre-packed weight images (weight bank with the grouped data-gradient
+    layout), the epilogue extras out = act(conv + bias + addend) * act'(mask_y), the same convolution as a data gradient
+    through the transposed images, and the grouped weight gradient -- each against torch's grouped conv2d on the CPU."""
+    import ctypes
+    from ebfi_amd import _native as N
+    from ebfi_amd import weightbank
+    torch.manual_seed(41)
+    B, C, H, W = 3, 64, 20, 72                       # 2 groups of 64 -> 128 output channels; ragged 64-px tiles
+    w = torch.nn.Parameter(torch.randn(2 * C, C, 3, 3) / (C * 9) ** 0.5)
+    b = torch.nn.Parameter(torch.randn(2 * C) * 0.1)
+    x = torch.randn(B, 2 * C, H, W)
+    addend, mask_y, g = torch.randn(B, 2 * C, H, W), torch.randn(B, 2 * C, H, W), torch.randn(B, 2 * C, H, W)
+    slope = 0.01
+    lrelu_d = lambda y: torch.where(y > 0, torch.ones_like(y), torch.full_like(y, slope))
+    ref = F.leaky_relu(F.conv2d(x, w, b, 1, 1, groups=2) + addend, slope) * lrelu_d(mask_y)
+    wd, bd = torch.nn.Parameter(w.detach().cuda()), torch.nn.Parameter(b.detach().cuda())
+    bank = weightbank.WeightBank([wd, bd])
+    site = bank.register([wd], [bd], kind="grouped", groups=2)
+    bank.refresh()
+    lib = N.lib()
+    st = N.stream_ptr(torch.device("cuda"))
+    dev = lambda t: t.cuda().contiguous()
+    xd, ad, md, gd = dev(x), dev(addend), dev(mask_y), dev(g)
+    out = torch.empty(B, 2 * C, H, W, device="cuda")
+    rc = lib.ebfi_conv2d_packed_x3(N.ptr(xd), site.fwd_ptr(), site.fwd_bytes, N.ptr(site.bias()), N.ptr(out), B, C, H, W, 2 * C, 3, 1, 2,
+                                   1, slope, N.ptr(ad), N.ptr(md), 1, slope, st)
+    N.check(rc, "ebfi_conv2d_packed_x3")
+    assert _rel(out, ref.detach()) < 1e-4
+    # data gradient of the grouped conv = the same kernel over g with the transposed images (no bias / activation)
+    gx_ref = torch.nn.grad.conv2d_input(x.shape, w.detach(), g, stride=1, padding=1, groups=2)
+    gx = torch.empty_like(xd)
+    rc = lib.ebfi_conv2d_packed_x3(N.ptr(gd), site.tr_ptr(), site.tr_bytes, N.ptr(None), N.ptr(gx), B, C, H, W, 2 * C, 3, 1, 2,
+                                   0, 0.0, N.ptr(None), N.ptr(None), 0, 0.0, st)
+    N.check(rc, "ebfi_conv2d_packed_x3 (data gradient)")
+    assert _rel(gx, gx_ref) < 1e-4
+    # grouped weight / bias gradient
+    gw_ref = torch.nn.grad.conv2d_weight(x, w.shape, g, stride=1, padding=1, groups=2)
+    need = int(lib.ebfi_conv2d_backward_weight_workspace(B, C, H, W, 2 * C, 3, 1, 1, N.EBFI_F32))
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    gw, gb = torch.empty(2 * C, C, 3, 3, device="cuda"), torch.empty(2 * C, device="cuda")
+    rc = lib.ebfi_conv2d_backward_weight_x3g(N.ptr(xd), N.ptr(gd), N.ptr(gw), N.ptr(gb), B, C, H, W, 2 * C, 3, 1, 2, N.ptr(ws), need, st)
+    N.check(rc, "ebfi_conv2d_backward_weight_x3g")
+    assert _rel(gw, gw_ref) < 1e-4 and _rel(gb, g.sum(dim=(0, 2, 3))) < 5e-5
+    # argument checks: groups that would split a workgroup's 64 output channels are refused, not mis-computed
+    rc = lib.ebfi_conv2d_packed_x3(N.ptr(xd), site.fwd_ptr(), site.fwd_bytes, N.ptr(None), N.ptr(out), B, 32, H, W, 2 * C, 3, 1, 4,
+                                   0, 0.0, N.ptr(None), N.ptr(None), 0, 0.0, st)
+    assert rc == -1 and b"groups" in lib.ebfi_last_error()
