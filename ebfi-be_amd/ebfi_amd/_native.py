@@ -77,6 +77,10 @@ SIGNATURES = {
     "ebfi_census_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ebfi_gauss5_forward": (_i, [_vp, _vp, _i64, _i, _i, _c.c_float, _vp]),
     "ebfi_gauss5_backward": (_i, [_vp, _vp, _i64, _i, _i, _c.c_float, _vp]),
+    "ebfi_laploss_workspace_floats": (_i64, [_i64, _i, _i, _i]),
+    "ebfi_laploss_partials": (_i64, [_i64, _i, _i, _i]),
+    "ebfi_laploss_forward": (_i, [_vp, _vp, _vp, _c.c_float, _c.c_float, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "ebfi_laploss_backward": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "ebfi_prof_enable": (None, [_i]),
     "ebfi_prof_set_capacity": (_i, [_i]),
     "ebfi_prof_reset": (None, []),

@@ -5,6 +5,8 @@ weight 2**i), :111-145 (Ternary census, 7x7), combined as in train_ours.py:258-2
 blur and the whole census term run as kernel pairs of libebfi_hip.so (csrc/imgops.hip); CPU tensors (host-logic
 tests) take the equivalent shifted-slice formulation below.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -64,6 +66,53 @@ class _Census(torch.autograd.Function):
             rc = N.lib().ebfi_census_backward(N.ptr(x), N.ptr(y), N.ptr(g), N.ptr(gx), B, C, H, W, N.stream_ptr(x.device))
         N.check(rc, "ebfi_census_backward")
         return gx, None
+
+
+class _LapLoss(torch.autograd.Function):
+    """coef_a * Lap(a, target) + coef_b * Lap(b, target) (restore.py:166-213) as ONE pyramid of the difference planes
+    [a - target ; b - target] on csrc/laploss.hip: the pyramid is linear, so lap_i(x) - lap_i(y) = lap_i(x - y)."""
+
+    LEVELS = 5
+
+    @staticmethod
+    def usable(a, b, target):
+        H, W = a.shape[-2:]
+        m = 1 << (_LapLoss.LEVELS - 1)
+        ok = lambda t: t.is_cuda and t.dtype == torch.float32 and t.shape == a.shape
+        return a.dim() == 4 and ok(a) and ok(target) and (b is None or ok(b)) and H % m == 0 and W % m == 0 and \
+            2 * H // m >= 3 and 2 * W // m >= 3 and not target.requires_grad and os.environ.get("EBFI_NO_LAPLOSS") is None
+
+    @staticmethod
+    def forward(ctx, a, b, target, coef_a, coef_b):
+        a, target = a.contiguous(), target.contiguous()
+        b = b.contiguous() if b is not None else None
+        B, C, H, W = a.shape
+        ppt, L = B * C, _LapLoss.LEVELS
+        planes = ppt * (2 if b is not None else 1)
+        lib = N.lib()
+        ws = torch.empty(int(lib.ebfi_laploss_workspace_floats(planes, H, W, L)), dtype=torch.float32, device=a.device)
+        partial = torch.empty(int(lib.ebfi_laploss_partials(planes, H, W, L)), dtype=torch.float32, device=a.device)
+        with torch.cuda.device_of(a):
+            rc = lib.ebfi_laploss_forward(N.ptr(a), N.ptr(b) if b is not None else None, N.ptr(target), float(coef_a),
+                                          float(coef_b), N.ptr(ws), N.ptr(partial), ppt, H, W, L, N.stream_ptr(a.device))
+        N.check(rc, "ebfi_laploss_forward")
+        ctx.ws, ctx.shape, ctx.two = ws, (B, C, H, W), b is not None
+        return partial.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.ws is None:
+            raise RuntimeError("laploss: the workspace of this forward was already consumed by a backward pass")
+        B, C, H, W = ctx.shape
+        n = 2 if ctx.two else 1
+        g = g.contiguous().float().reshape(1)
+        out = torch.empty((n * B, C, H, W), dtype=torch.float32, device=g.device)
+        with torch.cuda.device_of(out):
+            rc = N.lib().ebfi_laploss_backward(N.ptr(g), N.ptr(ctx.ws), N.ptr(out), n * B * C, H, W, _LapLoss.LEVELS,
+                                               N.stream_ptr(out.device))
+        N.check(rc, "ebfi_laploss_backward")
+        ctx.ws = None
+        return out[:B], (out[B:] if ctx.two else None), None, None, None
 
 
 class GaussianConv(nn.Module):
@@ -156,12 +205,19 @@ class TrainLoss(nn.Module):
         self.Lap, self.census, self.detail_enabled = LaplacianLoss(), Ternary(), detail_enabled
 
     def forward(self, sharp_pre, sharp, target, iteration=0, accu_step=1):
+        c_sharp, c_pre = (0.1, 1.0) if iteration < 10e3 else (1.0, 0.1)
+        if not self.detail_enabled:
+            c_sharp, c_pre, sharp_pre = 1.0, 0.0, None
+        if _LapLoss.usable(sharp, sharp_pre, target):
+            # one difference pyramid for both Laplacian terms; the census kernels work on the images themselves
+            total = _LapLoss.apply(sharp, sharp_pre, target, c_sharp, c_pre) + c_sharp * self.census(sharp, target)
+            if sharp_pre is not None:
+                total = total + c_pre * self.census(sharp_pre, target)
+            return total / accu_step
         with torch.no_grad():     # the target side of both terms is the same: compute it once
             yp = self.Lap.lap(target)
             ty = None if target.is_cuda else self.census.transform(target)   # the GPU census kernel works on the images
         term = lambda p: self.Lap(p, target, yp) + self.census(p, target, ty)
-        if not self.detail_enabled:
+        if sharp_pre is None:
             return term(sharp) / accu_step
-        if iteration < 10e3:
-            return (0.1 * term(sharp) + term(sharp_pre)) / accu_step
-        return (term(sharp) + 0.1 * term(sharp_pre)) / accu_step
+        return (c_sharp * term(sharp) + c_pre * term(sharp_pre)) / accu_step

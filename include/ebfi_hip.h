@@ -28,6 +28,7 @@
  *   ebfi_groupnorm_*            nn.GroupNorm of ExposureDecision (models/Ours/model_singleframe.py:36,66-67)
  *   ebfi_census_*               Ternary census loss (loss/restore.py:108-145)
  *   ebfi_gauss5_*               GaussianConv of the Laplacian-pyramid loss (loss/restore.py:149-163)
+ *   ebfi_laploss_*              whole Laplacian-pyramid L1 term of a step as one difference pyramid (loss/restore.py:166-213)
  *   ebfi_gather_sum             weight re-layouts of the depth-2 Conv3d / ConvTranspose3d (models/model_misc/resnet_3D.py)
  *   ebfi_events_to_stack        dataloader/encodings.py:307-350 (events_to_stack)
  *   ebfi_frame2lap / _frame2dcp myutils/utils.py:34-49 / :15-31
@@ -304,6 +305,23 @@ int64_t ebfi_census_partials(int B, int H, int W);
 int ebfi_census_forward(const float *x, const float *y, float *partial, int B, int C, int H, int W, void *stream);
 int ebfi_census_backward(const float *x, const float *y, const float *grad_loss, float *grad_x,
                          int B, int C, int H, int W, void *stream);
+
+/* Laplacian-pyramid L1 term of the training loss for up to two predictions against one target
+ * (loss/restore.py:166-213 LaplacianPyramid + LaplacianLoss: sum_i 2^i * L1sum(lap_i(pred), lap_i(target)), `levels` = 5;
+ * combined for (Sharp, SharpPre) with the coefficients of train_ours.py:258-268).  The pyramid operators are linear,
+ * so the library builds ONE pyramid of [pred_a - target ; pred_b - target] (planes_per_term = B*C planes of H x W each;
+ * pred_b may be NULL).  forward fills `workspace` (ebfi_laploss_workspace_floats(planes, ...) floats, planes = 1 or 2
+ * x planes_per_term) and writes ebfi_laploss_partials(planes, ...) block sums:
+ *   loss = coef_a * Lap(pred_a, target) + coef_b * Lap(pred_b, target) = sum(partial)   (summed by the caller, fixed order).
+ * backward turns the workspace left by forward (consumed in place: once per forward) into
+ *   grad_pred[planes, H, W] = grad_loss[0] * d loss / d [pred_a ; pred_b].
+ * H, W multiples of 2^(levels-1), >= 3 pixels on the coarsest blurred level, 2 <= levels <= 8. */
+int64_t ebfi_laploss_workspace_floats(int64_t planes, int H, int W, int levels);
+int64_t ebfi_laploss_partials(int64_t planes, int H, int W, int levels);
+int ebfi_laploss_forward(const float *pred_a, const float *pred_b, const float *target, float coef_a, float coef_b,
+                         float *workspace, float *partial, int64_t planes_per_term, int H, int W, int levels, void *stream);
+int ebfi_laploss_backward(const float *grad_loss, float *workspace, float *grad_pred, int64_t planes, int H, int W,
+                          int levels, void *stream);
 
 /* ------------------------------------------------------------------ per-kernel device timing
  * When enabled, every launch made by this library is bracketed by a hipEvent pair recorded on the

@@ -154,6 +154,41 @@ def test_gauss5_kernel_pair_vs_reference_conv():
         assert _rel(xd.grad, x.grad) < 1e-5, (H, W)
 
 
+def test_laplacian_difference_pyramid_vs_operator_formulation():
+    """csrc/laploss.hip: both Laplacian terms of a step as ONE pyramid of [sharp - target ; sharp_pre - target]
+    (lap_i is linear) against the operator-by-operator TrainLoss on CPU tensors (the formulation pinned by
+    tests/golden/loss_small.npz) and the oracle: value, and gradients of both predictions.  The L1 gradient is a sign:
+    an element whose Laplacian difference is ~0 may flip, so gradients are compared by the share of deviating elements."""
+    from ebfi_amd import _native as N
+    from ebfi_amd.loss import TrainLoss
+    torch.manual_seed(21)
+    for (B, H, W, it, detail, accu) in [(2, 64, 64, 0, True, 1), (1, 32, 48, 20000, True, 2), (2, 48, 32, 0, False, 1),
+                                        (1, 256, 256, 0, True, 1)]:     # (valid sizes: multiples of 16, >= 32)
+        a, b, t = torch.rand(B, 3, H, W), torch.rand(B, 3, H, W), torch.rand(B, 3, H, W)
+        a[:, :, :4, :4] = t[:, :, :4, :4]                       # an exactly matching patch: zero differences, zero sign
+        ar, br = a.clone().requires_grad_(), b.clone().requires_grad_()
+        ref = TrainLoss(detail)(br, ar, t, iteration=it, accu_step=accu)
+        ref.backward()
+        ad, bd = a.cuda().requires_grad_(), b.cuda().requires_grad_()
+        N.prof_reset()
+        N.prof_enable(True)
+        out = TrainLoss(detail).cuda()(bd, ad, t.cuda(), iteration=it, accu_step=accu)
+        out.backward()
+        torch.cuda.synchronize()
+        N.prof_enable(False)
+        names = {k for k, v in N.prof_collect().items() if v[0] > 0}
+        assert "lap_level" in names and "gauss5_fwd" not in names, names
+        assert abs(out.item() - ref.item()) <= 2e-5 * abs(ref.item()), (H, W)
+        if detail and H <= 64:
+            orc = loss_ref.train_loss(b, a, t, iteration=it) / accu
+            assert abs(out.item() - orc.item()) <= 2e-5 * abs(orc.item())
+        for d, r in ((ad, ar), (bd, br)) if detail else ((ad, ar),):
+            dev = (d.grad.cpu() - r.grad).abs() > 1e-4 * r.grad.abs().max()
+            assert dev.float().mean().item() < 2e-3, (H, W, dev.sum().item())
+        if not detail:
+            assert bd.grad is None
+
+
 def test_groupnorm_kernels_vs_torch_cpu():
     import torch.nn as nn
     from ebfi_amd.norm import group_norm

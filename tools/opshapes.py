@@ -23,9 +23,9 @@ with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, tor
 agg = collections.defaultdict(lambda: [0, 0.0])
 for ev in prof.events():
     name = ev.name.replace("aten::", "")
-    if name in want and ev.device_time_total > 0:
+    if (name in want or want == ["all"]) and ev.device_time_total > 0 and not name.startswith("ebfi"):
         key = (name, str(ev.input_shapes)[:110])
         agg[key][0] += 1
         agg[key][1] += ev.device_time_total
-for (name, shp), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
+for (name, shp), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:90]:
     print("%-10s x%3d %8.1f us  %s" % (name, n, us, shp))
