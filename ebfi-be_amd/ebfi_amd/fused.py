@@ -94,3 +94,57 @@ def product_mean(a, b):
             (a.shape[2] * a.shape[3]) % 4 == 0 and not torch.is_autocast_enabled():
         return _ProdMean.apply(a, b)
     return (a * b).mean(dim=(2, 3), keepdim=True)
+
+
+class _EDHead(torch.autograd.Function):
+    """cat([ev * sigmoid(AVGPool(GN(ev) * GN(bl))), bl], 1) of ExposureDecision (model_singleframe.py:66-72) as one node on
+    csrc/edhead.hip: plane moments instead of normalised maps forward, closed-form gradients of both maps backward."""
+
+    @staticmethod
+    def forward(ctx, ev, bl, gamma, beta, groups, eps):
+        ev, bl = ev.contiguous(), bl.contiguous()
+        B, C = ev.shape[0], ev.shape[1]
+        HW = ev.numel() // (B * C)
+        lib = N.lib()
+        out = torch.empty((B, 2 * C) + tuple(ev.shape[2:]), dtype=torch.float32, device=ev.device)
+        atten = torch.empty(B * C, dtype=torch.float32, device=ev.device)
+        stats = torch.empty(B * C * 5 + B * groups * 4, dtype=torch.float64, device=ev.device)
+        need = int(lib.ebfi_ed_head_workspace(B, C, HW))
+        ws = torch.empty(need, dtype=torch.uint8, device=ev.device)
+        with torch.cuda.device_of(ev):
+            rc = lib.ebfi_ed_head_forward(N.ptr(ev), N.ptr(bl), N.ptr(gamma), N.ptr(beta), N.ptr(out), N.ptr(atten), N.ptr(stats),
+                                          B, C, HW, groups, float(eps), N.ptr(ws), need, N.stream_ptr(ev.device))
+        N.check(rc, "ebfi_ed_head_forward")
+        ctx.groups = groups
+        ctx.save_for_backward(ev, bl, gamma, beta, atten, stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ev, bl, gamma, beta, atten, stats = ctx.saved_tensors
+        g = g.contiguous()
+        B, C = ev.shape[0], ev.shape[1]
+        HW = ev.numel() // (B * C)
+        lib = N.lib()
+        gev, gbl = torch.empty_like(ev), torch.empty_like(bl)
+        affine = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        gg = torch.empty(C, dtype=torch.float32, device=ev.device) if affine else None
+        gb = torch.empty(C, dtype=torch.float32, device=ev.device) if affine else None
+        need = int(lib.ebfi_ed_head_workspace(B, C, HW))
+        ws = torch.empty(need, dtype=torch.uint8, device=ev.device)
+        with torch.cuda.device_of(ev):
+            rc = lib.ebfi_ed_head_backward(N.ptr(g), N.ptr(ev), N.ptr(bl), N.ptr(gamma), N.ptr(beta), N.ptr(atten), N.ptr(stats),
+                                           N.ptr(gev), N.ptr(gbl), N.ptr(gg), N.ptr(gb), B, C, HW, ctx.groups, N.ptr(ws), need,
+                                           N.stream_ptr(ev.device))
+        N.check(rc, "ebfi_ed_head_backward")
+        return gev, gbl, gg, gb, None, None
+
+
+def ed_head(ev, bl, gn):
+    """`gn`: the nn.GroupNorm ExposureDecision applies to both maps.  None when the tensors do not qualify."""
+    import os
+    if not (ev.is_cuda and ev.dtype == torch.float32 and bl.dtype == torch.float32 and ev.dim() == 4 and ev.shape == bl.shape and
+            (ev.shape[2] * ev.shape[3]) % 4 == 0 and gn.weight is not None and gn.bias is not None and ev.shape[1] <= 1024 and
+            ev.shape[1] == gn.num_channels and not torch.is_autocast_enabled() and os.environ.get("EBFI_NO_EDHEAD") is None):
+        return None
+    return _EDHead.apply(ev, bl, gn.weight, gn.bias, gn.num_groups, gn.eps)

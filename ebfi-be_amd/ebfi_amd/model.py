@@ -139,9 +139,12 @@ class ExposureDecision(BaseModel):
     def forward(self, Event, BlurryLevel):
         ev = self.EventFeatExtract(Event)
         bl = self.BLFeatExtract(BlurryLevel)
-        # sigmoid(AVGPool(GN(ev) * GN(bl))): the pooled product as one reduction (the product map is never written)
-        atten = torch.sigmoid(fused.product_mean(norm.group_norm(ev, self.GroupNorm), norm.group_norm(bl, self.GroupNorm)))
-        ex = self.Conv1(fused.scale_cat(ev, atten, bl))          # cat([ev * atten, bl], 1) as one fused stage
+        cat = fused.ed_head(ev, bl, self.GroupNorm)    # GN x2 -> pooled product -> sigmoid -> cat([ev * atten, bl]) as one node
+        if cat is None:
+            # sigmoid(AVGPool(GN(ev) * GN(bl))): the pooled product as one reduction (the product map is never written)
+            atten = torch.sigmoid(fused.product_mean(norm.group_norm(ev, self.GroupNorm), norm.group_norm(bl, self.GroupNorm)))
+            cat = fused.scale_cat(ev, atten, bl)                # cat([ev * atten, bl], 1) as one fused stage
+        ex = self.Conv1(cat)
         return torch.sigmoid(self.AVGPool(ex).view(-1, 1))
 
 

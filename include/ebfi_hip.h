@@ -25,6 +25,7 @@
  *   ebfi_scale_residual_cat_*   exposure/time-scaled residual + concat of ResidualControl (model_singleframe.py:124-134)
  *   ebfi_prodmean_*             AdaptiveAvgPool2d(1) of a product of two maps (ExposureDecision, model_singleframe.py:66-68)
  *   ebfi_se_gate_*              SEGating (+ residual + ReLU / LeakyReLU) of the detail branch (models/model_misc/resnet_3D.py:89-141)
+ *   ebfi_ed_head_*              GroupNorm x2 -> pooled product -> sigmoid -> scaled concat of ExposureDecision (model_singleframe.py:66-72)
  *   ebfi_groupnorm_*            nn.GroupNorm of ExposureDecision (models/Ours/model_singleframe.py:36,66-67)
  *   ebfi_census_*               Ternary census loss (loss/restore.py:108-145)
  *   ebfi_gauss5_*               GaussianConv of the Laplacian-pyramid loss (loss/restore.py:149-163)
@@ -288,6 +289,24 @@ int ebfi_groupnorm_backward(const float *grad_y, const float *x, const float *ga
                             const float *rstd, float *grad_x, float *grad_gamma, float *grad_beta,
                             int B, int C, int64_t HW, int groups,
                             void *workspace, size_t workspace_bytes, void *stream);
+
+/* ExposureDecision head (models/Ours/model_singleframe.py:66-72) for contiguous [B,C,H,W] maps ev, bl and ONE GroupNorm
+ * (gamma, beta [C], `groups`, eps) applied to both:
+ *   atten[B*C] = sigmoid(mean_HW(GN(ev) * GN(bl)));   out[B,2C,H,W] = cat([ev * atten, bl], 1).
+ * GN is affine per plane, so the pooled product follows from five plane moments: one pass over the maps, no normalised
+ * map is written.  forward also writes `stats` (B*C*5 + B*groups*4 doubles: plane means of ev, ev^2, bl, bl^2, ev*bl,
+ * then (mean, rstd) of both maps per group) for backward, which returns the gradients of the whole head
+ *   grad_ev, grad_bl [B,C,H,W], grad_gamma, grad_beta [C] (may be NULL)
+ * from grad_out [B,2C,H,W] in one reduction + one elementwise pass (closed form in the moments).
+ * HW % 4 == 0, C % groups == 0, C <= 1024; workspace: ebfi_ed_head_workspace(B, C, HW) bytes.  Deterministic. */
+size_t ebfi_ed_head_workspace(int B, int C, int64_t HW);
+int ebfi_ed_head_forward(const float *ev, const float *bl, const float *gamma, const float *beta, float *out, float *atten,
+                         double *stats, int B, int C, int64_t HW, int groups, float eps,
+                         void *workspace, size_t workspace_bytes, void *stream);
+int ebfi_ed_head_backward(const float *grad_out, const float *ev, const float *bl, const float *gamma, const float *beta,
+                          const float *atten, const double *stats, float *grad_ev, float *grad_bl, float *grad_gamma,
+                          float *grad_beta, int B, int C, int64_t HW, int groups,
+                          void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------ loss image operators
  * 5x5 binomial blur ([1,4,6,4,1]/16 twice, times `factor`) with reflect padding over `planes` contiguous

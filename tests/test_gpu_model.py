@@ -212,6 +212,38 @@ def test_groupnorm_kernels_vs_torch_cpu():
         assert _rel(gnd.weight.grad, gn.weight.grad) < 2e-5 and _rel(gnd.bias.grad, gn.bias.grad) < 2e-5
 
 
+def test_exposure_decision_head_vs_torch_cpu():
+    """csrc/edhead.hip: cat([ev * sigmoid(AVGPool(GN(ev) * GN(bl))), bl], 1) (model_singleframe.py:66-72) from plane moments,
+    gradients of ev, bl and the shared GroupNorm's affine parameters in closed form, against float64 autograd on the CPU."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from ebfi_amd import fused
+    torch.manual_seed(15)
+    for (B, C, G, H, W) in [(2, 8, 4, 8, 12), (3, 64, 4, 32, 32), (1, 6, 3, 6, 6), (2, 64, 4, 128, 160)]:
+        gn = nn.GroupNorm(G, C)
+        with torch.no_grad():
+            gn.weight.copy_(torch.randn(C) * 0.5 + 1.0)
+            gn.bias.copy_(torch.randn(C) * 0.3)
+        ev = (torch.randn(B, C, H, W) * 1.5 + 0.4)
+        bl = (torch.randn(B, C, H, W) * 0.7 - 0.2 + 0.5 * ev)        # correlated maps: the pooled product is not ~0
+        gnd = nn.GroupNorm(G, C).double()
+        gnd.load_state_dict(gn.state_dict())
+        evr, blr = ev.double().requires_grad_(), bl.double().requires_grad_()
+        atten = torch.sigmoid(F.adaptive_avg_pool2d(gnd(evr) * gnd(blr), 1))
+        ref = torch.cat([evr * atten, blr], dim=1)
+        g = torch.randn(B, 2 * C, H, W)
+        ref.backward(g.double())
+        gdev = nn.GroupNorm(G, C).cuda()
+        gdev.load_state_dict(gn.state_dict())
+        evd, bld = ev.cuda().requires_grad_(), bl.cuda().requires_grad_()
+        out = fused.ed_head(evd, bld, gdev)
+        assert out is not None
+        out.backward(g.cuda())
+        assert _rel(out.detach(), ref.detach().float()) < 1e-5, (C, H, W)
+        assert _rel(evd.grad, evr.grad.float()) < 2e-5 and _rel(bld.grad, blr.grad.float()) < 2e-5, (C, H, W)
+        assert _rel(gdev.weight.grad, gnd.weight.grad.float()) < 5e-5 and _rel(gdev.bias.grad, gnd.bias.grad.float()) < 5e-5
+
+
 def test_census_kernel_pair_vs_slice_formulation():
     from ebfi_amd.loss import Ternary
     torch.manual_seed(9)
