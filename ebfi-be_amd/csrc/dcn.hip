@@ -372,8 +372,14 @@ __global__ __launch_bounds__(256, X3 ? 3 : 4) void dcn_fwd_f32(const float *__re
 // Workgroup = 16x16 output pixels of one sample, walked as 4 bands of 4x16 = 64 pixels.  Per
 // deformable-group chunk: colgrad = W^T . grad_out per band (16x16x4 fp32 MFMA, grad_out fragments
 // loaded straight into registers), the sampling walk, and the grad_input scatter -- which lands in an
-// LDS box covering the tile's footprint +- R pixels (ds_add_f32), flushed once per chunk with
-// CONTIGUOUS fp32 global atomics.  The reference issues 4 global atomics per (pixel, tap, channel)
+// LDS box covering the tile's footprint +- R pixels, flushed once per chunk with CONTIGUOUS fp32 global atomics.
+// The box accumulates in 32-bit FIXED POINT with integer LDS atomics: `ds_add_f32` measured ~25x slower than `ds_add_u32`
+// on gfx950 (the kernel ran 1.72 ms with float adds, 0.58 ms with integer ones).  The scale is a power of two chosen per
+// (tile, chunk) from an a-priori bound of any cell's sum -- |colgrad| <= max_px ||gout[:,px]|| * max_k ||W[:,k]||
+// (Cauchy-Schwarz), times max |mask| of the tile, times the largest sum of bilinear weights x |mask| / max|mask| any
+// cell receives (counted exactly, rounded up, by a positions-only pass over the chunk's samples) -- so no sum can
+// overflow, one unit is <= 2^-30 of that bound (~1e-8 of the largest possible contribution: on a par with fp32
+// rounding) and the box sums do not depend on the order of arrival.  The reference issues 4 global atomics per (pixel, tap, channel)
 // (dcn_v2_im2col_cuda.cu:236-250); here that is ~3.5 per (pixel, channel), row-contiguous, which is what
 // the memory-side atomic units like.  Samples that fall outside the box (|offset| > R) go to global
 // memory directly; shapes whose footprint does not fit the box run with the box disabled.
@@ -385,11 +391,45 @@ struct BoxGeom {
     int use, R, BH, BW;                // box = tile footprint in input space +- R, BH x BW cells per channel
 };
 
-__global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict__ x, const float *__restrict__ wgt,
+// wn2[k] = sum_co W[co][k]^2: with the tile's largest |grad_out| column norm it bounds every column-gradient value
+// (Cauchy-Schwarz), which fixes the fixed-point scale of the LDS box before anything is scattered into it
+__global__ void dcn_colnorm2_kernel(const float *__restrict__ wgt, float *__restrict__ wn2, int Co, int Kd) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= Kd) return;
+    float s = 0.f;
+    for (int co = 0; co < Co; ++co) {
+        const float v = wgt[(int64_t)co * Kd + k];
+        s += v * v;
+    }
+    wn2[k] = s;
+}
+
+// max over the 256 threads of a workgroup (all threads get it); `red` = 4 floats of LDS, free before and after
+__device__ __forceinline__ float wg_max256(float v, float *red) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+#ifdef DCN_STAMPS
+__device__ unsigned long long g_dcn_stamps[16];
+#define DSTAMP(k)                                                       \
+    do {                                                                \
+        const unsigned long long _t = __builtin_amdgcn_s_memtime();     \
+        _acc[k] += _t - _t0;                                            \
+        _t0 = _t;                                                       \
+    } while (0)
+#else
+#define DSTAMP(k)
+#endif
+
+__global__ __launch_bounds__(256, 2) void dcn_bwd_data_f32(const float *__restrict__ x, const float *__restrict__ wgt,
                                                         const float *__restrict__ off, const float *__restrict__ msk,
                                                         const float *__restrict__ gout, float *__restrict__ gx,
-                                                        float *__restrict__ goff, float *__restrict__ gmsk, Geom g,
-                                                        BoxGeom bx) {
+                                                        float *__restrict__ goff, float *__restrict__ gmsk,
+                                                        const float *__restrict__ wn2, Geom g, BoxGeom bx) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sWt = smem;                      // weight slice    [co][kl]   64 x S80
     float *sCG = sWt + 64 * S80;            // column gradient [kl][px]   KCP x NP
@@ -416,13 +456,97 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
     const __amdgpu_buffer_rsrc_t rmsk = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(msk + (int64_t)b * g.dg * g.kk * g.HWo), 0, (unsigned)(g.dg * g.kk) * (unsigned)g.HWo * 4u, 0x00020000);
 
+#ifdef DCN_STAMPS
+    unsigned long long _acc[16] = {0};
+    unsigned long long _t0 = __builtin_amdgcn_s_memtime();
+#endif
+    // largest squared column norm of grad_out over the tile's pixels (thread = pixel)
+    float gmax2 = 0.f;
+    const int t_ho = y0 + (tid >> 4), t_wo = x0 + (tid & 15);
+    const bool t_ok = t_ho < g.Ho && t_wo < g.Wo;
+    if (bx.use) {
+        float s2 = 0.f;
+        const unsigned pb = t_ok ? (unsigned)(t_ho * g.Wo + t_wo) * 4u : 0x80000000u;
+        for (int co = 0; co < g.Co; ++co) {
+            const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rgo, pb + (unsigned)co * (unsigned)g.HWo * 4u, 0, 0));
+            s2 += v * v;
+        }
+        gmax2 = wg_max256(s2, sCG);
+    }
     for (int chunk = 0; chunk < g.nchunks; ++chunk) {
         const Chunk ck = get_chunk(g, chunk);
         const bool box_on = bx.use && ck.cb <= BOX_CH;
         __syncthreads();                   // previous chunk's flush has read the box
-        if (box_on)
+        float fx_scale = 1.f, fx_inv = 1.f;
+        if (box_on) {
             for (int i = tid; i < ck.cb * bx.BH * bx.BW; i += 256) sBox[i] = 0.f;
+            // fixed-point scale of this chunk's box: bound of any cell sum -> the power of two that maps it below 2^30
+            float w2 = tid < ck.KL ? wn2[ck.cbase * g.kk + tid] : 0.f;
+            for (int k = tid + 256; k < ck.KL; k += 256) w2 = fmaxf(w2, wn2[ck.cbase * g.kk + k]);
+            float mm = 0.f;
+            const unsigned mb0 = t_ok ? (unsigned)(t_ho * g.Wo + t_wo) * 4u : 0x80000000u;
+            for (int tap = 0; tap < g.kk; ++tap)
+                mm = fmaxf(mm, fabsf(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                                   rmsk, mb0 + (unsigned)(ck.grp * g.kk + tap) * (unsigned)g.HWo * 4u, 0, 0))));
+            w2 = wg_max256(w2, sCG);
+            mm = wg_max256(mm, sCG);
+            // the largest sum of (bilinear weight * |mask| / max|mask|) any cell of this chunk's box will receive, in
+            // 1/1024 units rounded up: the same walk over (pixel, tap) as the scatter below, positions only
+            int *cnt = reinterpret_cast<int *>(sCG);
+            const int cells = bx.BH * bx.BW;
+            __syncthreads();
+            for (int i = tid; i < cells; i += 256) cnt[i] = 0;
+            __syncthreads();
+            const float mnorm = mm > 0.f ? 1024.f / mm : 0.f;
+            {   // thread = pixel (BT*BT == 256 threads); its taps in batches of 9 with all 27 loads of a batch in flight
+                const unsigned plane = (unsigned)g.HWo * 4u;
+                const unsigned p4 = t_ok ? (unsigned)(t_ho * g.Wo + t_wo) * 4u : 0x80000000u;
+                for (int tap0 = 0; tap0 < g.kk; tap0 += 9) {
+                    float dy[9], dx[9], mk[9];
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) {
+                        const int tap = tap0 + j;
+                        const unsigned sel = tap < g.kk ? p4 : 0x80000000u;
+                        const unsigned ob = (unsigned)(ck.grp * 2 * g.kk + 2 * tap) * plane + sel;
+                        dy[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(roff, ob, 0, 0));
+                        dx[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(roff, ob + plane, 0, 0));
+                        mk[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rmsk, (unsigned)(ck.grp * g.kk + tap) * plane + sel, 0, 0));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) {
+                        const int tap = tap0 + j;
+                        if (tap >= g.kk || !t_ok) continue;
+                        const int ki = tap / g.kw, kj = tap - ki * g.kw;
+                        // grad_input positions (the pad_h-for-pad_w quirk of col2im applies to them)
+                        const Tap tq = make_tap((float)(t_ho * g.sh - g.ph + ki * g.dh) + dy[j],
+                                                (float)(t_wo * g.sw - pad_w_quirk + kj * g.dw) + dx[j], g.H, g.W);
+                        if (!tq.valid) continue;
+                        const int r0 = tq.h0 - by0, c0 = tq.w0 - bx0;
+                        if (r0 < 0 || r0 + 1 >= bx.BH || c0 < 0 || c0 + 1 >= bx.BW) continue;
+                        const float am = fabsf(mk[j]) * mnorm;
+                        int *cc = cnt + r0 * bx.BW + c0;
+                        atomicAdd(cc, (int)ceilf(tq.w1 * am));
+                        atomicAdd(cc + 1, (int)ceilf(tq.w2 * am));
+                        atomicAdd(cc + bx.BW, (int)ceilf(tq.w3 * am));
+                        atomicAdd(cc + bx.BW + 1, (int)ceilf(tq.w4 * am));
+                    }
+                }
+            }
+            __syncthreads();
+            int cmax = 0;
+            for (int i = tid; i < cells; i += 256) cmax = max(cmax, cnt[i]);
+            const float load = wg_max256((float)cmax, sCG + cells) * (1.f / 1024.f);   // exact: counts < 2^24
+            const float bound = sqrtf(gmax2) * sqrtf(w2) * mm * load * 1.001f;
+            if (bound > 0.f && bound < 3.0e38f) {
+                int e;
+                (void)frexpf(bound, &e);                       // bound = m * 2^e, 0.5 <= m < 1
+                e = min(max(30 - e, -120), 120);
+                fx_scale = ldexpf(1.f, e);
+                fx_inv = ldexpf(1.f, -e);
+            }
+        }
         const bool first_sub = (chunk % g.nsub) == 0;   // first channel sub-block of this group
+        DSTAMP(0);
 
         for (int band = 0; band < 4; ++band) {
             // this lane's pixel for the MFMA B operand: n-tile `wave` = row band*4 + wave of the tile
@@ -464,6 +588,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
                     }
                     __syncthreads();
                 }
+                DSTAMP(1);
                 // colgrad[kl][px] += sum_co W[co][kl] * gout[co][px]
                 const float *ap = sWt + (lane >> 4) * S80 + (lane & 15);
                 // all KCP/16 row tiles unconditionally (rows >= KL of the slice are zero): a per-MFMA `if (m < mtiles)`
@@ -475,6 +600,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
                         acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[ks * 4 * S80 + m * 16], bv[ks], acc[m], 0, 0, 0);
                 }
             }
+            DSTAMP(2);
             __syncthreads();               // previous band's sampling has read sCG
 #pragma unroll
             for (int m = 0; m < KCP / 16; ++m) {
@@ -483,14 +609,20 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
                     sCG[(m * 16 + (lane >> 4) * 4 + r) * NP + wave * 16 + (lane & 15)] = acc[m][r];
             }
             __syncthreads();
+            DSTAMP(3);
 
             for (int it = tid; it < g.kk * NP; it += 256) {
+                DSTAMP(7);
                 const int px = it & (NP - 1), tap = it / NP;
                 const int ho = y0 + band * 4 + (px >> 4), wo = x0 + (px & 15);
                 if (ho >= g.Ho || wo >= g.Wo) continue;
                 const int p = ho * g.Wo + wo;
                 const TapPos tp = tap_pos_hw(g, roff, rmsk, ck.grp, tap, (unsigned)p * 4u, ho, wo);
                 const Tap t = make_tap(tp.h, tp.w, g.H, g.W);
+#ifdef DCN_STAMPS
+                asm volatile("" ::"v"(t.w1));
+#endif
+                DSTAMP(8);
                 // grad_input positions follow the quirk; identical to `t` whenever pad_h == pad_w
                 Tap tq = t;
                 if (pad_w_quirk != g.pw) {
@@ -525,6 +657,9 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
                     const int cl = cg0 + cj;
                     if (cl >= ck.cb) break;
                     const float cg = sCG[(cl * g.kk + tap) * NP + px];
+#ifdef DCN_STAMPS
+                    if (cj == 0) { asm volatile("" ::"v"(qa[0].x), "v"(qb[0].x)); DSTAMP(9); }
+#endif
                     if (t.valid) {
                         const u32x2 pa = qa[cj], pb = qb[cj];
                         const float ax = __uint_as_float(pa.x), ay = __uint_as_float(pa.y);
@@ -541,10 +676,12 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
                     if (tq.valid) {
                         const float top = cg * tp.mask;
                         if (cell >= 0) {   // whole 2x2 footprint inside the LDS box; cells outside the image are dropped by the flush
-                            atomicAdd(bplane + cell, tq.w1 * top);
-                            atomicAdd(bplane + cell + 1, tq.w2 * top);
-                            atomicAdd(bplane + cell + bx.BW, tq.w3 * top);
-                            atomicAdd(bplane + cell + bx.BW + 1, tq.w4 * top);
+                            int *icell = reinterpret_cast<int *>(bplane) + cell;
+                            const float tops = top * fx_scale;
+                            atomicAdd(icell, __float2int_rn(tq.w1 * tops));
+                            atomicAdd(icell + 1, __float2int_rn(tq.w2 * tops));
+                            atomicAdd(icell + bx.BW, __float2int_rn(tq.w3 * tops));
+                            atomicAdd(icell + bx.BW + 1, __float2int_rn(tq.w4 * tops));
                         } else {
                             if (tq.o1 >= 0) atomicAdd(gplane + tq.o1, tq.w1 * top);
                             if (tq.o2 >= 0) atomicAdd(gplane + tq.o2, tq.w2 * top);
@@ -554,6 +691,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
                     }
                 }
                 }   // channel batches
+                DSTAMP(10);
                 const int64_t ob = ((int64_t)(b * g.dg + ck.grp) * 2 * g.kk + 2 * tap) * g.HWo + p;
                 const int64_t mb = ((int64_t)(b * g.dg + ck.grp) * g.kk + tap) * g.HWo + p;
                 if (first_sub) {
@@ -565,22 +703,31 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
                     goff[ob + g.HWo] += val_w;
                     gmsk[mb] += mval;
                 }
+                DSTAMP(11);
             }
+            DSTAMP(4);
         }
         // ---- flush the box: row-contiguous global atomics, untouched cells skipped
         __syncthreads();
+        DSTAMP(5);
         if (box_on) {
             const int cells = bx.BH * bx.BW;
             for (int i = tid; i < ck.cb * cells; i += 256) {
-                const float v = sBox[i];
-                if (v == 0.f) continue;
+                const int q = reinterpret_cast<const int *>(sBox)[i];
+                if (q == 0) continue;
+                const float v = (float)q * fx_inv;
                 const int cl = i / cells, rem = i - cl * cells;
                 const int yy = by0 + rem / bx.BW, xx = bx0 + rem % bx.BW;
                 if (yy >= 0 && yy < g.H && xx >= 0 && xx < g.W)
                     atomicAdd(gx + ((int64_t)(b * g.C + ck.cbase + cl) * g.H + yy) * g.W + xx, v);
             }
         }
+        DSTAMP(6);
     }
+#ifdef DCN_STAMPS
+    if (blockIdx.x == 37 && threadIdx.x == 0)
+        for (int k = 0; k < 16; ++k) g_dcn_stamps[k] = _acc[k];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ backward: weight
@@ -838,10 +985,17 @@ extern "C" int ebfi_dcn_backward(const void *input, const void *weight, const vo
         const size_t lds = (size_t)(64 * S80 + KCP * NP + BOX_CH * BOX_CELLS) * sizeof(float);
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&dcn_bwd_data_f32), (int)lds)) return rc;
         const int64_t tiles = (int64_t)B * ceil_div(g.Ho, BT) * ceil_div(g.Wo, BT);
+        // squared column norms of the weight for the box scale; they live at the head of the workspace, which the
+        // weight-gradient kernel only starts to fill after the data kernel (same stream)
+        float *wn2 = static_cast<float *>(workspace);
+        {
+            ProfScope ps("dcn_colnorm2", st);
+            hipLaunchKernelGGL(dcn_colnorm2_kernel, dim3((unsigned)ceil_div(g.Kd, 256)), dim3(256), 0, st, wgt, wn2, Co, g.Kd);
+        }
         ProfScope ps("dcn_bwd_data_f32", st);
         hipLaunchKernelGGL(dcn_bwd_data_f32, dim3((unsigned)tiles), dim3(256), lds, st, x, wgt, off, msk, go,
                            static_cast<float *>(grad_input), static_cast<float *>(grad_offset),
-                           static_cast<float *>(grad_mask), g, bx);
+                           static_cast<float *>(grad_mask), wn2, g, bx);
     }
     if (int rc = check_launch("dcn_bwd_data_f32")) return rc;
     const int nwg = weight_grid(g);
@@ -860,3 +1014,14 @@ extern "C" int ebfi_dcn_backward(const void *input, const void *weight, const vo
     }
     return check_launch("dcn_bwd_reduce_f32");
 }
+
+#ifdef DCN_STAMPS
+extern "C" int ebfi_dcn_debug_stamps(unsigned long long *host_out, int reset) {
+    if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dcn_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_dcn_stamps), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
