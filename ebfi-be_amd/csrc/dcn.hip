@@ -391,6 +391,22 @@ struct BoxGeom {
     int use, R, BH, BW;                // box = tile footprint in input space +- R, BH x BW cells per channel
 };
 
+// two maxima over the 256 threads with one barrier pair; `red` = 8 floats of LDS
+__device__ __forceinline__ void wg_max256_2(float &a, float &b, float *red) {
+    for (int o = 32; o > 0; o >>= 1) {
+        a = fmaxf(a, __shfl_xor(a, o, 64));
+        b = fmaxf(b, __shfl_xor(b, o, 64));
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = a;
+        red[4 + (threadIdx.x >> 6)] = b;
+    }
+    __syncthreads();
+    a = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    b = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+}
+
 // wn2[k] = sum_co W[co][k]^2: with the tile's largest |grad_out| column norm it bounds every column-gradient value
 // (Cauchy-Schwarz), which fixes the fixed-point scale of the LDS box before anything is scattered into it
 __global__ void dcn_colnorm2_kernel(const float *__restrict__ wgt, float *__restrict__ wn2, int Co, int Kd) {
@@ -488,7 +504,6 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_f32(const float *__restri
             for (int tap = 0; tap < g.kk; ++tap)
                 mm = fmaxf(mm, fabsf(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
                                    rmsk, mb0 + (unsigned)(ck.grp * g.kk + tap) * (unsigned)g.HWo * 4u, 0, 0))));
-            w2 = wg_max256(w2, sCG);
             mm = wg_max256(mm, sCG);
             // the largest sum of (bilinear weight * |mask| / max|mask|) any cell of this chunk's box will receive, in
             // 1/1024 units rounded up: the same walk over (pixel, tap) as the scatter below, positions only
@@ -535,7 +550,9 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_f32(const float *__restri
             __syncthreads();
             int cmax = 0;
             for (int i = tid; i < cells; i += 256) cmax = max(cmax, cnt[i]);
-            const float load = wg_max256((float)cmax, sCG + cells) * (1.f / 1024.f);   // exact: counts < 2^24
+            float load = (float)cmax;                                                  // exact: counts < 2^24
+            wg_max256_2(load, w2, sCG + cells);
+            load *= 1.f / 1024.f;
             const float bound = sqrtf(gmax2) * sqrtf(w2) * mm * load * 1.001f;
             if (bound > 0.f && bound < 3.0e38f) {
                 int e;
