@@ -1949,13 +1949,173 @@ extern "C" size_t ebfi_conv2d_bf16_workspace(int Cin, int Cout, int ksize) {
 }
 
 namespace {
+// ------------------------------------------------------------------------------------------------
+// conv7_x3: 7x7, stride 1, at most 16 output rows, split precision -- the detail branch's output conv (16 -> 3 on the
+// reflection-padded map, models/Ours/model_singleframe.py:207) forward, and the data gradients of the two 7x7 layers
+// (16 <- 3; the 6-channel stem input from 64 zero-inserted gradient channels).  The fp32 matrix-core kernel spent
+// 195 / 233 us per launch on 32-row tiles with 3..16 live rows; the bf16x3 instructions do the same padded tile 16x
+// faster per product.  One 512-thread workgroup per 8 x 64 output tile; per 16-channel chunk the 14 x 70 input tile is
+// staged as the usual hi / lo `[pos][16 ch]` images (half-swapped rows), the weights are read as fp32 (forward:
+// W[m][k][tap]; tr: W[k][m][48 - tap], i.e. the transposed, flipped filter of the data gradient), split in registers and
+// stored as `[tap][16 rows][16 ch]` images -- 16 rows, the upper half of the 32-row matrix tile re-reads them and is
+// never stored.  Single-buffered (113 KB): a chunk is load -> commit -> 49 taps x 6 MFMA per wave.
+constexpr int C7_IH = TYB + 6, C7_IW = TX + 6, C7_PS = C7_IH * C7_IW;
+constexpr int C7_INB = C7_PS * 32, C7_ROWS = 16, C7_WB = 49 * C7_ROWS * 32;
+constexpr int C7_LDS = 2 * C7_INB + 2 * C7_WB;
+constexpr int C7_NPOS = (C7_PS + NTB - 1) / NTB;
+constexpr int C7_PIECES = 49 * C7_ROWS * 2;            // 16-byte pieces of one weight image
+constexpr int C7_NWP = (C7_PIECES + NTB - 1) / NTB;
+
+__global__ __launch_bounds__(NTB) void conv7_x3_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                       const float *__restrict__ bias, float *__restrict__ out, int K, int H,
+                                                       int W, int M, int Ho, int Wo, int pad, int tr, int act, float slope) {
+    extern __shared__ __attribute__((aligned(16))) char smd[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = (Wo + TX - 1) / TX, tiles_y = (Ho + TYB - 1) / TYB;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int y0 = ty * TYB, x0 = tx * TX;
+    const int iy0 = y0 - pad, ix0 = x0 - pad;
+    const unsigned plane_bytes = (unsigned)(H * W) * 4u;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (int64_t)b * K * H * W, (unsigned)K * plane_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(w, (unsigned)(M * K * 49) * 4u);
+
+    unsigned in_off[C7_NPOS];
+    int in_dst[C7_NPOS];
+#pragma unroll
+    for (int q = 0; q < C7_NPOS; ++q) {
+        const int pos = tid + q * NTB;
+        const int r = pos / C7_IW, c = pos - r * C7_IW;
+        const int yy = iy0 + r, xx = ix0 + c;
+        in_off[q] = (pos < C7_PS && yy >= 0 && yy < H && xx >= 0 && xx < W) ? (unsigned)(yy * W + xx) * 4u : SENT;
+        in_dst[q] = pos * 32 + (((pos >> 3) & 1) << 4);
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    const int hsel = lane >> 5, l31 = lane & 31;
+
+    const int nchunks = (K + CKB - 1) / CKB;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        if (chunk > 0) __syncthreads();                    // the taps of the previous chunk have read the images
+        float rin[C7_NPOS * CKB];
+        const unsigned cb = (unsigned)(chunk * CKB) * plane_bytes;
+#pragma unroll
+        for (int q = 0; q < C7_NPOS; ++q)
+#pragma unroll
+            for (int ci = 0; ci < CKB; ++ci) rin[q * CKB + ci] = buf_ld(rx, in_off[q] + cb + (unsigned)ci * plane_bytes);
+        float wv[C7_NWP][8];
+#pragma unroll
+        for (int it = 0; it < C7_NWP; ++it) {
+            const int i = tid + it * NTB;
+            const int row = i >> 1, half = i & 1;          // row = tap * 16 + m
+            const int tap = row >> 4, m = row & 15;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = chunk * CKB + half * 8 + j;
+                const bool ok = i < C7_PIECES && m < M && k < K;
+                const int e = tr ? (k * M + m) * 49 + 48 - tap : (m * K + k) * 49 + tap;
+                wv[it][j] = buf_ld(rw, ok ? (unsigned)e * 4u : SENT);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < C7_NPOS; ++q)
+            if (tid + q * NTB < C7_PS) {
+                u32x4 h0, h1, l0, l1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v0 = rin[q * CKB + 2 * j], v1 = rin[q * CKB + 2 * j + 1];
+                    const __bf16 a0 = (__bf16)v0, a1 = (__bf16)v1;
+                    const unsigned hp = pack_bf16((float)a0, (float)a1);
+                    const unsigned lp = pack_bf16(v0 - (float)a0, v1 - (float)a1);
+                    if (j < 4) { h0[j] = hp; l0[j] = lp; } else { h1[j - 4] = hp; l1[j - 4] = lp; }
+                }
+                const int d0 = in_dst[q], d1 = in_dst[q] ^ 16;
+                *reinterpret_cast<u32x4 *>(smd + d0) = h0;
+                *reinterpret_cast<u32x4 *>(smd + d1) = h1;
+                *reinterpret_cast<u32x4 *>(smd + C7_INB + d0) = l0;
+                *reinterpret_cast<u32x4 *>(smd + C7_INB + d1) = l1;
+            }
+#pragma unroll
+        for (int it = 0; it < C7_NWP; ++it) {
+            const int i = tid + it * NTB;
+            if (i < C7_PIECES) {
+                const int row = i >> 1, half = i & 1;
+                u32x4 hv, lv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v0 = wv[it][2 * j], v1 = wv[it][2 * j + 1];
+                    const __bf16 a0 = (__bf16)v0, a1 = (__bf16)v1;
+                    hv[j] = pack_bf16((float)a0, (float)a1);
+                    lv[j] = pack_bf16(v0 - (float)a0, v1 - (float)a1);
+                }
+                const int d = 2 * C7_INB + row * 32 + ((half ^ ((row >> 3) & 1)) << 4);
+                *reinterpret_cast<u32x4 *>(smd + d) = hv;
+                *reinterpret_cast<u32x4 *>(smd + C7_WB + d) = lv;
+            }
+        }
+        __syncthreads();
+        for (int ky = 0; ky < 7; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+                const int tap = ky * 7 + kx;
+                const int ra = tap * C7_ROWS + (l31 & 15);
+                const char *ap = smd + 2 * C7_INB + ra * 32 + ((hsel ^ ((ra >> 3) & 1)) << 4);
+                const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(ap), al = *reinterpret_cast<const bf16x8 *>(ap + C7_WB);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int pos = (wave + ky) * C7_IW + kx + l31 + n * 32;
+                    const char *bp = smd + pos * 32 + ((hsel ^ ((pos >> 3) & 1)) << 4);
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(bp), bl = *reinterpret_cast<const bf16x8 *>(bp + C7_INB);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[n], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const int yo = y0 + wave;
+    if (yo >= Ho) return;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int xo = x0 + n * 32 + l31;
+        if (xo >= Wo) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * hsel;
+            if (m < M) out[(((int64_t)b * M + m) * Ho + yo) * Wo + xo] = act_apply(acc[n][r] + (bias ? bias[m] : 0.f), act, slope);
+        }
+    }
+}
+
+// x: [B, K, H, W] -> out: [B, M, Ho, Wo];  w: forward [M][K][7][7], tr [K][M][7][7]
+int launch_conv7_x3(hipStream_t st, const float *x, const float *w, const float *bias, float *out, int B, int K, int H, int W,
+                    int M, int Ho, int Wo, int pad, int tr, int act, float slope, const char *role) {
+    if (M > C7_ROWS) return fail(EBFI_ERR_UNSUPPORTED, "conv7_x3: %d output channels (at most %d)", M, C7_ROWS);
+    if ((int64_t)K * H * W >= (int64_t)1 << 29) return fail(EBFI_ERR_UNSUPPORTED, "conv7_x3: a sample of 2 GiB or more");
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv7_x3_kernel), C7_LDS)) return rc;
+    const int64_t tiles = (int64_t)B * ceil_div(Ho, TYB) * ceil_div(Wo, TX);
+    {
+        ProfScope ps(role, st, 2.0 * B * (double)Ho * Wo * M * K * 49, 4.0 * B * ((double)K * H * W + (double)M * Ho * Wo));
+        hipLaunchKernelGGL(conv7_x3_kernel, dim3((unsigned)tiles), dim3(NTB), C7_LDS, st, x, w, bias, out, K, H, W, M, Ho, Wo, pad,
+                           tr, act, slope);
+    }
+    return check_launch("conv7_x3");
+}
+
 int conv_forward_bf16_impl(const char *who, int x3, const void *input, const void *weight, const void *bias, void *output, int B,
                            int Cin, int H, int W, int Cout, int ksize, int stride, int pad, int act, float slope,
                            void *workspace, size_t workspace_bytes, void *stream) {
     if (!input || !output || (!weight && !(x3 && workspace))) return fail(EBFI_ERR_ARG, "%s: null argument", who);
     if (act < 0 || act > 2) return fail(EBFI_ERR_ARG, "%s: unknown activation %d", who, act);
-    if (stride != 1 || (ksize != 1 && ksize != 3))
-        return fail(EBFI_ERR_UNSUPPORTED, "%s: k=%d stride=%d (k in {1,3}, stride 1)", who, ksize, stride);
+    const bool k7 = x3 && ksize == 7 && stride == 1 && weight;      // few-output-channel 7x7 (reads the fp32 weight itself)
+    if (!k7 && (stride != 1 || (ksize != 1 && ksize != 3)))
+        return fail(EBFI_ERR_UNSUPPORTED, "%s: k=%d stride=%d (k in {1,3}, stride 1; split precision also k=7 with <= 16 output channels)",
+                    who, ksize, stride);
     ConvGeom g;
     if (int rc = make_geom(g, B, Cin, H, W, Cout, ksize, stride, pad)) return rc;
     if (B == 0) return EBFI_OK;
@@ -1963,6 +2123,7 @@ int conv_forward_bf16_impl(const char *who, int x3, const void *input, const voi
     const float *x = static_cast<const float *>(input), *w = static_cast<const float *>(weight);
     const float *bs = static_cast<const float *>(bias);
     float *o = static_cast<float *>(output);
+    if (k7) return launch_conv7_x3(st, x, w, bs, o, B, Cin, H, W, Cout, g.Ho, g.Wo, pad, 0, act, slope, "conv7_x3/fwd");
     if (ksize == 3) return launch_fwd_bf16<3>(st, x, nullptr, w, bs, o, g, 0, act, slope, 0, 0.f, workspace, workspace_bytes, x3);
     return launch_fwd_bf16<1>(st, x, nullptr, w, bs, o, g, 0, act, slope, 0, 0.f, workspace, workspace_bytes, x3);
 }
@@ -1972,11 +2133,16 @@ int conv_backward_data_bf16_impl(const char *who, int x3, const void *grad_outpu
                                  int act, float slope, void *workspace, size_t workspace_bytes, void *stream) {
     if (!grad_output || !grad_input || (!weight && !(x3 && workspace))) return fail(EBFI_ERR_ARG, "%s: null argument", who);
     if (act != ACT_NONE && !saved_output) return fail(EBFI_ERR_ARG, "%s: activation needs saved_output", who);
-    if (stride != 1 || pad > ksize - 1 || (ksize != 1 && ksize != 3))
+    const bool k7 = x3 && ksize == 7 && stride == 1 && weight && act == ACT_NONE;
+    if (stride != 1 || pad > ksize - 1 || (!k7 && ksize != 1 && ksize != 3))
         return fail(EBFI_ERR_UNSUPPORTED, "%s: k=%d stride=%d pad=%d", who, ksize, stride, pad);
     ConvGeom f;
     if (int rc = make_geom(f, B, Cin, H, W, Cout, ksize, stride, pad)) return rc;
     if (B == 0) return EBFI_OK;
+    if (k7)     // transposed, flipped filter on grad_output: [B, Cout, Ho, Wo] -> [B, Cin, H, W]
+        return launch_conv7_x3(static_cast<hipStream_t>(stream), static_cast<const float *>(grad_output),
+                               static_cast<const float *>(weight), nullptr, static_cast<float *>(grad_input), B, Cout, f.Ho, f.Wo,
+                               Cin, H, W, ksize - 1 - pad, 1, ACT_NONE, 0.f, "conv7_x3/dgrad");
     ConvGeom g{B, Cout, f.Ho, f.Wo, Cin, H, W, ksize - 1 - pad};
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float *go = static_cast<const float *>(grad_output), *yo = static_cast<const float *>(saved_output);

@@ -9,6 +9,8 @@ staging (`ebfi_conv2d_backward_data`) plus a deterministic weight/bias gradient
 GPU library path, never a CPU fallback.  Feature maps of any size >= 2 pixels take the native kernels (partial tiles are
 masked): MIOpen would otherwise JIT-compile a kernel per small, unusual shape -- minutes on a fresh machine.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
@@ -42,8 +44,10 @@ def _bf16_ok(k, stride):
     return _COMPUTE == "bf16" and k in (1, 3) and stride == 1
 
 
-def _x3_ok(k, stride):
-    return _COMPUTE == "bf16x3" and k in (1, 3) and stride == 1
+def _x3_ok(k, stride, rows=None):
+    """rows: output rows of the product (Cout forward, Cin for the data gradient): 7x7 runs in split precision up to 16."""
+    return _COMPUTE == "bf16x3" and stride == 1 and (k in (1, 3) or (k == 7 and rows is not None and rows <= 16 and
+                                                                     os.environ.get("EBFI_NO_CONV7X3") is None))
 
 
 def _bf16_ws(lib, geo, device):
@@ -90,7 +94,7 @@ class ConvBiasAct(Function):
         lib = N.lib()
         bptr = N.ptr(bias.contiguous() if bias is not None else None)
         with torch.cuda.device_of(x):
-            if _bf16_ok(k, stride) or _x3_ok(k, stride):
+            if _bf16_ok(k, stride) or _x3_ok(k, stride, geo[4]):
                 ws, need = _bf16_ws(lib, geo, x.device)
                 fn = lib.ebfi_conv2d_forward_bf16mma if _COMPUTE == "bf16" else lib.ebfi_conv2d_forward_bf16x3
                 rc = fn(N.ptr(x), N.ptr(weight), bptr, N.ptr(out), *geo, act, slope, N.ptr(ws), need, N.stream_ptr(x.device))
@@ -138,7 +142,8 @@ class ConvBiasAct(Function):
                     ws, need = _bf16_ws(lib, geo, x.device)
                     rc = lib.ebfi_conv2d_backward_data_bf16mma(N.ptr(gout), N.ptr(y), N.ptr(weight), N.ptr(gx), *geo, act,
                                                                slope, N.ptr(ws), need, st)
-                elif _x3_ok(k, stride):     # split-precision data gradient (on grad * act' when the weight gradient left it)
+                elif _x3_ok(k, stride, geo[1]) and (k != 7 or gpre is not None or act == ACT_NONE):
+                    # split-precision data gradient (on grad * act' when the weight gradient left it)
                     ws, need = _bf16_ws(lib, geo, x.device)
                     src, sy, a = (gpre, None, ACT_NONE) if gpre is not None else (gout, y, act)
                     rc = lib.ebfi_conv2d_backward_data_bf16x3(N.ptr(src), N.ptr(sy), N.ptr(weight), N.ptr(gx), *geo, a,
@@ -159,8 +164,13 @@ class ConvBiasAct(Function):
                     up = gout.new_zeros((geo[0], geo[4], uh, uw))
                     up[:, :, ::stride, ::stride][:, :, :gout.shape[2], :gout.shape[3]] = gpre
                     geo1 = geo[:6] + [1, pad]
-                    rc = lib.ebfi_conv2d_backward_data(N.ptr(up), N.ptr(None), N.ptr(weight), N.ptr(gx), *geo1, ACT_NONE, 0.0,
-                                                       N.EBFI_F32, st)
+                    if k == 7 and _x3_ok(k, 1, geo[1]):
+                        ws, need = _bf16_ws(lib, geo1, x.device)
+                        rc = lib.ebfi_conv2d_backward_data_bf16x3(N.ptr(up), N.ptr(None), N.ptr(weight), N.ptr(gx), *geo1, ACT_NONE,
+                                                                  0.0, N.ptr(ws), need, st)
+                    else:
+                        rc = lib.ebfi_conv2d_backward_data(N.ptr(up), N.ptr(None), N.ptr(weight), N.ptr(gx), *geo1, ACT_NONE, 0.0,
+                                                           N.EBFI_F32, st)
                 N.check(rc, "ebfi_conv2d_backward_data")
         return gx, gw, gb, None, None, None, None, None
 

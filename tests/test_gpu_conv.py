@@ -154,6 +154,9 @@ def test_bf16_mma_mode_vs_fp32_reference(B, Cin, H, W, Cout, k, act):
                                                   (2, 64, 16, 32, 64, 1, 1), (1, 64, 17, 33, 3, 3, 2), (1, 4, 24, 40, 64, 3, 1),
                                                   (1, 70, 9, 130, 33, 3, 1), (2, 8, 4, 5, 8, 3, 1), (1, 16, 8, 8, 12, 3, 0),
                                                   (2, 8, 2, 2, 8, 1, 1), (1, 16, 38, 70, 3, 7, 0), (2, 20, 9, 33, 5, 7, 1),
+                                                  # 7x7 with <= 16 output rows on conv7_x3: several channel chunks / 16 rows forward,
+                                                  # the stem-shaped data gradient (6 <- 64 channels)
+                                                  (2, 40, 21, 75, 16, 7, 0), (1, 6, 30, 40, 64, 7, 1),
                                                   # persistent forward workgroups walking SEVERAL pixel tiles each (ragged last
                                                   # round, 5 output-channel blocks) and weight-gradient workgroups of both shapes
                                                   (5, 64, 100, 130, 300, 3, 1), (3, 32, 70, 200, 64, 3, 0)])
@@ -180,7 +183,10 @@ def test_bf16x3_split_precision_mode_vs_fp32_reference(B, Cin, H, W, Cout, k, ac
     finally:
         conv.set_compute_dtype("fp32")
         N.prof_enable(False)
-    want = {"conv_wgrad_x3"} if k == 7 else {"conv_fwd_bf16x3_db/fwd", "conv_fwd_bf16x3_db/dgrad", "conv_wgrad_x3"}   # 7x7: wgrad only
+    if k == 7:      # split precision where the product has <= 16 output rows, the exact fp32 kernels otherwise
+        want = {"conv_wgrad_x3", "conv7_x3/fwd" if Cout <= 16 else "conv_fwd_f32/fwd", "conv7_x3/dgrad" if Cin <= 16 else "conv_fwd_f32/dgrad"}
+    else:
+        want = {"conv_fwd_bf16x3_db/fwd", "conv_fwd_bf16x3_db/dgrad", "conv_wgrad_x3"}
     assert want <= set(N.prof_collect())
     assert _rel(out.detach(), ref) < 1e-4
     # derivative mask from the op's own output (a pre-activation within 1e-5 of zero may flip slope w.r.t. the CPU run)
