@@ -148,9 +148,39 @@ class FlatAdam:
         """`flat_grad`: the packed gradient in the order of `params` (FlatGradBucket.flat)."""
         if flat_grad.numel() != self.flat.numel():
             raise ValueError("packed gradient has %d elements, parameters %d" % (flat_grad.numel(), self.flat.numel()))
+        if self._native_step(flat_grad):
+            return
         self.flat.grad = flat_grad
         self.inner.step()
         self.flat.grad = None
+
+    def _native_step(self, flat_grad):
+        """The update as ONE bandwidth-bound launch of libebfi_hip.so (csrc/optim.hip) on the state tensors of the inner
+        torch.optim.Adam (which keeps owning hyper-parameters, state and checkpoint layout).  CPU tensors, weight decay,
+        amsgrad or maximize take torch's own step."""
+        import os
+        grp = self.inner.param_groups[0]
+        if not (self.flat.is_cuda and self.flat.dtype == torch.float32 and flat_grad.dtype == torch.float32 and
+                flat_grad.is_contiguous() and not grp.get("amsgrad") and not grp.get("maximize") and
+                float(grp.get("weight_decay", 0.0)) == 0.0 and not torch.is_tensor(grp["lr"]) and
+                os.environ.get("EBFI_NO_NATIVE_ADAM") is None):
+            return False
+        from . import _native as N
+        st = self.inner.state[self.flat]
+        if not st:
+            st["step"] = torch.zeros((), dtype=torch.float32, device=self.flat.device)
+            st["exp_avg"] = torch.zeros_like(self.flat.data)
+            st["exp_avg_sq"] = torch.zeros_like(self.flat.data)
+        if not (torch.is_tensor(st["step"]) and st["step"].is_cuda):
+            st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32, device=self.flat.device)
+        st["step"] += 1
+        b1, b2 = grp["betas"]
+        with torch.cuda.device_of(self.flat):
+            rc = N.lib().ebfi_adam_step(N.ptr(self.flat.data), N.ptr(flat_grad), N.ptr(st["exp_avg"]), N.ptr(st["exp_avg_sq"]),
+                                        N.ptr(st["step"]), self.flat.numel(), float(grp["lr"]), float(b1), float(b2),
+                                        float(grp["eps"]), N.stream_ptr(self.flat.device))
+        N.check(rc, "ebfi_adam_step")
+        return True
 
     def views_intact(self):
         base = self.flat.untyped_storage().data_ptr()

@@ -30,6 +30,7 @@
  *   ebfi_census_*               Ternary census loss (loss/restore.py:108-145)
  *   ebfi_gauss5_*               GaussianConv of the Laplacian-pyramid loss (loss/restore.py:149-163)
  *   ebfi_laploss_*              whole Laplacian-pyramid L1 term of a step as one difference pyramid (loss/restore.py:166-213)
+ *   ebfi_adam_step              optimizer.step() of train_ours.py:276-277 over the flat parameter buffer
  *   ebfi_gather_sum             weight re-layouts of the depth-2 Conv3d / ConvTranspose3d (models/model_misc/resnet_3D.py)
  *   ebfi_events_to_stack        dataloader/encodings.py:307-350 (events_to_stack)
  *   ebfi_frame2lap / _frame2dcp myutils/utils.py:34-49 / :15-31
@@ -341,6 +342,14 @@ int ebfi_laploss_forward(const float *pred_a, const float *pred_b, const float *
                          float *workspace, float *partial, int64_t planes_per_term, int H, int W, int levels, void *stream);
 int ebfi_laploss_backward(const float *grad_loss, float *workspace, float *grad_pred, int64_t planes, int H, int W,
                           int levels, void *stream);
+
+/* Adam update (torch.optim.Adam of train_ours.py:276-277, amsgrad / weight decay off as in config/train_ours.yml:59-65)
+ * over one flat fp32 buffer of n elements, in place: exp_avg <- exp_avg + (1-beta1)(grad - exp_avg);
+ * exp_avg_sq <- beta2 exp_avg_sq + (1-beta2) grad^2; param <- param - lr/(1-beta1^t) * exp_avg / (sqrt(exp_avg_sq)/sqrt(1-beta2^t) + eps)
+ * with t = step[0] (a device scalar holding the ALREADY incremented step count: no host synchronisation).
+ * All buffers 16-byte aligned. */
+int ebfi_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *step, int64_t n,
+                   double lr, double beta1, double beta2, double eps, void *stream);
 
 /* ------------------------------------------------------------------ per-kernel device timing
  * When enabled, every launch made by this library is bracketed by a hipEvent pair recorded on the
