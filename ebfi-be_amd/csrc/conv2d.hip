@@ -2092,6 +2092,181 @@ __global__ __launch_bounds__(NTB) void conv7_x3_kernel(const float *__restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv7s2_dgrad_x3: data gradient of a 7x7 STRIDE-2 convolution with at most 16 input channels (the detail branch's stem,
+// 6 <- 64 folded channels), by output parity instead of zero insertion:
+//     gx[ci][2u+py][2v+px] = sum_co sum_{ky = (py+pad) mod 2, +2, ..} sum_{kx likewise} W[co][ci][ky][kx] g[co][u + (py+pad-ky)/2][v + (px+pad-kx)/2]
+// -- each output pixel takes the 9..16 taps of its parity class, the 49 taps are spread over the four classes, and the
+// input tile is the gradient itself (11 x 67 positions per 8 x 64 tile of (u, v)), not a 4x larger zero-inserted map:
+// a quarter of the matrix work and staging of conv7_x3 on the zero-inserted tensor, no fill / strided copy in front.
+// Same images and half-swap as conv7_x3; acc[py][px][n]; the two px classes of a row pair up into 8-byte stores.
+constexpr int C7S_IH = TYB + 3, C7S_IW = TX + 3, C7S_PS = C7S_IH * C7S_IW;
+constexpr int C7S_INB = C7S_PS * 32;
+constexpr int C7S_LDS = 2 * C7S_INB + 2 * C7_WB;
+constexpr int C7S_NPOS = (C7S_PS + NTB - 1) / NTB;
+
+template <int pad>                         // compile-time: the parity class of a tap selects its accumulator
+__global__ __launch_bounds__(NTB) void conv7s2_dgrad_x3_kernel(const float *__restrict__ g, const float *__restrict__ w,
+                                                               float *__restrict__ gx, int K, int Hg, int Wg, int M, int H, int W) {
+    static_assert(pad == 3, "the 11 x 67 tile covers the row / column offsets -1 .. 2 of pad 3");
+    extern __shared__ __attribute__((aligned(16))) char smd[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Hu = (H + 1) / 2, Wu = (W + 1) / 2;          // grid of (u, v): output pixels (2u + py, 2v + px)
+    const int tiles_x = (Wu + TX - 1) / TX, tiles_y = (Hu + TYB - 1) / TYB;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int u0 = ty * TYB, v0 = tx * TX;
+    const unsigned plane_bytes = (unsigned)(Hg * Wg) * 4u;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(g + (int64_t)b * K * Hg * Wg, (unsigned)K * plane_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(w, (unsigned)(M * K * 49) * 4u);
+
+    unsigned in_off[C7S_NPOS];
+    int in_dst[C7S_NPOS];
+#pragma unroll
+    for (int q = 0; q < C7S_NPOS; ++q) {
+        const int pos = tid + q * NTB;
+        const int r = pos / C7S_IW, c = pos - r * C7S_IW;
+        const int yy = u0 - 1 + r, xx = v0 - 1 + c;
+        in_off[q] = (pos < C7S_PS && yy >= 0 && yy < Hg && xx >= 0 && xx < Wg) ? (unsigned)(yy * Wg + xx) * 4u : SENT;
+        in_dst[q] = pos * 32 + (((pos >> 3) & 1) << 4);
+    }
+    f32x16 acc[2][2][2];                   // [py][px][n]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i >> 2][(i >> 1) & 1][i & 1][r] = 0.f;
+    const int hsel = lane >> 5, l31 = lane & 31;
+
+    const int nchunks = (K + CKB - 1) / CKB;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        if (chunk > 0) __syncthreads();
+        float rin[C7S_NPOS * CKB];
+        const unsigned cb = (unsigned)(chunk * CKB) * plane_bytes;
+#pragma unroll
+        for (int q = 0; q < C7S_NPOS; ++q)
+#pragma unroll
+            for (int ci = 0; ci < CKB; ++ci) rin[q * CKB + ci] = buf_ld(rx, in_off[q] + cb + (unsigned)ci * plane_bytes);
+        // (inputs are committed before the weight pieces are fetched, the pieces in two halves: with the eight accumulator
+        // tiles of the four parity classes the kernel has no registers for all staging values at once)
+#pragma unroll
+        for (int q = 0; q < C7S_NPOS; ++q)
+            if (tid + q * NTB < C7S_PS) {
+                u32x4 h0, h1, l0, l1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v0f = rin[q * CKB + 2 * j], v1f = rin[q * CKB + 2 * j + 1];
+                    const __bf16 a0 = (__bf16)v0f, a1 = (__bf16)v1f;
+                    const unsigned hp = pack_bf16((float)a0, (float)a1);
+                    const unsigned lp = pack_bf16(v0f - (float)a0, v1f - (float)a1);
+                    if (j < 4) { h0[j] = hp; l0[j] = lp; } else { h1[j - 4] = hp; l1[j - 4] = lp; }
+                }
+                const int d0 = in_dst[q], d1 = in_dst[q] ^ 16;
+                *reinterpret_cast<u32x4 *>(smd + d0) = h0;
+                *reinterpret_cast<u32x4 *>(smd + d1) = h1;
+                *reinterpret_cast<u32x4 *>(smd + C7S_INB + d0) = l0;
+                *reinterpret_cast<u32x4 *>(smd + C7S_INB + d1) = l1;
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it0 = 0; it0 < C7_NWP; it0 += 2) {
+            float wv[2][8];
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = tid + (it0 + ii) * NTB;
+                const int row = i >> 1, half = i & 1;          // row = tap * 16 + m
+                const int tap = row >> 4, m = row & 15;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int kc = chunk * CKB + half * 8 + j;
+                    const bool ok = it0 + ii < C7_NWP && i < C7_PIECES && m < M && kc < K;
+                    wv[ii][j] = buf_ld(rw, ok ? (unsigned)((kc * M + m) * 49 + tap) * 4u : SENT);   // W[co = kc][ci = m][tap]
+                }
+            }
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = tid + (it0 + ii) * NTB;
+                if (it0 + ii < C7_NWP && i < C7_PIECES) {
+                    const int row = i >> 1, half = i & 1;
+                    u32x4 hv, lv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v0f = wv[ii][2 * j], v1f = wv[ii][2 * j + 1];
+                        const __bf16 a0 = (__bf16)v0f, a1 = (__bf16)v1f;
+                        hv[j] = pack_bf16((float)a0, (float)a1);
+                        lv[j] = pack_bf16(v0f - (float)a0, v1f - (float)a1);
+                    }
+                    const int d = 2 * C7S_INB + row * 32 + ((half ^ ((row >> 3) & 1)) << 4);
+                    *reinterpret_cast<u32x4 *>(smd + d) = hv;
+                    *reinterpret_cast<u32x4 *>(smd + C7_WB + d) = lv;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) {
+            const int py = (ky + pad) & 1, dy = (py + pad - ky) / 2;           // exact: py + pad - ky is even
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+                const int px = (kx + pad) & 1, dx = (px + pad - kx) / 2;
+                const int ra = (ky * 7 + kx) * C7_ROWS + (l31 & 15);
+                const char *ap = smd + 2 * C7S_INB + ra * 32 + ((hsel ^ ((ra >> 3) & 1)) << 4);
+                const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(ap), al = *reinterpret_cast<const bf16x8 *>(ap + C7_WB);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int pos = (wave + dy + 1) * C7S_IW + l31 + n * 32 + dx + 1;
+                    const char *bp = smd + pos * 32 + ((hsel ^ ((pos >> 3) & 1)) << 4);
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(bp), bl = *reinterpret_cast<const bf16x8 *>(bp + C7S_INB);
+                    f32x16 &a = acc[py][px][n];
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, a, 0, 0, 0);
+                }
+                if ((kx & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // operands of at most two taps in registers (128 accumulators)
+            }
+        }
+    }
+    const int u = u0 + wave;
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+        const int Y = 2 * u + py;
+        if (u >= Hu || Y >= H) continue;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int v = v0 + n * 32 + l31, X = 2 * v;
+            if (v >= Wu) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * hsel;
+                if (m >= M) continue;
+                float *o = gx + (((int64_t)b * M + m) * H + Y) * W + X;
+                if (X + 1 < W && (W & 1) == 0) *reinterpret_cast<float2 *>(o) = make_float2(acc[py][0][n][r], acc[py][1][n][r]);
+                else {
+                    o[0] = acc[py][0][n][r];
+                    if (X + 1 < W) o[1] = acc[py][1][n][r];
+                }
+            }
+        }
+    }
+}
+
+// g: [B, K = Cout, Hg, Wg] (already multiplied by act') -> gx: [B, M = Cin, H, W];  w: the layer's [Cout][Cin][7][7]
+int launch_conv7s2_dgrad_x3(hipStream_t st, const float *g, const float *w, float *gx, int B, int K, int Hg, int Wg, int M, int H,
+                            int W, int pad) {
+    if (M > C7_ROWS) return fail(EBFI_ERR_UNSUPPORTED, "conv7s2_dgrad_x3: %d input channels (at most %d)", M, C7_ROWS);
+    if (pad != 3) return fail(EBFI_ERR_UNSUPPORTED, "conv7s2_dgrad_x3: pad %d (3 only)", pad);
+    if ((int64_t)K * Hg * Wg >= (int64_t)1 << 29) return fail(EBFI_ERR_UNSUPPORTED, "conv7s2_dgrad_x3: a sample of 2 GiB or more");
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv7s2_dgrad_x3_kernel<3>), C7S_LDS)) return rc;
+    const int64_t tiles = (int64_t)B * ceil_div((H + 1) / 2, TYB) * ceil_div((W + 1) / 2, TX);
+    {
+        ProfScope ps("conv7_x3/dgrad_s2", st, 2.0 * B * (double)Hg * Wg * M * K * 49, 4.0 * B * ((double)K * Hg * Wg + (double)M * H * W));
+        hipLaunchKernelGGL(conv7s2_dgrad_x3_kernel<3>, dim3((unsigned)tiles), dim3(NTB), C7S_LDS, st, g, w, gx, K, Hg, Wg, M, H, W);
+    }
+    return check_launch("conv7s2_dgrad_x3");
+}
+
 // x: [B, K, H, W] -> out: [B, M, Ho, Wo];  w: forward [M][K][7][7], tr [K][M][7][7]
 int launch_conv7_x3(hipStream_t st, const float *x, const float *w, const float *bias, float *out, int B, int K, int H, int W,
                     int M, int Ho, int Wo, int pad, int tr, int act, float slope, const char *role) {
@@ -2214,6 +2389,20 @@ extern "C" int ebfi_conv2d_backward_data_bf16x3(const void *grad_output, const v
                                                 size_t workspace_bytes, void *stream) {
     return conv_backward_data_bf16_impl("conv2d_backward_data_bf16x3", 1, grad_output, saved_output, weight, grad_input, B, Cin,
                                         H, W, Cout, ksize, stride, pad, act, slope, workspace, workspace_bytes, stream);
+}
+
+// grad_input[B,Cin,H,W] of a 7x7 STRIDE-2 convolution with Cin <= 16 from grad_preact[B,Cout,Ho,Wo] (= grad_output times the
+// activation derivative), split precision, by output parity (no zero-inserted tensor).
+extern "C" int ebfi_conv2d_backward_data_s2_bf16x3(const void *grad_preact, const void *weight, void *grad_input, int B, int Cin,
+                                                   int H, int W, int Cout, int ksize, int pad, void *stream) {
+    if (!grad_preact || !weight || !grad_input) return fail(EBFI_ERR_ARG, "conv2d_backward_data_s2_bf16x3: null argument");
+    if (ksize != 7) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_data_s2_bf16x3: k=%d (7 only)", ksize);
+    ConvGeom f;
+    if (int rc = make_geom(f, B, Cin, H, W, Cout, ksize, 2, pad)) return rc;
+    if (B == 0) return EBFI_OK;
+    return launch_conv7s2_dgrad_x3(static_cast<hipStream_t>(stream), static_cast<const float *>(grad_preact),
+                                   static_cast<const float *>(weight), static_cast<float *>(grad_input), B, Cout, f.Ho, f.Wo, Cin, H, W,
+                                   pad);
 }
 
 extern "C" int ebfi_conv2d_forward(const void *input, const void *weight, const void *bias, void *output, int B, int Cin,

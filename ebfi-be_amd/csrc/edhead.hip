@@ -67,14 +67,16 @@ __global__ __launch_bounds__(ET) void ed_stats_kernel(const float *__restrict__ 
 }
 
 // stats: [B*C][5] plane means (x, xx, z, zz, xz), then [B*G][4] = (mu_x, rstd_x, mu_z, rstd_z)
-// one workgroup of >= C threads; dynamic LDS: (5 C + 4 G) doubles
+// one workgroup of >= C threads per sample; dynamic LDS: (5 C + 4 G) doubles
 __global__ void ed_fwd_finalize_kernel(const float *__restrict__ partial, const float *__restrict__ gamma,
                                        const float *__restrict__ beta, double *__restrict__ stats, float *__restrict__ atten, int B,
                                        int C, int G, int64_t HW, int S, float eps) {
     extern __shared__ double sh[];
     double *M = sh, *grp = sh + 5 * C;
     const int c = threadIdx.x, cpg = C / G;
-    for (int b = 0; b < B; ++b) {
+    (void)B;
+    {
+        const int b = blockIdx.x;          // one workgroup per sample (samples are independent)
         if (c < C) {
             const float *pp = partial + ((int64_t)(b * C + c) * S) * 5;
             for (int k = 0; k < 5; ++k) {
@@ -100,7 +102,7 @@ __global__ void ed_fwd_finalize_kernel(const float *__restrict__ partial, const 
             grp[c * 4 + 1] = 1.0 / sqrt(vx + (double)eps);
             grp[c * 4 + 2] = mz;
             grp[c * 4 + 3] = 1.0 / sqrt(vz + (double)eps);
-            for (int k = 0; k < 4; ++k) stats[(int64_t)B * C * 5 + ((int64_t)b * G + c) * 4 + k] = grp[c * 4 + k];
+            for (int k = 0; k < 4; ++k) stats[(int64_t)gridDim.x * C * 5 + ((int64_t)b * G + c) * 4 + k] = grp[c * 4 + k];
         }
         __syncthreads();
         if (c < C) {
@@ -113,7 +115,6 @@ __global__ void ed_fwd_finalize_kernel(const float *__restrict__ partial, const 
                              be * ga * rz * (Mz - muz) + be * be;
             atten[b * C + c] = (float)(1.0 / (1.0 + exp(-s)));
         }
-        __syncthreads();
     }
 }
 
@@ -285,7 +286,7 @@ extern "C" int ebfi_ed_head_forward(const float *ev, const float *bl, const floa
     }
     {
         ProfScope ps("ed_finalize", st);
-        hipLaunchKernelGGL(ed_fwd_finalize_kernel, dim3(1), dim3(fin_threads), fin_lds, st, partial, gamma, beta, stats, atten, B, C,
+        hipLaunchKernelGGL(ed_fwd_finalize_kernel, dim3((unsigned)B), dim3(fin_threads), fin_lds, st, partial, gamma, beta, stats, atten, B, C,
                            groups, HW, pl.slices, eps);
     }
     {

@@ -80,6 +80,7 @@ SIGNATURES = {
     "ebfi_ed_head_workspace": (_sz, [_i, _i, _i64]),
     "ebfi_ed_head_forward": (_i, [_vp] * 7 + [_i, _i, _i64, _i, _c.c_float, _vp, _sz, _vp]),
     "ebfi_ed_head_backward": (_i, [_vp] * 11 + [_i, _i, _i64, _i, _vp, _sz, _vp]),
+    "ebfi_conv2d_backward_data_s2_bf16x3": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ebfi_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64] + [_c.c_double] * 4 + [_vp]),
     "ebfi_laploss_workspace_floats": (_i64, [_i64, _i, _i, _i]),
     "ebfi_laploss_partials": (_i64, [_i64, _i, _i, _i]),

@@ -160,6 +160,12 @@ class ConvBiasAct(Function):
                     # Only the small stems / down-sampling convs take this path.
                     if gpre is None:
                         gpre = gout if act == ACT_NONE else gout * _act_grad(y, act, slope)
+                    if k == 7 and stride == 2 and _x3_ok(k, 1, geo[1]) and pad == 3:
+                        # by output parity on the gradient itself: no zero-inserted tensor (csrc/conv2d.hip conv7s2_dgrad_x3)
+                        rc = lib.ebfi_conv2d_backward_data_s2_bf16x3(N.ptr(gpre.contiguous()), N.ptr(weight), N.ptr(gx), geo[0], geo[1],
+                                                                     geo[2], geo[3], geo[4], k, pad, st)
+                        N.check(rc, "ebfi_conv2d_backward_data_s2_bf16x3")
+                        return gx, gw, gb, None, None, None, None, None
                     uh, uw = geo[2] + 2 * pad - k + 1, geo[3] + 2 * pad - k + 1
                     up = gout.new_zeros((geo[0], geo[4], uh, uw))
                     up[:, :, ::stride, ::stride][:, :, :gout.shape[2], :gout.shape[3]] = gpre

@@ -187,6 +187,12 @@ int ebfi_conv2d_backward_data_bf16x3(const void *grad_output, const void *saved_
                                      int stride, int pad, int act, float slope,
                                      void *workspace, size_t workspace_bytes, void *stream);
 
+/* Data gradient of a 7x7 STRIDE-2 convolution with at most 16 input channels (the detail branch's stem,
+ * models/model_misc/resnet_3D.py BasicStem folded to 2-D: 6 <- 64 channels) from grad_preact = grad_output * act'(output),
+ * split precision, evaluated per output parity class (no zero-inserted gradient tensor).  pad = 3. */
+int ebfi_conv2d_backward_data_s2_bf16x3(const void *grad_preact, const void *weight, void *grad_input, int B, int Cin,
+                                        int H, int W, int Cout, int ksize, int pad, void *stream);
+
 /* Weights packed ahead of the call.  ebfi_conv2d_forward_bf16x3 / ebfi_conv2d_backward_data_bf16x3 re-pack `weight` into
  * `workspace` on every call; when `weight` is NULL they take `workspace` as ALREADY holding the packed images
  * ([hi | lo], bf16 [tap][M][K16]: forward M = Cout, K = Cin; data gradient `transposed`: M = Cin, K = Cout, taps flipped;

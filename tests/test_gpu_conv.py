@@ -197,6 +197,39 @@ def test_bf16x3_split_precision_mode_vs_fp32_reference(B, Cin, H, W, Cout, k, ac
     assert _rel(bd.grad, gpre.sum(dim=(0, 2, 3))) < 5e-5
 
 
+@pytest.mark.parametrize("B,Cin,H,W,Cout,pad,act", [(2, 6, 64, 96, 64, 3, 1), (1, 3, 37, 51, 20, 3, 0), (1, 16, 24, 130, 33, 3, 1),
+                                                    (2, 6, 18, 20, 8, 2, 0), (1, 1, 9, 9, 5, 0, 0)])
+def test_stride2_7x7_data_gradient_by_parity_vs_cpu(B, Cin, H, W, Cout, pad, act):
+    """The stem of the detail branch (7x7, stride 2, few input channels): its data gradient in split precision by output
+    parity class (csrc/conv2d.hip conv7s2_dgrad_x3) instead of zero insertion; odd sizes, several channel chunks, pads 0..3."""
+    from ebfi_amd import _native as N
+    from ebfi_amd import conv
+    torch.manual_seed(B + Cin + H + W + Cout)
+    x = torch.randn(B, Cin, H, W)
+    w = torch.randn(Cout, Cin, 7, 7) / (Cin * 49) ** 0.5
+    b = torch.randn(Cout) * 0.1
+    ref = _ref(x, w, b, 2, pad, act, 0.01)
+    g = torch.randn_like(ref)
+    xd, wd, bd = x.cuda().requires_grad_(), w.cuda().requires_grad_(), b.cuda().requires_grad_()
+    conv.set_compute_dtype("bf16x3")
+    N.prof_reset()
+    N.prof_enable(True)
+    try:
+        out = conv.conv_bias_act(xd, wd, bd, 2, pad, act, 0.01)
+        out.backward(g.cuda())
+        torch.cuda.synchronize()
+    finally:
+        conv.set_compute_dtype("fp32")
+        N.prof_enable(False)
+    prof = N.prof_collect()       # pad 3 (the stem): by parity; other pads: zero insertion + the stride-1 kernel
+    assert prof.get("conv7_x3/dgrad_s2", (0,))[0] == (1 if pad == 3 else 0) and (pad == 3 or prof["conv7_x3/dgrad"][0] == 1)
+    y = out.detach().cpu()
+    gpre = g if act == 0 else g * torch.where(y > 0, torch.ones_like(y), torch.full_like(y, 0.01))
+    assert _rel(out.detach(), ref) < 2e-5
+    assert _rel(xd.grad, torch.nn.grad.conv2d_input(x.shape, w, gpre, stride=2, padding=pad)) < 1e-4
+    assert _rel(wd.grad, torch.nn.grad.conv2d_weight(x, w.shape, gpre, stride=2, padding=pad)) < 2e-5
+
+
 @pytest.mark.parametrize("mode", ["bf16x3", "fp32"])
 def test_hd_config5_kernelconv_128_to_1600(mode):
     """BASELINE.json config 5 feature size: the 128 -> 1600 KernelConv at B=8, 360x640 (output 2.95e9 elements, 1.47 GB
