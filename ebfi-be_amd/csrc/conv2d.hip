@@ -1880,7 +1880,10 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
     const char *name = x3 ? (transposed ? "conv_fwd_bf16x3_db/dgrad" : "conv_fwd_bf16x3_db/fwd")
                           : (transposed ? "conv_fwd_bf16/dgrad" : "conv_fwd_bf16/fwd");   // label = kernel symbol / role
     const double flops = 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS;
-    const int mt = g.Cout <= 32 ? 1 : 2;
+    // 32 output channels per workgroup when 64 would leave more than half of the CUs without one (small feature maps of the
+    // detail branch): twice the workgroups, each with half the matrix work per staged chunk
+    const bool few = x3 && tiles * ceil_div(g.Cout, 64) <= 128 && getenv("EBFI_CONV_NO_MT1") == nullptr;
+    const int mt = (g.Cout <= 32 || few) ? 1 : 2;
     dim3 grid((unsigned)tiles, (unsigned)ceil_div(g.Cout, 32 * mt));
     if (x3) {
         constexpr int PSX = (TYB - 1 + KS) * (TX - 1 + KS);
