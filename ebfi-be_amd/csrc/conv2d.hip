@@ -1414,6 +1414,223 @@ __global__ __launch_bounds__(WX) void conv_wgrad_x3(const float *__restrict__ x,
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv_wgrad_x3_ws: the 3x3 split-precision weight gradient with SPECIALISED waves.  In conv_wgrad_x3 every wave stages,
+// commits and multiplies in turn, and the ablations (tools/kbench) showed the four phases of a tile adding up: at 64 -> 128
+// 38 us of commit / slab / reduce + 14 of loads + 10 of LDS operand reads + 21 of matrix work, nothing overlapping, a second
+// resident workgroup changing little.  Here waves 4..7 (256 threads) are PRODUCERS: they keep two tiles of global loads in
+// flight (they hold no accumulators, so the second register set that spilled in conv_wgrad_x3 fits), split and write the
+// next tile's images; waves 0..3, one per SIMD, are CONSUMERS: each owns BOTH 32-row output tiles of its n-tiles (every
+// B-operand read serves two MFMA triples) and does nothing but operand reads, peels and MFMAs.  One workgroup barrier per
+// tile hands the double-buffered image from one side to the other; the two roles run separate loops with the same number
+// of barriers, so the register allocation is the maximum of the two paths, not their sum.
+template <int DACT>
+__global__ __launch_bounds__(512) void conv_wgrad_x3_ws(const float *__restrict__ x, const float *__restrict__ gout,
+                                                        const float *__restrict__ yact, float *__restrict__ slab,
+                                                        float *__restrict__ gpre_out, ConvGeom g, float dslope, int total_tiles,
+                                                        int need_bias) {
+    using C = WCfg<3, 1, 32>;
+    constexpr int KS = 3, KK = 9, WTX = C::WTX, IH = C::IH, IW = C::IW;
+    constexpr int IWP = 32, EXC = IW - IWP, CIB = 64, PS = C::PS, IWS = C::IWS;
+    constexpr int PT = 256, NW64 = PT / 64;                // producer threads; thread rows of 64 grad_out slots
+    constexpr int TROWS = PT / IWP, CPR = CIB / TROWS, NI = IH * CPR, NG = 64 / NW64;
+    constexpr int NEX = (EXC * IH * CIB + PT - 1) / PT;
+    constexpr int NQ = 4, NTW = (CIB * KK + 32 * NQ - 1) / (32 * NQ);   // consumer waves = column groups; n-tiles per wave
+    constexpr int BUF = 64 * GS + (CIB + 1) * PS;
+    static_assert(WTX == 32 && EXC == 2 && CIB % TROWS == 0, "tile configuration");
+    extern __shared__ __attribute__((aligned(16))) unsigned smw[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co_base = blockIdx.y * 64, ci_base = blockIdx.z * CIB;
+    const int grp = co_base / (g.Cout / g.groups);
+    const int ci_cnt = min(CIB, g.Cin - ci_base);
+    const int ncols = ci_cnt * KK;
+    const int tiles_x = (g.Wo + WTX - 1) / WTX, tiles_y = (g.Ho + WTY - 1) / WTY;
+    const int HW = g.H * g.W, HWo = g.Ho * g.Wo;
+    const int G = gridDim.x;
+    const int64_t wsz = (int64_t)g.Cout * g.Cin * KK;
+    float *my = slab + (int64_t)blockIdx.x * (wsz + g.Cout);
+
+    for (int i = tid; i < 2 * BUF; i += 512) smw[i] = 0u;   // pad slots, pad columns and the zero plane stay zero
+    __syncthreads();
+
+    if (wave < NQ) {
+        // ------------------------------------------------------------------ consumers
+        const int nq = wave;
+        f32x16 acc[2][NTW];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NTW; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+        int boff[NTW];
+#pragma unroll
+        for (int q = 0; q < NTW; ++q) {
+            const int n = (nq + NQ * q) * 32 + (lane & 31);
+            const int ci = n / KK, tap = n - ci * KK;
+            const int ky = tap / KS, kx = tap - ky * KS;
+            boff[q] = 64 * GS + ((n < ncols) ? ci * PS + ky * IWS + kx : CIB * PS) + 8 * (lane >> 5);
+        }
+        const int aoff = (lane & 31) * GS + 8 * (lane >> 5);
+        const bool last_live = (nq + NQ * (NTW - 1)) * 32 < ncols;
+        __syncthreads();                   // (A) the first tile is committed
+        int cur = 0;
+        for (int tile = blockIdx.x; tile < total_tiles; tile += G) {
+            const unsigned *sA = smw + cur * BUF + aoff;
+            const unsigned *sB = smw + cur * BUF;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int row = kk >> 1, px0 = (kk & 1) * 16;
+                bf16x8 ah[2], al[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    unsigned aw[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) aw[j] = sA[m * 32 * GS + row * 32 + px0 + j];
+                    peel(aw, ah[m], al[m]);
+                }
+#pragma unroll
+                for (int q = 0; q < NTW; ++q) {
+                    if (q == NTW - 1 && !last_live) continue;
+                    unsigned bw[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bw[j] = sB[boff[q] + row * IWS + px0 + j];
+                    bf16x8 bh, bl;
+                    peel(bw, bh, bl);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh, acc[m][q], 0, 0, 0);
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl, acc[m][q], 0, 0, 0);
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m][q], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();               // (B) this image has been read, the other one is complete
+            cur ^= 1;
+        }
+        const __amdgpu_buffer_rsrc_t rsl = make_rsrc(my, (unsigned)wsz * 4u);   // rows co >= Cout fall past the slab: dropped
+        const unsigned co_row = (unsigned)(g.Cin * KK) * 4u;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < NTW; ++q) {
+                const int n = (nq + NQ * q) * 32 + (lane & 31);
+                const unsigned o0 = n < ncols ? (unsigned)(((co_base + m * 32 + 4 * (lane >> 5)) * g.Cin + ci_base) * KK + n) * 4u : SENT;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) buf_st(rsl, o0 + (unsigned)((r & 3) + 8 * (r >> 2)) * co_row, acc[m][q][r]);
+            }
+        return;
+    }
+    // ---------------------------------------------------------------------- producers
+    const int ptid = tid - 64 * NQ;
+    const int gslot = ptid & 63, gpy = gslot >> 5, gpx = gslot & 31, gco = ptid >> 6;
+    const int icol = ptid & (IWP - 1), irow = ptid / IWP;
+    const unsigned go_bytes = (unsigned)g.Cout * (unsigned)HWo * 4u, x_bytes = (unsigned)g.Cin * (unsigned)HW * 4u;
+    struct Stage {
+        float rg[NG], ry[DACT != 0 ? NG : 1], ri[NI], rex[NEX];
+    };
+    Stage sa, sb;
+    float bacc[NG];
+#pragma unroll
+    for (int it = 0; it < NG; ++it) bacc[it] = 0.f;
+    auto prefetch = [&](int tile, Stage &s) {
+        int t = tile;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        const int b = t / tiles_y;
+        const int y0 = ty * WTY, x0 = tx * WTX;
+        const int iy0 = y0 - g.pad, ix0 = x0 - g.pad;
+        const bool live = tile < total_tiles;
+        const __amdgpu_buffer_rsrc_t rgo = make_rsrc(gout + (int64_t)(live ? b : 0) * g.Cout * HWo, live ? go_bytes : 0u);
+        const __amdgpu_buffer_rsrc_t rya = make_rsrc((DACT ? yact : gout) + (int64_t)(live ? b : 0) * g.Cout * HWo,
+                                                     (live && DACT) ? go_bytes : 0u);
+        const __amdgpu_buffer_rsrc_t rxi = make_rsrc(x + ((int64_t)(live ? b : 0) * g.groups + grp) * g.Cin * HW, live ? x_bytes : 0u);
+        const int gy = y0 + gpy, gx = x0 + gpx;
+        const unsigned g0 = (gpx < WTX && gy < g.Ho && gx < g.Wo) ? (unsigned)((co_base + gco) * HWo + gy * g.Wo + gx) * 4u : SENT;
+#pragma unroll
+        for (int it = 0; it < NG; ++it) {
+            const unsigned o = g0 + (unsigned)(NW64 * it) * (unsigned)HWo * 4u;
+            s.rg[it] = buf_ld(rgo, o);
+            if constexpr (DACT != 0) s.ry[it] = buf_ld(rya, o);
+        }
+        const int xx = ix0 + icol;
+        const bool col_ok = icol < IW && xx >= 0 && xx < g.W;
+#pragma unroll
+        for (int r = 0; r < IH; ++r) {
+            const int yy = iy0 + r;
+            const unsigned base = (col_ok && yy >= 0 && yy < g.H) ? (unsigned)((ci_base + irow) * HW + yy * g.W + xx) * 4u : SENT;
+#pragma unroll
+            for (int k = 0; k < CPR; ++k) s.ri[r * CPR + k] = buf_ld(rxi, base + (unsigned)(k * TROWS) * (unsigned)HW * 4u);
+        }
+#pragma unroll
+        for (int i = 0; i < NEX; ++i) {
+            const int e = ptid + i * PT, rc = e / CIB;
+            const int yy = iy0 + rc / EXC, xe = ix0 + IWP + rc % EXC;
+            const bool ok = e < EXC * IH * CIB && yy >= 0 && yy < g.H && xe >= 0 && xe < g.W;
+            s.rex[i] = buf_ld(rxi, ok ? (unsigned)((ci_base + (e & (CIB - 1))) * HW + yy * g.W + xe) * 4u : SENT);
+        }
+    };
+    auto commit = [&](int tile, int buf, Stage &s) {
+        unsigned *sG = smw + buf * BUF, *sIn = sG + 64 * GS;
+#pragma unroll
+        for (int it = 0; it < NG; ++it) {
+            if constexpr (DACT != 0) s.rg[it] *= act_grad_c<DACT>(s.ry[it], dslope);
+            bacc[it] += s.rg[it];
+            sG[(gco + NW64 * it) * GS + gslot] = split_word(s.rg[it]);
+        }
+        if (gpre_out != nullptr && blockIdx.z == 0) {
+            int t = tile;
+            const int tx = t % tiles_x; t /= tiles_x;
+            const int ty = t % tiles_y;
+            const int b = t / tiles_y;
+            const int gy = ty * WTY + gpy, gx = tx * WTX + gpx;
+            const bool live = tile < total_tiles;
+            const __amdgpu_buffer_rsrc_t rgp = make_rsrc(gpre_out + (int64_t)(live ? b : 0) * g.Cout * HWo, live ? go_bytes : 0u);
+            const unsigned o0 = (gpx < WTX && gy < g.Ho && gx < g.Wo) ? (unsigned)((co_base + gco) * HWo + gy * g.Wo + gx) * 4u : SENT;
+#pragma unroll
+            for (int it = 0; it < NG; ++it) buf_st(rgp, o0 + (unsigned)(NW64 * it) * (unsigned)HWo * 4u, s.rg[it]);
+        }
+        if (icol < IW) {
+#pragma unroll
+            for (int r = 0; r < IH; ++r)
+#pragma unroll
+                for (int k = 0; k < CPR; ++k) sIn[(irow + k * TROWS) * PS + r * IWS + icol] = split_word(s.ri[r * CPR + k]);
+        }
+#pragma unroll
+        for (int i = 0; i < NEX; ++i) {
+            const int e = ptid + i * PT, rc = e / CIB;
+            if (e < EXC * IH * CIB) sIn[(e & (CIB - 1)) * PS + (rc / EXC) * IWS + IWP + rc % EXC] = split_word(s.rex[i]);
+        }
+    };
+    prefetch(blockIdx.x, sa);
+    commit(blockIdx.x, 0, sa);
+    prefetch(blockIdx.x + G, sa);          // two tiles of loads in flight from here on
+    prefetch(blockIdx.x + 2 * G, sb);
+    __syncthreads();                       // (A)
+    int cur = 0;
+    for (int tile = blockIdx.x; tile < total_tiles; tile += 2 * G) {
+        commit(tile + G, cur ^ 1, sa);     // while the consumers multiply tile `tile` from image `cur`
+        prefetch(tile + 3 * G, sa);        // (past the end: zero-record descriptors, nothing is read)
+        __syncthreads();                   // (B)
+        cur ^= 1;
+        if (tile + G >= total_tiles) break;
+        commit(tile + 2 * G, cur ^ 1, sb);
+        prefetch(tile + 4 * G, sb);
+        __syncthreads();                   // (B)
+        cur ^= 1;
+    }
+    if (need_bias && blockIdx.z == 0) {    // lanes of a wave hold the 64 slots of channels gco + 4*it: fixed-order butterfly
+#pragma unroll
+        for (int it = 0; it < NG; ++it) {
+            float v = bacc[it];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+            if (lane == 0 && co_base + gco + NW64 * it < g.Cout) my[wsz + co_base + gco + NW64 * it] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // bf16 matrix-core weight gradient (KS in {1,3}, stride 1): M = out channels, N = (tap, ci), K = pixels.
 // MFMA wants 8 consecutive k = 8 consecutive PIXELS per lane.  NCHW gives exactly that for grad_out
 // ([co][2 rows x 32 slots], pitch 72 = 9*16 B).  For the input operand the 8 pixels start at x + kx, which
@@ -1775,9 +1992,14 @@ int pick_wtx_x3(int) { return 32; }
 // otherwise.  Measured (tools/kbench, 128x128, B=8): 64->64 54.5 vs 58.1 us, 128->64 87.1 vs 89.5, 64->128 85.9 vs 86.8,
 // 128->1600 1765 vs 1671 (the grad_out tile is fetched once per 32-channel block: with 25 output blocks that costs more
 // than the second resident workgroup hides).
+// wave-specialised form (conv_wgrad_x3_ws): every 3x3 layer; EBFI_WGRAD_WS=0 restores the uniform-wave kernels (A/B runs)
+bool wgrad_x3_ws(const ConvGeom &, int ks) {
+    const char *e = getenv("EBFI_WGRAD_WS");
+    return ks == 3 && !(e && e[0] == '0');
+}
 bool wgrad_x3_small_wg(const ConvGeom &g, int ks) {
     const bool off = getenv("EBFI_WGRAD_BIGWG") != nullptr;            // development switch (A/B runs)
-    return !off && ks == 3 && g.Cin % 32 == 0 && g.Cout <= 256;
+    return !off && !wgrad_x3_ws(g, ks) && ks == 3 && g.Cin % 32 == 0 && g.Cout <= 256;
 }
 
 int wgrad_x3_splits(const ConvGeom &g, int ks) {
@@ -1807,10 +2029,25 @@ int launch_wgrad_x3_w(hipStream_t st, const float *x, const float *gout, const f
     return check_launch("conv_wgrad_x3");
 }
 
+template <int DACT>
+int launch_wgrad_x3_ws(hipStream_t st, const float *x, const float *gout, const float *yact, float *slab, float *gpre_out,
+                       const ConvGeom &g, float dslope, int nsplit, int need_bias) {
+    using C = WCfg<3, 1, 32>;
+    const size_t lds = (size_t)2 * (64 * GS + 65 * C::PS) * sizeof(unsigned);
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_wgrad_x3_ws<DACT>), (int)lds)) return rc;
+    const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, C::WTX);
+    dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, 64));
+    ProfScope ps("conv_wgrad_x3", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * 9,
+                 conv_bytes_wgrad(g, 9, DACT != 0, gpre_out != nullptr));
+    hipLaunchKernelGGL((conv_wgrad_x3_ws<DACT>), grid, dim3(512), lds, st, x, gout, yact, slab, gpre_out, g, dslope, (int)tiles, need_bias);
+    return check_launch("conv_wgrad_x3_ws");
+}
+
 template <int KS, int WTXO, int DACT>
 int launch_wgrad_x3_d(hipStream_t st, const float *x, const float *gout, const float *yact, float *slab, float *gpre_out,
                       const ConvGeom &g, float dslope, int nsplit, int need_bias) {
     if constexpr (KS == 3) {
+        if (wgrad_x3_ws(g, KS)) return launch_wgrad_x3_ws<DACT>(st, x, gout, yact, slab, gpre_out, g, dslope, nsplit, need_bias);
         if (wgrad_x3_small_wg(g, KS))
             return launch_wgrad_x3_w<KS, WTXO, DACT, 256, 32>(st, x, gout, yact, slab, gpre_out, g, dslope, nsplit, need_bias);
     }
