@@ -1478,6 +1478,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3_ws(const float *__restrict_
         for (int tile = blockIdx.x; tile < total_tiles; tile += G) {
             const unsigned *sA = smw + cur * BUF + aoff;
             const unsigned *sB = smw + cur * BUF;
+#ifdef WS_NO_CONSUME
+            if (g.pad != 12345) { } else
+#endif
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int row = kk >> 1, px0 = (kk & 1) * 16;
@@ -1489,20 +1492,28 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3_ws(const float *__restrict_
                     for (int j = 0; j < 8; ++j) aw[j] = sA[m * 32 * GS + row * 32 + px0 + j];
                     peel(aw, ah[m], al[m]);
                 }
+                // the operand words of n-tile q+1 are requested before the six MFMAs of n-tile q are issued: with one consumer
+                // wave per SIMD nothing else covers the LDS latency
+                unsigned bw[2][8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bw[0][j] = sB[boff[0] + row * IWS + px0 + j];
 #pragma unroll
                 for (int q = 0; q < NTW; ++q) {
-                    if (q == NTW - 1 && !last_live) continue;
-                    unsigned bw[8];
+                    if (q + 1 < NTW) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) bw[j] = sB[boff[q] + row * IWS + px0 + j];
+                        for (int j = 0; j < 8; ++j) bw[(q + 1) & 1][j] = sB[boff[q + 1] + row * IWS + px0 + j];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (q == NTW - 1 && !last_live) continue;
                     bf16x8 bh, bl;
-                    peel(bw, bh, bl);
+                    peel(bw[q & 1], bh, bl);
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh, acc[m][q], 0, 0, 0);
                         acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl, acc[m][q], 0, 0, 0);
                         acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m][q], 0, 0, 0);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __syncthreads();               // (B) this image has been read, the other one is complete
@@ -1609,13 +1620,17 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3_ws(const float *__restrict_
     __syncthreads();                       // (A)
     int cur = 0;
     for (int tile = blockIdx.x; tile < total_tiles; tile += 2 * G) {
+#ifndef WS_NO_PRODUCE
         commit(tile + G, cur ^ 1, sa);     // while the consumers multiply tile `tile` from image `cur`
         prefetch(tile + 3 * G, sa);        // (past the end: zero-record descriptors, nothing is read)
+#endif
         __syncthreads();                   // (B)
         cur ^= 1;
         if (tile + G >= total_tiles) break;
+#ifndef WS_NO_PRODUCE
         commit(tile + 2 * G, cur ^ 1, sb);
         prefetch(tile + 4 * G, sb);
+#endif
         __syncthreads();                   // (B)
         cur ^= 1;
     }
@@ -1993,9 +2008,9 @@ int pick_wtx_x3(int) { return 32; }
 // 128->1600 1765 vs 1671 (the grad_out tile is fetched once per 32-channel block: with 25 output blocks that costs more
 // than the second resident workgroup hides).
 // wave-specialised form (conv_wgrad_x3_ws): every 3x3 layer; EBFI_WGRAD_WS=0 restores the uniform-wave kernels (A/B runs)
-bool wgrad_x3_ws(const ConvGeom &, int ks) {
+bool wgrad_x3_ws(const ConvGeom &g, int ks) {   // 64-channel input blocks: layers with other channel counts keep the 32-channel form
     const char *e = getenv("EBFI_WGRAD_WS");
-    return ks == 3 && !(e && e[0] == '0');
+    return ks == 3 && g.Cin % 64 == 0 && !(e && e[0] == '0');
 }
 bool wgrad_x3_small_wg(const ConvGeom &g, int ks) {
     const bool off = getenv("EBFI_WGRAD_BIGWG") != nullptr;            // development switch (A/B runs)
