@@ -1499,10 +1499,17 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3_ws(const float *__restrict_
                 for (int j = 0; j < 8; ++j) bw[0][j] = sB[boff[0] + row * IWS + px0 + j];
 #pragma unroll
                 for (int q = 0; q < NTW; ++q) {
+#ifndef WS_NO_LDSREAD
                     if (q + 1 < NTW) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) bw[(q + 1) & 1][j] = sB[boff[q + 1] + row * IWS + px0 + j];
                     }
+#else
+                    if (q + 1 < NTW) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) bw[(q + 1) & 1][j] = bw[q & 1][j] + (unsigned)boff[q + 1];
+                    }
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                     if (q == NTW - 1 && !last_live) continue;
                     bf16x8 bh, bl;
