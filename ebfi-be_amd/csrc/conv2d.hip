@@ -1455,24 +1455,31 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3_ws(const float *__restrict_
 
     if (wave < NQ) {
         // ------------------------------------------------------------------ consumers
+        // 18 n-tiles x 2 output tiles = 36 blocks, 9 per wave: n-tiles nq, nq+4, nq+8, nq+12 with BOTH output tiles, plus output
+        // tile (nq & 1) of n-tile 16 + (nq >> 1)  (5 / 5 / 4 / 4 whole n-tiles left two waves waiting a fifth of the time)
         const int nq = wave;
-        f32x16 acc[2][NTW];
+        constexpr int NTF = NTW - 1;       // n-tiles held with both output tiles
+        static_assert(NTW == 5, "block distribution assumes 18 n-tiles over 4 waves");
+        const int xm = nq & 1, xt = 16 + (nq >> 1);
+        f32x16 acc[2][NTF], accx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accx[r] = 0.f;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int n = 0; n < NTW; ++n)
+            for (int n = 0; n < NTF; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-        int boff[NTW];
-#pragma unroll
-        for (int q = 0; q < NTW; ++q) {
-            const int n = (nq + NQ * q) * 32 + (lane & 31);
+        auto col_off = [&](int n) {
             const int ci = n / KK, tap = n - ci * KK;
             const int ky = tap / KS, kx = tap - ky * KS;
-            boff[q] = 64 * GS + ((n < ncols) ? ci * PS + ky * IWS + kx : CIB * PS) + 8 * (lane >> 5);
-        }
+            return 64 * GS + ((n < ncols) ? ci * PS + ky * IWS + kx : CIB * PS) + 8 * (lane >> 5);
+        };
+        int boff[NTW];
+#pragma unroll
+        for (int q = 0; q < NTF; ++q) boff[q] = col_off((nq + NQ * q) * 32 + (lane & 31));
+        boff[NTF] = col_off(xt * 32 + (lane & 31));
         const int aoff = (lane & 31) * GS + 8 * (lane >> 5);
-        const bool last_live = (nq + NQ * (NTW - 1)) * 32 < ncols;
         __syncthreads();                   // (A) the first tile is committed
         int cur = 0;
         for (int tile = blockIdx.x; tile < total_tiles; tile += G) {
@@ -1492,7 +1499,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3_ws(const float *__restrict_
                     for (int j = 0; j < 8; ++j) aw[j] = sA[m * 32 * GS + row * 32 + px0 + j];
                     peel(aw, ah[m], al[m]);
                 }
-                // the operand words of n-tile q+1 are requested before the six MFMAs of n-tile q are issued: with one consumer
+                // the operand words of n-tile q+1 are requested before the MFMAs of n-tile q are issued: with one consumer
                 // wave per SIMD nothing else covers the LDS latency
                 unsigned bw[2][8];
 #pragma unroll
@@ -1511,14 +1518,20 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3_ws(const float *__restrict_
                     }
 #endif
                     __builtin_amdgcn_sched_barrier(0);
-                    if (q == NTW - 1 && !last_live) continue;
                     bf16x8 bh, bl;
                     peel(bw[q & 1], bh, bl);
+                    if (q < NTF) {
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh, acc[m][q], 0, 0, 0);
-                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl, acc[m][q], 0, 0, 0);
-                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m][q], 0, 0, 0);
+                        for (int m = 0; m < 2; ++m) {
+                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh, acc[m][q], 0, 0, 0);
+                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl, acc[m][q], 0, 0, 0);
+                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m][q], 0, 0, 0);
+                        }
+                    } else {               // the ninth block: one output tile of the extra n-tile
+                        const bf16x8 xh = xm ? ah[1] : ah[0], xl = xm ? al[1] : al[0];
+                        accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh, accx, 0, 0, 0);
+                        accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl, accx, 0, 0, 0);
+                        accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, accx, 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -1528,15 +1541,17 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3_ws(const float *__restrict_
         }
         const __amdgpu_buffer_rsrc_t rsl = make_rsrc(my, (unsigned)wsz * 4u);   // rows co >= Cout fall past the slab: dropped
         const unsigned co_row = (unsigned)(g.Cin * KK) * 4u;
+        auto store_block = [&](const f32x16 &a, int m, int ntile) {
+            const int n = ntile * 32 + (lane & 31);
+            const unsigned o0 = n < ncols ? (unsigned)(((co_base + m * 32 + 4 * (lane >> 5)) * g.Cin + ci_base) * KK + n) * 4u : SENT;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) buf_st(rsl, o0 + (unsigned)((r & 3) + 8 * (r >> 2)) * co_row, a[r]);
+        };
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int q = 0; q < NTW; ++q) {
-                const int n = (nq + NQ * q) * 32 + (lane & 31);
-                const unsigned o0 = n < ncols ? (unsigned)(((co_base + m * 32 + 4 * (lane >> 5)) * g.Cin + ci_base) * KK + n) * 4u : SENT;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) buf_st(rsl, o0 + (unsigned)((r & 3) + 8 * (r >> 2)) * co_row, acc[m][q][r]);
-            }
+            for (int q = 0; q < NTF; ++q) store_block(acc[m][q], m, nq + NQ * q);
+        store_block(accx, xm, xt);
         return;
     }
     // ---------------------------------------------------------------------- producers
