@@ -2129,6 +2129,230 @@ int launch_wgrad_bf16(hipStream_t st, const float *x, const float *gout, const f
     return launch_wgrad_bf16_d<KS, ACT_NONE>(st, x, gout, yact, slab, g, dslope, nsplit, need_bias);
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv_fwd_bf16x3_ws: the 3x3 split-precision forward / data gradient (64 output channels per workgroup, no folded activation
+// derivative: the bulk of a training step) with SPECIALISED waves, after the weight gradient (conv_wgrad_x3_ws).  Waves 4..7
+// are producers: they keep TWO chunks of global loads in flight, convert and write the next chunk's input and weight images;
+// waves 0..3, one per SIMD, are consumers: each owns two of the tile's eight output rows, so a weight-operand read serves
+// both rows, and issues nothing but operand reads and MFMAs (24 per tap).  Same LDS images, same persistent walk over pixel
+// tiles and the same epilogue as conv_fwd_bf16x3_db; one workgroup barrier per 16-channel chunk hands a buffer over.
+template <bool EXTRA>
+__global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_ws(const float *__restrict__ x, const __bf16 *__restrict__ wp,
+                                                          const float *__restrict__ bias, float *__restrict__ out, ConvGeom g, int K16,
+                                                          int act, float slope, EpiExtra epi, int tiles_total) {
+    constexpr int KS = 3, KK = 9, MT = 2;
+    constexpr int IH = TYB - 1 + KS, IW = TX - 1 + KS, PS = IH * IW, COS = 32 * MT;
+    constexpr int PT = 256;                                    // producer threads
+    constexpr int NPOS = (PS + PT - 1) / PT;                   // input positions per producer thread
+    constexpr int WPIECES = KK * COS * 2, NWB = (2 * WPIECES + PT - 1) / PT;
+    constexpr int INB = PS * 32, WB = KK * COS * 32, BUFB = 2 * INB + 2 * WB;
+    extern __shared__ __attribute__((aligned(16))) char smd[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = (g.Wo + TX - 1) / TX, tiles_y = (g.Ho + TYB - 1) / TYB;
+    const int co_base = blockIdx.y * COS;
+    const int grp = co_base / (g.Cout / g.groups);
+    const int HW = g.H * g.W;
+    const unsigned plane_bytes = (unsigned)HW * 4u, x_bytes = (unsigned)g.Cin * plane_bytes;
+    const int nchunks = K16 / CKB;
+    const int G = gridDim.x;
+    int ntiles_mine = 0;
+    for (int t = blockIdx.x; t < tiles_total; t += G) ++ntiles_mine;
+    const int nitems = ntiles_mine * nchunks;
+    auto tile_coords = [&](int tt, int &tb, int &ty0, int &tx0) {
+        int u = tt;
+        const int txi = u % tiles_x; u /= tiles_x;
+        const int tyi = u % tiles_y;
+        tb = u / tiles_y; ty0 = tyi * TYB; tx0 = txi * TX;
+    };
+
+    if (wave < 4) {
+        // ------------------------------------------------------------------ consumers: rows 2*wave, 2*wave + 1
+        f32x16 acc[2][MT][2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[r][m][n][e] = 0.f;
+        const int hsel = lane >> 5, l31 = lane & 31;
+        const int a_lane = 2 * INB + l31 * 32 + ((hsel ^ ((l31 >> 3) & 1)) << 4);
+        const int pbase = 2 * wave * IW + l31;
+        unsigned fbits[2] = {0u, 0u};      // per row: bit tap = half-swap of this lane's position for that tap
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int tap = 0; tap < KK; ++tap)
+                fbits[r] |= (unsigned)((((pbase + r * IW + (tap / KS) * IW + (tap % KS)) >> 3) & 1) ^ hsel) << tap;
+        __syncthreads();                   // (A) the first chunk is committed
+        int item = 0, tcur = blockIdx.x;
+        for (int ti = 0; ti < ntiles_mine; ++ti, tcur += G) {
+            for (int chunk = 0; chunk < nchunks; ++chunk, ++item) {
+                const char *base = smd + (item & 1) * BUFB;
+#ifdef WSF_NO_CONSUME
+                if (g.pad != 12345) { } else
+#endif
+#pragma unroll
+                for (int tap = 0; tap < KK; ++tap) {
+                    const int ky = tap / KS, kx = tap - ky * KS;
+                    const char *ap = base + a_lane + tap * COS * 32;
+                    bf16x8 ah[MT], al[MT];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        ah[m] = *reinterpret_cast<const bf16x8 *>(ap + m * 1024);
+                        al[m] = *reinterpret_cast<const bf16x8 *>(ap + m * 1024 + WB);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const char *bp = base + (pbase + r * IW) * 32 + (int)(((fbits[r] >> tap) & 1u) << 4) + (ky * IW + kx) * 32;
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) {
+                            const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(bp + n * 1024);
+                            const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(bp + n * 1024 + INB);
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) {
+                                acc[r][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh, acc[r][m][n], 0, 0, 0);
+                                acc[r][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl, acc[r][m][n], 0, 0, 0);
+                                acc[r][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[r][m][n], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+                __syncthreads();           // (B) this buffer has been read, the other one is complete
+            }
+            int cb_, cy0, cx0;
+            tile_coords(tcur, cb_, cy0, cx0);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                store_out_tile<MT, EXTRA>(out, bias, acc[r], g, cb_, co_base, cy0 + 2 * wave + r, cx0, lane, act, slope, epi);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[r][m][n][e] = 0.f;
+            }
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------- producers
+    // The input tile is fetched as 16-byte quads of 4 consecutive pixels x 8 channels (W % 4 == 0, same padding, aligned
+    // tensors: the launcher checks): 16 + 9 vector-memory instructions per thread and chunk.  With one dword per load a chunk
+    // took 57 and two chunks in flight exceeded the 63 outstanding operations a wave can have: the producers stalled in issue
+    // and the consumers (85-96 % of the matrix peak on their own) waited for them.
+    const int ptid = tid - 256;
+    const unsigned img_bytes = (unsigned)KK * (unsigned)g.Cout * (unsigned)K16 * 2u;
+    const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(wp), 0, 2u * img_bytes, 0x00020000);
+    constexpr int SH = (4 - (KS / 2) % 4) % 4;             // tile column of a quad's first pixel: 4 qq - SH
+    constexpr int NQ = (IW + SH + 3) / 4;                  // quads per tile row
+    constexpr int NITEM = IH * NQ * 2;                     // (row, quad, channel half)
+    constexpr int NIT = (NITEM + PT - 1) / PT;             // items per producer thread
+    int it_qh[NIT], it_qr[NIT], it_qq[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int id = ptid + k * PT;
+        it_qh[k] = id & 1;
+        it_qr[k] = (id >> 1) / NQ;
+        it_qq[k] = (id >> 1) - it_qr[k] * NQ;
+    }
+    unsigned w_off[NWB];
+    int w_dst[NWB];
+#pragma unroll
+    for (int it = 0; it < NWB; ++it) {
+        const int i = ptid + it * PT;
+        const int sel = i >= WPIECES ? 1 : 0, j = i - sel * WPIECES;
+        const int row = j >> 1, half = j & 1;
+        const int tap = row / COS, co = row - tap * COS;
+        w_off[it] = i < 2 * WPIECES ? (unsigned)sel * img_bytes + (unsigned)(((tap * g.Cout + co_base + co) * K16 + half * 8) * 2) : SENT;
+        w_dst[it] = 2 * INB + sel * WB + row * 32 + ((half ^ ((row >> 3) & 1)) << 4);
+    }
+    struct Stage {
+        u32x4 rq[NIT][8];                  // 4 pixels of channels 8*qh + k
+        u32x4 rw[NWB];
+    };
+    Stage s0, s1;
+    int pf_tile = blockIdx.x, pf_chunk = 0;
+    unsigned pf_off[NIT];
+    const float *pf_src = x;
+    unsigned pf_bytes = 0u;
+    auto pf_setup = [&]() {
+        const bool live = pf_tile < tiles_total;
+        int tb, ty0, tx0;
+        tile_coords(live ? pf_tile : 0, tb, ty0, tx0);
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int yy = ty0 - g.pad + it_qr[k], xq = tx0 - g.pad - SH + 4 * it_qq[k];
+            const bool ok = live && ptid + k * PT < NITEM && yy >= 0 && yy < g.H && xq >= 0 && xq + 3 < g.W;
+            pf_off[k] = ok ? (unsigned)(yy * g.W + xq) * 4u + (unsigned)(8 * it_qh[k]) * plane_bytes : SENT;
+        }
+        pf_src = x + ((int64_t)tb * g.groups + grp) * g.Cin * HW;
+        pf_bytes = live ? x_bytes : 0u;
+    };
+    auto prefetch = [&](Stage &s) {
+        const __amdgpu_buffer_rsrc_t r = make_rsrc(pf_src, pf_bytes);
+        const unsigned cb = (unsigned)pf_chunk * (unsigned)CKB * plane_bytes;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) s.rq[k][c] = __builtin_amdgcn_raw_buffer_load_b128(r, pf_off[k] + cb + (unsigned)c * plane_bytes, 0, 0);
+        const unsigned wb = (unsigned)pf_chunk * (unsigned)(CKB * 2);
+#pragma unroll
+        for (int it = 0; it < NWB; ++it) s.rw[it] = __builtin_amdgcn_raw_buffer_load_b128(rwt, w_off[it] + wb, 0, 0);
+        if (++pf_chunk == nchunks) {
+            pf_chunk = 0;
+            pf_tile += G;
+            pf_setup();
+        }
+    };
+    auto commit = [&](int buf, Stage &s) {
+        char *base = smd + buf * BUFB;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+            if (ptid + k * PT < NITEM) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = 4 * it_qq[k] + j - SH;
+                    if (c < 0 || c >= IW) continue;
+                    u32x4 hv, lv;
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const float v0 = __uint_as_float(s.rq[k][e][j]), v1 = __uint_as_float(s.rq[k][e + 1][j]);
+                        const __bf16 a0 = (__bf16)v0, a1 = (__bf16)v1;
+                        hv[e >> 1] = pack_bf16((float)a0, (float)a1);
+                        lv[e >> 1] = pack_bf16(v0 - (float)a0, v1 - (float)a1);
+                    }
+                    const int pos = it_qr[k] * IW + c;
+                    const int d = pos * 32 + ((it_qh[k] ^ ((pos >> 3) & 1)) << 4);
+                    *reinterpret_cast<u32x4 *>(base + d) = hv;
+                    *reinterpret_cast<u32x4 *>(base + INB + d) = lv;
+                }
+            }
+#pragma unroll
+        for (int it = 0; it < NWB; ++it)
+            if (ptid + it * PT < 2 * WPIECES) *reinterpret_cast<u32x4 *>(base + w_dst[it]) = s.rw[it];
+    };
+    pf_setup();
+    prefetch(s0);
+    commit(0, s0);                         // item 0
+    prefetch(s1);                          // item 1
+    prefetch(s0);                          // item 2
+    __syncthreads();                       // (A)
+    for (int item = 0; item < nitems; item += 2) {
+#ifndef WSF_NO_PRODUCE
+        commit((item + 1) & 1, s1);        // item + 1, while the consumers multiply item
+        prefetch(s1);                      // item + 3
+#endif
+        __syncthreads();                   // (B)
+        if (item + 1 >= nitems) break;
+#ifndef WSF_NO_PRODUCE
+        commit(item & 1, s0);              // item + 2
+        prefetch(s0);                      // item + 4
+#endif
+        __syncthreads();                   // (B)
+    }
+}
+
 size_t bf16_pack_bytes(int M, int K, int ks) { return (size_t)ks * ks * M * (size_t)((K + 15) / 16 * 16) * 2; }
 
 // shared by forward (TR = 0) and data gradient (TR = 1); g is the geometry of the conv actually run.
@@ -2186,6 +2410,27 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
         if (gx < 1) gx = 1;
         if (gx > tiles || getenv("EBFI_CONV_NOPERSIST")) gx = tiles;
         const dim3 pgrid((unsigned)gx, (unsigned)co_blocks);
+        if constexpr (KS == 3) {
+            const char *ws_env = getenv("EBFI_CONV_WS");       // development switch: 0 = uniform waves (A/B runs)
+            const bool extra = epi.addend != nullptr || epi.mask_y != nullptr;
+            const bool ws_extra = getenv("EBFI_CONV_WS_EXTRA") != nullptr;
+            // measured (B=8, 128x128): 128 -> 1600 forward 1.12 vs 1.24 ms, its data gradient (1600 -> 128) 1.10 vs 1.18 ms; layers with
+            // few output-channel blocks and short channel loops 2-4 % slower than the uniform-wave kernel (the producers and the
+            // consumers slow each other down: alone they take 0.74 / 0.83 ms on the forward) -- so only the long ones take this form
+            const bool ws_long = ceil_div(g.Cout, 64) >= 8 || K16 >= 512 || (ws_env && ws_env[0] == '2');
+            if (mt == 2 && vec4 && dact == ACT_NONE && (!extra || ws_extra) && ws_long && !(ws_env && ws_env[0] == '0')) {
+                if (extra) {
+                    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_bf16x3_ws<true>), 160 * 1024)) return rc_;
+                    hipLaunchKernelGGL((conv_fwd_bf16x3_ws<true>), pgrid, dim3(NTB), lds, st, x, wp, bias, out, g, K16, act, slope, epi,
+                                       (int)tiles);
+                } else {
+                    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_bf16x3_ws<false>), 160 * 1024)) return rc_;
+                    hipLaunchKernelGGL((conv_fwd_bf16x3_ws<false>), pgrid, dim3(NTB), lds, st, x, wp, bias, out, g, K16, act, slope, epi,
+                                       (int)tiles);
+                }
+                return check_launch(name);
+            }
+        }
         if (mt == 1) {
             if (dact == ACT_LEAKY) EBFI_LAUNCH_X3(1, ACT_LEAKY);
             else if (dact == ACT_SIGMOID) EBFI_LAUNCH_X3(1, ACT_SIGMOID);
