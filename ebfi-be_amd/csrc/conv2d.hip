@@ -2074,7 +2074,7 @@ int launch_wgrad_x3_ws(hipStream_t st, const float *x, const float *gout, const 
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_wgrad_x3_ws<DACT>), (int)lds)) return rc;
     const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, C::WTX);
     dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, 64));
-    ProfScope ps("conv_wgrad_x3", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * 9,
+    ProfScope ps("conv_wgrad_x3_ws", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * 9,
                  conv_bytes_wgrad(g, 9, DACT != 0, gpre_out != nullptr));
     hipLaunchKernelGGL((conv_wgrad_x3_ws<DACT>), grid, dim3(512), lds, st, x, gout, yact, slab, gpre_out, g, dslope, (int)tiles, need_bias);
     return check_launch("conv_wgrad_x3_ws");
@@ -2386,6 +2386,18 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
     if (x3) {
         constexpr int PSX = (TYB - 1 + KS) * (TX - 1 + KS);
         const size_t lds = (size_t)2 * (2 * PSX * 32 + 2 * KS * KS * 32 * mt * 32) + KB_LDS_BYTES;   // two buffers of unpadded hi/lo images
+        // 16-byte input quads: rows must keep quads aligned, same-padding only; used where they pay (see the kernel's header)
+        const bool vec4 = g.W % 4 == 0 && g.pad == KS / 2 && aligned16(x) && (!dact_y || aligned16(dact_y));
+        const char *ws_env = getenv("EBFI_CONV_WS");       // development switch: 0 = uniform waves, 2 = every eligible layer
+        const bool extra = epi.addend != nullptr || epi.mask_y != nullptr;
+        // wave-specialised form (conv_fwd_bf16x3_ws).  Measured (B=8, 128x128): 128 -> 1600 forward 1.12 vs 1.24 ms, its data
+        // gradient (1600 -> 128) 1.10 vs 1.18 ms; layers with few output-channel blocks and short channel loops 2-4 % slower than
+        // the uniform-wave kernel (the producers and the consumers slow each other down: alone they take 0.74 / 0.83 ms on the
+        // forward) -- so only the long ones take this form
+        const bool ws_long = ceil_div(g.Cout, 64) >= 8 || K16 >= 512 || (ws_env && ws_env[0] == '2');
+        const bool use_ws = KS == 3 && mt == 2 && vec4 && dact == ACT_NONE && (!extra || getenv("EBFI_CONV_WS_EXTRA") != nullptr) &&
+                            ws_long && !(ws_env && ws_env[0] == '0');
+        if (use_ws) name = transposed ? "conv_fwd_bf16x3_ws/dgrad" : "conv_fwd_bf16x3_ws/fwd";
         ProfScope ps(name, st, flops, conv_bytes_fwd(g, KS * KS, dact != 0));
 #define EBFI_LAUNCH_X3V(MT_, DA_, VEC_)                                                                                   \
     do {                                                                                                                 \
@@ -2399,8 +2411,6 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
         if (vec == 4) EBFI_LAUNCH_X3V(MT_, DA_, 4);                                                                      \
         else EBFI_LAUNCH_X3V(MT_, DA_, 1);                                                                               \
     } while (0)
-        // 16-byte input quads: rows must keep quads aligned, same-padding only; used where they pay (see the kernel's header)
-        const bool vec4 = g.W % 4 == 0 && g.pad == KS / 2 && aligned16(x) && (!dact_y || aligned16(dact_y));
         const char *vec_env = getenv("EBFI_CONV_VEC");     // development switch (tools/kbench): 1 = dword loads, 4 = quad loads
         const int vec = !vec4 ? 1 : (vec_env ? atoi(vec_env) : (dact != ACT_NONE ? 4 : 1));
         // the persistent form (3x3, dword loads, no folded derivative): one round of workgroups, each walking
@@ -2411,14 +2421,7 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
         if (gx > tiles || getenv("EBFI_CONV_NOPERSIST")) gx = tiles;
         const dim3 pgrid((unsigned)gx, (unsigned)co_blocks);
         if constexpr (KS == 3) {
-            const char *ws_env = getenv("EBFI_CONV_WS");       // development switch: 0 = uniform waves (A/B runs)
-            const bool extra = epi.addend != nullptr || epi.mask_y != nullptr;
-            const bool ws_extra = getenv("EBFI_CONV_WS_EXTRA") != nullptr;
-            // measured (B=8, 128x128): 128 -> 1600 forward 1.12 vs 1.24 ms, its data gradient (1600 -> 128) 1.10 vs 1.18 ms; layers with
-            // few output-channel blocks and short channel loops 2-4 % slower than the uniform-wave kernel (the producers and the
-            // consumers slow each other down: alone they take 0.74 / 0.83 ms on the forward) -- so only the long ones take this form
-            const bool ws_long = ceil_div(g.Cout, 64) >= 8 || K16 >= 512 || (ws_env && ws_env[0] == '2');
-            if (mt == 2 && vec4 && dact == ACT_NONE && (!extra || ws_extra) && ws_long && !(ws_env && ws_env[0] == '0')) {
+            if (use_ws) {
                 if (extra) {
                     if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_bf16x3_ws<true>), 160 * 1024)) return rc_;
                     hipLaunchKernelGGL((conv_fwd_bf16x3_ws<true>), pgrid, dim3(NTB), lds, st, x, wp, bias, out, g, K16, act, slope, epi,

@@ -524,8 +524,8 @@ def test_fused_residual_control_equals_layerwise():
         for n in gp0:
             assert _rel(gp1[n], gp0[n]) < 5e-5, n
         # 3 convolutions forward and 3 data gradients per round on one kernel, 3 weight gradients per round
-        assert prof1["conv_fwd_bf16x3_db/fwd"][0] == 6 * step and prof1["conv_wgrad_x3"][0] == 3 * step
-        assert prof0["conv_fwd_bf16x3_db/fwd"][0] == 5 * step and prof0["conv_wgrad_x3"][0] == 5 * step
+        assert prof1["conv_fwd_bf16x3_db/fwd"][0] == 6 * step and prof1["conv_wgrad_x3_ws"][0] == 3 * step
+        assert prof0["conv_fwd_bf16x3_db/fwd"][0] == 5 * step and prof0["conv_wgrad_x3_ws"][0] == 5 * step
     finally:
         conv.set_compute_dtype("fp32")
 

@@ -96,7 +96,8 @@ def main():
         sfx = "bf16" if a.bf16 else "f32"
         convmod.set_compute_dtype("bf16" if a.bf16 else ("bf16x3" if a.x3 else "fp32"))
         names = {"conv_fwd_%s/fwd" % sfx, "conv_fwd_%s/dgrad" % sfx, "conv_wgrad_" + sfx, "conv_wgrad_reduce_f32", "conv_pack_w_bf16",
-                 "conv_fwd_bf16x3_db/fwd", "conv_fwd_bf16x3_db/dgrad", "conv_wgrad_x3"}
+                 "conv_fwd_bf16x3_db/fwd", "conv_fwd_bf16x3_db/dgrad", "conv_wgrad_x3", "conv_wgrad_x3_ws",
+                 "conv_fwd_bf16x3_ws/fwd", "conv_fwd_bf16x3_ws/dgrad"}
         peak = 2500.0 if a.bf16 else F32_MFMA_PEAK
         for (cin, cout, hh, ww, tag) in [(64, 64, h, w, "ResidualControl 64->64"), (128, 64, h, w, "Conv5 128->64"),
                                          (128, 1600, h, w, "KernelConv 128->1600"), (64, 64, 2 * h, 2 * w, "Recon 64->64 @2x")]:
