@@ -2131,19 +2131,22 @@ int launch_wgrad_bf16(hipStream_t st, const float *x, const float *gout, const f
 
 // ------------------------------------------------------------------------------------------------
 // conv_fwd_bf16x3_ws: the 3x3 split-precision forward / data gradient (64 output channels per workgroup, no folded activation
-// derivative: the bulk of a training step) with SPECIALISED waves, after the weight gradient (conv_wgrad_x3_ws).  Waves 4..7
-// are producers: they keep TWO chunks of global loads in flight, convert and write the next chunk's input and weight images;
-// waves 0..3, one per SIMD, are consumers: each owns two of the tile's eight output rows, so a weight-operand read serves
-// both rows, and issues nothing but operand reads and MFMAs (24 per tap).  Same LDS images, same persistent walk over pixel
-// tiles and the same epilogue as conv_fwd_bf16x3_db; one workgroup barrier per 16-channel chunk hands a buffer over.
+// derivative: the bulk of a training step) with SPECIALISED waves, after the weight gradient (conv_wgrad_x3_ws).  768 threads:
+// waves 8..11 are producers -- they fetch the next chunk's input tile as 16-byte quads and its weight pieces one chunk ahead,
+// convert and write both images; waves 0..7, two per SIMD, are consumers -- one output row each, operand fragments of tap
+// t+1 read before the MFMAs of tap t (168 registers per wave: three waves per SIMD).  Same LDS images, persistent walk over
+// pixel tiles and epilogue as conv_fwd_bf16x3_db; one workgroup barrier per 16-channel chunk hands a buffer over.
+// Measured (B=8, 128x128): 128 -> 1600 forward / its data gradient 1.04 ms (uniform waves 1.24 / 1.18); all eligible layers
+// of the step -0.42 ms.  A first form with FOUR consumer waves (two rows each, single-buffered operands, 254 registers) ran
+// its consumers ALONE at 84-96 % of the real-clock matrix peak but lost it again beside the producers (1.10-1.12 ms).
+constexpr int NTWS = 768;              // conv_fwd_bf16x3_ws: 8 consumer waves + 4 producer waves
 template <bool EXTRA>
-__global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_ws(const float *__restrict__ x, const __bf16 *__restrict__ wp,
-                                                          const float *__restrict__ bias, float *__restrict__ out, ConvGeom g, int K16,
-                                                          int act, float slope, EpiExtra epi, int tiles_total) {
+__global__ __launch_bounds__(NTWS) void conv_fwd_bf16x3_ws(const float *__restrict__ x, const __bf16 *__restrict__ wp,
+                                                           const float *__restrict__ bias, float *__restrict__ out, ConvGeom g, int K16,
+                                                           int act, float slope, EpiExtra epi, int tiles_total) {
     constexpr int KS = 3, KK = 9, MT = 2;
     constexpr int IH = TYB - 1 + KS, IW = TX - 1 + KS, PS = IH * IW, COS = 32 * MT;
-    constexpr int PT = 256;                                    // producer threads
-    constexpr int NPOS = (PS + PT - 1) / PT;                   // input positions per producer thread
+    constexpr int NCW = 8, PT = 256;                           // consumer waves (one output row each); producer threads
     constexpr int WPIECES = KK * COS * 2, NWB = (2 * WPIECES + PT - 1) / PT;
     constexpr int INB = PS * 32, WB = KK * COS * 32, BUFB = 2 * INB + 2 * WB;
     extern __shared__ __attribute__((aligned(16))) char smd[];
@@ -2165,26 +2168,48 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_ws(const float *__restric
         tb = u / tiles_y; ty0 = tyi * TYB; tx0 = txi * TX;
     };
 
-    if (wave < 4) {
-        // ------------------------------------------------------------------ consumers: rows 2*wave, 2*wave + 1
-        f32x16 acc[2][MT][2];
+    if (wave < NCW) {
+        // ------------------------------------------------------------------ consumers: output row `wave`, two per SIMD
+        f32x16 acc[MT][2];
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+        const int hsel = lane >> 5, l31 = lane & 31;
+        const int a_lane = 2 * INB + l31 * 32 + ((hsel ^ ((l31 >> 3) & 1)) << 4);
+        const int pbase = wave * IW + l31;
+        unsigned fbits = 0;
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap)
+            fbits |= (unsigned)((((pbase + (tap / KS) * IW + (tap % KS)) >> 3) & 1) ^ hsel) << tap;
+        bf16x8 ah[2][MT], al[2][MT], bh[2][2], bl[2][2];
+        auto tap_read = [&](const char *base, int tap, int set) {
+            const int ky = tap / KS, kx = tap - ky * KS;
+            const char *bp = base + pbase * 32 + (int)(((fbits >> tap) & 1u) << 4) + (ky * IW + kx) * 32;
+            const char *ap = base + a_lane + tap * COS * 32;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                ah[set][m] = *reinterpret_cast<const bf16x8 *>(ap + m * 1024);
+                al[set][m] = *reinterpret_cast<const bf16x8 *>(ap + m * 1024 + WB);
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                bh[set][n] = *reinterpret_cast<const bf16x8 *>(bp + n * 1024);
+                bl[set][n] = *reinterpret_cast<const bf16x8 *>(bp + n * 1024 + INB);
+            }
+        };
+        auto tap_mfma = [&](int set) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[r][m][n][e] = 0.f;
-        const int hsel = lane >> 5, l31 = lane & 31;
-        const int a_lane = 2 * INB + l31 * 32 + ((hsel ^ ((l31 >> 3) & 1)) << 4);
-        const int pbase = 2 * wave * IW + l31;
-        unsigned fbits[2] = {0u, 0u};      // per row: bit tap = half-swap of this lane's position for that tap
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int tap = 0; tap < KK; ++tap)
-                fbits[r] |= (unsigned)((((pbase + r * IW + (tap / KS) * IW + (tap % KS)) >> 3) & 1) ^ hsel) << tap;
+                for (int n = 0; n < 2; ++n) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[set][m], bh[set][n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][m], bl[set][n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][m], bh[set][n], acc[m][n], 0, 0, 0);
+                }
+        };
         __syncthreads();                   // (A) the first chunk is committed
         int item = 0, tcur = blockIdx.x;
         for (int ti = 0; ti < ntiles_mine; ++ti, tcur += G) {
@@ -2193,55 +2218,34 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_ws(const float *__restric
 #ifdef WSF_NO_CONSUME
                 if (g.pad != 12345) { } else
 #endif
+                {
+                    tap_read(base, 0, 0);
 #pragma unroll
-                for (int tap = 0; tap < KK; ++tap) {
-                    const int ky = tap / KS, kx = tap - ky * KS;
-                    const char *ap = base + a_lane + tap * COS * 32;
-                    bf16x8 ah[MT], al[MT];
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        ah[m] = *reinterpret_cast<const bf16x8 *>(ap + m * 1024);
-                        al[m] = *reinterpret_cast<const bf16x8 *>(ap + m * 1024 + WB);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) {
-                        const char *bp = base + (pbase + r * IW) * 32 + (int)(((fbits[r] >> tap) & 1u) << 4) + (ky * IW + kx) * 32;
-#pragma unroll
-                        for (int n = 0; n < 2; ++n) {
-                            const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(bp + n * 1024);
-                            const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(bp + n * 1024 + INB);
-#pragma unroll
-                            for (int m = 0; m < MT; ++m) {
-                                acc[r][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh, acc[r][m][n], 0, 0, 0);
-                                acc[r][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl, acc[r][m][n], 0, 0, 0);
-                                acc[r][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[r][m][n], 0, 0, 0);
-                            }
-                        }
+                    for (int tap = 0; tap < KK; ++tap) {
+                        if (tap + 1 < KK) tap_read(base, tap + 1, (tap + 1) & 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        tap_mfma(tap & 1);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 __syncthreads();           // (B) this buffer has been read, the other one is complete
             }
             int cb_, cy0, cx0;
             tile_coords(tcur, cb_, cy0, cx0);
+            store_out_tile<MT, EXTRA>(out, bias, acc, g, cb_, co_base, cy0 + wave, cx0, lane, act, slope, epi);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                store_out_tile<MT, EXTRA>(out, bias, acc[r], g, cb_, co_base, cy0 + 2 * wave + r, cx0, lane, act, slope, epi);
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
+                for (int n = 0; n < 2; ++n)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) acc[r][m][n][e] = 0.f;
-            }
+                    for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
         }
         return;
     }
     // ---------------------------------------------------------------------- producers
     // The input tile is fetched as 16-byte quads of 4 consecutive pixels x 8 channels (W % 4 == 0, same padding, aligned
-    // tensors: the launcher checks): 16 + 9 vector-memory instructions per thread and chunk.  With one dword per load a chunk
-    // took 57 and two chunks in flight exceeded the 63 outstanding operations a wave can have: the producers stalled in issue
-    // and the consumers (85-96 % of the matrix peak on their own) waited for them.
-    const int ptid = tid - 256;
+    // tensors: the launcher checks): 16 + 9 vector-memory instructions per thread and chunk, one chunk ahead of the consumers.
+    const int ptid = tid - 64 * NCW;
     const unsigned img_bytes = (unsigned)KK * (unsigned)g.Cout * (unsigned)K16 * 2u;
     const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(wp), 0, 2u * img_bytes, 0x00020000);
     constexpr int SH = (4 - (KS / 2) % 4) % 4;             // tile column of a quad's first pixel: 4 qq - SH
@@ -2267,11 +2271,8 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_ws(const float *__restric
         w_off[it] = i < 2 * WPIECES ? (unsigned)sel * img_bytes + (unsigned)(((tap * g.Cout + co_base + co) * K16 + half * 8) * 2) : SENT;
         w_dst[it] = 2 * INB + sel * WB + row * 32 + ((half ^ ((row >> 3) & 1)) << 4);
     }
-    struct Stage {
-        u32x4 rq[NIT][8];                  // 4 pixels of channels 8*qh + k
-        u32x4 rw[NWB];
-    };
-    Stage s0, s1;
+    u32x4 rq[NIT][8];                      // 4 pixels of channels 8*qh + k
+    u32x4 rw[NWB];
     int pf_tile = blockIdx.x, pf_chunk = 0;
     unsigned pf_off[NIT];
     const float *pf_src = x;
@@ -2289,23 +2290,23 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_ws(const float *__restric
         pf_src = x + ((int64_t)tb * g.groups + grp) * g.Cin * HW;
         pf_bytes = live ? x_bytes : 0u;
     };
-    auto prefetch = [&](Stage &s) {
+    auto prefetch = [&]() {
         const __amdgpu_buffer_rsrc_t r = make_rsrc(pf_src, pf_bytes);
         const unsigned cb = (unsigned)pf_chunk * (unsigned)CKB * plane_bytes;
 #pragma unroll
         for (int k = 0; k < NIT; ++k)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) s.rq[k][c] = __builtin_amdgcn_raw_buffer_load_b128(r, pf_off[k] + cb + (unsigned)c * plane_bytes, 0, 0);
+            for (int c = 0; c < 8; ++c) rq[k][c] = __builtin_amdgcn_raw_buffer_load_b128(r, pf_off[k] + cb + (unsigned)c * plane_bytes, 0, 0);
         const unsigned wb = (unsigned)pf_chunk * (unsigned)(CKB * 2);
 #pragma unroll
-        for (int it = 0; it < NWB; ++it) s.rw[it] = __builtin_amdgcn_raw_buffer_load_b128(rwt, w_off[it] + wb, 0, 0);
+        for (int it = 0; it < NWB; ++it) rw[it] = __builtin_amdgcn_raw_buffer_load_b128(rwt, w_off[it] + wb, 0, 0);
         if (++pf_chunk == nchunks) {
             pf_chunk = 0;
             pf_tile += G;
             pf_setup();
         }
     };
-    auto commit = [&](int buf, Stage &s) {
+    auto commit = [&](int buf) {
         char *base = smd + buf * BUFB;
 #pragma unroll
         for (int k = 0; k < NIT; ++k)
@@ -2317,7 +2318,7 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_ws(const float *__restric
                     u32x4 hv, lv;
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
-                        const float v0 = __uint_as_float(s.rq[k][e][j]), v1 = __uint_as_float(s.rq[k][e + 1][j]);
+                        const float v0 = __uint_as_float(rq[k][e][j]), v1 = __uint_as_float(rq[k][e + 1][j]);
                         const __bf16 a0 = (__bf16)v0, a1 = (__bf16)v1;
                         hv[e >> 1] = pack_bf16((float)a0, (float)a1);
                         lv[e >> 1] = pack_bf16(v0 - (float)a0, v1 - (float)a1);
@@ -2330,24 +2331,17 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_ws(const float *__restric
             }
 #pragma unroll
         for (int it = 0; it < NWB; ++it)
-            if (ptid + it * PT < 2 * WPIECES) *reinterpret_cast<u32x4 *>(base + w_dst[it]) = s.rw[it];
+            if (ptid + it * PT < 2 * WPIECES) *reinterpret_cast<u32x4 *>(base + w_dst[it]) = rw[it];
     };
     pf_setup();
-    prefetch(s0);
-    commit(0, s0);                         // item 0
-    prefetch(s1);                          // item 1
-    prefetch(s0);                          // item 2
+    prefetch();
+    commit(0);                             // item 0
+    prefetch();                            // item 1 in flight
     __syncthreads();                       // (A)
-    for (int item = 0; item < nitems; item += 2) {
+    for (int item = 0; item < nitems; ++item) {
 #ifndef WSF_NO_PRODUCE
-        commit((item + 1) & 1, s1);        // item + 1, while the consumers multiply item
-        prefetch(s1);                      // item + 3
-#endif
-        __syncthreads();                   // (B)
-        if (item + 1 >= nitems) break;
-#ifndef WSF_NO_PRODUCE
-        commit(item & 1, s0);              // item + 2
-        prefetch(s0);                      // item + 4
+        commit((item + 1) & 1);            // item + 1, while the consumers multiply item
+        prefetch();                        // item + 2
 #endif
         __syncthreads();                   // (B)
     }
@@ -2388,15 +2382,14 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
         const size_t lds = (size_t)2 * (2 * PSX * 32 + 2 * KS * KS * 32 * mt * 32) + KB_LDS_BYTES;   // two buffers of unpadded hi/lo images
         // 16-byte input quads: rows must keep quads aligned, same-padding only; used where they pay (see the kernel's header)
         const bool vec4 = g.W % 4 == 0 && g.pad == KS / 2 && aligned16(x) && (!dact_y || aligned16(dact_y));
-        const char *ws_env = getenv("EBFI_CONV_WS");       // development switch: 0 = uniform waves, 2 = every eligible layer
+        const char *ws_env = getenv("EBFI_CONV_WS");
         const bool extra = epi.addend != nullptr || epi.mask_y != nullptr;
-        // wave-specialised form (conv_fwd_bf16x3_ws).  Measured (B=8, 128x128): 128 -> 1600 forward 1.12 vs 1.24 ms, its data
-        // gradient (1600 -> 128) 1.10 vs 1.18 ms; layers with few output-channel blocks and short channel loops 2-4 % slower than
-        // the uniform-wave kernel (the producers and the consumers slow each other down: alone they take 0.74 / 0.83 ms on the
-        // forward) -- so only the long ones take this form
-        const bool ws_long = ceil_div(g.Cout, 64) >= 8 || K16 >= 512 || (ws_env && ws_env[0] == '2');
-        const bool use_ws = KS == 3 && mt == 2 && vec4 && dact == ACT_NONE && (!extra || getenv("EBFI_CONV_WS_EXTRA") != nullptr) &&
-                            ws_long && !(ws_env && ws_env[0] == '0');
+        // wave-specialised form (conv_fwd_bf16x3_ws): every 3x3 layer the quad-staging producers can serve (64-channel blocks, no
+        // folded activation derivative); EBFI_CONV_WS=0 / 1 = never / only the long layers (development switch, A/B runs)
+        const bool ws_long = ceil_div(g.Cout, 64) >= 8 || K16 >= 512;
+        const bool ws_extra_ok = !extra || getenv("EBFI_CONV_WS_NOEXTRA") == nullptr;
+        const bool use_ws = KS == 3 && mt == 2 && vec4 && dact == ACT_NONE && ws_extra_ok && !(ws_env && ws_env[0] == '0') &&
+                            (ws_long || !(ws_env && ws_env[0] == '1'));
         if (use_ws) name = transposed ? "conv_fwd_bf16x3_ws/dgrad" : "conv_fwd_bf16x3_ws/fwd";
         ProfScope ps(name, st, flops, conv_bytes_fwd(g, KS * KS, dact != 0));
 #define EBFI_LAUNCH_X3V(MT_, DA_, VEC_)                                                                                   \
@@ -2424,11 +2417,11 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
             if (use_ws) {
                 if (extra) {
                     if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_bf16x3_ws<true>), 160 * 1024)) return rc_;
-                    hipLaunchKernelGGL((conv_fwd_bf16x3_ws<true>), pgrid, dim3(NTB), lds, st, x, wp, bias, out, g, K16, act, slope, epi,
+                    hipLaunchKernelGGL((conv_fwd_bf16x3_ws<true>), pgrid, dim3(NTWS), lds, st, x, wp, bias, out, g, K16, act, slope, epi,
                                        (int)tiles);
                 } else {
                     if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_bf16x3_ws<false>), 160 * 1024)) return rc_;
-                    hipLaunchKernelGGL((conv_fwd_bf16x3_ws<false>), pgrid, dim3(NTB), lds, st, x, wp, bias, out, g, K16, act, slope, epi,
+                    hipLaunchKernelGGL((conv_fwd_bf16x3_ws<false>), pgrid, dim3(NTWS), lds, st, x, wp, bias, out, g, K16, act, slope, epi,
                                        (int)tiles);
                 }
                 return check_launch(name);
