@@ -32,5 +32,5 @@ timeout -k 10 300 python ebfi-be_amd/infer_ours.py --batch 4 --height 256 --widt
 timeout -k 10 300 python ebfi-be_amd/infer_ours.py --batch 4 --height 256 --width 256 > $OUT/config2_x3.log 2>&1; tail -1 $OUT/config2_x3.log
 timeout -k 10 400 python ebfi-be_amd/infer_ours.py --batch 8 --height 720 --width 1280 --num_ts 4 > $OUT/config5.log 2>&1; tail -1 $OUT/config5.log
 echo "[7] two-rank rehearsal of the bench (both ranks on this GPU, gloo)"
-EBFI_BENCH_REHEARSAL=1 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs > $OUT/bench_2rank_rehearsal.json 2> $OUT/bench_2rank_rehearsal.err; cut -c1-160 $OUT/bench_2rank_rehearsal.json
+EBFI_BENCH_REHEARSAL=1 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs > $OUT/bench_2rank_rehearsal.out 2> $OUT/bench_2rank_rehearsal.err; grep '^{' $OUT/bench_2rank_rehearsal.out > $OUT/bench_2rank_rehearsal.json; cut -c1-160 $OUT/bench_2rank_rehearsal.json   # (gloo prints a connection banner on stdout)
 du -sh $OUT
