@@ -1868,6 +1868,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_f32(const float *__rest
     if (j < n_total) {
         const float *p = slab + j;
         int k = kq;
+        for (; k + 28 < nslabs; k += 32) {   // eight loads in flight per thread (fixed order of the partial sums)
+            const float a0 = p[(int64_t)k * n_total], a1 = p[(int64_t)(k + 4) * n_total];
+            const float a2 = p[(int64_t)(k + 8) * n_total], a3 = p[(int64_t)(k + 12) * n_total];
+            const float a4 = p[(int64_t)(k + 16) * n_total], a5 = p[(int64_t)(k + 20) * n_total];
+            const float a6 = p[(int64_t)(k + 24) * n_total], a7 = p[(int64_t)(k + 28) * n_total];
+            s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+            s0 += a4; s1 += a5; s2 += a6; s3 += a7;
+        }
         for (; k + 12 < nslabs; k += 16) {
             s0 += p[(int64_t)k * n_total];
             s1 += p[(int64_t)(k + 4) * n_total];
