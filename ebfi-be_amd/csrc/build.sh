@@ -3,13 +3,17 @@
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="$HERE/../lib"
-mkdir -p "$OUT" "$HERE/obj"
+# EBFI_LIB_OUT / EBFI_OBJ_DIR: a second build beside the product one (ablation flags via EBFI_EXTRA_FLAGS, A/B runs with
+# EBFI_LIB_PATH); the defaults are the in-tree product library
+OUTLIB="${EBFI_LIB_OUT:-$OUT/libebfi_hip.so}"
+OBJ="${EBFI_OBJ_DIR:-$HERE/obj}"
+mkdir -p "$OUT" "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -munsafe-fp-atomics ${EBFI_EXTRA_FLAGS:-}"
 objs=()
 pids=()
 for src in "$HERE"/*.hip; do
-    obj="$HERE/obj/$(basename "${src%.hip}").o"
+    obj="$OBJ/$(basename "${src%.hip}").o"
     objs+=("$obj")
     if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/common.hpp" -nt "$obj" ] || [ "$HERE/../../include/ebfi_hip.h" -nt "$obj" ]; then
         $HIPCC $FLAGS -c "$src" -o "$obj" &
@@ -17,5 +21,5 @@ for src in "$HERE"/*.hip; do
     fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libebfi_hip.so" "${objs[@]}"
-echo "built $OUT/libebfi_hip.so"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUTLIB" "${objs[@]}"
+echo "built $OUTLIB"

@@ -149,6 +149,81 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
 }
 
 // ------------------------------------------------------------------------------------------------
+// KernelConv -> FAC fused epilogue (reference model_singleframe.py:159-163 + KernelConv2D.py:82-87 +
+// KernelConv2D_kernel.cu:25-53): the conv's output rows are the per-pixel 5x5 FILTERS of the filter-adaptive convolution
+// that follows it.  With the weight rows laid out one FAC channel per 32-row matrix tile (25 taps + 7 zero rows, see
+// ebfi_amd.weightbank kind "facrows"), a consumer wave holds, per output pixel (lane & 31), all 25 filters of channel
+// `m` split over its two lane halves (row = (r&3) + 8(r>>2) + 4h): it applies LeakyReLU(acc + bias), multiplies each by
+// the replicate-clamped neighbour of the feature map `ev` (fp32, fetched through the L1: the 12 x 68 window of a tile is
+// re-read 25 times), adds the two halves by one cross-lane exchange and stores ONE value.  The [B,1600,h,w] filter tensor
+// (839 MB at B=8 256x256, 11.8 GB at B=8 720x1280) is never written.  Inference only: the training step needs the filters
+// again in the backward pass (recomputing them costs a second 128 -> 1600 convolution, 1.0 ms against the 0.3 ms of the
+// store + the FAC launch), so training keeps the unfused pair.
+struct FacEpi {
+    const float *ev;       // [B, C, H, W]: the feature map the filters are applied to (unpadded; clamped here = ReplicationPad2d(2))
+    int C;                 // FAC channels (= weight rows / 32)
+};
+
+template <int MT>
+__device__ __forceinline__ void fac_epilogue_tile(float *__restrict__ out, const float *__restrict__ bias, const f32x16 (&acc)[MT][2],
+                                                  const ConvGeom &g, const FacEpi &fac, int b, int co_base, int yo, int x0, int lane,
+                                                  float slope) {
+    constexpr int K = 5, R = 2;
+    const int HW = g.Ho * g.Wo;                       // same-padded 3x3: output size = input size = the size of ev
+    const int h = lane >> 5, l31 = lane & 31;
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(bias, (unsigned)g.Cout * 4u);
+    float part[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int c = (co_base >> 5) + m;
+        const bool c_ok = c < fac.C;
+        const __amdgpu_buffer_rsrc_t rev = make_rsrc(fac.ev + ((int64_t)b * fac.C + (c_ok ? c : 0)) * HW, c_ok ? (unsigned)HW * 4u : 0u);
+        float bv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bv[r] = buf_ld(rb, (unsigned)(co_base + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 4u);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int xo = x0 + n * 32 + l31;
+            unsigned rowoff[K], coloff[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                rowoff[i] = (unsigned)(min(max(yo + i - R, 0), g.Ho - 1) * g.Wo) * 4u;
+                coloff[i] = (unsigned)min(max(xo + i - R, 0), g.Wo - 1) * 4u;
+            }
+            float e[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // tap of register r: t0 for the lower lane half, t0 + 4 for the upper one; rows >= 25 are the zero rows of the
+                // tile (their filter value is exactly 0): any valid address will do
+                constexpr int dummy = 0;
+                const int t0 = (r & 3) + 8 * (r >> 2), t1 = t0 + 4;
+                const unsigned o0 = t0 < K * K ? rowoff[t0 / K] + coloff[t0 % K] : rowoff[dummy] + coloff[dummy];
+                const unsigned o1 = t1 < K * K ? rowoff[t1 / K] + coloff[t1 % K] : rowoff[dummy] + coloff[dummy];
+                e[r] = buf_ld(rev, h ? o1 : o0);
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float f = acc[m][n][r] + bv[r];
+                f = f > 0.f ? f : f * slope;
+                sum = fmaf(f, e[r], sum);
+            }
+            part[m][n] = sum;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int c = (co_base >> 5) + m;
+        // the two lane halves hold disjoint tap subsets of the same pixel: exchange and add, then the lower half stores
+        // x-half 0 and the upper half x-half 1 (one coalesced 256-byte store per wave and channel)
+        const float p0 = part[m][0] + __shfl_xor(part[m][0], 32, 64);
+        const float p1 = part[m][1] + __shfl_xor(part[m][1], 32, 64);
+        const int xo = x0 + h * 32 + l31;
+        if (c < fac.C && yo < g.Ho && xo < g.Wo) out[((int64_t)b * fac.C + c) * HW + (int64_t)yo * g.Wo + xo] = h ? p1 : p0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward (TR = false) and stride-1 data gradient (TR = true)
 //   x    [B,Cin,H,W]   (for dgrad: grad_output [B,Cout_fwd,..])      dact_y: optional, same shape as x
 //   w    forward: [Cout,Cin,KS,KS];  TR: the FORWARD conv's weight [Cin,Cout,KS,KS] (its Cout = our Cin)
@@ -1523,14 +1598,18 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3_ws(const float *__restrict_
                     if (q < NTF) {
 #pragma unroll
                         for (int m = 0; m < 2; ++m) {
+#ifndef ABL_ONE_MFMA
                             acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh, acc[m][q], 0, 0, 0);
                             acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl, acc[m][q], 0, 0, 0);
+#endif
                             acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m][q], 0, 0, 0);
                         }
                     } else {               // the ninth block: one output tile of the extra n-tile
                         const bf16x8 xh = xm ? ah[1] : ah[0], xl = xm ? al[1] : al[0];
+#ifndef ABL_ONE_MFMA
                         accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh, accx, 0, 0, 0);
                         accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl, accx, 0, 0, 0);
+#endif
                         accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, accx, 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -2148,10 +2227,10 @@ int launch_wgrad_bf16(hipStream_t st, const float *x, const float *gout, const f
 // of the step -0.42 ms.  A first form with FOUR consumer waves (two rows each, single-buffered operands, 254 registers) ran
 // its consumers ALONE at 84-96 % of the real-clock matrix peak but lost it again beside the producers (1.10-1.12 ms).
 constexpr int NTWS = 768;              // conv_fwd_bf16x3_ws: 8 consumer waves + 4 producer waves
-template <bool EXTRA>
+template <bool EXTRA, bool FAC = false>
 __global__ __launch_bounds__(NTWS) void conv_fwd_bf16x3_ws(const float *__restrict__ x, const __bf16 *__restrict__ wp,
                                                            const float *__restrict__ bias, float *__restrict__ out, ConvGeom g, int K16,
-                                                           int act, float slope, EpiExtra epi, int tiles_total) {
+                                                           int act, float slope, EpiExtra epi, int tiles_total, FacEpi fac) {
     constexpr int KS = 3, KK = 9, MT = 2;
     constexpr int IH = TYB - 1 + KS, IW = TX - 1 + KS, PS = IH * IW, COS = 32 * MT;
     constexpr int NCW = 8, PT = 256;                           // consumer waves (one output row each); producer threads
@@ -2200,12 +2279,16 @@ __global__ __launch_bounds__(NTWS) void conv_fwd_bf16x3_ws(const float *__restri
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 ah[set][m] = *reinterpret_cast<const bf16x8 *>(ap + m * 1024);
+#ifndef ABL_ONE_MFMA
                 al[set][m] = *reinterpret_cast<const bf16x8 *>(ap + m * 1024 + WB);
+#endif
             }
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 bh[set][n] = *reinterpret_cast<const bf16x8 *>(bp + n * 1024);
+#ifndef ABL_ONE_MFMA
                 bl[set][n] = *reinterpret_cast<const bf16x8 *>(bp + n * 1024 + INB);
+#endif
             }
         };
         auto tap_mfma = [&](int set) {
@@ -2213,8 +2296,10 @@ __global__ __launch_bounds__(NTWS) void conv_fwd_bf16x3_ws(const float *__restri
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
+#ifndef ABL_ONE_MFMA     // (timing ablation: what a single-product operand format would leave of this kernel; results are wrong)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[set][m], bh[set][n], acc[m][n], 0, 0, 0);
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][m], bl[set][n], acc[m][n], 0, 0, 0);
+#endif
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][m], bh[set][n], acc[m][n], 0, 0, 0);
                 }
         };
@@ -2240,7 +2325,8 @@ __global__ __launch_bounds__(NTWS) void conv_fwd_bf16x3_ws(const float *__restri
             }
             int cb_, cy0, cx0;
             tile_coords(tcur, cb_, cy0, cx0);
-            store_out_tile<MT, EXTRA>(out, bias, acc, g, cb_, co_base, cy0 + wave, cx0, lane, act, slope, epi);
+            if constexpr (FAC) fac_epilogue_tile<MT>(out, bias, acc, g, fac, cb_, co_base, cy0 + wave, cx0, lane, slope);
+            else store_out_tile<MT, EXTRA>(out, bias, acc, g, cb_, co_base, cy0 + wave, cx0, lane, act, slope, epi);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -2307,7 +2393,12 @@ __global__ __launch_bounds__(NTWS) void conv_fwd_bf16x3_ws(const float *__restri
             for (int c = 0; c < 8; ++c) rq[k][c] = __builtin_amdgcn_raw_buffer_load_b128(r, pf_off[k] + cb + (unsigned)c * plane_bytes, 0, 0);
         const unsigned wb = (unsigned)pf_chunk * (unsigned)(CKB * 2);
 #pragma unroll
-        for (int it = 0; it < NWB; ++it) rw[it] = __builtin_amdgcn_raw_buffer_load_b128(rwt, w_off[it] + wb, 0, 0);
+        for (int it = 0; it < NWB; ++it) {
+#ifdef ABL_ONE_MFMA
+            if (ptid + it * PT >= WPIECES) continue;
+#endif
+            rw[it] = __builtin_amdgcn_raw_buffer_load_b128(rwt, w_off[it] + wb, 0, 0);
+        }
         if (++pf_chunk == nchunks) {
             pf_chunk = 0;
             pf_tile += G;
@@ -2334,12 +2425,18 @@ __global__ __launch_bounds__(NTWS) void conv_fwd_bf16x3_ws(const float *__restri
                     const int pos = it_qr[k] * IW + c;
                     const int d = pos * 32 + ((it_qh[k] ^ ((pos >> 3) & 1)) << 4);
                     *reinterpret_cast<u32x4 *>(base + d) = hv;
+#ifndef ABL_ONE_MFMA
                     *reinterpret_cast<u32x4 *>(base + INB + d) = lv;
+#endif
                 }
             }
 #pragma unroll
-        for (int it = 0; it < NWB; ++it)
+        for (int it = 0; it < NWB; ++it) {
+#ifdef ABL_ONE_MFMA
+            if (ptid + it * PT >= WPIECES) continue;
+#endif
             if (ptid + it * PT < 2 * WPIECES) *reinterpret_cast<u32x4 *>(base + w_dst[it]) = rw[it];
+        }
     };
     pf_setup();
     prefetch();
@@ -2426,11 +2523,11 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
                 if (extra) {
                     if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_bf16x3_ws<true>), 160 * 1024)) return rc_;
                     hipLaunchKernelGGL((conv_fwd_bf16x3_ws<true>), pgrid, dim3(NTWS), lds, st, x, wp, bias, out, g, K16, act, slope, epi,
-                                       (int)tiles);
+                                       (int)tiles, FacEpi{nullptr, 0});
                 } else {
                     if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_bf16x3_ws<false>), 160 * 1024)) return rc_;
                     hipLaunchKernelGGL((conv_fwd_bf16x3_ws<false>), pgrid, dim3(NTWS), lds, st, x, wp, bias, out, g, K16, act, slope, epi,
-                                       (int)tiles);
+                                       (int)tiles, FacEpi{nullptr, 0});
                 }
                 return check_launch(name);
             }
@@ -3082,6 +3179,46 @@ extern "C" int ebfi_conv2d_packed_x3(const void *input, const void *packed, size
     void *ws = const_cast<void *>(packed);
     if (ksize == 3) return launch_fwd_bf16<3>(st, x, nullptr, nullptr, bs, o, g, 0, act, slope, 0, 0.f, ws, packed_bytes, 1, epi);
     return launch_fwd_bf16<1>(st, x, nullptr, nullptr, bs, o, g, 0, act, slope, 0, 0.f, ws, packed_bytes, 1, epi);
+}
+
+// KernelConv (3x3, Cin -> C*25 filters, LeakyReLU) fused with the FAC that consumes the filters: see fac_epilogue_tile.
+// `packed`: split-precision forward images of the weight with rows re-tiled to 32 per FAC channel ([C*32, Cin, 3, 3], rows
+// 25..31 of every tile zero), `bias32` the bias in the same row layout ([C*32], zeros in the pad rows).
+extern "C" int ebfi_kernelconv_fac_fused_x3(const void *input, const void *packed, size_t packed_bytes, const void *bias32,
+                                            const void *feat, void *output, int B, int Cin, int H, int W, int C, int fac_ksize,
+                                            float slope, void *stream) {
+    if (!input || !packed || !bias32 || !feat || !output) return fail(EBFI_ERR_ARG, "kernelconv_fac_fused_x3: null argument");
+    if (fac_ksize != 5) return fail(EBFI_ERR_UNSUPPORTED, "kernelconv_fac_fused_x3: FAC kernel size %d (5 is built)", fac_ksize);
+    if (C < 1) return fail(EBFI_ERR_ARG, "kernelconv_fac_fused_x3: %d channels", C);
+    ConvGeom g;
+    if (int rc = make_geom(g, B, Cin, H, W, C * 32, 3, 1, 1)) return rc;
+    if ((int64_t)(Cin + 64) * H * W * 4 >= (1LL << 31) - (1LL << 26))
+        return fail(EBFI_ERR_ARG, "kernelconv_fac_fused_x3: one sample exceeds the 2 GiB reach of 32-bit buffer offsets");
+    const int K16 = (Cin + 15) / 16 * 16;
+    const size_t need = 2 * bf16_pack_bytes(g.Cout, g.Cin, 3);
+    if (packed_bytes < need) return fail(EBFI_ERR_WORKSPACE, "kernelconv_fac_fused_x3: packed images %zu bytes < required %zu", packed_bytes, need);
+    // the producers of the wave-specialised kernel stage 16-byte quads: rows must keep quads aligned
+    if (W % 4 != 0 || !aligned16(input))
+        return fail(EBFI_ERR_UNSUPPORTED, "kernelconv_fac_fused_x3: needs W %% 4 == 0 and a 16-byte aligned input (W = %d)", W);
+    if (B == 0) return EBFI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t tiles = (int64_t)B * ceil_div(g.Ho, TYB) * ceil_div(g.Wo, TX);
+    if (tiles > 2147483647LL) return fail(EBFI_ERR_ARG, "kernelconv_fac_fused_x3: too many tiles");
+    constexpr int PSX = (TYB - 1 + 3) * (TX - 1 + 3);
+    const size_t lds = (size_t)2 * (2 * PSX * 32 + 2 * 9 * 32 * 2 * 32) + KB_LDS_BYTES;
+    const int64_t co_blocks = ceil_div(g.Cout, 64);
+    int64_t gx = 256 / co_blocks;
+    if (gx < 1) gx = 1;
+    if (gx > tiles) gx = tiles;
+    const double flops = 2.0 * B * g.Ho * g.Wo * (double)(C * 25) * Cin * 9 + 2.0 * B * g.Ho * g.Wo * (double)C * 25;
+    const double bytes = 4.0 * B * (double)g.Ho * g.Wo * (Cin + 2.0 * C);      // conv input + feature map + output: no filter tensor
+    ProfScope ps("conv_fwd_bf16x3_ws/kernelconv_fac", st, flops, bytes);
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_bf16x3_ws<false, true>), 160 * 1024)) return rc;
+    hipLaunchKernelGGL((conv_fwd_bf16x3_ws<false, true>), dim3((unsigned)gx, (unsigned)co_blocks), dim3(NTWS), lds, st,
+                       static_cast<const float *>(input), static_cast<const __bf16 *>(packed), static_cast<const float *>(bias32),
+                       static_cast<float *>(output), g, K16, ACT_LEAKY, slope, EpiExtra{nullptr, nullptr, 0, 0.f}, (int)tiles,
+                       FacEpi{static_cast<const float *>(feat), C});
+    return check_launch("conv_fwd_bf16x3_ws/kernelconv_fac");
 }
 
 extern "C" int ebfi_conv2d_backward_weight_x3g(const void *input, const void *grad_output, void *grad_weight, void *grad_bias,

@@ -18,6 +18,7 @@ HEADER = os.path.join(REPO_ROOT, "include", "ebfi_hip.h")
 BUILD_SCRIPT = os.path.join(PKG_ROOT, "csrc", "build.sh")
 
 EBFI_F32, EBFI_BF16, EBFI_F32_BF16MMA, EBFI_F32_BF16X3MMA = 0, 1, 2, 3
+ABI_VERSION = 3          # include/ebfi_hip.h EBFI_ABI_VERSION
 
 
 class EbfiNativeError(RuntimeError):
@@ -54,6 +55,7 @@ SIGNATURES = {
     "ebfi_conv2d_packed_bytes": (_sz, [_i, _i, _i, _i]),
     "ebfi_conv2d_pack_bf16x3": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ebfi_pack_table_bf16": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "ebfi_kernelconv_fac_fused_x3": (_i, [_vp, _vp, _sz, _vp, _vp, _vp] + [_i] * 6 + [_c.c_float, _vp]),
     "ebfi_conv2d_packed_x3": (_i, [_vp, _vp, _sz, _vp, _vp] + [_i] * 8 + [_i, _c.c_float, _vp, _vp, _i, _c.c_float, _vp]),
     "ebfi_conv2d_backward_weight_x3g": (_i, [_vp] * 4 + [_i] * 8 + [_vp, _sz, _vp]),
     "ebfi_scale_residual_cat_forward_ex": (_i, [_vp] * 6 + [_i, _i, _i64, _i64, _vp]),
@@ -129,13 +131,16 @@ def lib():
             try:
                 fn = getattr(h, name)
             except AttributeError as e:
-                if os.environ.get("EBFI_LIB_PATH"):     # an older build under A/B: newer entry points simply stay unbound
+                if os.environ.get("EBFI_LIB_PATH"):     # an older build under A/B (tools/ab_bench.sh): say what stays unbound
+                    import sys
+                    print("ebfi_amd._native: %s (EBFI_LIB_PATH) does not export %s; calls to it will fail"
+                          % (LIB_PATH, name), file=sys.stderr)
                     continue
                 raise EbfiNativeError("%s does not export %s" % (LIB_PATH, name)) from e
             fn.restype = res
             fn.argtypes = args
-        if h.ebfi_abi_version() != 2:
-            raise EbfiNativeError("ABI version mismatch: library %d, binding 2" % h.ebfi_abi_version())
+        if h.ebfi_abi_version() != ABI_VERSION and not os.environ.get("EBFI_LIB_PATH"):
+            raise EbfiNativeError("ABI version mismatch: library %d, binding %d" % (h.ebfi_abi_version(), ABI_VERSION))
         _lib = h
     return _lib
 

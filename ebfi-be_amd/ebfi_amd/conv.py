@@ -40,14 +40,15 @@ def get_compute_dtype():
     return _COMPUTE
 
 
-def _bf16_ok(k, stride):
-    return _COMPUTE == "bf16" and k in (1, 3) and stride == 1
+def _bf16_ok(k, stride, mode=None):
+    return (mode or _COMPUTE) == "bf16" and k in (1, 3) and stride == 1
 
 
-def _x3_ok(k, stride, rows=None):
-    """rows: output rows of the product (Cout forward, Cin for the data gradient): 7x7 runs in split precision up to 16."""
-    return _COMPUTE == "bf16x3" and stride == 1 and (k in (1, 3) or (k == 7 and rows is not None and rows <= 16 and
-                                                                     os.environ.get("EBFI_NO_CONV7X3") is None))
+def _x3_ok(k, stride, rows=None, mode=None):
+    """rows: output rows of the product (Cout forward, Cin for the data gradient): 7x7 runs in split precision up to 16.
+    mode: the compute mode to decide for (None = the current process-wide one)."""
+    return (mode or _COMPUTE) == "bf16x3" and stride == 1 and (k in (1, 3) or (k == 7 and rows is not None and rows <= 16 and
+                                                                               os.environ.get("EBFI_NO_CONV7X3") is None))
 
 
 def _bf16_ws(lib, geo, device):
@@ -104,14 +105,16 @@ class ConvBiasAct(Function):
         N.check(rc, "ebfi_conv2d_forward")
         if grad_preact:
             act, slope = ACT_NONE, 0.0
-        ctx.cfg = (stride, pad, act, slope, bias is not None)
+        # the compute mode is part of the node: backward runs in the mode its forward ran in, whatever the process-wide
+        # switch says by then (a backward() issued outside the engine's precision context)
+        ctx.cfg = (stride, pad, act, slope, bias is not None, _COMPUTE)
         ctx.save_for_backward(x, weight, out if act != ACT_NONE else None)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         x, weight, y = ctx.saved_tensors
-        stride, pad, act, slope, has_bias = ctx.cfg
+        stride, pad, act, slope, has_bias, mode = ctx.cfg
         gout = gout.contiguous()
         geo = _geo(x, weight, stride, pad)
         k = geo[5]
@@ -119,7 +122,7 @@ class ConvBiasAct(Function):
         gx = gw = gb = None
         need_x = ctx.needs_input_grad[0]
         need_w = ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])
-        bf16 = _bf16_ok(k, stride)
+        bf16 = _bf16_ok(k, stride, mode)
         with torch.cuda.device_of(x):
             st = N.stream_ptr(x.device)
             gpre = None       # grad_output * act'(y): by-product of the fp32 weight-gradient kernel
@@ -131,7 +134,7 @@ class ConvBiasAct(Function):
                 if need_x and act != ACT_NONE and not bf16:
                     gpre = torch.empty_like(gout)
                 # (the split-precision weight gradient also covers 7x7 stride 1: the detail branch's output conv)
-                x3w = _COMPUTE == "bf16x3" and k in (1, 3, 7) and stride == 1
+                x3w = mode == "bf16x3" and k in (1, 3, 7) and stride == 1
                 wdt = N.EBFI_F32_BF16MMA if bf16 else (N.EBFI_F32_BF16X3MMA if x3w else N.EBFI_F32)
                 rc = lib.ebfi_conv2d_backward_weight_ex(N.ptr(x), N.ptr(gout), N.ptr(y), N.ptr(gw), N.ptr(gb), N.ptr(gpre),
                                                         *geo, act, slope, N.ptr(ws), need, wdt, st)
@@ -142,7 +145,7 @@ class ConvBiasAct(Function):
                     ws, need = _bf16_ws(lib, geo, x.device)
                     rc = lib.ebfi_conv2d_backward_data_bf16mma(N.ptr(gout), N.ptr(y), N.ptr(weight), N.ptr(gx), *geo, act,
                                                                slope, N.ptr(ws), need, st)
-                elif _x3_ok(k, stride, geo[1]) and (k != 7 or gpre is not None or act == ACT_NONE):
+                elif _x3_ok(k, stride, geo[1], mode) and (k != 7 or gpre is not None or act == ACT_NONE):
                     # split-precision data gradient (on grad * act' when the weight gradient left it)
                     ws, need = _bf16_ws(lib, geo, x.device)
                     src, sy, a = (gpre, None, ACT_NONE) if gpre is not None else (gout, y, act)
@@ -160,7 +163,7 @@ class ConvBiasAct(Function):
                     # Only the small stems / down-sampling convs take this path.
                     if gpre is None:
                         gpre = gout if act == ACT_NONE else gout * _act_grad(y, act, slope)
-                    if k == 7 and stride == 2 and _x3_ok(k, 1, geo[1]) and pad == 3:
+                    if k == 7 and stride == 2 and _x3_ok(k, 1, geo[1], mode) and pad == 3:
                         # by output parity on the gradient itself: no zero-inserted tensor (csrc/conv2d.hip conv7s2_dgrad_x3)
                         rc = lib.ebfi_conv2d_backward_data_s2_bf16x3(N.ptr(gpre.contiguous()), N.ptr(weight), N.ptr(gx), geo[0], geo[1],
                                                                      geo[2], geo[3], geo[4], k, pad, st)
@@ -170,7 +173,7 @@ class ConvBiasAct(Function):
                     up = gout.new_zeros((geo[0], geo[4], uh, uw))
                     up[:, :, ::stride, ::stride][:, :, :gout.shape[2], :gout.shape[3]] = gpre
                     geo1 = geo[:6] + [1, pad]
-                    if k == 7 and _x3_ok(k, 1, geo[1]):
+                    if k == 7 and _x3_ok(k, 1, geo[1], mode):
                         ws, need = _bf16_ws(lib, geo1, x.device)
                         rc = lib.ebfi_conv2d_backward_data_bf16x3(N.ptr(up), N.ptr(None), N.ptr(weight), N.ptr(gx), *geo1, ACT_NONE,
                                                                   0.0, N.ptr(ws), need, st)

@@ -173,6 +173,11 @@ class FlatAdam:
             st["exp_avg_sq"] = torch.zeros_like(self.flat.data)
         if not (torch.is_tensor(st["step"]) and st["step"].is_cuda):
             st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32, device=self.flat.device)
+        # the bookkeeping torch's own step() wrapper does: step hooks, and the marks the LR schedulers look at
+        # (`_opt_called`: without it every scheduler.step() warns "lr_scheduler.step() before optimizer.step()")
+        opt = self.inner
+        for hook in list(getattr(opt, "_optimizer_step_pre_hooks", {}).values()):
+            hook(opt, (), {})
         st["step"] += 1
         b1, b2 = grp["betas"]
         with torch.cuda.device_of(self.flat):
@@ -180,6 +185,11 @@ class FlatAdam:
                                         N.ptr(st["step"]), self.flat.numel(), float(grp["lr"]), float(b1), float(b2),
                                         float(grp["eps"]), N.stream_ptr(self.flat.device))
         N.check(rc, "ebfi_adam_step")
+        opt._opt_called = True
+        if hasattr(opt, "_step_count"):
+            opt._step_count += 1
+        for hook in list(getattr(opt, "_optimizer_step_post_hooks", {}).values()):
+            hook(opt, (), {})
         return True
 
     def views_intact(self):
@@ -207,9 +217,10 @@ class FlatAdam:
     def load_state_dict(self, sd):
         """Accepts torch's per-parameter Adam layout (what the reference's checkpoints hold, train_ours.py:621-671).
         Parameters without an entry (never received a gradient before the save) start from zero moments.  All parameters
-        share ONE step counter here (the update is one launch over the flat buffer, missing gradients count as zero): it is
-        restored as the largest per-parameter step of the checkpoint -- identical to torch whenever every parameter had a
-        gradient on every step, which is the case for this model."""
+        share ONE step counter here (the update is one launch over the flat buffer, missing gradients count as zero), so
+        the per-parameter steps of the checkpoint must agree -- they do whenever every parameter had a gradient on every
+        step, which is the case for this model; a checkpoint whose steps differ (parameters frozen for part of the run) is
+        refused instead of being silently re-timed."""
         groups = sd["param_groups"]
         if len(groups) != 1 or len(groups[0]["params"]) != len(self.params):
             raise ValueError("optimizer state has %d parameters in %d group(s), this model trains %d"
@@ -222,13 +233,17 @@ class FlatAdam:
             return
         ids = groups[0]["params"]
         m, v = torch.zeros_like(self.flat.data), torch.zeros_like(self.flat.data)
-        step = 0.0
+        step = None
         for pid, p, off in zip(ids, self.params, self._offsets):
             e = sd["state"].get(pid)
             if e is None:
                 continue
             m[off:off + p.numel()] = e["exp_avg"].reshape(-1).to(m)
             v[off:off + p.numel()] = e["exp_avg_sq"].reshape(-1).to(v)
-            step = max(step, float(e["step"]))
+            if step is not None and float(e["step"]) != step:
+                raise ValueError("optimizer state holds different step counts per parameter (%g and %g): the flat Adam keeps "
+                                 "one counter for all parameters" % (step, float(e["step"])))
+            step = float(e["step"])
+        step = 0.0 if step is None else step
         step = torch.tensor(step, dtype=torch.float32, device=self.flat.device if self.flat.is_cuda else "cpu")
         self.inner.state[self.flat] = {"step": step, "exp_avg": m, "exp_avg_sq": v}

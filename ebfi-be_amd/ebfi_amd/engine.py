@@ -20,9 +20,21 @@ DEFAULT_MODEL_ARGS = dict(
     channels=[16, 24, 32, 64])
 
 
-def synthetic_batch(B, H, W, TB=16, device="cuda", seed=123, rank=0):
+def synthetic_batch(B, H, W, TB=16, device="cuda", seed=123, rank=0, on_device=False):
     """Frame in [0,1], Event = Poisson(0.35) integer counts, T in [0,1),
-    GTEx in [0.55,0.95), random GT frame.  Seed = reference default (train_ours.py:806) + rank."""
+    GTEx in [0.55,0.95), random GT frame.  Seed = reference default (train_ours.py:806) + rank.
+    on_device: draw with the DEVICE generator (no host work, no PCIe copy: what a training loop that makes one batch per
+    step needs -- the host Poisson draw of a B=8 256x256 batch takes ~0.5 s against a 20 ms step); the default draws on the
+    host so that tests and benchmarks see the same numbers on every machine."""
+    dev = torch.device(device)
+    if on_device and dev.type == "cuda":
+        g = torch.Generator(device=dev).manual_seed(seed + rank)
+        rnd = lambda *shape: torch.rand(*shape, generator=g, device=dev)
+        frame = rnd(B, 3, H, W)
+        event = torch.poisson(torch.full((B, TB, 2, H, W), 0.35, device=dev), generator=g)
+        t = rnd(B, 1)
+        gtex = rnd(B, 1) * 0.4 + 0.55
+        return frame, event, t, gtex, rnd(B, 3, H, W)
     g = torch.Generator(device="cpu").manual_seed(seed + rank)
     frame = torch.rand(B, 3, H, W, generator=g)
     event = torch.poisson(torch.full((B, TB, 2, H, W), 0.35), generator=g)
@@ -32,20 +44,26 @@ def synthetic_batch(B, H, W, TB=16, device="cuda", seed=123, rank=0):
     return tuple(v.to(device) for v in (frame, event, t, gtex, target))
 
 
-def synthetic_batch_from_raw_events(B, H, W, TB=16, device="cuda", seed=123, rank=0, rate=0.35):
+def synthetic_batch_from_raw_events(B, H, W, TB=16, device="cuda", seed=123, rank=0, rate=0.35, on_device=False):
     """Same batch statistics as `synthetic_batch`, but the event tensor comes the way the reference produces it
     (h5dataset.py:327-352): a sorted raw event list per sample (N ~ rate*H*W*TB events uniform in x, y, sorted uniform t in
-    [0,1), polarity +-1) binned by the device `events_to_stack` kernel and transposed to [TB, 2, H, W]."""
+    [0,1), polarity +-1) binned by the device `events_to_stack` kernel and transposed to [TB, 2, H, W].
+    on_device: the event lists are drawn and sorted on the device too (see `synthetic_batch`)."""
     from .encodings import events_to_stack
-    frame, _, t, gtex, target = synthetic_batch(B, H, W, TB, device=device, seed=seed, rank=rank)
-    g = torch.Generator(device="cpu").manual_seed(seed + rank + 7919)
+    dev = torch.device(device)
+    on_device = on_device and dev.type == "cuda"
+    # (the Poisson voxel draw of synthetic_batch is skipped here: TB=0 gives an empty event tensor in the same stream position)
+    frame, _, t, gtex, target = synthetic_batch(B, H, W, 0 if on_device else TB, device=device, seed=seed, rank=rank,
+                                                on_device=on_device)
+    gdev = dev if on_device else torch.device("cpu")
+    g = torch.Generator(device=gdev).manual_seed(seed + rank + 7919)
     n = int(rate * H * W * TB)
     stacks = []
     for _ in range(B):
-        xs = torch.randint(0, W, (n,), generator=g).to(device)
-        ys = torch.randint(0, H, (n,), generator=g).to(device)
-        ts = torch.sort(torch.rand(n, generator=g, dtype=torch.float64))[0].to(device)
-        ps = (torch.randint(0, 2, (n,), generator=g) * 2 - 1).float().to(device)
+        xs = torch.randint(0, W, (n,), generator=g, device=gdev).to(device)
+        ys = torch.randint(0, H, (n,), generator=g, device=gdev).to(device)
+        ts = torch.sort(torch.rand(n, generator=g, dtype=torch.float64, device=gdev))[0].to(device)
+        ps = (torch.randint(0, 2, (n,), generator=g, device=gdev) * 2 - 1).float().to(device)
         stacks.append(events_to_stack(xs, ys, ts, ps, TB, sensor_size=(H, W)).transpose(0, 1))   # [TB, 2, H, W]
     return frame, torch.stack(stacks).contiguous(), t, gtex, target
 
@@ -89,7 +107,7 @@ class Engine:
         if self.device.type == "cuda" and os.environ.get("EBFI_NO_BANK", "0") != "1":     # (switch for A/B measurements)
             from . import weightbank
             self.bank = weightbank.build_for(self.model, flat=self.optimizer.flat.data, params=self.optimizer.params) if train \
-                else weightbank.build_for(self.model)
+                else weightbank.build_for(self.model, inference=True)
 
     @contextlib.contextmanager
     def _autocast(self):
@@ -147,7 +165,7 @@ class Engine:
         return loss
 
     def train_step_graph(self, frame, event, t, gtex, target):
-        """Same step with the ~2000 launches of forward + loss + backward + gradient packing replayed from one
+        """Same step with the ~560 launches of forward + loss + backward + gradient packing replayed from one
         hipGraph.  Inputs are copied into static buffers; gradients live in the graph's memory pool, `param.grad`
         are views of the packed buffer, so the eager all-reduce / Adam that follow see ordinary tensors."""
         inputs = (frame, event, t, gtex, target)

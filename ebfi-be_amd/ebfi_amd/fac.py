@@ -54,6 +54,38 @@ def fac_backward(input_pad, kernel, kernel_size, grad_output, need_input=True, n
     return gin, gk
 
 
+def fac_rows_fold_weight(w, ksize=5, tile=32):
+    """[C*K*K, Cin, 3, 3] -> [C*tile, Cin, 3, 3]: one FAC channel per `tile`-row matrix tile (K*K filter rows + zero rows): the
+    row layout `ebfi_kernelconv_fac_fused_x3` expects.  A 0/1 linear map (usable as a weight-bank fold)."""
+    kk = ksize * ksize
+    c = w.shape[0] // kk
+    return torch.nn.functional.pad(w.reshape(c, kk, *w.shape[1:]), (0, 0) * (w.dim() - 1) + (0, tile - kk)).reshape(c * tile, *w.shape[1:])
+
+
+def fac_rows_fold_bias(b, ksize=5, tile=32):
+    kk = ksize * ksize
+    return torch.nn.functional.pad(b.reshape(-1, kk), (0, tile - kk)).reshape(-1)
+
+
+def kernelconv_fac_fused(cat, feat, site, kernel_size, slope):
+    """filters = LeakyReLU(conv3x3(cat)) applied to the replicate-padded `feat` as ONE kernel (no filter tensor; inference
+    only -- no autograd node).  `site`: the weight bank's "facrows" images of the KernelConv layer."""
+    N.require_gpu(cat, feat)
+    cat, feat = cat.contiguous(), feat.contiguous()
+    B, Cin, H, W = (int(v) for v in cat.shape)
+    C = int(feat.shape[1])
+    if site.M != C * 32 or site.K != Cin or tuple(feat.shape) != (B, C, H, W):
+        raise RuntimeError("fused KernelConv -> FAC: packed weight [%d,%d] does not match input %s / feature %s"
+                           % (site.M, site.K, tuple(cat.shape), tuple(feat.shape)))
+    out = torch.empty_like(feat)
+    with torch.cuda.device_of(cat):
+        rc = N.lib().ebfi_kernelconv_fac_fused_x3(N.ptr(cat), site.fwd_ptr(), site.fwd_bytes, N.ptr(site.bias()), N.ptr(feat),
+                                                  N.ptr(out), B, Cin, H, W, C, int(kernel_size), float(slope),
+                                                  N.stream_ptr(cat.device))
+    N.check(rc, "ebfi_kernelconv_fac_fused_x3")
+    return out
+
+
 class KernelConv2DFunction(Function):
     @staticmethod
     def forward(ctx, input, kernel, kernel_size, kernel_leaky_slope=None):

@@ -26,8 +26,36 @@ from . import conv, weightbank
 ACT = conv.ACT_LEAKY
 
 
+def _plain_layer(m, ks, cin=None):
+    """ConvLayer `m` is exactly conv(ks x ks, stride 1, same padding, bias) + LeakyReLU with no norm layer: the only form the
+    fused node computes.  Anything else (norm='BN' drops the bias, norm='IN' adds a norm layer, another activation or
+    kernel size) must run layer by layer."""
+    c = m.conv2d
+    return (getattr(m, "norm", None) is None and isinstance(m.activation, torch.nn.LeakyReLU) and c.bias is not None and
+            tuple(c.kernel_size) == (ks, ks) and tuple(c.stride) == (1, 1) and tuple(c.padding) == (ks // 2, ks // 2) and
+            tuple(c.dilation) == (1, 1) and c.groups == 1 and (cin is None or c.in_channels == cin))
+
+
+def fusable(rc):
+    """Every layer of the module has the plain form the fused node assumes (checked once per call: a few attribute reads)."""
+    for i in range(rc.step):
+        if not (_plain_layer(rc.Conv1[i][0], 1) and _plain_layer(rc.Conv2[i][0], 1)):
+            return False
+        for bank in (rc.Conv3, rc.Conv4):
+            if len(bank[i]) != 2 or not all(_plain_layer(m, 3) for m in bank[i]):
+                return False
+        if len(rc.Conv5[i]) != 1 or not _plain_layer(rc.Conv5[i][0], 3):
+            return False
+    slopes = {float(m.activation.negative_slope) for bank in (rc.Conv1, rc.Conv2, rc.Conv3, rc.Conv4, rc.Conv5)
+              for seq in bank for m in seq}
+    return len(slopes) == 1
+
+
 def register(bank, rc):
-    """Sites of one ResidualControl module: concatenated first layers, grouped second layers (Conv5 is a plain site)."""
+    """Sites of one ResidualControl module: concatenated first layers, grouped second layers (Conv5 is a plain site).
+    A module that is not `fusable` registers nothing and keeps running layer by layer."""
+    if not fusable(rc):
+        return
     for i in range(rc.step):
         a3, a4 = rc.Conv3[i][0].conv2d, rc.Conv4[i][0].conv2d
         b3, b4 = rc.Conv3[i][1].conv2d, rc.Conv4[i][1].conv2d
@@ -55,8 +83,7 @@ def usable(rc, x):
         return False
     if x.shape[1] % 64 != 0:          # a workgroup's 64 output channels must lie inside one group of the grouped layers
         return False
-    acts = {type(m.activation) for bank in (rc.Conv3, rc.Conv4, rc.Conv5) for seq in bank for m in seq}
-    return acts == {torch.nn.LeakyReLU} and weightbank.active_bank() is not None
+    return weightbank.active_bank() is not None and fusable(rc)
 
 
 def _conv(lib, st, x, packed, nbytes, bias, out, B, cin_g, H, W, cout, groups, act, slope, addend=None, mask=None):

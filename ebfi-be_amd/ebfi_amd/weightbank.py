@@ -77,9 +77,12 @@ def _adjoint_table(src_ids, n_src, first):
 
 
 class WeightBank:
-    def __init__(self, params, flat=None):
+    def __init__(self, params, flat=None, inference=False):
         """`params`: the tensors the sites may draw from.  `flat`: one fp32 buffer the params are views of, in this order
-        (FlatAdam.flat); None = the bank keeps its own concatenation and re-copies it when a parameter's version changes."""
+        (FlatAdam.flat); None = the bank keeps its own concatenation and re-copies it when a parameter's version changes.
+        `inference`: modules may register forward-only sites that a training step would not use (the fused KernelConv -> FAC
+        layout of Modification) -- they would only lengthen the per-step pack launch of a training bank."""
+        self.inference = bool(inference)
         self.params = list(params)
         self.owns_flat = flat is None
         self._offsets, off = {}, 0
@@ -106,13 +109,18 @@ class WeightBank:
             raise KeyError("parameter is not part of this bank")
         return ent[0]
 
-    def register(self, weights, biases=None, kind="id", fold_w=None, fold_b=None, groups=1):
+    def register(self, weights, biases=None, kind="id", fold_w=None, fold_b=None, groups=1, need_tr=True):
         """`weights`: one parameter, or a list concatenated along the (folded) output-channel axis.  `fold_w` / `fold_b`:
         0/1 linear maps from the parameter's shape to [M, K, ks, ks] / [M] (None = identity).  Keyed by the FIRST weight.
         `groups` > 1: the M rows form that many groups, each convolving its own K input channels (a grouped convolution:
-        the data-gradient image is then [tap][(group, ci)][co within the group])."""
+        the data-gradient image is then [tap][(group, ci)][co within the group]).  `need_tr` = False: forward images only
+        (a site no data gradient will ever be taken through)."""
         weights = list(weights) if isinstance(weights, (list, tuple)) else [weights]
         biases = list(biases) if isinstance(biases, (list, tuple)) else ([biases] if biases is not None else [])
+        if any(b is None for b in biases):
+            if not all(b is None for b in biases):
+                raise ValueError("a concatenated site needs a bias on every part or on none")
+            biases = []
         key = (weights[0].data_ptr(), kind)
         if key in self.sites:
             return self.sites[key]
@@ -132,7 +140,8 @@ class WeightBank:
                  (Mg + 15) // 16 * 16).reshape(-1)                                               # [tap][(g, ci)][co16], taps flipped
         s = Site()
         s.bank, s.kind, s.M, s.K, s.ks, s.groups = self, kind, int(M), int(K), int(ks), int(groups)
-        for name, img in (("fwd", fwd), ("tr", tr)):
+        s.tr_off, s.tr_bytes = 0, 0
+        for name, img in (("fwd", fwd), ("tr", tr)) if need_tr else (("fwd", fwd),):
             lo = torch.where(img >= 0, img | LO_FLAG, img)
             setattr(s, name + "_off", 2 * self._n_packed)
             setattr(s, name + "_bytes", 4 * img.numel())
@@ -208,14 +217,14 @@ class WeightBank:
             _ACTIVE = prev
 
 
-def build_for(model, flat=None, params=None):
+def build_for(model, flat=None, params=None, inference=False):
     """A bank over every eligible convolution of `model` (nn.Conv2d 1x1 / 3x3 stride 1; the depth-2 Conv3d /
     ConvTranspose3d of the detail branch), plus the concatenations modules declare through `_ebfi_bank_register(bank)`."""
     import torch.nn as nn
 
     from . import fold3d
     params = list(params) if params is not None else [p for p in model.parameters()]
-    bank = WeightBank(params, flat)
+    bank = WeightBank(params, flat, inference=inference)
     known = set(p.data_ptr() for p in params)
     ok = lambda *ts: all(t is None or t.data_ptr() in known for t in ts)
     for m in model.modules():

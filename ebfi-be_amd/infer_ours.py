@@ -4,7 +4,9 @@
 builds the model by name and runs `model(Frame, Event, T, GTEx)[-1]` under no_grad.  Inputs are
 synthetic clips (BASELINE.json configs 1/2/5); metrics / PNG dumps / HDF5 lists are out of scope.
 
-    python infer_ours.py --model_path output/models/Ours/run/checkpoint-iteration100.pth --batch 4 --height 256 --width 256
+    python infer_ours.py --model_path output/models/Ours/run/checkpoint-iteration99.pth --batch 4 --height 256 --width 256
+    (train_ours.py names a checkpoint after the LAST COMPLETED iteration, counted from 0 like the reference: a 100-iteration
+    run writes checkpoint-iteration99.pth and is resumed at iteration 100)
     python infer_ours.py --batch 1 --height 128 --width 128          # random-init weights
 """
 import argparse
@@ -54,7 +56,7 @@ def main():
     from ebfi_amd import weightbank
     stack = contextlib.ExitStack()
     if a.precision == "bf16x3":        # conv weight images packed ONCE for the whole run instead of inside every conv call
-        bank = weightbank.build_for(model)
+        bank = weightbank.build_for(model, inference=True)   # incl. the fused KernelConv -> FAC layout
         bank.refresh()
         stack.enter_context(bank.active())
     frame, event, _, gtex, _ = synthetic_batch(a.batch, a.height, a.width, margs["TB"], device=device, seed=a.seed)

@@ -128,6 +128,9 @@ def main():
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16"],
                     help="matrix-core operands of the convs: bf16x3 = split bf16 pairs, fp32-grade accuracy (default); fp32 = exact")
     ap.add_argument("--graph", action="store_true", help="replay forward+loss+backward from a captured hipGraph")
+    ap.add_argument("--host-data", action="store_true",
+                    help="draw every synthetic batch on the host (bit-identical across machines, ~0.5 s per B=8 256x256 batch) "
+                         "instead of with the device generator (default: the data path must not be slower than the 20 ms step)")
     ap.add_argument("--raw-events", action="store_true",
                     help="build the event tensor from synthetic raw event lists with the device events_to_stack kernel "
                          "(the reference's data path, h5dataset.py:327-352) instead of drawing voxel counts directly")
@@ -151,21 +154,31 @@ def main():
     TB = int(config["model"]["args"]["TB"])
     out_dir = os.path.join(tr.get("output_path", "./output"), "models", config.get("experiment", "Ours"), args.runid)
 
-    t0, frames, it = time.perf_counter(), 0, start
+    # throughput is counted from the end of the FIRST iteration of this run (which pays module load, allocator growth and,
+    # with --graph, the capture): what is logged is the steady-state rate, whole job (all ranks)
+    t0, frames, it = None, 0, start
     make = synthetic_batch_from_raw_events if args.raw_events else synthetic_batch
     while it < st["iterations"]:
         for micro in range(st["accu_step"]):
-            # one fresh synthetic batch per pass, different on every rank (seed + rank, like the reference)
-            batch = make(B, H, W, TB, device=device, seed=args.seed + 1000 * (it * st["accu_step"] + micro), rank=rank)
+            # one fresh synthetic batch per pass, different on every rank (seed + rank, like the reference); drawn by the
+            # device generator unless --host-data: the host draw alone would cap the loop at ~15 frames/s
+            batch = make(B, H, W, TB, device=device, seed=args.seed + 1000 * (it * st["accu_step"] + micro), rank=rank,
+                         on_device=not args.host_data)
             loss = eng.train_step(*batch)
-            frames += B * world
-        loss = reduce_tensor(loss.clone())
+            if t0 is not None:
+                frames += B * world
+        log_now = it % st["log_step"] == 0 or it == st["iterations"] - 1
+        if log_now:                      # the loss all-reduce is for logging only (train_ours.py:278-279): do it when logging
+            loss = reduce_tensor(loss.clone())
         lr_now = scheduler.get_last_lr()[0] if scheduler is not None else eng.optimizer.param_groups[0]["lr"]
-        if rank == 0 and (it % st["log_step"] == 0 or it == st["iterations"] - 1):
+        if rank == 0 and log_now:
             torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
+            rate = frames / (time.perf_counter() - t0) if t0 is not None and frames else float("nan")
             print("Iteration: %d/%d train_loss: %.4e learning rate: %.4e  %.1f frames/s"
-                  % (it, st["iterations"], loss.item(), lr_now, frames / dt), flush=True)
+                  % (it, st["iterations"], loss.item(), lr_now, rate), flush=True)
+        if t0 is None:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
         # periodic checkpoints as train_ours.py:331-333 (saved BEFORE this iteration's scheduler step, like there), plus one
         # after the last iteration
         if rank == 0 and ((st["save_period"] and it % st["save_period"] == 0 and it != 0) or it == st["iterations"] - 1):
@@ -174,8 +187,6 @@ def main():
             print("saved", path, flush=True)
         if scheduler is not None and it % st["lr_change_rate"] == 0 and it != 0 and lr_now >= st["lr_min"]:   # :335-338
             scheduler.step()
-        if world > 1:
-            dist.barrier()
         it += 1
     if world > 1:
         dist.destroy_process_group()

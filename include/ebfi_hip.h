@@ -45,7 +45,9 @@
 extern "C" {
 #endif
 
-#define EBFI_ABI_VERSION 2
+/* 3: round 2/3 additions (ebfi_ed_head_*, ebfi_laploss_*, ebfi_se_gate_*, ebfi_adam_step, ebfi_pack_table_bf16,
+ * ebfi_conv2d_packed_x3, the fused KernelConv -> FAC forward, ...).  Bumped whenever an entry point is added or changed. */
+#define EBFI_ABI_VERSION 3
 
 typedef enum {
     EBFI_OK = 0,
@@ -216,6 +218,20 @@ int ebfi_pack_table_bf16(const float *src, const int32_t *table, int64_t n, void
 int ebfi_conv2d_packed_x3(const void *input, const void *packed, size_t packed_bytes, const void *bias, void *output,
                           int B, int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups, int act,
                           float slope, const void *addend, const void *mask_y, int mask_act, float mask_slope, void *stream);
+/* KernelConv -> FAC as ONE kernel (inference).  Replaces, for the pair
+ *   filters = LeakyReLU(KernelConv(cat))                 reference models/Ours/model_singleframe.py:161 (ConvLayer 3x3, 2C -> C*K*K)
+ *   out     = KernelConv2D(K)(feat, filters)             :162, models/FAC/kernelconv2d/KernelConv2D.py:77-87 (ReplicationPad2d(K//2)
+ *                                                        + kernelconv2d_cuda.forward, KernelConv2D_kernel.cu:25-53)
+ * the conv launch, the [B, C*K*K, H, W] filter tensor and the FAC launch: the filters exist only in the accumulators of
+ * the conv's workgroups, whose epilogue applies them to the replicate-clamped `feat`.
+ *   input   [B, Cin, H, W] fp32 (cat([feat, frame_feat]) in the reference model)
+ *   packed  split-precision forward images ([hi | lo], bf16 [tap][C*32][Cin16]) of the conv weight re-tiled to 32 rows per
+ *           FAC channel: row c*32 + t = weight row c*K*K + t for t < K*K, zero otherwise (ebfi_amd/weightbank.py "facrows")
+ *   bias32  [C*32] fp32, same row layout (zeros in the pad rows)
+ *   feat    [B, C, H, W] fp32, output [B, C, H, W] fp32; K = 5; W % 4 == 0. */
+int ebfi_kernelconv_fac_fused_x3(const void *input, const void *packed, size_t packed_bytes, const void *bias32,
+                                 const void *feat, void *output, int B, int Cin, int H, int W, int C, int fac_ksize,
+                                 float slope, void *stream);
 /* weight / bias gradient of such a (grouped) convolution from a pre-activation gradient: grad_weight
  * [Cout, Cin_per_group, k, k]; workspace as ebfi_conv2d_backward_weight_workspace(B, Cin_per_group, H, W, Cout, k, 1, pad) */
 int ebfi_conv2d_backward_weight_x3g(const void *input, const void *grad_output, void *grad_weight, void *grad_bias,

@@ -71,12 +71,16 @@ def test_bench_two_rank_rehearsal():
 
 def test_graph_replay_step_equals_eager_step():
     """Engine(graph=True) replays fwd + loss + bwd + gradient packing from one hipGraph: same losses and
-    parameters as the eager engine over several steps (inputs change between steps)."""
+    parameters as the eager engine over several steps (inputs change between steps).  Run in the mode bench.py times --
+    split-precision convs, so the weight-bank refresh (first node of the capture) and the fused ResidualControl node
+    (default width 64) are inside the replayed graph and must pick up every optimiser update."""
     import torch
+    from ebfi_amd import rc_fused
     from ebfi_amd.engine import Engine, synthetic_batch
     cfg = dict(step=2, channels=[8, 8, 16, 16])
-    engines = [Engine(cfg, device="cuda", seed=7, graph=g) for g in (False, True)]
+    engines = [Engine(cfg, device="cuda", seed=7, graph=g, precision="bf16x3") for g in (False, True)]
     engines[1].model.load_state_dict(engines[0].model.state_dict())
+    assert all(e.bank is not None and rc_fused.fusable(e.model.ResidualControl) for e in engines)
     for it in range(4):
         batch = synthetic_batch(2, 64, 64, device="cuda", seed=100 + it)
         losses = [e.train_step(*batch) for e in engines]

@@ -152,3 +152,86 @@ def test_empty_batch():
     from ebfi_amd.fac import fac_forward
     out = fac_forward(torch.zeros(0, 2, 8, 8).cuda(), torch.zeros(0, 18, 6, 6).cuda(), 3)
     assert out.shape == (0, 2, 6, 6)
+
+
+FUSED_CASES = [
+    # B, C (FAC channels), Cin, H, W
+    (2, 8, 16, 20, 36),      # ragged tiles both ways, one 16-channel chunk, 4 row blocks
+    (1, 3, 24, 8, 64),       # odd channel count: the last 64-row block holds one channel; Cin not a multiple of 16
+    (2, 64, 128, 16, 128),   # the model's widths (128 -> 1600): 8 chunks, 32 row blocks, two x tiles
+    (1, 5, 16, 9, 4),        # a feature map smaller than the 5x5 window: every tap clamps
+]
+
+
+@pytest.mark.parametrize("B,C,Cin,H,W", FUSED_CASES)
+def test_fused_kernelconv_fac_vs_unfused_pair_and_oracle(B, C, Cin, H, W):
+    """filters = LeakyReLU(conv3x3(cat)) -> FAC(feat, filters) as ONE kernel (the filter tensor never exists)
+    against (a) the unfused product pair -- the same split-precision conv kernel writing the filters, then the FAC kernel --
+    and (b) the CPU oracle: fp32 conv + the FAC restatement with ReplicationPad2d(2) (KernelConv2D.py:82-87)."""
+    from ebfi_amd import conv, weightbank
+    from ebfi_amd.fac import KernelConv2D, fac_rows_fold_bias, fac_rows_fold_weight, kernelconv_fac_fused
+    torch.manual_seed(B * 1000 + C * 10 + H + W)
+    K, slope = 5, 0.01
+    w = torch.randn(C * K * K, Cin, 3, 3) * (1.0 / (Cin * 9) ** 0.5)
+    b = torch.randn(C * K * K) * 0.1
+    cat, feat = torch.randn(B, Cin, H, W), torch.randn(B, C, H, W)
+    filt = F.leaky_relu(F.conv2d(cat, w, b, 1, 1), slope)
+    ref = ref_ops.fac_forward(F.pad(feat, (2, 2, 2, 2), mode="replicate"), filt.contiguous(), K)
+    wd, bd = torch.nn.Parameter(w.cuda()), torch.nn.Parameter(b.cuda())
+    bank = weightbank.WeightBank([wd, bd], inference=True)
+    site = bank.register(wd, bd, "facrows", fac_rows_fold_weight, fac_rows_fold_bias, need_tr=False)
+    bank.refresh()
+    conv.set_compute_dtype("bf16x3")
+    try:
+        with torch.no_grad():
+            out = kernelconv_fac_fused(cat.cuda(), feat.cuda(), site, K, slope)
+            filt_d = conv.conv_bias_act(cat.cuda(), wd, bd, 1, 1, conv.ACT_LEAKY, slope)
+            pair = KernelConv2D(K)(feat.cuda(), filt_d)
+    finally:
+        conv.set_compute_dtype("fp32")
+    assert _rel(out.cpu(), pair.cpu()) < 2e-6          # same filter bits, another summation order over the 25 taps
+    assert _rel(out.cpu(), ref) < 1e-4                 # split-precision conv vs fp32 conv (path tolerance: 1e-3)
+
+
+def test_inference_bank_runs_modification_fused():
+    """An inference weight bank (Engine(train=False), infer_ours.py) makes Modification.forward take the fused kernel: one
+    launch labelled .../kernelconv_fac, no FAC launch, no filter tensor -- and the module output still matches the unfused
+    module and the CPU oracle (oracle.model_ref.modification) at the path's 1e-3."""
+    from oracle import model_ref
+    from ebfi_amd import _native as N
+    from ebfi_amd import conv, weightbank
+    from ebfi_amd.model import Modification
+    torch.manual_seed(17)
+    mod = Modification(FrameBasech=64, EventBasech=64)
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.copy_(torch.randn_like(p) * (1.2 / p[0].numel() ** 0.5) if p.dim() > 1 else 0.05 * torch.randn_like(p))
+    frame_feat, event_feat = torch.randn(2, 64, 24, 40), torch.randn(2, 64, 24, 40)
+    sd = {"Modification." + k: v.detach().clone() for k, v in mod.state_dict().items()}
+    ref = model_ref.modification(sd, "Modification", frame_feat, event_feat)
+    mod = mod.cuda().eval()
+    conv.set_compute_dtype("bf16x3")
+    try:
+        def run(bank):
+            N.prof_reset()
+            N.prof_enable(True)
+            with torch.no_grad():
+                if bank is None:
+                    y = mod(frame_feat.cuda(), event_feat.cuda())
+                else:
+                    bank.ensure_fresh()
+                    with bank.active():
+                        y = mod(frame_feat.cuda(), event_feat.cuda())
+            torch.cuda.synchronize()
+            N.prof_enable(False)
+            return y, {k: v[0] for k, v in N.prof_collect().items() if v[0] > 0}
+        y0, prof0 = run(None)
+        y1, prof1 = run(weightbank.build_for(mod, inference=True))
+        y2, prof2 = run(weightbank.build_for(mod))                      # a training bank: packed weights, unfused pair
+    finally:
+        conv.set_compute_dtype("fp32")
+    assert prof1.get("conv_fwd_bf16x3_ws/kernelconv_fac") == 1 and not any(k.startswith("fac_fwd") for k in prof1), prof1
+    assert any(k.startswith("fac_fwd") for k in prof0) and any(k.startswith("fac_fwd") for k in prof2)
+    assert "conv_fwd_bf16x3_ws/kernelconv_fac" not in prof0 and "conv_fwd_bf16x3_ws/kernelconv_fac" not in prof2
+    assert _rel(y1.cpu(), y0.cpu()) < 1e-5 and _rel(y2.cpu(), y0.cpu()) < 1e-5
+    assert _rel(y1.cpu(), ref) < 1e-3

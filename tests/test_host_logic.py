@@ -284,3 +284,26 @@ def test_weight_bank_tables_reproduce_the_per_call_packing():
     assert sb.has_bias and torch.equal(bias_buf[sb.bias_off:sb.bias_off + sb.M], dec.bias.detach().repeat_interleave(2))
     assert torch.equal(bias_buf[cat_site.bias_off:cat_site.bias_off + cat_site.M],
                        torch.cat([rc.Conv3[0][0].conv2d.bias, rc.Conv4[0][0].conv2d.bias]).detach())
+
+
+def test_fused_residual_control_declines_norm_variants():
+    """ebfi_amd.rc_fused: the fused node computes conv + bias + LeakyReLU only.  The reference's `norm` option ('BN' drops
+    the conv bias, 'IN' inserts a norm layer, submodules.py:159-200) must leave the module on its layer-by-layer path and
+    must not break the weight-bank construction (round-2 advisory: norm='BN' raised AttributeError in Engine.__init__,
+    norm='IN' silently skipped the InstanceNorm layers)."""
+    from ebfi_amd import rc_fused, weightbank
+    small = dict(DEFAULT_MODEL_ARGS, FrameBasech=8, EventBasech=8, InterCH=8, TB=4, step=2, channels=[4, 4, 8, 8])
+    for norm, fus in ((None, True), ("BN", False), ("IN", False)):
+        net = EVFIAutoEx(**dict(small, norm=norm))
+        assert rc_fused.fusable(net.ResidualControl) is fus, norm
+        bank = weightbank.build_for(net)                      # host-side registration only: must not raise
+        kinds = {k for _, k in bank.sites}
+        assert ("rcA" in kinds) is fus and ("rcB" in kinds) is fus, (norm, kinds)
+        with bank.active():
+            assert (rc_fused.sites_of(net.ResidualControl) is not None) is fus
+            x = torch.zeros(1, 8, 8, 8)
+            assert not rc_fused.usable(net.ResidualControl, x)          # CPU tensor / fp32 mode: never the fused node
+    # another activation on the scalar-conditioned 1x1 layers also declines
+    net = EVFIAutoEx(**small)
+    net.ResidualControl.Conv1[0][0].activation = torch.nn.ReLU()
+    assert not rc_fused.fusable(net.ResidualControl)
