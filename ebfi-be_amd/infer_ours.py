@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--seed", type=int, default=123)
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16"],
                     help="matrix-core operands of the convs: bf16x3 = split bf16 pairs, fp32-grade accuracy (default); fp32 = exact")
+    ap.add_argument("--rand-init", action="store_true",
+                    help="without --model_path: draw O(1)-gain random weights instead of the reference's x0.1 initialisation, "
+                         "whose output is the constant 0.5 (benchmark / profile runs: the printed mean then depends on the data)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
     a = ap.parse_args()
     from ebfi_amd import conv
@@ -52,6 +55,13 @@ def main():
     torch.manual_seed(a.seed)
     device = torch.device("cuda", 0)
     model, margs = load_model(a.model_path, device)
+    if a.rand_init and a.model_path is None:
+        with torch.no_grad():
+            for p in model.parameters():
+                if p.dim() > 1:
+                    p.copy_(torch.randn_like(p) * (1.2 / p[0].numel() ** 0.5))
+                else:
+                    p.add_(0.05 * torch.randn_like(p))
     import contextlib
     from ebfi_amd import weightbank
     stack = contextlib.ExitStack()
@@ -87,8 +97,9 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     out = torch.stack(preds, 1)
-    print("interpolated %d frames of %dx%d in %.3f s: %.1f frames/s; output %s, mean %.4f"
-          % (a.batch * a.num_ts, a.height, a.width, dt, a.batch * a.num_ts / dt, tuple(out.shape), out.mean().item()))
+    print("interpolated %d frames of %dx%d in %.3f s: %.1f frames/s; output %s, mean %.4f std %.4f, peak memory %.1f GB"
+          % (a.batch * a.num_ts, a.height, a.width, dt, a.batch * a.num_ts / dt, tuple(out.shape), out.mean().item(),
+             out.std().item(), torch.cuda.max_memory_allocated(device) / 1e9))
 
 
 if __name__ == "__main__":
