@@ -15,7 +15,11 @@ pids=()
 for src in "$HERE"/*.hip; do
     obj="$OBJ/$(basename "${src%.hip}").o"
     objs+=("$obj")
-    if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/common.hpp" -nt "$obj" ] || [ "$HERE/../../include/ebfi_hip.h" -nt "$obj" ]; then
+    stale=0
+    for dep in "$src" "$HERE"/*.hpp "$HERE/../../include/ebfi_hip.h"; do   # (every header of csrc/: conv2d_f16.inc.hpp is one)
+        [ "$dep" -nt "$obj" ] && stale=1
+    done
+    if [ ! -f "$obj" ] || [ "$stale" = 1 ]; then
         $HIPCC $FLAGS -c "$src" -o "$obj" &
         pids+=($!)
     fi

@@ -96,7 +96,8 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, unsigned byte_o
 template <int MT, bool EXTRA = false>
 __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const float *__restrict__ bias, const f32x16 (&acc)[MT][2],
                                                const ConvGeom &g, int b, int co_base, int yo, int x0, int lane, int act,
-                                               float slope, EpiExtra ex = EpiExtra{nullptr, nullptr, 0, 0.f}) {
+                                               float slope, EpiExtra ex = EpiExtra{nullptr, nullptr, 0, 0.f}, float oscale = 1.f) {
+    // oscale: the accumulators are oscale-times too small (operands were scaled by powers of two: conv2d_f16.inc.hpp); 1 otherwise
     const int HWo = g.Ho * g.Wo;
     const unsigned plane = (unsigned)HWo * 4u;
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(out + (int64_t)b * g.Cout * HWo, (unsigned)g.Cout * plane);
@@ -130,7 +131,7 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
                     const bool leaky = ex.mask_act == ACT_LEAKY, sig = ex.mask_act == ACT_SIGMOID, has_m = ex.mask_y != nullptr;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        float v = actf(acc[m][n][r] + bv[m][r] + av[r]);
+                        float v = actf(acc[m][n][r] * oscale + bv[m][r] + av[r]);
                         const float d = leaky ? (mv[r] > 0.f ? 1.f : ex.mask_slope) : (sig ? mv[r] * (1.f - mv[r]) : 1.f);
                         v = has_m ? v * d : v;
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, base + (unsigned)((r & 3) + 8 * (r >> 2)) * plane, 0, 0);
@@ -138,7 +139,7 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(actf(acc[m][n][r] + bv[m][r])), ro,
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(actf(acc[m][n][r] * oscale + bv[m][r])), ro,
                                                               base + (unsigned)((r & 3) + 8 * (r >> 2)) * plane, 0, 0);
                 }
             }
@@ -2452,6 +2453,8 @@ __global__ __launch_bounds__(NTWS) void conv_fwd_bf16x3_ws(const float *__restri
     }
 }
 
+#include "conv2d_f16.inc.hpp"
+
 size_t bf16_pack_bytes(int M, int K, int ks) { return (size_t)ks * ks * M * (size_t)((K + 15) / 16 * 16) * 2; }
 
 // shared by forward (TR = 0) and data gradient (TR = 1); g is the geometry of the conv actually run.
@@ -3219,6 +3222,141 @@ extern "C" int ebfi_kernelconv_fac_fused_x3(const void *input, const void *packe
                        static_cast<float *>(output), g, K16, ACT_LEAKY, slope, EpiExtra{nullptr, nullptr, 0, 0.f}, (int)tiles,
                        FacEpi{static_cast<const float *>(feat), C});
     return check_launch("conv_fwd_bf16x3_ws/kernelconv_fac");
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp16 single-product forms for the BACKWARD pass of the training step (conv2d_f16.inc.hpp): the data gradient as a
+// convolution of the (pre-activation) gradient with packed fp16 TRANSPOSED weight images, and the weight gradient, both
+// with power-of-two operand scales kept in device slots {scale, running |max|}.
+extern "C" int ebfi_conv2d_packed_f16(const void *input, const void *packed16, size_t packed_bytes, const void *bias, void *output,
+                                      int B, int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups, int act,
+                                      float slope, const void *addend, const void *mask_y, int mask_act, float mask_slope,
+                                      void *in_slot, const void *w_slot, void *stream) {
+    if (!input || !packed16 || !output) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: null argument");
+    if (act < 0 || act > 2 || mask_act < 0 || mask_act > 2) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: unknown activation");
+    if (ksize != 3 || pad != 1) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_f16: 3x3 same-padded convolutions only (k=%d pad=%d)", ksize, pad);
+    if (groups < 1 || Cout % groups != 0 || (groups > 1 && (Cout / groups) % 64 != 0))
+        return fail(EBFI_ERR_ARG, "conv2d_packed_f16: %d output channels in %d groups (groups need multiples of 64 channels)", Cout, groups);
+    if (W % 4 != 0 || !aligned16(input))
+        return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_f16: needs W %% 4 == 0 and a 16-byte aligned input (W = %d)", W);
+    ConvGeom g;
+    if (int rc = make_geom(g, B, Cin_per_group, H, W, Cout, ksize, 1, pad)) return rc;
+    if ((int64_t)groups * (Cin_per_group + 64) * H * W * 4 >= (1LL << 31) - (1LL << 26))
+        return fail(EBFI_ERR_ARG, "conv2d_packed_f16: one sample exceeds the 2 GiB reach of 32-bit buffer offsets");
+    g.groups = groups;
+    const int K16 = (g.Cin + 15) / 16 * 16;
+    const size_t need = (size_t)9 * g.Cout * K16 * 2;
+    if (packed_bytes < need) return fail(EBFI_ERR_WORKSPACE, "conv2d_packed_f16: packed image %zu bytes < required %zu", packed_bytes, need);
+    if (B == 0) return EBFI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const EpiExtra epi{static_cast<const float *>(addend), static_cast<const float *>(mask_y), mask_act, mask_slope};
+    const int64_t tiles = (int64_t)B * ceil_div(g.Ho, TYB) * ceil_div(g.Wo, TX);
+    if (tiles > 2147483647LL) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: too many tiles");
+    constexpr int PSX = (TYB - 1 + 3) * (TX - 1 + 3);
+    const size_t lds = (size_t)2 * (PSX * 32 + 9 * 64 * 32);
+    const int64_t co_blocks = ceil_div(g.Cout, 64);
+    int64_t gx = 256 / co_blocks;
+    if (gx < 1) gx = 1;
+    if (gx > tiles) gx = tiles;
+    const dim3 grid((unsigned)gx, (unsigned)co_blocks);
+    const bool extra = epi.addend != nullptr || epi.mask_y != nullptr;
+    const double flops = 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * 9;
+    ProfScope ps("conv_fwd_f16_ws", st, flops, conv_bytes_fwd(g, 9, false));
+    const ScaleSlot isl{static_cast<float *>(in_slot)};
+    const float *x = static_cast<const float *>(input), *bs = static_cast<const float *>(bias);
+    const _Float16 *wp = static_cast<const _Float16 *>(packed16);
+    float *o = static_cast<float *>(output);
+    if (extra) {
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_f16_ws<true>), 160 * 1024)) return rc_;
+        hipLaunchKernelGGL((conv_fwd_f16_ws<true>), grid, dim3(NTF16), lds, st, x, wp, bs, o, g, K16, act, slope, epi, (int)tiles, isl,
+                           static_cast<const float *>(w_slot));
+    } else {
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_f16_ws<false>), 160 * 1024)) return rc_;
+        hipLaunchKernelGGL((conv_fwd_f16_ws<false>), grid, dim3(NTF16), lds, st, x, wp, bs, o, g, K16, act, slope, epi, (int)tiles, isl,
+                           static_cast<const float *>(w_slot));
+    }
+    return check_launch("conv_fwd_f16_ws");
+}
+
+// weight / bias gradient of a (grouped) 3x3 convolution with fp16 operands: grad_output optionally times act'(saved_output)
+// (side output grad_preact_out as in ebfi_conv2d_backward_weight_ex); Cin_per_group a multiple of 64.
+extern "C" int ebfi_conv2d_backward_weight_f16g(const void *input, const void *grad_output, const void *saved_output,
+                                                void *grad_weight, void *grad_bias, void *grad_preact_out, int B,
+                                                int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups, int act,
+                                                float slope, void *x_slot, void *g_slot, void *workspace,
+                                                size_t workspace_bytes, void *stream) {
+    if (!input || !grad_output || !grad_weight) return fail(EBFI_ERR_ARG, "conv2d_backward_weight_f16g: null argument");
+    if (ksize != 3) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_weight_f16g: k=%d", ksize);
+    if (Cin_per_group % 64 != 0) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_weight_f16g: %d input channels per group (multiples of 64)", Cin_per_group);
+    if (act < 0 || act > 2 || (act != ACT_NONE && !saved_output)) return fail(EBFI_ERR_ARG, "conv2d_backward_weight_f16g: activation / saved_output");
+    if (groups < 1 || Cout % groups != 0 || (groups > 1 && (Cout / groups) % 64 != 0))
+        return fail(EBFI_ERR_ARG, "conv2d_backward_weight_f16g: %d output channels in %d groups", Cout, groups);
+    ConvGeom g;
+    if (int rc = make_geom(g, B, Cin_per_group, H, W, Cout, ksize, 1, pad)) return rc;
+    g.groups = groups;
+    const size_t need = ebfi_conv2d_backward_weight_workspace(B, Cin_per_group, H, W, Cout, ksize, 1, pad, EBFI_F32);
+    if (!workspace || workspace_bytes < need)
+        return fail(EBFI_ERR_WORKSPACE, "conv2d_backward_weight_f16g: workspace %zu bytes < required %zu", workspace_bytes, need);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t n_weight = (int64_t)Cout * Cin_per_group * 9, n_total = n_weight + Cout;
+    if (B == 0) {
+        (void)hipMemsetAsync(grad_weight, 0, (size_t)n_weight * sizeof(float), st);
+        if (grad_bias) (void)hipMemsetAsync(grad_bias, 0, (size_t)Cout * sizeof(float), st);
+        return EBFI_OK;
+    }
+    float *slab = static_cast<float *>(workspace);
+    const int nsplit = wgrad_x3_splits(g, 3);
+    {
+        using C = WCfg<3, 1, 32>;
+        const size_t lds = (size_t)2 * (32 * GS + 33 * C::PS) * sizeof(unsigned);
+        const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, C::WTX);
+        dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, 64));
+        const float *x = static_cast<const float *>(input), *go = static_cast<const float *>(grad_output);
+        const float *yo = static_cast<const float *>(saved_output);
+        float *gpre = static_cast<float *>(grad_preact_out);
+        const ScaleSlot xs{static_cast<float *>(x_slot)}, gs{static_cast<float *>(g_slot)};
+        const int need_bias = grad_bias != nullptr;
+        ProfScope ps("conv_wgrad_f16_ws", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * 9,
+                     conv_bytes_wgrad(g, 9, act != ACT_NONE, gpre != nullptr));
+#define EBFI_LAUNCH_WF16(DA_)                                                                                              \
+    do {                                                                                                                   \
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_wgrad_f16_ws<DA_>), (int)lds)) return rc_;     \
+        hipLaunchKernelGGL((conv_wgrad_f16_ws<DA_>), grid, dim3(512), lds, st, x, go, yo, slab, gpre, g, slope, (int)tiles,    \
+                           need_bias, xs, gs);                                                                             \
+    } while (0)
+        if (act == ACT_LEAKY) EBFI_LAUNCH_WF16(ACT_LEAKY);
+        else if (act == ACT_SIGMOID) EBFI_LAUNCH_WF16(ACT_SIGMOID);
+        else EBFI_LAUNCH_WF16(ACT_NONE);
+#undef EBFI_LAUNCH_WF16
+        if (int rc = check_launch("conv_wgrad_f16_ws")) return rc;
+    }
+    {
+        ProfScope ps("conv_wgrad_reduce_f32", st);
+        hipLaunchKernelGGL(conv_wgrad_reduce_f32, dim3((unsigned)ceil_div(n_total, 64)), dim3(256), 0, st, slab, nsplit, n_weight,
+                           n_total, static_cast<float *>(grad_weight), static_cast<float *>(grad_bias), 0, 9);
+    }
+    return check_launch("conv_wgrad_reduce_f32");
+}
+
+extern "C" int ebfi_f16_scales_finish(void *slots, int n, void *flag, void *stream) {
+    if (!slots || !flag || n < 0) return fail(EBFI_ERR_ARG, "f16_scales_finish: bad argument");
+    if (n == 0) return EBFI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope ps("f16_scales_finish", st);
+    hipLaunchKernelGGL(f16_scales_finish_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, static_cast<float *>(slots), n,
+                       static_cast<int *>(flag));
+    return check_launch("f16_scales_finish");
+}
+
+extern "C" int ebfi_pack_table_f16(const float *src, const int32_t *table, int64_t n, void *out, const int32_t *block_slot,
+                                   void *slots, void *stream) {
+    if (!src || !table || !out || !block_slot || !slots) return fail(EBFI_ERR_ARG, "pack_table_f16: null argument");
+    if (n <= 0) return EBFI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope ps("pack_table_f16", st);
+    hipLaunchKernelGGL(pack_table_f16_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, src, table, n,
+                       static_cast<_Float16 *>(out), block_slot, static_cast<float *>(slots));
+    return check_launch("pack_table_f16");
 }
 
 extern "C" int ebfi_conv2d_backward_weight_x3g(const void *input, const void *grad_output, void *grad_weight, void *grad_bias,

@@ -1,0 +1,578 @@
+// Single-product fp16 forms of the wave-specialised 3x3 kernels (included by conv2d.hip inside its anonymous namespace).
+//
+// Why: the split-precision kernels carry every operand as a bf16 pair and issue three MFMAs per product so that the
+// FORWARD pass agrees with fp32 to ~1e-5 -- which the training step needs, because the L1 / census loss terms turn forward
+// errors into sign flips of the gradient (measured with the oracle: fp16-rounded forward operands move the packed gradient
+// by 9e-3 in norm, split-precision ones by 1e-3).  The BACKWARD products have no such amplifier: rounding grad_output,
+// weights and saved inputs to fp16 (11-bit significand, 8x finer than bf16) moves the packed gradient from 0.95e-3 to
+// 1.09e-3 ("precision of the backward products").  So the data gradient and the weight gradient run
+// ONE v_mfma_f32_32x32x16_f16 per product on ONE 16-bit image per operand: a third of the matrix work, half the LDS
+// bytes and a third of the conversion instructions of the split form.
+//
+// Range: fp16 spans 2^-24 .. 65504, and with the reference's x0.1 initialisation gradients fall to 1e-29 in the early
+// layers.  Every operand is therefore multiplied by a POWER OF TWO on its way into LDS (exact in fp32) and the accumulator
+// is multiplied by the inverse product on its way out.  The scale of an operand lives in a two-word device slot
+// {scale, running |max|}: the staging code records |max| of what it reads (it touches every element anyway), and one tiny
+// kernel per step (ebfi_f16_scales_finish) turns the maxima into the next step's scales (max * scale in [128, 256): 7
+// binades of headroom above, 22 below before fp16 loses precision) and raises a flag if a product could have overflowed
+// -- delayed scaling, as used for fp8 training; the first use of a slot is calibrated just in time by the host side
+// (ebfi_amd/f16scale.py).
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {   // v_cvt_pk_f16_f32: round to nearest even, a in the low half
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, f16x2));
+}
+
+// Scale slot: [0] = scale (power of two), [1] = running |max| of the fp32 values staged through it (float bits, ordered as
+// unsigned for non-negative floats).
+struct ScaleSlot {
+    float *p;
+    __device__ __forceinline__ float scale() const { return p ? p[0] : 1.f; }
+    __device__ __forceinline__ void record(float wave_max_candidate) const {
+        // one atomic per wave: butterfly over the 64 lanes, lane 0 publishes (NaN / Inf propagate as large unsigned values)
+        float m = wave_max_candidate;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+        // (many workgroups report into one word: only a value above the one already there needs the atomic -- NaN compares
+        // false and goes through)
+        if (p && (threadIdx.x & 63) == 0 && !(m <= __builtin_nontemporal_load(p + 1)))
+            atomicMax(reinterpret_cast<unsigned *>(p + 1), __float_as_uint(m));
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// conv_fwd_f16_ws: the wave-specialised 3x3 forward / data gradient (64 output channels per workgroup, 8 rows x 64 px
+// tiles, 16-channel chunks, persistent tile walk: see conv_fwd_bf16x3_ws) with fp16 operand images.  With a third of the
+// matrix work per chunk the kernel is paced by the arrival of its staging loads, so the roles are re-balanced: FOUR
+// consumer waves (one per SIMD, two output rows each: an A fragment serves two rows) and four producer waves that, at 256
+// registers per wave, hold TWO chunks of global loads in flight (the split-precision form had room for one).  Used as the
+// DATA GRADIENT (transposed weight images) of the training step.
+//   x       [B, groups*Cin, H, W] fp32, multiplied by in_slot.scale() while it is converted; |max| recorded into in_slot
+//   wp      fp16 image [tap][Cout][K16], already scaled by w_slot[0] (the pack launch applied and recorded it)
+//   out     act(acc / (in_scale * w_scale) + bias + addend) * act'(mask_y)
+constexpr int NTF16 = 512;
+template <bool EXTRA>
+__global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict__ x, const _Float16 *__restrict__ wp,
+                                                         const float *__restrict__ bias, float *__restrict__ out, ConvGeom g, int K16,
+                                                         int act, float slope, EpiExtra epi, int tiles_total, ScaleSlot in_slot,
+                                                         const float *__restrict__ w_slot) {
+    constexpr int KS = 3, KK = 9, MT = 2, RW = 2;              // RW: output rows per consumer wave
+    constexpr int IH = TYB - 1 + KS, IW = TX - 1 + KS, PS = IH * IW, COS = 32 * MT;
+    constexpr int NCW = TYB / RW, PT = 256;
+    constexpr int WPIECES = KK * COS * 2, NWB = (WPIECES + PT - 1) / PT;
+    constexpr int INB = PS * 32, WB = KK * COS * 32, BUFB = INB + WB;
+    static_assert(NCW == 4 && NTF16 == 64 * NCW + PT, "wave roles");
+    extern __shared__ __attribute__((aligned(16))) char smd[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = (g.Wo + TX - 1) / TX, tiles_y = (g.Ho + TYB - 1) / TYB;
+    const int co_base = blockIdx.y * COS;
+    const int grp = co_base / (g.Cout / g.groups);
+    const int HW = g.H * g.W;
+    const unsigned plane_bytes = (unsigned)HW * 4u, x_bytes = (unsigned)g.Cin * plane_bytes;
+    const int nchunks = K16 / CKB;
+    const int G = gridDim.x;
+    int ntiles_mine = 0;
+    for (int t = blockIdx.x; t < tiles_total; t += G) ++ntiles_mine;
+    const int nitems = ntiles_mine * nchunks;
+    auto tile_coords = [&](int tt, int &tb, int &ty0, int &tx0) {
+        int u = tt;
+        const int txi = u % tiles_x; u /= tiles_x;
+        const int tyi = u % tiles_y;
+        tb = u / tiles_y; ty0 = tyi * TYB; tx0 = txi * TX;
+    };
+    const float sx = in_slot.scale();
+
+    if (wave < NCW) {
+        // ------------------------------------------------------------------ consumers: output rows 2*wave, 2*wave + 1
+        f32x16 acc[RW][MT][2];
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[r][m][n][e] = 0.f;
+        const float oscale = 1.f / (sx * (w_slot ? w_slot[0] : 1.f));
+        const int hsel = lane >> 5, l31 = lane & 31;
+        const int a_lane = INB + l31 * 32 + ((hsel ^ ((l31 >> 3) & 1)) << 4);
+        const int pbase = RW * wave * IW + l31;
+        // bit (r*9 + tap): which 16-byte half of position (pbase + r*IW + ky*IW + kx) this lane's k-half lives in
+        unsigned fbits = 0;
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int tap = 0; tap < KK; ++tap)
+                fbits |= (unsigned)((((pbase + r * IW + (tap / KS) * IW + (tap % KS)) >> 3) & 1) ^ hsel) << (r * KK + tap);
+        f16x8 af[2][MT], bf[2][RW][2];
+        auto tap_read = [&](const char *base, int tap, int set) {
+            const int ky = tap / KS, kx = tap - ky * KS;
+            const char *ap = base + a_lane + tap * COS * 32;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) af[set][m] = *reinterpret_cast<const f16x8 *>(ap + m * 1024);
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const char *bp = base + (pbase + r * IW) * 32 + (int)(((fbits >> (r * KK + tap)) & 1u) << 4) + (ky * IW + kx) * 32;
+#pragma unroll
+                for (int n = 0; n < 2; ++n) bf[set][r][n] = *reinterpret_cast<const f16x8 *>(bp + n * 1024);
+            }
+        };
+        auto tap_mfma = [&](int set) {
+#pragma unroll
+            for (int r = 0; r < RW; ++r)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[r][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[set][m], bf[set][r][n], acc[r][m][n], 0, 0, 0);
+        };
+        __syncthreads();                   // (A) the first chunk is committed
+        int item = 0, tcur = blockIdx.x;
+        for (int ti = 0; ti < ntiles_mine; ++ti, tcur += G) {
+            for (int chunk = 0; chunk < nchunks; ++chunk, ++item) {
+                const char *base = smd + (item & 1) * BUFB;
+                tap_read(base, 0, 0);
+#pragma unroll
+                for (int tap = 0; tap < KK; ++tap) {
+                    if (tap + 1 < KK) tap_read(base, tap + 1, (tap + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    tap_mfma(tap & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __syncthreads();           // (B) this buffer has been read, the other one is complete
+            }
+            int cb_, cy0, cx0;
+            tile_coords(tcur, cb_, cy0, cx0);
+            // (written out per row: as a loop the EXTRA variant was not unrolled, `acc[r]` became a runtime index and the whole
+            // accumulator array moved to scratch memory -- 410 instead of 45 us per launch)
+            static_assert(RW == 2, "epilogue is written out for two rows");
+            store_out_tile<MT, EXTRA>(out, bias, acc[0], g, cb_, co_base, cy0 + RW * wave, cx0, lane, act, slope, epi, oscale);
+            store_out_tile<MT, EXTRA>(out, bias, acc[1], g, cb_, co_base, cy0 + RW * wave + 1, cx0, lane, act, slope, epi, oscale);
+#pragma unroll
+            for (int r = 0; r < RW; ++r)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[r][m][n][e] = 0.f;
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------- producers
+    // 16-byte quads of 4 consecutive pixels x 8 channels (as conv_fwd_bf16x3_ws) and the chunk's weight pieces; two register
+    // stages, so the loads of items i+2 and i+3 are in flight while item i+1 is converted and written.
+    const int ptid = tid - 64 * NCW;
+    const unsigned img_bytes = (unsigned)KK * (unsigned)g.Cout * (unsigned)K16 * 2u;
+    const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(wp), 0, img_bytes, 0x00020000);
+    constexpr int SH = (4 - (KS / 2) % 4) % 4;
+    constexpr int NQ = (IW + SH + 3) / 4;
+    constexpr int NITEM = IH * NQ * 2;
+    constexpr int NIT = (NITEM + PT - 1) / PT;
+    int it_qh[NIT], it_qr[NIT], it_qq[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int id = ptid + k * PT;
+        it_qh[k] = id & 1;
+        it_qr[k] = (id >> 1) / NQ;
+        it_qq[k] = (id >> 1) - it_qr[k] * NQ;
+    }
+    unsigned w_off[NWB];
+    int w_dst[NWB];
+#pragma unroll
+    for (int it = 0; it < NWB; ++it) {
+        const int j = ptid + it * PT;
+        const int row = j >> 1, half = j & 1;
+        const int tap = row / COS, co = row - tap * COS;
+        w_off[it] = j < WPIECES ? (unsigned)(((tap * g.Cout + co_base + co) * K16 + half * 8) * 2) : SENT;
+        w_dst[it] = INB + row * 32 + ((half ^ ((row >> 3) & 1)) << 4);
+    }
+    struct Stage {
+        u32x4 rq[NIT][8];
+        u32x4 rw[NWB];
+    };
+    Stage sa, sb;
+    int pf_tile = blockIdx.x, pf_chunk = 0;
+    unsigned pf_off[NIT];
+    const float *pf_src = x;
+    unsigned pf_bytes = 0u;
+    float amax = 0.f;
+    auto pf_setup = [&]() {
+        const bool live = pf_tile < tiles_total;
+        int tb, ty0, tx0;
+        tile_coords(live ? pf_tile : 0, tb, ty0, tx0);
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int yy = ty0 - g.pad + it_qr[k], xq = tx0 - g.pad - SH + 4 * it_qq[k];
+            const bool ok = live && ptid + k * PT < NITEM && yy >= 0 && yy < g.H && xq >= 0 && xq + 3 < g.W;
+            pf_off[k] = ok ? (unsigned)(yy * g.W + xq) * 4u + (unsigned)(8 * it_qh[k]) * plane_bytes : SENT;
+        }
+        pf_src = x + ((int64_t)tb * g.groups + grp) * g.Cin * HW;
+        pf_bytes = live ? x_bytes : 0u;
+    };
+    auto prefetch = [&](Stage &s) {
+        // the descriptor words are wave-uniform, but with two call sites the compiler no longer proves it and wraps every load
+        // in a waterfall loop (measured: 214 instead of ~60 us per launch): make the uniformity explicit
+        const uint64_t pa = reinterpret_cast<uint64_t>(pf_src);
+        // (the builtin returns a signed int: widen through unsigned, or a low half with bit 31 set smears into the high half)
+        const uint64_t pu = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(pa >> 32)) << 32) |
+                            (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)pa);
+        const __amdgpu_buffer_rsrc_t r = make_rsrc(reinterpret_cast<const float *>(pu), (unsigned)__builtin_amdgcn_readfirstlane(pf_bytes));
+        const unsigned cb = (unsigned)__builtin_amdgcn_readfirstlane(pf_chunk) * (unsigned)CKB * plane_bytes;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) s.rq[k][c] = __builtin_amdgcn_raw_buffer_load_b128(r, pf_off[k] + cb + (unsigned)c * plane_bytes, 0, 0);
+        const unsigned wb = (unsigned)__builtin_amdgcn_readfirstlane(pf_chunk) * (unsigned)(CKB * 2);
+#pragma unroll
+        for (int it = 0; it < NWB; ++it) s.rw[it] = __builtin_amdgcn_raw_buffer_load_b128(rwt, w_off[it] + wb, 0, 0);
+        if (++pf_chunk == nchunks) {
+            pf_chunk = 0;
+            pf_tile += G;
+            pf_setup();
+        }
+    };
+    auto commit = [&](int buf, Stage &s) {
+        char *base = smd + buf * BUFB;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+            if (ptid + k * PT < NITEM) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = 4 * it_qq[k] + j - SH;
+                    if (c < 0 || c >= IW) continue;
+                    u32x4 hv;
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const float v0 = __uint_as_float(s.rq[k][e][j]), v1 = __uint_as_float(s.rq[k][e + 1][j]);
+                        amax = fmaxf(amax, fmaxf(fabsf(v0), fabsf(v1)));
+                        hv[e >> 1] = pack_f16(v0 * sx, v1 * sx);
+                    }
+                    const int pos = it_qr[k] * IW + c;
+                    const int d = pos * 32 + ((it_qh[k] ^ ((pos >> 3) & 1)) << 4);
+                    *reinterpret_cast<u32x4 *>(base + d) = hv;
+                }
+            }
+#pragma unroll
+        for (int it = 0; it < NWB; ++it)
+            if (ptid + it * PT < WPIECES) *reinterpret_cast<u32x4 *>(base + w_dst[it]) = s.rw[it];
+    };
+    pf_setup();
+    prefetch(sa);
+    commit(0, sa);                         // item 0
+    prefetch(sa);                          // item 1
+    prefetch(sb);                          // item 2: two chunks of loads in flight from here on
+    __syncthreads();                       // (A)
+    for (int item = 0; item < nitems; item += 2) {
+        commit((item + 1) & 1, sa);        // item + 1, while the consumers multiply item
+        prefetch(sa);                      // item + 3 (past the end: empty descriptors, nothing is read)
+        __syncthreads();                   // (B)
+        if (item + 1 >= nitems) break;
+        commit(item & 1, sb);              // item + 2
+        prefetch(sb);                      // item + 4
+        __syncthreads();                   // (B)
+    }
+    // (halo positions are read by several workgroups, padded / dead lanes contribute 0: the maximum is unaffected)
+    in_slot.record(amax);
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_wgrad_f16_ws: conv_wgrad_x3_ws (3x3 weight gradient, 64 co x 64 ci per workgroup, 2 x 32-pixel contraction tiles,
+// four producer + four consumer waves, split-K slabs) with fp16 operands.  The GEMM contracts over PIXELS, so a lane's 8
+// k-slots are 8 consecutive pixels and a tap's kx shift moves them by ONE element: the images therefore stay one pixel per
+// 32-bit LDS word (any shift is word-aligned), and the two halves of a word now carry the SAME pixel of channels c and
+// c + 32 instead of the hi / lo halves of one value.  One 8-word operand read then yields the fragments of TWO output
+// tiles (grad_out: both 32-row tiles; input: the n-tiles of channel blocks 0 and 1) through the same two `v_perm_b32` per
+// word pair that used to peel hi from lo: half the LDS words written and read, a third of the MFMAs, and the staging
+// code converts with one v_cvt_pk_f16_f32 per word instead of two roundings and a subtraction per value.
+//   36 blocks of 32 x 32 per workgroup = 9 pair-column tiles x {c, c+32} x 2 row tiles; wave w owns pair tiles w and
+//   w + 4 completely (8 blocks) and block (row tile w & 1, half w >> 1) of pair tile 8.
+// Scales: grad_out * g_slot.scale(), input * x_slot.scale() on the way into LDS (|max| of both recorded), the accumulators
+// leave multiplied by 1 / (g_scale * x_scale); bias sums and the grad * act' side output stay exact fp32.
+template <int DACT>
+__global__ __launch_bounds__(512) void conv_wgrad_f16_ws(const float *__restrict__ x, const float *__restrict__ gout,
+                                                         const float *__restrict__ yact, float *__restrict__ slab,
+                                                         float *__restrict__ gpre_out, ConvGeom g, float dslope, int total_tiles,
+                                                         int need_bias, ScaleSlot x_slot, ScaleSlot g_slot) {
+    using C = WCfg<3, 1, 32>;
+    constexpr int KS = 3, KK = 9, WTX = C::WTX, IH = C::IH, IW = C::IW;
+    constexpr int IWP = 32, EXC = IW - IWP, CIB = 64, CP = CIB / 2, PS = C::PS, IWS = C::IWS;
+    constexpr int PT = 256, NW64 = PT / 64;
+    constexpr int TROWS = PT / IWP, CPR = CIB / TROWS, NI = IH * CPR, NG = 64 / NW64;
+    constexpr int NEX = (EXC * IH * CIB + PT - 1) / PT;
+    constexpr int NQ = 4;                                   // consumer waves
+    constexpr int NPT = (CP * KK + 31) / 32;                // pair-column tiles of 32 (9)
+    constexpr int BUF = 32 * GS + (CP + 1) * PS;            // words per buffer: 32 grad_out pair rows, 32 pair planes + a zero plane
+    static_assert(WTX == 32 && EXC == 2 && CIB % TROWS == 0 && NPT == 9 && CPR == 8 && NG == 16, "tile configuration");
+    extern __shared__ __attribute__((aligned(16))) unsigned smw[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co_base = blockIdx.y * 64, ci_base = blockIdx.z * CIB;
+    const int grp = co_base / (g.Cout / g.groups);
+    const int ci_cnt = min(CIB, g.Cin - ci_base);
+    const int tiles_x = (g.Wo + WTX - 1) / WTX, tiles_y = (g.Ho + WTY - 1) / WTY;
+    const int HW = g.H * g.W, HWo = g.Ho * g.Wo;
+    const int G = gridDim.x;
+    const int64_t wsz = (int64_t)g.Cout * g.Cin * KK;
+    float *my = slab + (int64_t)blockIdx.x * (wsz + g.Cout);
+    const float sx = x_slot.scale(), sg = g_slot.scale();
+
+    for (int i = tid; i < 2 * BUF; i += 512) smw[i] = 0u;   // pad slots, pad columns and the zero plane stay zero
+    __syncthreads();
+
+    if (wave < NQ) {
+        // ------------------------------------------------------------------ consumers
+        const int nq = wave;
+        const int xm = nq & 1, xh = nq >> 1;
+        f32x16 acc[2][2][2], accx;                          // [pair tile nq + 4 j][half: channel c / c + 32][row tile m]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accx[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][hf][m][r] = 0.f;
+        auto col_off = [&](int n) {                          // pair column n = cp * 9 + tap
+            const int cp = n / KK, tap = n - cp * KK;
+            const int ky = tap / KS, kx = tap - ky * KS;
+            return 32 * GS + ((cp < CP) ? cp * PS + ky * IWS + kx : CP * PS) + 8 * (lane >> 5);
+        };
+        int boff[3];
+        boff[0] = col_off(nq * 32 + (lane & 31));
+        boff[1] = col_off((nq + NQ) * 32 + (lane & 31));
+        boff[2] = col_off(8 * 32 + (lane & 31));
+        const int aoff = (lane & 31) * GS + 8 * (lane >> 5);
+        // low halves = channel c (row tile 0 / channel block 0), high halves = channel c + 32
+        auto unzip = [&](const unsigned (&w)[8], f16x8 &c_lo, f16x8 &c_hi) {
+            u32x4 hq, lq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                hq[i] = __builtin_amdgcn_perm(w[2 * i + 1], w[2 * i], 0x07060302u);
+                lq[i] = __builtin_amdgcn_perm(w[2 * i + 1], w[2 * i], 0x05040100u);
+            }
+            c_hi = __builtin_bit_cast(f16x8, hq);
+            c_lo = __builtin_bit_cast(f16x8, lq);
+        };
+        __syncthreads();                   // (A) the first tile is committed
+        int cur = 0;
+        for (int tile = blockIdx.x; tile < total_tiles; tile += G) {
+            const unsigned *sA = smw + cur * BUF + aoff;
+            const unsigned *sB = smw + cur * BUF;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int row = kk >> 1, px0 = (kk & 1) * 16;
+                unsigned aw[8], bw[3][8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) aw[j] = sA[row * 32 + px0 + j];
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bw[q][j] = sB[boff[q] + row * IWS + px0 + j];
+                f16x8 a[2];
+                unzip(aw, a[0], a[1]);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    f16x8 b[2];
+                    unzip(bw[q], b[0], b[1]);
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+                            acc[q][hf][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b[hf], acc[q][hf][m], 0, 0, 0);
+                }
+                {
+                    f16x8 b[2];
+                    unzip(bw[2], b[0], b[1]);
+                    accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(xm ? a[1] : a[0], xh ? b[1] : b[0], accx, 0, 0, 0);
+                }
+            }
+            __syncthreads();               // (B) this image has been read, the other one is complete
+            cur ^= 1;
+        }
+        const float oscale = 1.f / (sx * sg);
+        const __amdgpu_buffer_rsrc_t rsl = make_rsrc(my, (unsigned)wsz * 4u);   // rows co >= Cout fall past the slab: dropped
+        const unsigned co_row = (unsigned)(g.Cin * KK) * 4u;
+        auto store_block = [&](const f32x16 &a, int m, int ptile, int hf) {
+            const int n = ptile * 32 + (lane & 31);            // pair column: cp * 9 + tap
+            const bool ok = n < CP * KK && n / KK + CP * hf < ci_cnt;
+            const unsigned o0 = ok ? (unsigned)(((co_base + m * 32 + 4 * (lane >> 5)) * g.Cin + ci_base + CP * hf) * KK + n) * 4u : SENT;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) buf_st(rsl, o0 + (unsigned)((r & 3) + 8 * (r >> 2)) * co_row, a[r] * oscale);
+        };
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) store_block(acc[j][hf][m], m, nq + NQ * j, hf);
+        store_block(accx, xm, 8, xh);
+        return;
+    }
+    // ---------------------------------------------------------------------- producers
+    const int ptid = tid - 64 * NQ;
+    const int gslot = ptid & 63, gpy = gslot >> 5, gpx = gslot & 31, gco = ptid >> 6;
+    const int icol = ptid & (IWP - 1), irow = ptid / IWP;
+    const unsigned go_bytes = (unsigned)g.Cout * (unsigned)HWo * 4u, x_bytes = (unsigned)g.Cin * (unsigned)HW * 4u;
+    struct Stage {
+        float rg[NG], ry[DACT != 0 ? NG : 1], ri[NI], rex[NEX];
+    };
+    Stage sa, sb;
+    float bacc[NG];
+    float amax_g = 0.f, amax_x = 0.f;
+#pragma unroll
+    for (int it = 0; it < NG; ++it) bacc[it] = 0.f;
+    auto prefetch = [&](int tile, Stage &s) {
+        int t = tile;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        const int b = t / tiles_y;
+        const int y0 = ty * WTY, x0 = tx * WTX;
+        const int iy0 = y0 - g.pad, ix0 = x0 - g.pad;
+        const bool live = tile < total_tiles;
+        const __amdgpu_buffer_rsrc_t rgo = make_rsrc(gout + (int64_t)(live ? b : 0) * g.Cout * HWo, live ? go_bytes : 0u);
+        const __amdgpu_buffer_rsrc_t rya = make_rsrc((DACT ? yact : gout) + (int64_t)(live ? b : 0) * g.Cout * HWo,
+                                                     (live && DACT) ? go_bytes : 0u);
+        const __amdgpu_buffer_rsrc_t rxi = make_rsrc(x + ((int64_t)(live ? b : 0) * g.groups + grp) * g.Cin * HW, live ? x_bytes : 0u);
+        const int gy = y0 + gpy, gx = x0 + gpx;
+        const unsigned g0 = (gpx < WTX && gy < g.Ho && gx < g.Wo) ? (unsigned)((co_base + gco) * HWo + gy * g.Wo + gx) * 4u : SENT;
+#pragma unroll
+        for (int it = 0; it < NG; ++it) {
+            const unsigned o = g0 + (unsigned)(NW64 * it) * (unsigned)HWo * 4u;
+            s.rg[it] = buf_ld(rgo, o);
+            if constexpr (DACT != 0) s.ry[it] = buf_ld(rya, o);
+        }
+        const int xx = ix0 + icol;
+        const bool col_ok = icol < IW && xx >= 0 && xx < g.W;
+#pragma unroll
+        for (int r = 0; r < IH; ++r) {
+            const int yy = iy0 + r;
+            const unsigned base = (col_ok && yy >= 0 && yy < g.H) ? (unsigned)((ci_base + irow) * HW + yy * g.W + xx) * 4u : SENT;
+#pragma unroll
+            for (int k = 0; k < CPR; ++k) s.ri[r * CPR + k] = buf_ld(rxi, base + (unsigned)(k * TROWS) * (unsigned)HW * 4u);
+        }
+#pragma unroll
+        for (int i = 0; i < NEX; ++i) {
+            const int e = ptid + i * PT, rc = e / CIB;
+            const int yy = iy0 + rc / EXC, xe = ix0 + IWP + rc % EXC;
+            const bool ok = e < EXC * IH * CIB && yy >= 0 && yy < g.H && xe >= 0 && xe < g.W;
+            s.rex[i] = buf_ld(rxi, ok ? (unsigned)((ci_base + (e & (CIB - 1))) * HW + yy * g.W + xe) * 4u : SENT);
+        }
+    };
+    auto commit = [&](int tile, int buf, Stage &s) {
+        unsigned *sG = smw + buf * BUF, *sIn = sG + 32 * GS;
+#pragma unroll
+        for (int it = 0; it < NG; ++it) {
+            if constexpr (DACT != 0) s.rg[it] *= act_grad_c<DACT>(s.ry[it], dslope);
+            bacc[it] += s.rg[it];
+            amax_g = fmaxf(amax_g, fabsf(s.rg[it]));
+        }
+        // thread row gco holds channels gco + 4 it: `it` and `it + 8` are channels c and c + 32 of pair row gco + 4 it
+#pragma unroll
+        for (int it = 0; it < NG / 2; ++it)
+            sG[(gco + NW64 * it) * GS + gslot] = pack_f16(s.rg[it] * sg, s.rg[it + NG / 2] * sg);
+        if (gpre_out != nullptr && blockIdx.z == 0) {
+            int t = tile;
+            const int tx = t % tiles_x; t /= tiles_x;
+            const int ty = t % tiles_y;
+            const int b = t / tiles_y;
+            const int gy = ty * WTY + gpy, gx = tx * WTX + gpx;
+            const bool live = tile < total_tiles;
+            const __amdgpu_buffer_rsrc_t rgp = make_rsrc(gpre_out + (int64_t)(live ? b : 0) * g.Cout * HWo, live ? go_bytes : 0u);
+            const unsigned o0 = (gpx < WTX && gy < g.Ho && gx < g.Wo) ? (unsigned)((co_base + gco) * HWo + gy * g.Wo + gx) * 4u : SENT;
+#pragma unroll
+            for (int it = 0; it < NG; ++it) buf_st(rgp, o0 + (unsigned)(NW64 * it) * (unsigned)HWo * 4u, s.rg[it]);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) amax_x = fmaxf(amax_x, fabsf(s.ri[i]));
+        if (icol < IW) {
+            // thread row irow holds channels irow + 8 k: k and k + 4 are channels c and c + 32 of pair plane irow + 8 k
+#pragma unroll
+            for (int r = 0; r < IH; ++r)
+#pragma unroll
+                for (int k = 0; k < CPR / 2; ++k)
+                    sIn[(irow + k * TROWS) * PS + r * IWS + icol] = pack_f16(s.ri[r * CPR + k] * sx, s.ri[r * CPR + k + CPR / 2] * sx);
+        }
+#pragma unroll
+        for (int i = 0; i < NEX; ++i) {
+            // element e: channel e & 63; its pair partner (channel ^ 32) sits 32 lanes away in the same wave
+            const int e = ptid + i * PT, rc = e / CIB, ch = e & (CIB - 1);
+            const float v = s.rex[i];
+            amax_x = fmaxf(amax_x, fabsf(v));
+            const float o = __shfl_xor(v, 32, 64);
+            if (e < EXC * IH * CIB && ch < CP) sIn[ch * PS + (rc / EXC) * IWS + IWP + rc % EXC] = pack_f16(v * sx, o * sx);
+        }
+    };
+    prefetch(blockIdx.x, sa);
+    commit(blockIdx.x, 0, sa);
+    prefetch(blockIdx.x + G, sa);          // two tiles of loads in flight from here on
+    prefetch(blockIdx.x + 2 * G, sb);
+    __syncthreads();                       // (A)
+    int cur = 0;
+    for (int tile = blockIdx.x; tile < total_tiles; tile += 2 * G) {
+        commit(tile + G, cur ^ 1, sa);     // while the consumers multiply tile `tile` from image `cur`
+        prefetch(tile + 3 * G, sa);        // (past the end: zero-record descriptors, nothing is read)
+        __syncthreads();                   // (B)
+        cur ^= 1;
+        if (tile + G >= total_tiles) break;
+        commit(tile + 2 * G, cur ^ 1, sb);
+        prefetch(tile + 4 * G, sb);
+        __syncthreads();                   // (B)
+        cur ^= 1;
+    }
+    if (need_bias && blockIdx.z == 0) {    // lanes of a wave hold the 64 slots of channels gco + 4*it: fixed-order butterfly
+#pragma unroll
+        for (int it = 0; it < NG; ++it) {
+            float v = bacc[it];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+            if (lane == 0 && co_base + gco + NW64 * it < g.Cout) my[wsz + co_base + gco + NW64 * it] = v;
+        }
+    }
+    x_slot.record(amax_x);
+    g_slot.record(amax_g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Delayed scaling bookkeeping: slots[2i] = scale, slots[2i + 1] = |max| seen since the last call.  For every slot that saw
+// data: flag[0] |= 1 when the data was not finite or max * scale could have left the fp16 range (the step's gradients are
+// then suspect: the optimiser launch skips the update), the next scale puts max into [128, 256), the maximum is cleared.
+__global__ __launch_bounds__(256) void f16_scales_finish_kernel(float *__restrict__ slots, int n, int *__restrict__ flag) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float a = slots[2 * i + 1], s = slots[2 * i];
+    if (!(a > 0.f)) {                      // nothing staged through this slot (or all zeros): keep the scale
+        if (a != a) atomicOr(flag, 1);
+        slots[2 * i + 1] = 0.f;
+        return;
+    }
+    if (!(a <= 3.0e38f) || a * s > 60000.f) atomicOr(flag, 1);
+    if (a <= 3.0e38f) {
+        int e;
+        (void)frexpf(a, &e);               // a = m * 2^e, m in [0.5, 1)
+        slots[2 * i] = ldexpf(1.f, 8 - e);
+    }
+    slots[2 * i + 1] = 0.f;
+}
+
+// fp16 images from an index table (the bf16 pack launch's table format, hi entries only): packed[e] = fp16(src[table[e]] *
+// scale(slot of e)), 0 for table[e] < 0.  Every site's image starts on a 256-element boundary, so a workgroup lies inside one
+// image: block_slot[blockIdx.x] names its scale slot; |max| of the source values is recorded there (one atomic per wave).
+__global__ __launch_bounds__(256) void pack_table_f16_kernel(const float *__restrict__ src, const int32_t *__restrict__ table,
+                                                             int64_t n, _Float16 *__restrict__ out,
+                                                             const int32_t *__restrict__ block_slot, float *__restrict__ slots) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float *slot = slots + 2 * (int64_t)block_slot[blockIdx.x];
+    const int32_t t = e < n ? table[e] : -1;
+    const float v = t >= 0 ? src[t & 0x3fffffff] : 0.f;
+    if (e < n) out[e] = (_Float16)(v * slot[0]);
+    float m = fabsf(v);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    if ((threadIdx.x & 63) == 0 && m > __builtin_nontemporal_load(slot + 1)) atomicMax(reinterpret_cast<unsigned *>(slot + 1), __float_as_uint(m));
+}

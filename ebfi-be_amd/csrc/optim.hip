@@ -11,8 +11,18 @@ using namespace ebfi;
 namespace {
 
 __global__ __launch_bounds__(256) void adam_flat_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
-                                                        float *__restrict__ v, const float *__restrict__ step, int64_t n4,
-                                                        int64_t n, double lr, double beta1, double beta2, double eps) {
+                                                        float *__restrict__ v, float *__restrict__ step, int64_t n4,
+                                                        int64_t n, double lr, double beta1, double beta2, double eps,
+                                                        int *__restrict__ guard) {
+    // guard (optional): guard[0] != 0 marks this step's gradient as unusable (an fp16 operand of the backward pass left its
+    // range, conv2d_f16.inc.hpp): nothing is updated, the step count is taken back, guard[1] counts the skipped steps
+    if (guard != nullptr && guard[0] != 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            step[0] -= 1.f;
+            guard[1] += 1;
+        }
+        return;
+    }
     const double t = (double)step[0];
     const double c1 = 1.0 - pow(beta1, t), c2 = 1.0 - pow(beta2, t);
     const float step_size = (float)(lr / c1), c2s = (float)sqrt(c2);
@@ -41,8 +51,16 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float *__restrict__ p, c
 
 }  // namespace
 
+extern "C" int ebfi_adam_step_guarded(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *step, int64_t n,
+                                      double lr, double beta1, double beta2, double eps, int *guard, void *stream);
+
 extern "C" int ebfi_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *step, int64_t n,
                               double lr, double beta1, double beta2, double eps, void *stream) {
+    return ebfi_adam_step_guarded(param, grad, exp_avg, exp_avg_sq, const_cast<float *>(step), n, lr, beta1, beta2, eps, nullptr, stream);
+}
+
+extern "C" int ebfi_adam_step_guarded(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *step, int64_t n,
+                                      double lr, double beta1, double beta2, double eps, int *guard, void *stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step || n < 0) return fail(EBFI_ERR_ARG, "adam_step: null argument");
     if (!aligned16(param) || !aligned16(grad) || !aligned16(exp_avg) || !aligned16(exp_avg_sq))
         return fail(EBFI_ERR_ARG, "adam_step: buffers must be 16-byte aligned");
@@ -52,7 +70,7 @@ extern "C" int ebfi_adam_step(float *param, const float *grad, float *exp_avg, f
     {
         ProfScope ps("adam_flat", st, 0.0, 28.0 * (double)n);
         hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)ceil_div(std::max<int64_t>(n4, 1), 256)), dim3(256), 0, st, param, grad,
-                           exp_avg, exp_avg_sq, step, n4, n, lr, beta1, beta2, eps);
+                           exp_avg, exp_avg_sq, step, n4, n, lr, beta1, beta2, eps, guard);
     }
     return check_launch("adam_flat");
 }

@@ -55,6 +55,10 @@ SIGNATURES = {
     "ebfi_conv2d_packed_bytes": (_sz, [_i, _i, _i, _i]),
     "ebfi_conv2d_pack_bf16x3": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ebfi_pack_table_bf16": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "ebfi_f16_scales_finish": (_i, [_vp, _i, _vp, _vp]),
+    "ebfi_pack_table_f16": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "ebfi_conv2d_packed_f16": (_i, [_vp, _vp, _sz, _vp, _vp] + [_i] * 8 + [_i, _c.c_float, _vp, _vp, _i, _c.c_float, _vp, _vp, _vp]),
+    "ebfi_conv2d_backward_weight_f16g": (_i, [_vp] * 6 + [_i] * 8 + [_i, _c.c_float, _vp, _vp, _vp, _sz, _vp]),
     "ebfi_kernelconv_fac_fused_x3": (_i, [_vp, _vp, _sz, _vp, _vp, _vp] + [_i] * 6 + [_c.c_float, _vp]),
     "ebfi_conv2d_packed_x3": (_i, [_vp, _vp, _sz, _vp, _vp] + [_i] * 8 + [_i, _c.c_float, _vp, _vp, _i, _c.c_float, _vp]),
     "ebfi_conv2d_backward_weight_x3g": (_i, [_vp] * 4 + [_i] * 8 + [_vp, _sz, _vp]),
@@ -84,6 +88,7 @@ SIGNATURES = {
     "ebfi_ed_head_backward": (_i, [_vp] * 11 + [_i, _i, _i64, _i, _vp, _sz, _vp]),
     "ebfi_conv2d_backward_data_s2_bf16x3": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ebfi_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64] + [_c.c_double] * 4 + [_vp]),
+    "ebfi_adam_step_guarded": (_i, [_vp, _vp, _vp, _vp, _vp, _i64] + [_c.c_double] * 4 + [_vp, _vp]),
     "ebfi_laploss_workspace_floats": (_i64, [_i64, _i, _i, _i]),
     "ebfi_laploss_partials": (_i64, [_i64, _i, _i, _i]),
     "ebfi_laploss_forward": (_i, [_vp, _vp, _vp, _c.c_float, _c.c_float, _vp, _vp, _i64, _i, _i, _i, _vp]),

@@ -224,6 +224,14 @@ class SiteConvBiasAct(Function):
         need_x = ctx.needs_input_grad[0]
         need_p = any(ctx.needs_input_grad[6:])
         gx, pgrads = None, [None] * (len(site.w_shapes) + len(site.b_shapes))
+        # fp16 single-product backward (ebfi_amd.f16scale, csrc/conv2d_f16.inc.hpp) where the kernels apply: 3x3 same-padded
+        # layers; weight gradient with 64-channel input blocks, data gradient with quad-aligned rows and >= 48 input channels
+        from . import f16scale
+        book = f16scale.active_book()
+        B, Cin, H, W, M, ks, _, pad = geo
+        f16 = book is not None and ks == 3 and pad == 1
+        f16_w = f16 and Cin % 64 == 0
+        f16_x = f16 and W % 4 == 0 and Cin >= 48 and site.tr16_ptr() is not None
         with torch.cuda.device_of(x):
             st = N.stream_ptr(x.device)
             gpre = None
@@ -234,16 +242,30 @@ class SiteConvBiasAct(Function):
                 ws = torch.empty(max(need, 4), dtype=torch.uint8, device=x.device)
                 if need_x and act != ACT_NONE:
                     gpre = torch.empty_like(gout)
-                rc = lib.ebfi_conv2d_backward_weight_ex(N.ptr(x), N.ptr(gout), N.ptr(y), N.ptr(gw2), N.ptr(gb2), N.ptr(gpre), *geo,
-                                                        act, slope, N.ptr(ws), need, N.EBFI_F32_BF16X3MMA, st)
+                if f16_w:
+                    rc = lib.ebfi_conv2d_backward_weight_f16g(N.ptr(x), N.ptr(gout), N.ptr(y), N.ptr(gw2), N.ptr(gb2), N.ptr(gpre),
+                                                              B, Cin, H, W, M, ks, pad, 1, act, slope,
+                                                              book.operand((site.key, "x"), x), book.operand((site.key, "g"), gout),
+                                                              N.ptr(ws), need, st)
+                else:
+                    rc = lib.ebfi_conv2d_backward_weight_ex(N.ptr(x), N.ptr(gout), N.ptr(y), N.ptr(gw2), N.ptr(gb2), N.ptr(gpre), *geo,
+                                                            act, slope, N.ptr(ws), need, N.EBFI_F32_BF16X3MMA, st)
                 N.check(rc, "ebfi_conv2d_backward_weight")
                 pgrads = _route_site_grads(site, gw2, gb2, st)
             if need_x:
                 gx = torch.empty_like(x)
                 src, sy, a = (gpre, None, ACT_NONE) if gpre is not None else (gout, y, act)
-                rc = lib.ebfi_conv2d_backward_data_bf16x3(N.ptr(src), N.ptr(sy), N.ptr(None), N.ptr(gx), *geo, a,
-                                                          slope if a != ACT_NONE else 0.0, site.tr_ptr(), site.tr_bytes, st)
-                N.check(rc, "ebfi_conv2d_backward_data_bf16x3 (packed)")
+                if f16_x and a == ACT_NONE:
+                    # the data gradient as a convolution of the pre-activation gradient with the transposed fp16 image
+                    rc = lib.ebfi_conv2d_packed_f16(N.ptr(src), site.tr16_ptr(), site.tr16_bytes, N.ptr(None), N.ptr(gx), B,
+                                                    M // site.groups, H, W, Cin * site.groups, ks, pad, site.groups, ACT_NONE, 0.0,
+                                                    N.ptr(None), N.ptr(None), 0, 0.0, book.operand((site.key, "g"), src),
+                                                    site.w_slot_ptr(), st)
+                    N.check(rc, "ebfi_conv2d_packed_f16 (data gradient)")
+                else:
+                    rc = lib.ebfi_conv2d_backward_data_bf16x3(N.ptr(src), N.ptr(sy), N.ptr(None), N.ptr(gx), *geo, a,
+                                                              slope if a != ACT_NONE else 0.0, site.tr_ptr(), site.tr_bytes, st)
+                    N.check(rc, "ebfi_conv2d_backward_data_bf16x3 (packed)")
         return (gx, None, None, None, None, None) + tuple(pgrads)
 
 

@@ -144,17 +144,21 @@ class FlatAdam:
     def param_groups(self):
         return self.inner.param_groups
 
-    def step(self, flat_grad):
-        """`flat_grad`: the packed gradient in the order of `params` (FlatGradBucket.flat)."""
+    def step(self, flat_grad, guard=None):
+        """`flat_grad`: the packed gradient in the order of `params` (FlatGradBucket.flat).  `guard`: int32[2] device tensor
+        of ebfi_amd.f16scale.ScaleBook -- a non-zero guard[0] makes the native launch skip this update (guard[1] counts)."""
         if flat_grad.numel() != self.flat.numel():
             raise ValueError("packed gradient has %d elements, parameters %d" % (flat_grad.numel(), self.flat.numel()))
-        if self._native_step(flat_grad):
+        if self._native_step(flat_grad, guard):
+            return
+        if guard is not None and int(guard[0].item()) != 0:       # torch's own step (CPU / unusual options): host-side check
+            guard[1] += 1
             return
         self.flat.grad = flat_grad
         self.inner.step()
         self.flat.grad = None
 
-    def _native_step(self, flat_grad):
+    def _native_step(self, flat_grad, guard=None):
         """The update as ONE bandwidth-bound launch of libebfi_hip.so (csrc/optim.hip) on the state tensors of the inner
         torch.optim.Adam (which keeps owning hyper-parameters, state and checkpoint layout).  CPU tensors, weight decay,
         amsgrad or maximize take torch's own step."""
@@ -181,10 +185,10 @@ class FlatAdam:
         st["step"] += 1
         b1, b2 = grp["betas"]
         with torch.cuda.device_of(self.flat):
-            rc = N.lib().ebfi_adam_step(N.ptr(self.flat.data), N.ptr(flat_grad), N.ptr(st["exp_avg"]), N.ptr(st["exp_avg_sq"]),
-                                        N.ptr(st["step"]), self.flat.numel(), float(grp["lr"]), float(b1), float(b2),
-                                        float(grp["eps"]), N.stream_ptr(self.flat.device))
-        N.check(rc, "ebfi_adam_step")
+            rc = N.lib().ebfi_adam_step_guarded(N.ptr(self.flat.data), N.ptr(flat_grad), N.ptr(st["exp_avg"]), N.ptr(st["exp_avg_sq"]),
+                                                N.ptr(st["step"]), self.flat.numel(), float(grp["lr"]), float(b1), float(b2),
+                                                float(grp["eps"]), N.ptr(guard), N.stream_ptr(self.flat.device))
+        N.check(rc, "ebfi_adam_step_guarded")
         opt._opt_called = True
         if hasattr(opt, "_step_count"):
             opt._step_count += 1

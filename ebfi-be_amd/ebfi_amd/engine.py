@@ -70,7 +70,11 @@ def synthetic_batch_from_raw_events(B, H, W, TB=16, device="cuda", seed=123, ran
 
 class Engine:
     def __init__(self, model_args=None, device="cuda", precision="fp32", lr=1e-4, seed=None, train=True, graph=False,
-                 accu_step=1, betas=(0.9, 0.999)):
+                 accu_step=1, betas=(0.9, 0.999), backward_f16=None):
+        """backward_f16 (training, precision 'bf16x3' only; default on): the data / weight gradients of the 3x3 layers run ONE
+        fp16 MFMA per product with delayed power-of-two operand scales (ebfi_amd.f16scale) instead of three bf16 ones; the
+        forward pass keeps the split-precision kernels.  Gradient parity is unchanged (tests/test_gpu_model.py:
+        test_benchmarked_step_vs_oracle); False restores the split-precision backward."""
         if precision not in ("fp32", "bf16x3", "bf16"):
             raise ValueError("precision must be 'fp32', 'bf16x3' or 'bf16'")
         self.device = torch.device(device)
@@ -108,6 +112,13 @@ class Engine:
             from . import weightbank
             self.bank = weightbank.build_for(self.model, flat=self.optimizer.flat.data, params=self.optimizer.params) if train \
                 else weightbank.build_for(self.model, inference=True)
+        self.book = None
+        if backward_f16 is None:
+            backward_f16 = os.environ.get("EBFI_NO_F16_BWD", "0") != "1"
+        if train and self.bank is not None and precision == "bf16x3" and backward_f16:
+            from . import f16scale
+            self.book = f16scale.ScaleBook(self.device)
+            self.bank.attach_scale_book(self.book)
 
     @contextlib.contextmanager
     def _autocast(self):
@@ -129,11 +140,21 @@ class Engine:
         self.bank.refresh()
         return self.bank.active()
 
+    def _book(self):
+        """Context of one pass: the fp16 backward kernels active on the scale book (a no-op without one)."""
+        if self.book is None or self.precision != "bf16x3":
+            return contextlib.nullcontext()
+        return self.book.active()
+
     def _fwd_bwd(self, frame, event, t, gtex, target):
-        with self._autocast(), self._bank():
+        with self._autocast(), self._bank(), self._book() as book:
+            if book is not None and self._micro == 0:
+                book.begin_step()                   # clear the overflow guard of this optimiser step
             sharp_pre, sharp = self.model(frame, event, t, gtex)
             loss = self.loss(sharp_pre.float(), sharp.float(), target, self.iteration, self.accu_step)
             loss.backward()
+            if book is not None:
+                book.finish()                       # next step's operand scales from this pass's maxima; guard on overflow
         return loss.detach()
 
     def _finish_micro_step(self, flat):
@@ -150,7 +171,14 @@ class Engine:
             self._micro = 0
             self.bucket.flat = self._accum
         self.bucket.reduce_mean_packed()
-        self.optimizer.step(self.bucket.flat)
+        guard = None
+        if self.book is not None and self.precision == "bf16x3":
+            guard = self.book.guard
+            from .dp import is_distributed
+            if is_distributed():                    # every rank must take (or skip) the same update
+                import torch.distributed as dist
+                dist.all_reduce(guard[0:1], op=dist.ReduceOp.MAX)
+        self.optimizer.step(self.bucket.flat, guard=guard)
         self.iteration += 1
         return True
 

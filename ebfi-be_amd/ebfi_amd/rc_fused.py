@@ -92,7 +92,9 @@ def _conv(lib, st, x, packed, nbytes, bias, out, B, cin_g, H, W, cout, groups, a
     N.check(rc, "ebfi_conv2d_packed_x3")
 
 
-def _wgrad(lib, st, x, g, B, cin_g, H, W, cout, groups, ws_cache):
+def _wgrad(lib, st, x, g, B, cin_g, H, W, cout, groups, ws_cache, book=None, site=None):
+    """Weight / bias gradient of a (grouped) layer from its pre-activation gradient; `book` (fp16 backward active): the
+    single-product kernel with the operand scales of slots (site, 'x') / (site, 'g')."""
     gw = torch.empty((cout, cin_g, 3, 3), dtype=x.dtype, device=x.device)
     gb = torch.empty(cout, dtype=x.dtype, device=x.device)
     key = (cin_g, cout)
@@ -100,10 +102,28 @@ def _wgrad(lib, st, x, g, B, cin_g, H, W, cout, groups, ws_cache):
         need = int(lib.ebfi_conv2d_backward_weight_workspace(B, cin_g, H, W, cout, 3, 1, 1, N.EBFI_F32))
         ws_cache[key] = (torch.empty(max(need, 4), dtype=torch.uint8, device=x.device), need)
     ws, need = ws_cache[key]
+    if book is not None and cin_g % 64 == 0:
+        rc = lib.ebfi_conv2d_backward_weight_f16g(N.ptr(x), N.ptr(g), N.ptr(None), N.ptr(gw), N.ptr(gb), N.ptr(None), B, cin_g, H, W,
+                                                  cout, 3, 1, groups, 0, 0.0, book.operand((site.key, "x"), x),
+                                                  book.operand((site.key, "g"), g), N.ptr(ws), need, st)
+        N.check(rc, "ebfi_conv2d_backward_weight_f16g")
+        return gw, gb
     rc = lib.ebfi_conv2d_backward_weight_x3g(N.ptr(x), N.ptr(g), N.ptr(gw), N.ptr(gb), B, cin_g, H, W, cout, 3, 1, groups,
                                              N.ptr(ws), need, st)
     N.check(rc, "ebfi_conv2d_backward_weight_x3g")
     return gw, gb
+
+
+def _dgrad(lib, st, g, site, out, B, cin_g, H, W, cout, groups, slope, addend=None, mask=None, book=None):
+    """Data gradient of `site`'s layer as a convolution of the pre-activation gradient `g` with the transposed images
+    (+ addend, * act'(mask): the epilogue extras that hand a PRE-activation gradient to the layer below)."""
+    if book is not None and W % 4 == 0 and site.tr16_ptr() is not None:
+        rc = lib.ebfi_conv2d_packed_f16(N.ptr(g), site.tr16_ptr(), site.tr16_bytes, N.ptr(None), N.ptr(out), B, cin_g, H, W, cout, 3, 1,
+                                        groups, 0, slope, N.ptr(addend), N.ptr(mask), ACT if mask is not None else 0,
+                                        slope if mask is not None else 0.0, book.operand((site.key, "g"), g), site.w_slot_ptr(), st)
+        N.check(rc, "ebfi_conv2d_packed_f16")
+        return
+    _conv(lib, st, g, site.tr_ptr(), site.tr_bytes, None, out, B, cin_g, H, W, cout, groups, 0, slope, addend, mask)
 
 
 class ResidualControlFn(Function):
@@ -111,15 +131,16 @@ class ResidualControlFn(Function):
     params per round: W3a, b3a, W4a, b4a, W3b, b3b, W4b, b4b, W5, b5 (inputs only so that autograd routes their gradients)."""
 
     @staticmethod
-    def forward(ctx, data, s_ex, s_t, sites, slope, *params):
+    def forward(ctx, data, s_ex, s_t, sites_keep, slope, *params):
         x = data.contiguous()
         B, C, H, W = (int(v) for v in x.shape)
         HW = H * W
         s_ex, s_t = s_ex.contiguous(), s_t.contiguous()
         lib = N.lib()
         saved = []
-        # inference (no input needs a gradient): nothing is kept -- at B=8 720x1280 the 12 rounds' intermediates are 40 GB
-        keep = any(ctx.needs_input_grad)
+        # inference (grad mode off at the call): nothing is kept -- at B=8 720x1280 the 12 rounds' intermediates are 40 GB
+        keep = bool(sites_keep[1])
+        sites = sites_keep[0]
         with torch.cuda.device_of(x):
             st = N.stream_ptr(x.device)
             new = lambda ch: torch.empty((B, ch, H, W), dtype=x.dtype, device=x.device)
@@ -145,6 +166,8 @@ class ResidualControlFn(Function):
         HW = H * W
         lib = N.lib()
         nstep = len(sites)
+        from . import f16scale
+        book = f16scale.active_book()
         gs_ex, gs_t = torch.empty_like(s_ex), torch.empty_like(s_t)
         pgrads = [None] * (10 * nstep)
         ws_cache = {}
@@ -157,23 +180,23 @@ class ResidualControlFn(Function):
             for i in range(nstep - 1, -1, -1):
                 sa, sb, sc = sites[i]
                 x, ya, a, c = saved[4 * i:4 * i + 4]
-                gw5, gb5 = _wgrad(lib, st, c, gpre5, B, 2 * C, H, W, C, 1, ws_cache)
+                gw5, gb5 = _wgrad(lib, st, c, gpre5, B, 2 * C, H, W, C, 1, ws_cache, book, sc)
                 gc = new(2 * C)
-                _conv(lib, st, gpre5, sc.tr_ptr(), sc.tr_bytes, None, gc, B, C, H, W, 2 * C, 1, 0, 0.0)
+                _dgrad(lib, st, gpre5, sc, gc, B, C, H, W, 2 * C, 1, 0.0, book=book)
                 gpre_b, gxres = new(2 * C), new(C)
                 rc = lib.ebfi_scale_residual_cat_backward_ex(
                     N.ptr(gc), N.ptr(a), N.ptr(s_ex[i]), N._vp(a.data_ptr() + 4 * C * HW), N.ptr(s_t[i]), N.ptr(gpre_b),
                     N._vp(gpre_b.data_ptr() + 4 * C * HW), N.ptr(gxres), N.ptr(gs_ex[i]), N.ptr(gs_t[i]), B, C, HW, 2 * C * HW,
                     2 * C * HW, 1, slope, st)
                 N.check(rc, "ebfi_scale_residual_cat_backward_ex")
-                gwb, gbb = _wgrad(lib, st, ya, gpre_b, B, C, H, W, 2 * C, 2, ws_cache)
+                gwb, gbb = _wgrad(lib, st, ya, gpre_b, B, C, H, W, 2 * C, 2, ws_cache, book, sb)
                 gpre_a = new(2 * C)
-                _conv(lib, st, gpre_b, sb.tr_ptr(), sb.tr_bytes, None, gpre_a, B, C, H, W, 2 * C, 2, 0, slope, None, ya)
-                gwa, gba = _wgrad(lib, st, x, gpre_a, B, C, H, W, 2 * C, 1, ws_cache)
+                _dgrad(lib, st, gpre_b, sb, gpre_a, B, C, H, W, 2 * C, 2, slope, None, ya, book)
+                gwa, gba = _wgrad(lib, st, x, gpre_a, B, C, H, W, 2 * C, 1, ws_cache, book, sa)
                 gx = new(C)
                 # grad wrt x of this round = data gradient of the merged first layers + the residual path; for i > 0 it
                 # leaves as the pre-activation gradient of the previous round's Conv5 (x is that layer's LeakyReLU output)
-                _conv(lib, st, gpre_a, sa.tr_ptr(), sa.tr_bytes, None, gx, B, 2 * C, H, W, C, 1, 0, slope, gxres, x if i > 0 else None)
+                _dgrad(lib, st, gpre_a, sa, gx, B, 2 * C, H, W, C, 1, slope, gxres, x if i > 0 else None, book)
                 if i > 0:
                     gpre5 = gx
                 else:
@@ -200,4 +223,5 @@ def residual_control(rc, data, Ex, T):
     for i in range(rc.step):
         for m in (rc.Conv3[i][0], rc.Conv4[i][0], rc.Conv3[i][1], rc.Conv4[i][1], rc.Conv5[i][0]):
             params += [m.conv2d.weight, m.conv2d.bias]
-    return ResidualControlFn.apply(data, s_ex, s_t, sites, slope, *params)
+    keep = torch.is_grad_enabled()      # (inside Function.forward grad mode is always off: decide here)
+    return ResidualControlFn.apply(data, s_ex, s_t, (sites, keep), slope, *params)

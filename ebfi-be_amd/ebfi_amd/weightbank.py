@@ -41,13 +41,22 @@ def lookup(param, kind="id"):
 class Site:
     """Packed images of one (possibly folded / concatenated) conv weight [M = Cout, K = Cin, ks, ks]."""
     __slots__ = ("bank", "kind", "M", "K", "ks", "groups", "fwd_off", "tr_off", "fwd_bytes", "tr_bytes", "bias_off", "has_bias",
-                 "w_inv", "w_R", "b_inv", "b_R", "w_shapes", "b_shapes")
+                 "w_inv", "w_R", "b_inv", "b_R", "w_shapes", "b_shapes", "key", "tr16_off", "tr16_bytes", "w_slot", "weights")
 
     def fwd_ptr(self):
         return N._vp(self.bank.packed.data_ptr() + self.fwd_off)
 
     def tr_ptr(self):
         return N._vp(self.bank.packed.data_ptr() + self.tr_off)
+
+    def tr16_ptr(self):
+        """fp16 transposed (data-gradient) image, scaled by the site's weight slot (None while the bank has no scale book)."""
+        if self.bank.packed16 is None or self.tr16_bytes == 0:
+            return None
+        return N._vp(self.bank.packed16.data_ptr() + 2 * self.tr16_off)
+
+    def w_slot_ptr(self):
+        return self.bank.book.ptr(self.w_slot)
 
     def bias(self):
         """fp32 [M] view of the (folded) bias inside the bank, or None."""
@@ -101,6 +110,10 @@ class WeightBank:
         self._bias_tables, self._n_bias = [], 0
         self.packed = self.table = self.bias_buf = self.bias_table = None
         self._stamp = None
+        # fp16 data-gradient images (ebfi_amd.f16scale / csrc/conv2d_f16.inc.hpp): built once a scale book is attached
+        self.book = None
+        self._tables16, self._n16, self._segs = [], 0, []
+        self.packed16 = self.table16 = self.block_slot = None
 
     # ------------------------------------------------------------------ registration (host side, once)
     def _offset(self, p):
@@ -140,7 +153,14 @@ class WeightBank:
                  (Mg + 15) // 16 * 16).reshape(-1)                                               # [tap][(g, ci)][co16], taps flipped
         s = Site()
         s.bank, s.kind, s.M, s.K, s.ks, s.groups = self, kind, int(M), int(K), int(ks), int(groups)
-        s.tr_off, s.tr_bytes = 0, 0
+        s.key, s.weights = key, weights
+        s.tr_off, s.tr_bytes, s.tr16_off, s.tr16_bytes, s.w_slot = 0, 0, 0, 0, -1
+        if need_tr and ks == 3:           # one fp16 image (scaled by the site's weight slot); images start on 256-element bounds
+            s.tr16_off, s.tr16_bytes = self._n16, 2 * tr.numel()
+            padn = (-tr.numel()) % 256
+            self._tables16.append(torch.cat([tr.to(torch.int32), torch.full((padn,), -1, dtype=torch.int32)]))
+            self._segs.append((self._n16, s))
+            self._n16 += tr.numel() + padn
         for name, img in (("fwd", fwd), ("tr", tr)) if need_tr else (("fwd", fwd),):
             lo = torch.where(img >= 0, img | LO_FLAG, img)
             setattr(s, name + "_off", 2 * self._n_packed)
@@ -178,6 +198,20 @@ class WeightBank:
         self.packed = torch.empty(max(self._n_packed, 8), dtype=torch.bfloat16, device=self.device)
         self.bias_table = torch.cat(self._bias_tables).to(self.device) if self._bias_tables else None
         self.bias_buf = torch.empty(max(self._n_bias, 1), dtype=torch.float32, device=self.device)
+        if self.book is not None and self._tables16:
+            self.table16 = torch.cat(self._tables16).to(self.device)
+            self.packed16 = torch.empty(self._n16, dtype=torch.float16, device=self.device)
+            counts = []
+            for (off, site), nxt in zip(self._segs, [o for o, _ in self._segs[1:]] + [self._n16]):
+                site.w_slot = self.book.slot((site.key, "w"))
+                counts.append((nxt - off) // 256)
+            self.block_slot = torch.repeat_interleave(torch.tensor([site.w_slot for _, site in self._segs], dtype=torch.int32),
+                                                      torch.tensor(counts)).to(self.device)
+
+    def attach_scale_book(self, book):
+        """Enable the fp16 data-gradient images: every 3x3 site gets a transposed fp16 image scaled by its own slot of `book`."""
+        self.book = book
+        self.packed = None            # (re)built, with the fp16 tables, at the next refresh
 
     # ------------------------------------------------------------------ per step
     def _current_stamp(self):
@@ -201,6 +235,11 @@ class WeightBank:
             if self.bias_table is not None:
                 N.check(lib.ebfi_gather_sum(N.ptr(self.flat), N.ptr(self.bias_table), N.ptr(self.bias_buf), self._n_bias, 1, st),
                         "ebfi_gather_sum")
+            if self.packed16 is not None:
+                for _, site in self._segs:      # first refresh: the weight scales from the weights themselves (later: delayed)
+                    self.book.calibrate(site.w_slot, *site.weights)
+                N.check(lib.ebfi_pack_table_f16(N.ptr(self.flat), N.ptr(self.table16), self.table16.numel(), N.ptr(self.packed16),
+                                                N.ptr(self.block_slot), N.ptr(self.book.slots), st), "ebfi_pack_table_f16")
         self._stamp = self._current_stamp()
 
     def ensure_fresh(self):

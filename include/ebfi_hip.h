@@ -232,6 +232,31 @@ int ebfi_conv2d_packed_x3(const void *input, const void *packed, size_t packed_b
 int ebfi_kernelconv_fac_fused_x3(const void *input, const void *packed, size_t packed_bytes, const void *bias32,
                                  const void *feat, void *output, int B, int Cin, int H, int W, int C, int fac_ksize,
                                  float slope, void *stream);
+/* ------------------------------------------------------------------ fp16 single-product backward (training step)
+ * The data gradient and the weight gradient of the 3x3 layers with ONE fp16 MFMA per product (the forward keeps the
+ * split-precision kernels: DESIGN.md section 4).  Every operand is scaled by a power of two kept in a device SLOT
+ * float[2] = {scale, running |max| of the values staged through it}; kernels apply slot[0] and atomically raise slot[1];
+ * ebfi_f16_scales_finish (once per step, after the backward pass) turns the maxima of all `n` slots into the next step's
+ * scales (|max| * scale in [128, 256)), clears them, and sets flag[0] when a value was not finite or |max| * scale could
+ * have left the fp16 range.  A new slot is initialised by the caller (ebfi_amd/f16scale.py calibrates it just in time).
+ *   ebfi_pack_table_f16      fp16 weight images from the index table of ebfi_pack_table_bf16 (hi entries); images start on
+ *                            256-element boundaries, elements [256 k, 256 k + 256) are scaled by slot block_slot[k]
+ *   ebfi_conv2d_packed_f16   ebfi_conv2d_packed_x3 on an fp16 image (3x3, pad 1, W % 4 == 0): out = act(conv / (in_scale *
+ *                            w_scale) + bias + addend) * act'(mask_y); with transposed images: the data gradient
+ *   ebfi_conv2d_backward_weight_f16g   ebfi_conv2d_backward_weight_x3g / _ex (act'(saved_output) folded, optional
+ *                            grad_preact_out) with fp16 operands; Cin_per_group a multiple of 64 */
+int ebfi_f16_scales_finish(void *slots, int n, void *flag, void *stream);
+int ebfi_pack_table_f16(const float *src, const int32_t *table, int64_t n, void *out, const int32_t *block_slot,
+                        void *slots, void *stream);
+int ebfi_conv2d_packed_f16(const void *input, const void *packed16, size_t packed_bytes, const void *bias, void *output,
+                           int B, int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups, int act,
+                           float slope, const void *addend, const void *mask_y, int mask_act, float mask_slope,
+                           void *in_slot, const void *w_slot, void *stream);
+int ebfi_conv2d_backward_weight_f16g(const void *input, const void *grad_output, const void *saved_output,
+                                     void *grad_weight, void *grad_bias, void *grad_preact_out, int B,
+                                     int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups, int act,
+                                     float slope, void *x_slot, void *g_slot, void *workspace,
+                                     size_t workspace_bytes, void *stream);
 /* weight / bias gradient of such a (grouped) convolution from a pre-activation gradient: grad_weight
  * [Cout, Cin_per_group, k, k]; workspace as ebfi_conv2d_backward_weight_workspace(B, Cin_per_group, H, W, Cout, k, 1, pad) */
 int ebfi_conv2d_backward_weight_x3g(const void *input, const void *grad_output, void *grad_weight, void *grad_bias,
@@ -372,6 +397,11 @@ int ebfi_laploss_backward(const float *grad_loss, float *workspace, float *grad_
  * All buffers 16-byte aligned. */
 int ebfi_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *step, int64_t n,
                    double lr, double beta1, double beta2, double eps, void *stream);
+/* Same update, guarded: when guard[0] != 0 (set by ebfi_f16_scales_finish: an fp16 operand of this step's backward pass
+ * left its range) nothing is updated, step[0] is decremented again and guard[1] counts the skipped step.  guard may be NULL. */
+int ebfi_adam_step_guarded(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *step, int64_t n,
+                           double lr, double beta1, double beta2, double eps, int *guard, void *stream);
+
 
 /* ------------------------------------------------------------------ per-kernel device timing
  * When enabled, every launch made by this library is bracketed by a hipEvent pair recorded on the

@@ -312,3 +312,109 @@ def test_packed_grouped_conv_with_epilogue_extras_vs_cpu():
     rc = lib.ebfi_conv2d_packed_x3(N.ptr(xd), site.fwd_ptr(), site.fwd_bytes, N.ptr(None), N.ptr(out), B, 32, H, W, 2 * C, 3, 1, 4,
                                    0, 0.0, N.ptr(None), N.ptr(None), 0, 0.0, st)
     assert rc == -1 and b"groups" in lib.ebfi_last_error()
+
+
+# ------------------------------------------------------------------------------------------------ fp16 backward (round 3)
+def _banked_layer(Cin, Cout, scale_w=1.0):
+    """A 3x3 conv whose weight images live in a bank with a scale book attached (what Engine builds for training)."""
+    from ebfi_amd import f16scale, weightbank
+    w = torch.nn.Parameter((torch.randn(Cout, Cin, 3, 3) * (scale_w / (Cin * 9) ** 0.5)).cuda())
+    b = torch.nn.Parameter((torch.randn(Cout) * 0.1 * scale_w).cuda())
+    bank = weightbank.WeightBank([w, b])
+    bank.register(w, b, "id")
+    book = f16scale.ScaleBook("cuda")
+    bank.attach_scale_book(book)
+    bank.refresh()
+    return w, b, bank, book
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,act,xs,gs", [
+    (2, 64, 16, 64, 64, 1, 1.0, 1.0),          # ResidualControl shape, whole tiles
+    (1, 128, 13, 36, 64, 1, 1.0, 1.0),         # ragged tiles, two input-channel blocks
+    (2, 64, 20, 36, 200, 0, 1.0, 1.0),         # Cout not a multiple of 64, no activation
+    (1, 64, 16, 64, 128, 1, 1e-12, 1e-20),     # magnitudes far below fp16's range: what the x0.1 initialisation produces
+    (1, 64, 8, 64, 64, 0, 3e4, 1e6),           # ... and far above it (no activation: at |y| ~ 1e5 the fp32 forward's last bits
+                                               #     decide the sign of y ~ 0, a kink of the test, not of the kernels)
+])
+def test_fp16_backward_kernels_vs_cpu(B, Cin, H, W, Cout, act, xs, gs):
+    """csrc/conv2d_f16.inc.hpp through the autograd node the model uses (conv.SiteConvBiasAct with a scale book active): data
+    gradient and weight / bias gradient with ONE fp16 MFMA per product and power-of-two operand scales against the fp32 CPU
+    conv.  fp16 operands: 2^-12 per product, a few 1e-4 of the result's scale -- at any magnitude of the operands, because the
+    just-in-time calibrated scales move them into fp16's range (cases 4, 5 would be all-zero / all-inf without)."""
+    from ebfi_amd import _native as N
+    from ebfi_amd import conv
+    torch.manual_seed(B * 7 + Cin + Cout + H)
+    w, b, bank, book = _banked_layer(Cin, Cout)
+    x = torch.randn(B, Cin, H, W) * xs
+    g = torch.randn(B, Cout, H, W) * gs
+    xr, wr, br = x.clone().requires_grad_(), w.detach().cpu().clone().requires_grad_(), b.detach().cpu().clone().requires_grad_()
+    _ref(xr, wr, br, 1, 1, act, 0.01).backward(g)
+    xd = x.cuda().requires_grad_()
+    conv.set_compute_dtype("bf16x3")
+    try:
+        N.prof_reset()
+        N.prof_enable(True)
+        with bank.active(), book.active():
+            y = conv.conv_bias_act(xd, w, b, 1, 1, act, 0.01)
+            y.backward(g.cuda())
+            book.finish()
+        torch.cuda.synchronize()
+        N.prof_enable(False)
+        prof = {k: v[0] for k, v in N.prof_collect().items() if v[0] > 0}
+    finally:
+        conv.set_compute_dtype("fp32")
+    assert prof.get("conv_wgrad_f16_ws") == 1 and prof.get("conv_fwd_f16_ws") == 1, prof      # both gradients took the fp16 kernels
+    assert "conv_wgrad_x3_ws" not in prof and "conv_fwd_bf16x3_ws/dgrad" not in prof
+    assert _rel(xd.grad, xr.grad) < 1e-3 and _rel(w.grad, wr.grad) < 1e-3 and _rel(b.grad, br.grad) < 1e-5
+    assert int(book.guard[0].item()) == 0                   # calibrated scales: nothing left the range
+    # the maxima recorded by the kernels became the next scales: |max| * scale in [128, 256)
+    gi, xi = book.index[((w.data_ptr(), "id"), "g")], book.index[((w.data_ptr(), "id"), "x")]
+    gpre = g if act == 0 else g * torch.where(_ref(x, w.detach().cpu(), b.detach().cpu(), 1, 1, act, 0.01) > 0, 1.0, 0.01)
+    for i, t in ((gi, gpre), (xi, x)):
+        v = t.abs().max().item() * book.slots[2 * i].item()
+        assert 128 <= v < 256, (i, v)
+        assert book.slots[2 * i + 1].item() == 0.0
+
+
+def test_fp16_backward_overflow_raises_the_guard_and_adam_skips():
+    """A stale scale that would push an operand past fp16's 65504 is detected by ebfi_f16_scales_finish from the recorded
+    maximum: the guard flag is set, the guarded Adam launch leaves parameters and moments untouched and counts the skip;
+    the scale is repaired for the next step, which goes through."""
+    from ebfi_amd import conv
+    from ebfi_amd.dp import FlatAdam, FlatGradBucket
+    torch.manual_seed(3)
+    w, b, bank, book = _banked_layer(64, 64)
+    net = torch.nn.ParameterList([w, b])
+    opt, bucket = FlatAdam(list(net.parameters()), lr=1e-2), FlatGradBucket(net)
+    bank2 = None
+    x = torch.randn(1, 64, 16, 64).cuda()
+    g = torch.randn(1, 64, 16, 64).cuda()
+    from ebfi_amd import weightbank
+    bank2 = weightbank.WeightBank(opt.params, flat=opt.flat.data)
+    w2, b2 = opt.params
+    bank2.register(w2, b2, "id")
+    bank2.attach_scale_book(book)
+    conv.set_compute_dtype("bf16x3")
+    try:
+        def step(scale_g):
+            bucket.zero()
+            bank2.refresh()
+            with bank2.active(), book.active():
+                book.begin_step()
+                xd = x.clone().requires_grad_()
+                conv.conv_bias_act(xd, w2, b2, 1, 1, 1, 0.01).backward(g * scale_g)
+                book.finish()
+            before = opt.flat.detach().clone()
+            opt.step(bucket.gather(), guard=book.guard)
+            torch.cuda.synchronize()
+            return before, int(book.guard[0].item())
+        before, flag = step(1.0)                                # calibrates
+        assert flag == 0 and not torch.equal(before, opt.flat.detach())
+        before, flag = step(1e6)                                # 2^20 times larger than the scale expects: 200 * 1e6 > 65504
+        assert flag == 1 and torch.equal(before, opt.flat.detach()) and book.skipped_steps() == 1
+        assert float(opt.inner.state[opt.flat]["step"]) == 1.0  # the skipped step does not count
+        before, flag = step(1e6)                                # the scale has followed: the same data now goes through
+        assert flag == 0 and not torch.equal(before, opt.flat.detach()) and book.skipped_steps() == 1
+        assert torch.isfinite(opt.flat).all()
+    finally:
+        conv.set_compute_dtype("fp32")
