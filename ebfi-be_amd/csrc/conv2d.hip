@@ -3305,8 +3305,29 @@ extern "C" int ebfi_conv2d_backward_weight_f16g(const void *input, const void *g
         return EBFI_OK;
     }
     float *slab = static_cast<float *>(workspace);
-    const int nsplit = wgrad_x3_splits(g, 3);
-    {
+    int nsplit = wgrad_x3_splits(g, 3);
+    // pre-activation gradients on quad-aligned rows: the pixel-major kernel with transposing LDS reads (conv_wgrad_f16_tr)
+    // ... where a workgroup walks enough tiles to pipeline them (>= 32: the 128 -> 1600 layer, 205 tiles per workgroup, 889 against
+    // 1017 us inside the step).  With the 4-8 tiles per workgroup of the 64 / 128-channel layers the kernel is faster in isolation
+    // (40 / 51 / 59 against 45 / 57 / 66 us) but slower inside a training step (102 against 72 us at 64 -> 128): its one grad_out
+    // stage in flight leaves the fill of every tile exposed once all 256 workgroups burst together behind another kernel's
+    // write-back; EBFI_WGRAD_TR=1 / 0 forces / forbids it (development switch).
+    const char *tr_env = getenv("EBFI_WGRAD_TR");
+    const int64_t tr_tiles = (int64_t)g.B * ceil_div(g.Ho, TRH) * ceil_div(g.Wo, TRW);
+    const bool tr_pays = tr_env ? tr_env[0] == '1' : tr_tiles >= 32 * (int64_t)nsplit;
+    const bool tr_ok = act == ACT_NONE && !grad_preact_out && pad == 1 && W % 4 == 0 && aligned16(input) && aligned16(grad_output) && tr_pays;
+    if (tr_ok) {
+        const int64_t tiles = tr_tiles;
+        if (tiles > 2147483647LL) return fail(EBFI_ERR_ARG, "conv2d_backward_weight_f16g: too many tiles");
+        if (nsplit > tiles) nsplit = (int)tiles;
+        dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, 64));
+        const ScaleSlot xs{static_cast<float *>(x_slot)}, gs{static_cast<float *>(g_slot)};
+        ProfScope ps("conv_wgrad_f16_tr", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * 9, conv_bytes_wgrad(g, 9, false, false));
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_wgrad_f16_tr), TR_LDS)) return rc_;
+        hipLaunchKernelGGL(conv_wgrad_f16_tr, grid, dim3(512), TR_LDS, st, static_cast<const float *>(input),
+                           static_cast<const float *>(grad_output), slab, g, (int)tiles, grad_bias != nullptr ? 1 : 0, xs, gs);
+        if (int rc = check_launch("conv_wgrad_f16_tr")) return rc;
+    } else {
         using C = WCfg<3, 1, 32>;
         const size_t lds = (size_t)2 * (32 * GS + 33 * C::PS) * sizeof(unsigned);
         const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, C::WTX);
@@ -3333,7 +3354,7 @@ extern "C" int ebfi_conv2d_backward_weight_f16g(const void *input, const void *g
     {
         ProfScope ps("conv_wgrad_reduce_f32", st);
         hipLaunchKernelGGL(conv_wgrad_reduce_f32, dim3((unsigned)ceil_div(n_total, 64)), dim3(256), 0, st, slab, nsplit, n_weight,
-                           n_total, static_cast<float *>(grad_weight), static_cast<float *>(grad_bias), 0, 9);
+                           n_total, static_cast<float *>(grad_weight), static_cast<float *>(grad_bias), tr_ok ? Cin_per_group : 0, 9);
     }
     return check_launch("conv_wgrad_reduce_f32");
 }

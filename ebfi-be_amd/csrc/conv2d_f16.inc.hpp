@@ -11,7 +11,7 @@
 //
 // Range: fp16 spans 2^-24 .. 65504, and with the reference's x0.1 initialisation gradients fall to 1e-29 in the early
 // layers.  Every operand is therefore multiplied by a POWER OF TWO on its way into LDS (exact in fp32) and the accumulator
-// is multiplied by the inverse product on its way out.  The scale of an operand lives in a two-word device slot
+// is multiplied by the inverse product on its way out.  The scale of an operand lives in a device slot
 // {scale, running |max|}: the staging code records |max| of what it reads (it touches every element anyway), and one tiny
 // kernel per step (ebfi_f16_scales_finish) turns the maxima into the next step's scales (max * scale in [128, 256): 7
 // binades of headroom above, 22 below before fp16 loses precision) and raises a flag if a product could have overflowed
@@ -26,8 +26,11 @@ __device__ __forceinline__ unsigned pack_f16(float a, float b) {   // v_cvt_pk_f
     return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, f16x2));
 }
 
-// Scale slot: [0] = scale (power of two), [1] = running |max| of the fp32 values staged through it (float bits, ordered as
-// unsigned for non-negative floats).
+// Scale slot: 64 floats (256 bytes); [0] = scale (power of two), [32] = running |max| of the fp32 values staged through it
+// (float bits, ordered as unsigned for non-negative floats).  The two words sit in different 128-byte lines on purpose: the
+// atomic that raises the maximum executes at the memory side and drops its line from L2 -- next to the scale, which every
+// workgroup reads, that turned the 30 000-workgroup pack launch into a queue on one line (0.44 ms for 5.5 M elements).
+constexpr int SLOT_STRIDE = 64, SLOT_AMAX = 32;
 struct ScaleSlot {
     float *p;
     __device__ __forceinline__ float scale() const { return p ? p[0] : 1.f; }
@@ -38,8 +41,8 @@ struct ScaleSlot {
         for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
         // (many workgroups report into one word: only a value above the one already there needs the atomic -- NaN compares
         // false and goes through)
-        if (p && (threadIdx.x & 63) == 0 && !(m <= __builtin_nontemporal_load(p + 1)))
-            atomicMax(reinterpret_cast<unsigned *>(p + 1), __float_as_uint(m));
+        if (p && (threadIdx.x & 63) == 0 && !(m <= __builtin_nontemporal_load(p + SLOT_AMAX)))
+            atomicMax(reinterpret_cast<unsigned *>(p + SLOT_AMAX), __float_as_uint(m));
     }
 };
 
@@ -539,25 +542,26 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_ws(const float *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// Delayed scaling bookkeeping: slots[2i] = scale, slots[2i + 1] = |max| seen since the last call.  For every slot that saw
+// Delayed scaling bookkeeping over slots 0 .. n-1 (SLOT_STRIDE floats each: scale at [0], |max| seen since the last call at [32]).  For every slot that saw
 // data: flag[0] |= 1 when the data was not finite or max * scale could have left the fp16 range (the step's gradients are
 // then suspect: the optimiser launch skips the update), the next scale puts max into [128, 256), the maximum is cleared.
 __global__ __launch_bounds__(256) void f16_scales_finish_kernel(float *__restrict__ slots, int n, int *__restrict__ flag) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float a = slots[2 * i + 1], s = slots[2 * i];
+    float *slot = slots + (int64_t)SLOT_STRIDE * i;
+    const float a = slot[SLOT_AMAX], s = slot[0];
     if (!(a > 0.f)) {                      // nothing staged through this slot (or all zeros): keep the scale
         if (a != a) atomicOr(flag, 1);
-        slots[2 * i + 1] = 0.f;
+        slot[SLOT_AMAX] = 0.f;
         return;
     }
     if (!(a <= 3.0e38f) || a * s > 60000.f) atomicOr(flag, 1);
     if (a <= 3.0e38f) {
         int e;
         (void)frexpf(a, &e);               // a = m * 2^e, m in [0.5, 1)
-        slots[2 * i] = ldexpf(1.f, 8 - e);
+        slot[0] = ldexpf(1.f, 8 - e);
     }
-    slots[2 * i + 1] = 0.f;
+    slot[SLOT_AMAX] = 0.f;
 }
 
 // fp16 images from an index table (the bf16 pack launch's table format, hi entries only): packed[e] = fp16(src[table[e]] *
@@ -567,12 +571,282 @@ __global__ __launch_bounds__(256) void pack_table_f16_kernel(const float *__rest
                                                              int64_t n, _Float16 *__restrict__ out,
                                                              const int32_t *__restrict__ block_slot, float *__restrict__ slots) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    float *slot = slots + 2 * (int64_t)block_slot[blockIdx.x];
+    float *slot = slots + (int64_t)SLOT_STRIDE * block_slot[blockIdx.x];
     const int32_t t = e < n ? table[e] : -1;
     const float v = t >= 0 ? src[t & 0x3fffffff] : 0.f;
     if (e < n) out[e] = (_Float16)(v * slot[0]);
     float m = fabsf(v);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
-    if ((threadIdx.x & 63) == 0 && m > __builtin_nontemporal_load(slot + 1)) atomicMax(reinterpret_cast<unsigned *>(slot + 1), __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0 && m > __builtin_nontemporal_load(slot + SLOT_AMAX))
+        atomicMax(reinterpret_cast<unsigned *>(slot + SLOT_AMAX), __float_as_uint(m));
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_wgrad_f16_tr: the 3x3 weight gradient on PIXEL-MAJOR fp16 images read with the transposing LDS load.
+//
+// The weight gradient contracts over pixels.  The kernels above therefore keep pixel-contiguous images ([channel][pixel],
+// one pixel per 32-bit word so that a tap's one-pixel shift stays aligned), which forces dword-per-lane staging loads and
+// a ds_write_b32 per word: conv_wgrad_f16_ws runs exactly as fast as the split-precision kernel although it issues a third of
+// the MFMAs -- both are paced by their producers (~2.6 TB/s of 128-byte row segments through 50 load + 25-50 store
+// instructions per thread and tile).  gfx950's ds_read_b64_tr_b16 removes the constraint: it delivers, to each lane, FOUR
+// consecutive rows of ONE 16-bit column of a row-major LDS block -- a [pixel][channel] image is read as the
+// [channel][8 pixels] fragment the MFMA wants.  With pixel-major images
+//   * the staging is the forward kernel's: 16-byte global loads (4 pixels of one channel), eight of them packed into one
+//     ds_write_b128 per pixel (8 channels): 24 loads + 12 stores per thread and 128-pixel tile;
+//   * a tap shift is a ROW offset (128 bytes): no alignment problem, no shifted copies, no per-word permutes;
+//   * both operands come from the same kind of image: A = grad_out^T and B = the shifted input, two transposing reads per
+//     fragment, 14 reads for 9 MFMAs per consumer wave and k-step.
+// Tile = 4 rows x 32 pixels (input halo 6 x 36 positions), 64 co x 64 ci per workgroup, 44 KB per LDS buffer, two register
+// stages of loads in flight per producer thread.  Rows are 128 bytes (64 channels); the 16-byte chunk c of position p is
+// stored at chunk c ^ 4*((p >> 1) & 1): the four rows of a transposing read then fall into four different bank quarters.
+// Activation-free form only (pre-activation gradients: ResidualControl's fused node, KernelConv): the layers that fold
+// act'(y) keep conv_wgrad_f16_ws.
+typedef __fp16 hv4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __fp16 hv8 __attribute__((__vector_size__(8 * sizeof(__fp16))));
+__device__ __forceinline__ f16x8 tr_frag(const char *lds_lo, const char *lds_hi) {
+    typedef hv4 __attribute__((address_space(3))) *lp;
+    const hv4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(lds_lo));
+    const hv4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(lds_hi));
+    return __builtin_bit_cast(f16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+constexpr int TRH = 4, TRW = 32, TRXR = TRH + 2, TRXQ = 10, TRXW = 36;      // tile rows / px, halo rows, quads and stored positions per row
+constexpr int TR_XB = TRXR * TRXW * 128, TR_GB = TRH * TRW * 128, TR_BUFB = TR_XB + TR_GB;
+constexpr int TR_LDS = 2 * TR_BUFB + 4 * 64 * 4;                             // two buffers + the bias scratch
+
+__global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict__ x, const float *__restrict__ gout,
+                                                         float *__restrict__ slab, ConvGeom g, int total_tiles, int need_bias,
+                                                         ScaleSlot x_slot, ScaleSlot g_slot) {
+    constexpr int KK = 9, PT = 256, NQ = 4;
+    constexpr int NXI = TRXR * TRXQ * 8, NXK = (NXI + PT - 1) / PT;          // input items (row, quad, 8-channel group): 480, 2 per thread
+    static_assert(NXK == 2 && TRH * (TRW / 4) * 8 == PT, "one grad_out item and two input items per producer thread");
+    extern __shared__ __attribute__((aligned(16))) char smt[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co_base = blockIdx.y * 64, ci_base = blockIdx.z * 64;
+    const int grp = co_base / (g.Cout / g.groups);
+    const int tiles_x = (g.Wo + TRW - 1) / TRW, tiles_y = (g.Ho + TRH - 1) / TRH;
+    const int HW = g.H * g.W, HWo = g.Ho * g.Wo;
+    const int G = gridDim.x;
+    const int64_t wsz = (int64_t)g.Cout * g.Cin * KK;
+    float *my = slab + (int64_t)blockIdx.x * (wsz + g.Cout);
+    const float sx = x_slot.scale(), sg = g_slot.scale();
+
+    if (wave < NQ) {
+        // ------------------------------------------------------------------ consumers
+        // 36 blocks = 2 row tiles (co) x 18 column tiles (channel block cb, tap): wave w owns column tiles w, w+4, w+8, w+12
+        // with both row tiles and row tile (w & 1) of column tile 16 + (w >> 1)
+        const int nq = wave;
+        const int xm = nq & 1, xt = 16 + (nq >> 1);
+        f32x16 acc[4][2], accx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accx[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][m][r] = 0.f;
+        // lane geometry of the transposing read: 16-lane group G4 = k half (G4 >> 1) and 16-channel half (G4 & 1); inside a
+        // group lane 4q + p addresses row q, columns 4p .. 4p + 3
+        const int G4 = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+        const int kh = G4 >> 1, cg = G4 & 1;
+        const int rowoff = (8 * kh + q) * 128 + (p & 1) * 8;
+        const int chunk0 = 2 * cg + (p >> 1);                    // 16-byte chunk inside a 32-channel half
+        int aoff[2];                                             // grad_out image: pixel base is a multiple of 4 -> swizzle bit = q >> 1
+#pragma unroll
+        for (int m = 0; m < 2; ++m) aoff[m] = TR_XB + rowoff + (((4 * m + chunk0) ^ ((q >> 1) << 2)) << 4);
+        int boff[5];                                             // input image: per column tile (cb, ky, kx)
+        auto col_off = [&](int nt) {
+            const int cb = nt / KK, tap = nt - cb * KK;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int swz = (((kx + 1 + q) >> 1) & 1) << 2;      // (position >> 1) & 1 of row q of the read (row base = 4 t + kx + 1)
+            return (ky * TRXW + kx + 1) * 128 + rowoff + (((4 * cb + chunk0) ^ swz) << 4);
+        };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) boff[j] = col_off(nq + NQ * j);
+        boff[4] = col_off(xt);
+        __syncthreads();                   // (A) the first tile is committed
+        int cur = 0;
+        for (int tile = blockIdx.x; tile < total_tiles; tile += G) {
+            const char *base = smt + cur * TR_BUFB;
+#pragma unroll
+            for (int ks = 0; ks < TRH * 2; ++ks) {
+                const int y = ks >> 1, px0 = (ks & 1) * 16;
+                const char *ga = base + (y * TRW + px0) * 128;              // + 4 * 128 for the second half of a fragment
+                const char *xa = base + (y * TRXW + px0) * 128;
+                f16x8 a[2], b[5];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) a[m] = tr_frag(ga + aoff[m], ga + aoff[m] + 512);
+#pragma unroll
+                for (int j = 0; j < 5; ++j) b[j] = tr_frag(xa + boff[j], xa + boff[j] + 512);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        acc[j][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b[j], acc[j][m], 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(xm ? a[1] : a[0], b[4], accx, 0, 0, 0);
+            }
+            __syncthreads();               // (B) this image has been read, the other one is complete
+            cur ^= 1;
+        }
+        const float oscale = 1.f / (sx * sg);
+        const __amdgpu_buffer_rsrc_t rsl = make_rsrc(my, (unsigned)wsz * 4u);   // rows co >= Cout fall past the slab: dropped
+        // slab layout of THIS kernel: [co][tap][ci] -- a block's lanes are consecutive input channels of one tap, so the channel
+        // has to be the fastest index for the stores to be 128-byte segments (with the [co][ci][tap] layout of the other
+        // kernels every store instruction scattered 64 dwords over 2.3 KB); conv_wgrad_reduce_f32 un-permutes (perm_cin)
+        const unsigned co_row = (unsigned)(g.Cin * KK) * 4u;
+        auto store_block = [&](const f32x16 &a, int m, int nt) {
+            const int cb = nt / KK, tap = nt - cb * KK;
+            const int ci = ci_base + cb * 32 + (lane & 31);
+            const unsigned o0 = ci < g.Cin ? (unsigned)(((co_base + m * 32 + 4 * (lane >> 5)) * KK + tap) * g.Cin + ci) * 4u : SENT;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) buf_st(rsl, o0 + (unsigned)((r & 3) + 8 * (r >> 2)) * co_row, a[r] * oscale);
+        };
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) store_block(acc[j][m], m, nq + NQ * j);
+        store_block(accx, xm, xt);
+        __syncthreads();                   // (C) the producers' bias partials are in LDS
+        if (need_bias && blockIdx.z == 0 && wave == 0) {
+            const float *scr = reinterpret_cast<const float *>(smt + 2 * TR_BUFB);
+            const float v = ((scr[lane] + scr[64 + lane]) + scr[128 + lane]) + scr[192 + lane];
+            if (co_base + lane < g.Cout) my[wsz + co_base + lane] = v;
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------- producers
+    const int ptid = tid - 64 * NQ;
+    const unsigned go_bytes = (unsigned)g.Cout * (unsigned)HWo * 4u, x_bytes = (unsigned)g.Cin * (unsigned)HW * 4u;
+    const unsigned xplane = (unsigned)HW * 4u, gplane = (unsigned)HWo * 4u;
+    // item geometry (fixed per thread): 8-channel group `chg`; grad_out item (row gy, quad gq); input items (row, quad)
+    const int chg = ptid & 7;
+    const int g_y = (ptid >> 3) >> 3, g_q = (ptid >> 3) & 7;
+    int x_r[NXK], x_q[NXK];
+#pragma unroll
+    for (int k = 0; k < NXK; ++k) {
+        const int rq = (ptid + k * PT) >> 3;
+        x_r[k] = rq / TRXQ;
+        x_q[k] = rq - x_r[k] * TRXQ;
+    }
+    // register stages: the input quads (two thirds of a tile's bytes) of TWO tiles and the grad_out quads of one are in flight
+    // (three full stages spill: 2 x 96 + addressing > 256 registers; measured 49 spilled registers inside the loop)
+    struct XStage {
+        u32x4 rx[NXK][8];
+    };
+    XStage sa, sb;
+    u32x4 rg[8];
+    float bacc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bacc[e] = 0.f;
+    float amax_g = 0.f, amax_x = 0.f;
+    auto tile_coords = [&](int tile, int &b, int &y0, int &x0) {
+        int t = tile;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        b = t / tiles_y; y0 = ty * TRH; x0 = tx * TRW;
+    };
+    auto prefetch_g = [&](int tile) {
+        int b, y0, x0;
+        tile_coords(tile, b, y0, x0);
+        const bool live = tile < total_tiles;
+        const __amdgpu_buffer_rsrc_t rgo = make_rsrc(gout + (int64_t)(live ? b : 0) * g.Cout * HWo, live ? go_bytes : 0u);
+        const int gy = y0 + g_y, gx = x0 + 4 * g_q;
+        const unsigned o = (gy < g.Ho && gx + 3 < g.Wo) ? (unsigned)((co_base + 8 * chg) * HWo + gy * g.Wo + gx) * 4u : SENT;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rg[e] = __builtin_amdgcn_raw_buffer_load_b128(rgo, o + (unsigned)e * gplane, 0, 0);
+    };
+    auto prefetch_x = [&](int tile, XStage &s) {
+        int b, y0, x0;
+        tile_coords(tile, b, y0, x0);
+        const bool live = tile < total_tiles;
+        const __amdgpu_buffer_rsrc_t rxi = make_rsrc(x + ((int64_t)(live ? b : 0) * g.groups + grp) * g.Cin * HW, live ? x_bytes : 0u);
+#pragma unroll
+        for (int k = 0; k < NXK; ++k) {
+            const int yy = y0 - 1 + x_r[k], xq = x0 - 4 + 4 * x_q[k];
+            const bool ok = ptid + k * PT < NXI && yy >= 0 && yy < g.H && xq >= 0 && xq + 3 < g.W;
+            const unsigned o = ok ? (unsigned)((ci_base + 8 * chg) * HW + yy * g.W + xq) * 4u : SENT;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s.rx[k][e] = __builtin_amdgcn_raw_buffer_load_b128(rxi, o + (unsigned)e * xplane, 0, 0);
+        }
+    };
+    auto commit_g = [&](int buf) {
+        char *gi = smt + buf * TR_BUFB + TR_XB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32x4 hv;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const float v0 = __uint_as_float(rg[e][j]), v1 = __uint_as_float(rg[e + 1][j]);
+                bacc[e] += v0;
+                bacc[e + 1] += v1;
+                amax_g = fmaxf(amax_g, fmaxf(fabsf(v0), fabsf(v1)));
+                hv[e >> 1] = pack_f16(v0 * sg, v1 * sg);
+            }
+            const int pix = g_y * TRW + 4 * g_q + j;
+            *reinterpret_cast<u32x4 *>(gi + pix * 128 + ((chg ^ (((pix >> 1) & 1) << 2)) << 4)) = hv;
+        }
+    };
+    auto commit_x = [&](int buf, XStage &s) {
+        char *xi = smt + buf * TR_BUFB;
+#pragma unroll
+        for (int k = 0; k < NXK; ++k)
+            if (ptid + k * PT < NXI) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = 4 * x_q[k] + j - 2;                   // stored positions: tile columns -2 .. 33 of the quad grid
+                    u32x4 hv;
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const float v0 = __uint_as_float(s.rx[k][e][j]), v1 = __uint_as_float(s.rx[k][e + 1][j]);
+                        amax_x = fmaxf(amax_x, fmaxf(fabsf(v0), fabsf(v1)));
+                        hv[e >> 1] = pack_f16(v0 * sx, v1 * sx);
+                    }
+                    if (c < 0 || c >= TRXW) continue;
+                    const int pos = x_r[k] * TRXW + c;
+                    *reinterpret_cast<u32x4 *>(xi + pos * 128 + ((chg ^ (((pos >> 1) & 1) << 2)) << 4)) = hv;
+                }
+            }
+    };
+    prefetch_x(blockIdx.x, sa);
+    prefetch_g(blockIdx.x);
+    commit_x(0, sa);
+    commit_g(0);
+    prefetch_x(blockIdx.x + G, sa);        // from here on: input quads of two tiles, grad_out quads of one in flight
+    prefetch_g(blockIdx.x + G);
+    prefetch_x(blockIdx.x + 2 * G, sb);
+    __syncthreads();                       // (A)
+    int cur = 0;
+    for (int tile = blockIdx.x; tile < total_tiles; tile += 2 * G) {
+        commit_x(cur ^ 1, sa);             // tile + G, while the consumers multiply tile `tile` from image `cur`
+        prefetch_x(tile + 3 * G, sa);      // (past the end: zero-record descriptors, nothing is read)
+        commit_g(cur ^ 1);
+        prefetch_g(tile + 2 * G);
+        __syncthreads();                   // (B)
+        cur ^= 1;
+        if (tile + G >= total_tiles) break;
+        commit_x(cur ^ 1, sb);             // tile + 2 G
+        prefetch_x(tile + 4 * G, sb);
+        commit_g(cur ^ 1);
+        prefetch_g(tile + 3 * G);
+        __syncthreads();                   // (B)
+        cur ^= 1;
+    }
+    x_slot.record(amax_x);
+    g_slot.record(amax_g);
+    // bias partial of this workgroup: channel 8 chg + e summed over the 32 threads of a wave that share chg (lane bits 3..5);
+    // the four waves' sums go through LDS to the consumers, which add them in a fixed order after barrier (C)
+    if (need_bias && blockIdx.z == 0) {
+        float *scr = reinterpret_cast<float *>(smt + 2 * TR_BUFB);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = bacc[e];
+            v += __shfl_xor(v, 8, 64);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if ((lane >> 3) == 0) scr[(wave - NQ) * 64 + 8 * chg + e] = v;
+        }
+    }
+    __syncthreads();                       // (C)
 }

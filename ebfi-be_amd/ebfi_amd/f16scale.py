@@ -24,6 +24,7 @@ from . import _native as N
 
 _ACTIVE = None
 TARGET_EXP = 8                      # |max| * scale in [2^(TARGET_EXP-1), 2^TARGET_EXP)
+SLOT_STRIDE, SLOT_AMAX = 64, 32     # floats per slot; offset of the running |max| (csrc/conv2d_f16.inc.hpp: separate cache lines)
 
 
 def active_book():
@@ -34,9 +35,9 @@ class ScaleBook:
     def __init__(self, device, capacity=4096):
         self.device = torch.device(device)
         self.capacity = int(capacity)
-        init = torch.zeros(self.capacity, 2)
+        init = torch.zeros(self.capacity, SLOT_STRIDE)
         init[:, 0] = 1.0
-        self.slots = init.reshape(-1).to(self.device)          # [scale, |max|] pairs
+        self.slots = init.reshape(-1).to(self.device)          # per slot: scale at [0], running |max| at [SLOT_AMAX]
         self.guard = torch.zeros(2, dtype=torch.int32, device=self.device)   # [flag of the current step, skipped steps]
         self.index = {}
         self.calibrated = set()
@@ -52,10 +53,14 @@ class ScaleBook:
         return i
 
     def ptr(self, i):
-        return N._vp(self.slots.data_ptr() + 8 * i)
+        return N._vp(self.slots.data_ptr() + 4 * SLOT_STRIDE * i)
 
-    def scale_view(self, i):
-        return self.slots[2 * i:2 * i + 1]
+    def scale(self, i):
+        """Current scale of slot i (host value: synchronises; tests / diagnostics)."""
+        return float(self.slots[SLOT_STRIDE * i].item())
+
+    def amax(self, i):
+        return float(self.slots[SLOT_STRIDE * i + SLOT_AMAX].item())
 
     def calibrate(self, i, *tensors):
         """First use of slot i: set its scale from the tensors about to be staged through it (device-side, no sync)."""
@@ -66,7 +71,7 @@ class ScaleBook:
         amax = torch.stack([t.detach().abs().amax().float() for t in tensors]).amax()
         e = torch.floor(torch.log2(amax.clamp_min(1e-37))) + 1.0          # amax = m * 2^e, m in [0.5, 1)
         scale = torch.where((amax > 0) & torch.isfinite(amax), torch.exp2(TARGET_EXP - e), torch.ones_like(amax))
-        self.slots[2 * i:2 * i + 1].copy_(scale.reshape(1))
+        self.slots[SLOT_STRIDE * i:SLOT_STRIDE * i + 1].copy_(scale.reshape(1))
         self.calibrated.add(i)
 
     def operand(self, key, *tensors):

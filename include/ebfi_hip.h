@@ -234,8 +234,9 @@ int ebfi_kernelconv_fac_fused_x3(const void *input, const void *packed, size_t p
                                  float slope, void *stream);
 /* ------------------------------------------------------------------ fp16 single-product backward (training step)
  * The data gradient and the weight gradient of the 3x3 layers with ONE fp16 MFMA per product (the forward keeps the
- * split-precision kernels: DESIGN.md section 4).  Every operand is scaled by a power of two kept in a device SLOT
- * float[2] = {scale, running |max| of the values staged through it}; kernels apply slot[0] and atomically raise slot[1];
+ * split-precision kernels: DESIGN.md section 4).  Every operand is scaled by a power of two kept in a device SLOT of
+ * 64 floats (256 bytes): slot[0] = scale, slot[32] = running |max| of the values staged through it (separate cache lines);
+ * kernels apply slot[0] and atomically raise slot[32]; slot i of a book starts at slots + 64 i;
  * ebfi_f16_scales_finish (once per step, after the backward pass) turns the maxima of all `n` slots into the next step's
  * scales (|max| * scale in [128, 256)), clears them, and sets flag[0] when a value was not finite or |max| * scale could
  * have left the fp16 range.  A new slot is initialised by the caller (ebfi_amd/f16scale.py calibrates it just in time).

@@ -343,6 +343,12 @@ def test_fp16_backward_kernels_vs_cpu(B, Cin, H, W, Cout, act, xs, gs):
     just-in-time calibrated scales move them into fp16's range (cases 4, 5 would be all-zero / all-inf without)."""
     from ebfi_amd import _native as N
     from ebfi_amd import conv
+    import os
+    # the pixel-major weight-gradient kernel is picked for long tile walks only (the 128 -> 1600 layer): the small test shapes
+    # reach it through its development switch (read per launch), set around this test's backward only
+    force_tr = H >= 16
+    prev_env = os.environ.get("EBFI_WGRAD_TR")
+    os.environ["EBFI_WGRAD_TR"] = "1" if force_tr else "0"
     torch.manual_seed(B * 7 + Cin + Cout + H)
     w, b, bank, book = _banked_layer(Cin, Cout)
     x = torch.randn(B, Cin, H, W) * xs
@@ -363,7 +369,13 @@ def test_fp16_backward_kernels_vs_cpu(B, Cin, H, W, Cout, act, xs, gs):
         prof = {k: v[0] for k, v in N.prof_collect().items() if v[0] > 0}
     finally:
         conv.set_compute_dtype("fp32")
-    assert prof.get("conv_wgrad_f16_ws") == 1 and prof.get("conv_fwd_f16_ws") == 1, prof      # both gradients took the fp16 kernels
+        if prev_env is None:
+            os.environ.pop("EBFI_WGRAD_TR", None)
+        else:
+            os.environ["EBFI_WGRAD_TR"] = prev_env
+    # both gradients took the fp16 kernels: the weight gradient the pixel-major form (transposing LDS reads) when the layer has
+    # no activation to fold, the pair-word form otherwise
+    assert prof.get("conv_wgrad_f16_tr" if (act == 0 and force_tr) else "conv_wgrad_f16_ws") == 1 and prof.get("conv_fwd_f16_ws") == 1, prof
     assert "conv_wgrad_x3_ws" not in prof and "conv_fwd_bf16x3_ws/dgrad" not in prof
     assert _rel(xd.grad, xr.grad) < 1e-3 and _rel(w.grad, wr.grad) < 1e-3 and _rel(b.grad, br.grad) < 1e-5
     assert int(book.guard[0].item()) == 0                   # calibrated scales: nothing left the range
@@ -371,9 +383,9 @@ def test_fp16_backward_kernels_vs_cpu(B, Cin, H, W, Cout, act, xs, gs):
     gi, xi = book.index[((w.data_ptr(), "id"), "g")], book.index[((w.data_ptr(), "id"), "x")]
     gpre = g if act == 0 else g * torch.where(_ref(x, w.detach().cpu(), b.detach().cpu(), 1, 1, act, 0.01) > 0, 1.0, 0.01)
     for i, t in ((gi, gpre), (xi, x)):
-        v = t.abs().max().item() * book.slots[2 * i].item()
+        v = t.abs().max().item() * book.scale(i)
         assert 128 <= v < 256, (i, v)
-        assert book.slots[2 * i + 1].item() == 0.0
+        assert book.amax(i) == 0.0
 
 
 def test_fp16_backward_overflow_raises_the_guard_and_adam_skips():
