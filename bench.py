@@ -131,10 +131,13 @@ def kernel_table(kernels, elapsed, steps):
         if e["roles"]:
             entry["roles"] = e["roles"]
         secs = total_ms * 1e-3
-        mult = 3 if "x3" in name else 1
-        mfma_peak = BF16_MFMA_PEAK_TFS if "bf16" in name or "x3" in name else F32_MFMA_PEAK_TFS
+        mult = 3 if "x3" in name else 1                 # split precision: three MFMAs per product; fp16 / fp32 kernels: one
+        half = "bf16" in name or "x3" in name or "f16" in name
+        mfma_peak = BF16_MFMA_PEAK_TFS if half else F32_MFMA_PEAK_TFS      # (the fp16 MFMA runs at the bf16 rate)
         t_mfma = mult * flops / (mfma_peak * 1e12)
         t_hbm = nbytes / (HBM_PEAK_GBS * 1e9)
+        if nbytes > 0:
+            entry["algorithmic_bytes_per_launch"] = nbytes / launches        # (also for matrix-bound kernels: traffic_ratio)
         if flops > 0 and t_mfma >= t_hbm:
             entry.update(bound="mfma", algorithmic_flops_per_launch=flops / launches,
                          achieved=round(flops / secs / 1e12, 2), peak=mfma_peak, unit="TFLOP/s")
@@ -149,22 +152,33 @@ def kernel_table(kernels, elapsed, steps):
         if "achieved" in entry:
             entry["frac"] = round(entry["achieved"] / entry["peak"], 4)
         per_kernel[name] = entry
+    # HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE
+    # in separate passes over `bench.py --no-graph`; FETCH_SIZE doubled for the kernels that stage with 16-byte-per-lane
+    # loads, MI355X_MICROARCH.md section HBM), next to the algorithmic bytes of the same launch
+    pmc = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            pmc = json.load(fh)
+    except (OSError, ValueError):
+        pass
+    for name, entry in per_kernel.items():
+        t = pmc.get(name)
+        if isinstance(t, dict) and t.get("bytes_per_launch") and entry.get("algorithmic_bytes_per_launch"):
+            entry["traffic"] = t["bytes_per_launch"]
+            entry["traffic_ratio"] = round(t["bytes_per_launch"] / entry["algorithmic_bytes_per_launch"], 3)
     ranked = sorted((k for k in per_kernel if "frac" in per_kernel[k]), key=lambda k: -per_kernel[k]["total_ms"])
     roofline = None
     if ranked:
         d = per_kernel[ranked[0]]
-        traffic = None          # HBM bytes/launch from the committed rocprofv3 PMC passes, if any
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-                traffic = json.load(fh).get(ranked[0])
-        except (OSError, ValueError):
-            pass
         roofline = {"kernel": ranked[0], "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
-                    "unit": d["unit"], "frac": d["frac"], "traffic": traffic, "launches_per_step": d["launches_per_step"],
+                    "unit": d["unit"], "frac": d["frac"], "traffic": d.get("traffic"), "launches_per_step": d["launches_per_step"],
                     "avg_launch_ms": d["avg_ms"], "share_of_step": round(d["total_ms"] / (1e3 * elapsed), 4)}
-        for k in ("executed", "frac_executed", "matrix_flops_per_algorithmic_flop", "roles"):
+        for k in ("executed", "frac_executed", "matrix_flops_per_algorithmic_flop", "roles", "algorithmic_bytes_per_launch",
+                  "algorithmic_flops_per_launch", "traffic_ratio"):
             if k in d:
                 roofline[k] = d[k]
+        if isinstance(pmc.get(ranked[0]), dict):
+            roofline["traffic_detail"] = pmc[ranked[0]]
     return per_kernel, roofline
 
 
@@ -346,7 +360,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16x3": "bf16x3", "bf16": "bf16"}[args.precision], "data": "synthetic",
+            "dtype": {"fp32": "f32", "bf16x3": "bf16x3 fwd / f16 bwd" if eng.book is not None else "bf16x3", "bf16": "bf16"}[args.precision],
+            "data": "synthetic",
             "config": {"workload": "EVFIAutoEx (config/train_ours.yml defaults, 5.69 M params) train step: fwd + "
                                    "Lap/census loss + bwd + flat grad all-reduce + Adam; B=%d per GPU, %dx%d frames, "
                                    "TB=%d event bins, Poisson(0.35) event counts" % (B_PER_GPU, H, W, TB),
@@ -354,8 +369,11 @@ def main():
                        "world_size": world, "collective_backend": (dist.get_backend() if world > 1 else None),
                        "replica_param_checksum": {"sum": checks[0][0], "sum_sq": checks[0][1], "ranks_identical": True},
                        "precision": {"fp32": "fp32 tensors, exact fp32 matrix cores",
-                                     "bf16x3": "fp32 tensors and accumulation; conv operands split into bf16 hi+lo pairs, 3 MFMAs "
-                                               "per product (~1e-5 of fp32, parity-tested at 1e-3 like the fp32 mode)",
+                                     "bf16x3": "fp32 tensors and accumulation; forward conv operands split into bf16 hi+lo pairs, 3 MFMAs "
+                                               "per product (~1e-5 of fp32, parity-tested at 1e-3 like the fp32 mode)" +
+                                               ("; data / weight gradients of the 3x3 layers with fp16 operands, 1 MFMA per product, "
+                                                "delayed power-of-two operand scales (packed gradient within 5e-3 of the oracle's: "
+                                                "tests/test_gpu_model.py::test_benchmarked_step_vs_oracle)" if eng.book is not None else ""),
                                      "bf16": "fp32 tensors and accumulation; conv operands rounded once to bf16"}[args.precision],
                        "launch": "hipGraph replay of fwd+loss+bwd+grad packing; all-reduce and Adam eager" if eng.use_graph else "eager",
                        "rehearsal_single_device_gloo": rehearsal},

@@ -26,11 +26,20 @@ echo "[5b] kernel harness (in-kernel stamps of the forward kernel, weight gradie
 ( for a in "64 64" "128 64" "64 128" "128 1600"; do timeout -k 5 60 tools/bin/kbench fwd $a 128 128 8; timeout -k 5 60 tools/bin/kbench wgrad $a 128 128 8; done ) > $OUT/kbench.log 2>&1 || true
 timeout -k 10 300 python tools/opbench.py --ops conv --iters 20 > $OUT/opbench_fp32.jsonl 2> $OUT/opbench_fp32.err
 timeout -k 10 300 python tools/opbench.py --ops fac,dcn --iters 40 > $OUT/opbench_dcn_fac.jsonl 2> $OUT/opbench_dcn_fac.err; tail -1 $OUT/opbench_dcn_fac.jsonl | cut -c1-220
-echo "[6] other BASELINE configs"
-timeout -k 10 300 python ebfi-be_amd/infer_ours.py --batch 1 --height 128 --width 128 > $OUT/config1.log 2>&1; tail -1 $OUT/config1.log
-timeout -k 10 300 python ebfi-be_amd/infer_ours.py --batch 4 --height 256 --width 256 --precision fp32 > $OUT/config2_fp32.log 2>&1; tail -1 $OUT/config2_fp32.log
-timeout -k 10 300 python ebfi-be_amd/infer_ours.py --batch 4 --height 256 --width 256 > $OUT/config2_x3.log 2>&1; tail -1 $OUT/config2_x3.log
-timeout -k 10 400 python ebfi-be_amd/infer_ours.py --batch 8 --height 720 --width 1280 --num_ts 4 > $OUT/config5.log 2>&1; tail -1 $OUT/config5.log
+echo "[5c] backward kernels per shape, split-precision vs fp16"
+timeout -k 10 300 python tools/f16bench.py > $OUT/f16bench.log 2>&1 || true; tail -3 $OUT/f16bench.log
+echo "[6] other BASELINE configs (re-randomised weights: the x0.1 initialisation gives a constant output)"
+timeout -k 10 300 python ebfi-be_amd/infer_ours.py --rand-init --batch 1 --height 128 --width 128 > $OUT/config1.log 2>&1; tail -1 $OUT/config1.log
+timeout -k 10 300 python ebfi-be_amd/infer_ours.py --rand-init --batch 4 --height 256 --width 256 --precision fp32 > $OUT/config2_fp32.log 2>&1; tail -1 $OUT/config2_fp32.log
+timeout -k 10 300 python ebfi-be_amd/infer_ours.py --rand-init --batch 4 --height 256 --width 256 > $OUT/config2_x3.log 2>&1; tail -1 $OUT/config2_x3.log
+timeout -k 10 400 python ebfi-be_amd/infer_ours.py --rand-init --batch 8 --height 720 --width 1280 --num_ts 4 > $OUT/config5.log 2>&1; tail -1 $OUT/config5.log
+EBFI_NO_FAC_FUSION=1 timeout -k 10 400 python ebfi-be_amd/infer_ours.py --rand-init --batch 8 --height 720 --width 1280 --num_ts 4 > $OUT/config5_unfused.log 2>&1; tail -1 $OUT/config5_unfused.log
+echo "[6b] rocprofv3 kernel stats of the inference configs 2 and 5 (eager launches: a replayed graph is traced the same way)"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c2 -o c2 -- python3 ebfi-be_amd/infer_ours.py --rand-init --batch 4 --height 256 --width 256 --num_ts 8 > $OUT/config2_prof.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c5 -o c5 -- python3 ebfi-be_amd/infer_ours.py --rand-init --batch 8 --height 720 --width 1280 --num_ts 4 > $OUT/config5_prof.log 2>&1
+find $OUT/prof_c2 $OUT/prof_c5 -name "*kernel_trace*" -delete; find $OUT/prof_c2 $OUT/prof_c5 -name "*kernel_stats.csv" | head
+echo "[6c] train_ours.py steady-state rate (device-side synthetic batches, hipGraph replay)"
+( cd ebfi-be_amd && timeout -k 10 300 python train_ours.py --graph --iterations 120 ) > $OUT/train_ours_1gpu.log 2>&1; tail -2 $OUT/train_ours_1gpu.log
 echo "[7] two-rank rehearsal of the bench (both ranks on this GPU, gloo)"
 EBFI_BENCH_REHEARSAL=1 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs > $OUT/bench_2rank_rehearsal.out 2> $OUT/bench_2rank_rehearsal.err; grep '^{' $OUT/bench_2rank_rehearsal.out > $OUT/bench_2rank_rehearsal.json; cut -c1-160 $OUT/bench_2rank_rehearsal.json   # (gloo prints a connection banner on stdout)
 du -sh $OUT

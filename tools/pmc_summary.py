@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Average FETCH_SIZE / WRITE_SIZE (KiB, rocprofv3 --pmc, one pass each) per launch of every hand-written kernel.
 Usage: pmc_summary.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass>  ->  JSON on stdout.
-Raw counter values are reported as bytes (x1024); the x2 correction of MI355X_MICROARCH.md applies to 16-B-per-lane
-streaming reads only (the FAC kernels), the dword-per-lane conv staging is uncalibrated and left as counted."""
+Raw counter values are reported as bytes (x1024).  MI355X_MICROARCH.md (section HBM): on gfx950 FETCH_SIZE reports half of
+the bytes of a 16-B-per-lane streaming read -- `fetch_bytes_per_launch` doubles the raw value for the kernels whose staging
+loads are 16-byte quads (QUAD below); dword-per-lane staging is outside the guide's calibration and left as counted.
+`bytes_per_launch` = corrected fetch + write: the `traffic` figure of bench.py."""
 import collections
 import csv
 import glob
@@ -10,6 +12,9 @@ import json
 import os
 import re
 import sys
+
+
+QUAD = ("conv_fwd_bf16x3_ws", "conv_fwd_f16_ws", "conv_wgrad_f16_tr", "fac_fwd_tile_f32", "fac_bwd_rows_f32")
 
 
 def load(d):
@@ -29,9 +34,15 @@ def main():
     res = {}
     for k in sorted(set(fetch) | set(write)):
         f, w = fetch.get(k, []), write.get(k, [])
+        fr = sum(f) / len(f) if f else None
+        wr = sum(w) / len(w) if w else None
+        fc = None if fr is None else fr * (2 if k in QUAD else 1)
         res[k] = {"launches_seen": max(len(f), len(w)),
-                  "fetch_bytes_per_launch_raw": round(sum(f) / len(f)) if f else None,
-                  "write_bytes_per_launch": round(sum(w) / len(w)) if w else None}
+                  "fetch_bytes_per_launch_raw": None if fr is None else round(fr),
+                  "fetch_correction": 2 if k in QUAD else 1,
+                  "fetch_bytes_per_launch": None if fc is None else round(fc),
+                  "write_bytes_per_launch": None if wr is None else round(wr),
+                  "bytes_per_launch": None if fc is None or wr is None else round(fc + wr)}
     print(json.dumps(res, indent=1))
 
 

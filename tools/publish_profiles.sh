@@ -10,11 +10,24 @@ cp $S/bench_prof.json $D/bench_final_profiled_run.json
 cp $S/prof/bench_kernel_stats.csv $D/bench_final_kernel_stats.csv
 cp $S/graph_replay_timeline.txt $D/graph_replay_timeline_final.txt
 cp $S/pmc_traffic_summary.json $D/bench_final_pmc_traffic_summary.json
+# the figures bench.py quotes as `traffic` / `traffic_ratio`: the summary of the latest published collection
+python3 - "$S/pmc_traffic_summary.json" "$2" <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+d = {"_comment": "HBM-side bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --no-graph`, "
+                 "mean over all launches of a kernel; FETCH_SIZE doubled for the kernels that stage with 16-byte-per-lane loads as "
+                 "MI355X_MICROARCH.md prescribes: fetch_correction); source: profiles/%s/bench_final_pmc_traffic_summary.json" % sys.argv[2], **d}
+json.dump(d, open("profiles/pmc_traffic.json", "w"), indent=1)
+PY
 cp $S/kbench.log $D/kbench_final.log
 cp $S/opbench_x3.jsonl $D/opbench_final_bf16x3.jsonl
 cp $S/opbench_fp32.jsonl $D/opbench_final_fp32.jsonl
 cp $S/opbench_dcn_fac.jsonl $D/opbench_dcn_fac_final.jsonl
-cat $S/config1.log $S/config2_fp32.log $S/config2_x3.log $S/config5.log | grep -v amdgpu.ids > $D/configs_final.log
+cat $S/config1.log $S/config2_fp32.log $S/config2_x3.log $S/config5.log $S/config5_unfused.log | grep -v amdgpu.ids > $D/configs_final.log
+cp $(find $S/prof_c2 -name "*kernel_stats.csv" | head -1) $D/infer_config2_kernel_stats.csv
+cp $(find $S/prof_c5 -name "*kernel_stats.csv" | head -1) $D/infer_config5_kernel_stats.csv
+grep -v amdgpu.ids $S/train_ours_1gpu.log > $D/train_ours_1gpu.log
+grep -v amdgpu.ids $S/f16bench.log > $D/f16bench_final.log || true
 cp $S/bench_2rank_rehearsal.json $D/bench_final_2rank_rehearsal.json
 grep -v amdgpu.ids $S/smoke.log > $D/smoke_final.log
 echo "published $S -> $D"
