@@ -58,6 +58,18 @@ def main():
     print("%-72s %8s %10s %10s %8s" % ("kernel", "calls", "sum ms", "excl ms", "avg us"))
     for n, v in total.most_common(45):
         print("%-72s %8d %10.3f %10.3f %8.1f" % (n, calls[n], v / 1e6, excl[n] / 1e6, v / calls[n] / 1e3))
+    # where the idle time sits: gaps by the kernel that FOLLOWS them (a kernel that cannot start until something else is done)
+    gaps = collections.Counter()
+    ngaps = collections.Counter()
+    end = rows[0][1]
+    for (s, e, n), prev in zip(rows[1:], rows[:-1]):
+        if s > end:
+            gaps[(prev[2], n)] += s - end
+            ngaps[(prev[2], n)] += 1
+        end = max(end, e)
+    print("largest gaps (after -> before): total us, count, avg us")
+    for (a, b), v in gaps.most_common(12):
+        print("  %-50s -> %-50s %9.1f %5d %8.1f" % (a[:50], b[:50], v / 1e3, ngaps[(a, b)], v / 1e3 / ngaps[(a, b)]))
 
 
 if __name__ == "__main__":
