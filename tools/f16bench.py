@@ -33,7 +33,7 @@ def bench(fn, iters=20):
     return tot / iters * 1e3
 
 
-def run(Cin, Cout, H=128, W=128, B=8, gmag=1.0, sparse=0.0, cold=0):
+def run(Cin, Cout, H=128, W=128, B=8, gmag=1.0, sparse=0.0, cold=0, dirty=0):
     torch.manual_seed(0)
     w = torch.nn.Parameter((torch.randn(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5).cuda())
     b = torch.nn.Parameter(torch.zeros(Cout).cuda())
@@ -59,8 +59,12 @@ def run(Cin, Cout, H=128, W=128, B=8, gmag=1.0, sparse=0.0, cold=0):
             sets.append((xd, y, g + 0))
         state = {"i": 0}
 
+        scratch = [torch.empty(dirty * 1024 * 1024 // 4, device="cuda") for _ in range(2)] if dirty else None
+
         def nxt():
             state["i"] = (state["i"] + 1) % len(sets)
+            if scratch is not None:      # what precedes a backward kernel inside a step: another kernel's freshly written output
+                scratch[0].copy_(scratch[1])
             return sets[state["i"]]
 
         def both():
@@ -84,7 +88,7 @@ def run(Cin, Cout, H=128, W=128, B=8, gmag=1.0, sparse=0.0, cold=0):
                 both()
                 res[mode] = (bench(only_x), bench(only_w))
     gf = 2.0 * B * H * W * Cin * Cout * 9 / 1e9
-    print("cold %d " % cold, end="")
+    print("cold %d dirty %d MB " % (cold, dirty), end="")
     print("%4d -> %4d  %dx%d B=%d  %7.1f GFLOP | dgrad x3 %8.1f us  f16 %8.1f us (%.0f TF/s) | wgrad x3 %8.1f us  f16 %8.1f us (%.0f TF/s)"
           % (Cin, Cout, H, W, B, gf, res["x3"][0], res["f16"][0], gf / res["f16"][0] * 1e3, res["x3"][1], res["f16"][1],
              gf / res["f16"][1] * 1e3), flush=True)
@@ -122,6 +126,9 @@ if __name__ == "__main__":
     a = [int(v) for v in sys.argv[1:]]
     if a and a[0] == -2:
         run_direct()
+    elif a and a[0] == -4:
+        for shape in ((64, 128), (128, 64)):
+            run(*shape, cold=12, dirty=128)
     elif a and a[0] == -3:
         for shape in ((64, 64), (64, 128), (128, 64)):
             run(*shape, cold=12)
