@@ -3307,14 +3307,13 @@ extern "C" int ebfi_conv2d_backward_weight_f16g(const void *input, const void *g
     float *slab = static_cast<float *>(workspace);
     int nsplit = wgrad_x3_splits(g, 3);
     // pre-activation gradients on quad-aligned rows: the pixel-major kernel with transposing LDS reads (conv_wgrad_f16_tr)
-    // ... where a workgroup walks enough tiles to pipeline them (>= 32: the 128 -> 1600 layer, 205 tiles per workgroup, 889 against
-    // 1017 us inside the step).  With the 4-8 tiles per workgroup of the 64 / 128-channel layers the kernel is faster in isolation
-    // (40 / 51 / 59 against 45 / 57 / 66 us) but slower inside a training step (102 against 72 us at 64 -> 128): its one grad_out
-    // stage in flight leaves the fill of every tile exposed once all 256 workgroups burst together behind another kernel's
-    // write-back; EBFI_WGRAD_TR=1 / 0 forces / forbids it (development switch).
+    // (EBFI_WGRAD_TR=0 keeps the pair-word kernel for A/B runs.  A first in-step measurement had this kernel at 102 us against
+    // 72 us on the 64 / 128-channel layers although it was faster in isolation; after the later changes of the round -- operand
+    // scales and their running maxima on separate cache lines, channel blocks placed per XCD -- it runs 54-63 us inside the
+    // step as well: 18.95 -> 18.45 ms per step with it on every eligible layer.)
     const char *tr_env = getenv("EBFI_WGRAD_TR");
     const int64_t tr_tiles = (int64_t)g.B * ceil_div(g.Ho, TRH) * ceil_div(g.Wo, TRW);
-    const bool tr_pays = tr_env ? tr_env[0] == '1' : tr_tiles >= 32 * (int64_t)nsplit;
+    const bool tr_pays = !(tr_env && tr_env[0] == '0');
     const bool tr_ok = act == ACT_NONE && !grad_preact_out && pad == 1 && W % 4 == 0 && aligned16(input) && aligned16(grad_output) && tr_pays;
     if (tr_ok) {
         const int64_t tiles = tr_tiles;

@@ -344,8 +344,8 @@ def test_fp16_backward_kernels_vs_cpu(B, Cin, H, W, Cout, act, xs, gs):
     from ebfi_amd import _native as N
     from ebfi_amd import conv
     import os
-    # the pixel-major weight-gradient kernel is picked for long tile walks only (the 128 -> 1600 layer): the small test shapes
-    # reach it through its development switch (read per launch), set around this test's backward only
+    # the pixel-major weight-gradient kernel is the default for activation-free layers; its development switch (read per launch)
+    # selects the pair-word kernel for some of the cases so that both forms stay covered
     force_tr = H >= 16
     prev_env = os.environ.get("EBFI_WGRAD_TR")
     os.environ["EBFI_WGRAD_TR"] = "1" if force_tr else "0"

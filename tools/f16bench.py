@@ -33,7 +33,7 @@ def bench(fn, iters=20):
     return tot / iters * 1e3
 
 
-def run(Cin, Cout, H=128, W=128, B=8, gmag=1.0, sparse=0.0, cold=0, dirty=0):
+def run(Cin, Cout, H=128, W=128, B=8, gmag=1.0, sparse=0.0, cold=0, dirty=0, xmag=1.0):
     torch.manual_seed(0)
     w = torch.nn.Parameter((torch.randn(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5).cuda())
     b = torch.nn.Parameter(torch.zeros(Cout).cuda())
@@ -42,7 +42,7 @@ def run(Cin, Cout, H=128, W=128, B=8, gmag=1.0, sparse=0.0, cold=0, dirty=0):
     book = f16scale.ScaleBook("cuda")
     bank.attach_scale_book(book)
     bank.refresh()
-    x = torch.randn(B, Cin, H, W, device="cuda")
+    x = torch.randn(B, Cin, H, W, device="cuda") * xmag
     g = torch.randn(B, Cout, H, W, device="cuda") * gmag
     if sparse > 0:                       # a few large elements, the rest `sparse` times smaller (fp16 subnormals after scaling)
         g = torch.where(torch.rand_like(g) < 1e-4, g, g * sparse)
@@ -126,6 +126,10 @@ if __name__ == "__main__":
     a = [int(v) for v in sys.argv[1:]]
     if a and a[0] == -2:
         run_direct()
+    elif a and a[0] == -5:
+        for (xm, gm) in ((1.0, 1.0), (1e-19, 1e-22), (1e-30, 1e-30), (1e-36, 1e-36)):
+            print("xmag %.0e gmag %.0e" % (xm, gm))
+            run(64, 128, cold=4, xmag=xm, gmag=gm)
     elif a and a[0] == -4:
         for shape in ((64, 128), (128, 64)):
             run(*shape, cold=12, dirty=128)
