@@ -508,7 +508,8 @@ def test_hd_config5_forward_vs_oracle_and_batch_independence():
     # (measured: 17.9 GB unfused -- the filter tensor plus the 128-channel input next to it -- against 12.9 GB fused, where the
     # peak moves to the full-resolution maps of ExposureDecision)
     assert peak_unfused - peak_fused > 4.0e9 and peak_fused < 14.0e9, (peak_unfused, peak_fused)
-    assert _rel(s8f, s8) < 1e-5 and _rel(f8f, f8) < 1e-5
+    # (the bank run also takes the merged / grouped ResidualControl convolutions: another summation order, 2e-5 measured)
+    assert _rel(s8f, s8) < 1e-4 and _rel(f8f, f8) < 1e-4
     assert s8.shape == (8, 3, 720, 1280) and torch.isfinite(f8).all()
     # (global means over 921 600 pixels are reduced in a batch-dependent partition: 2e-5 measured)
     assert _rel(s8[5:6], s1) < 1e-4 and _rel(f8[5:6], f1) < 1e-4
