@@ -3314,17 +3314,28 @@ extern "C" int ebfi_conv2d_backward_weight_f16g(const void *input, const void *g
     const char *tr_env = getenv("EBFI_WGRAD_TR");
     const int64_t tr_tiles = (int64_t)g.B * ceil_div(g.Ho, TRH) * ceil_div(g.Wo, TRW);
     const bool tr_pays = !(tr_env && tr_env[0] == '0');
-    const bool tr_ok = act == ACT_NONE && !grad_preact_out && pad == 1 && W % 4 == 0 && aligned16(input) && aligned16(grad_output) && tr_pays;
+    const bool tr_ok = pad == 1 && W % 4 == 0 && aligned16(input) && aligned16(grad_output) && tr_pays &&
+                       (act == ACT_NONE || aligned16(saved_output)) && (!grad_preact_out || aligned16(grad_preact_out));
     if (tr_ok) {
         const int64_t tiles = tr_tiles;
         if (tiles > 2147483647LL) return fail(EBFI_ERR_ARG, "conv2d_backward_weight_f16g: too many tiles");
         if (nsplit > tiles) nsplit = (int)tiles;
         dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, 64));
         const ScaleSlot xs{static_cast<float *>(x_slot)}, gs{static_cast<float *>(g_slot)};
-        ProfScope ps("conv_wgrad_f16_tr", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * 9, conv_bytes_wgrad(g, 9, false, false));
-        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_wgrad_f16_tr), TR_LDS)) return rc_;
-        hipLaunchKernelGGL(conv_wgrad_f16_tr, grid, dim3(512), TR_LDS, st, static_cast<const float *>(input),
-                           static_cast<const float *>(grad_output), slab, g, (int)tiles, grad_bias != nullptr ? 1 : 0, xs, gs);
+        ProfScope ps("conv_wgrad_f16_tr", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * 9,
+                     conv_bytes_wgrad(g, 9, act != ACT_NONE, grad_preact_out != nullptr));
+#define EBFI_LAUNCH_WTR(DA_)                                                                                               \
+    do {                                                                                                                   \
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_wgrad_f16_tr<DA_>), TR_LDS)) return rc_;       \
+        hipLaunchKernelGGL((conv_wgrad_f16_tr<DA_>), grid, dim3(512), TR_LDS, st, static_cast<const float *>(input),           \
+                           static_cast<const float *>(grad_output), static_cast<const float *>(saved_output),              \
+                           static_cast<float *>(grad_preact_out), slab, g, slope, (int)tiles, grad_bias != nullptr ? 1 : 0,  \
+                           xs, gs);                                                                                        \
+    } while (0)
+        if (act == ACT_LEAKY) EBFI_LAUNCH_WTR(ACT_LEAKY);
+        else if (act == ACT_SIGMOID) EBFI_LAUNCH_WTR(ACT_SIGMOID);
+        else EBFI_LAUNCH_WTR(ACT_NONE);
+#undef EBFI_LAUNCH_WTR
         if (int rc = check_launch("conv_wgrad_f16_tr")) return rc;
     } else {
         using C = WCfg<3, 1, 32>;

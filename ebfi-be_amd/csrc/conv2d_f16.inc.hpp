@@ -615,9 +615,14 @@ constexpr int TRH = 4, TRW = 32, TRXR = TRH + 2, TRXQ = 10, TRXW = 36;      // t
 constexpr int TR_XB = TRXR * TRXW * 128, TR_GB = TRH * TRW * 128, TR_BUFB = TR_XB + TR_GB;
 constexpr int TR_LDS = 2 * TR_BUFB + 4 * 64 * 4;                             // two buffers + the bias scratch
 
+// DACT != 0: grad_out is multiplied by act'(saved output) on the way in (the layer's own activation folded, as in the other
+// weight-gradient kernels) and, with gpre_out, the product is written out for the data gradient; the saved-output quads take
+// the registers of the second input stage, so this form keeps ONE tile of input loads in flight.
+template <int DACT>
 __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict__ x, const float *__restrict__ gout,
-                                                         float *__restrict__ slab, ConvGeom g, int total_tiles, int need_bias,
-                                                         ScaleSlot x_slot, ScaleSlot g_slot) {
+                                                         const float *__restrict__ yact, float *__restrict__ gpre_out,
+                                                         float *__restrict__ slab, ConvGeom g, float dslope, int total_tiles,
+                                                         int need_bias, ScaleSlot x_slot, ScaleSlot g_slot) {
     constexpr int KK = 9, PT = 256, NQ = 4;
     constexpr int NXI = TRXR * TRXQ * 8, NXK = (NXI + PT - 1) / PT;          // input items (row, quad, 8-channel group): 480, 2 per thread
     static_assert(NXK == 2 && TRH * (TRW / 4) * 8 == PT, "one grad_out item and two input items per producer thread");
@@ -757,7 +762,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict
         u32x4 rx[NXK][8];
     };
     XStage sa, sb;
-    u32x4 rg[8];
+    u32x4 rg[8], ry[DACT != 0 ? 8 : 1];
     float bacc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bacc[e] = 0.f;
@@ -777,6 +782,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict
         const unsigned o = (gy < g.Ho && gx + 3 < g.Wo) ? (unsigned)((co_base + 8 * chg) * HWo + gy * g.Wo + gx) * 4u : SENT;
 #pragma unroll
         for (int e = 0; e < 8; ++e) rg[e] = __builtin_amdgcn_raw_buffer_load_b128(rgo, o + (unsigned)e * gplane, 0, 0);
+        if constexpr (DACT != 0) {
+            const __amdgpu_buffer_rsrc_t rya = make_rsrc(yact + (int64_t)(live ? b : 0) * g.Cout * HWo, live ? go_bytes : 0u);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ry[e] = __builtin_amdgcn_raw_buffer_load_b128(rya, o + (unsigned)e * gplane, 0, 0);
+        }
     };
     auto prefetch_x = [&](int tile, XStage &s) {
         int b, y0, x0;
@@ -792,8 +802,25 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict
             for (int e = 0; e < 8; ++e) s.rx[k][e] = __builtin_amdgcn_raw_buffer_load_b128(rxi, o + (unsigned)e * xplane, 0, 0);
         }
     };
-    auto commit_g = [&](int buf) {
+    auto commit_g = [&](int buf, int tile) {
         char *gi = smt + buf * TR_BUFB + TR_XB;
+        if constexpr (DACT != 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    rg[e][j] = __float_as_uint(__uint_as_float(rg[e][j]) * act_grad_c<DACT>(__uint_as_float(ry[e][j]), dslope));
+            if (gpre_out != nullptr && ci_blk == 0) {        // grad * act' for the data gradient: one writer per output-channel block
+                int b, y0, x0;
+                tile_coords(tile, b, y0, x0);
+                const bool live = tile < total_tiles;
+                const __amdgpu_buffer_rsrc_t rgp = make_rsrc(gpre_out + (int64_t)(live ? b : 0) * g.Cout * HWo, live ? go_bytes : 0u);
+                const int gy = y0 + g_y, gx = x0 + 4 * g_q;
+                const unsigned o = (gy < g.Ho && gx + 3 < g.Wo) ? (unsigned)((co_base + 8 * chg) * HWo + gy * g.Wo + gx) * 4u : SENT;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) __builtin_amdgcn_raw_buffer_store_b128(rg[e], rgp, o + (unsigned)e * gplane, 0, 0);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             u32x4 hv;
@@ -833,26 +860,39 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict
     prefetch_x(split, sa);
     prefetch_g(split);
     commit_x(0, sa);
-    commit_g(0);
-    prefetch_x(split + G, sa);        // from here on: input quads of two tiles, grad_out quads of one in flight
+    commit_g(0, split);
+    prefetch_x(split + G, sa);
     prefetch_g(split + G);
-    prefetch_x(split + 2 * G, sb);
-    __syncthreads();                       // (A)
-    int cur = 0;
-    for (int tile = split; tile < total_tiles; tile += 2 * G) {
-        commit_x(cur ^ 1, sa);             // tile + G, while the consumers multiply tile `tile` from image `cur`
-        prefetch_x(tile + 3 * G, sa);      // (past the end: zero-record descriptors, nothing is read)
-        commit_g(cur ^ 1);
-        prefetch_g(tile + 2 * G);
-        __syncthreads();                   // (B)
-        cur ^= 1;
-        if (tile + G >= total_tiles) break;
-        commit_x(cur ^ 1, sb);             // tile + 2 G
-        prefetch_x(tile + 4 * G, sb);
-        commit_g(cur ^ 1);
-        prefetch_g(tile + 3 * G);
-        __syncthreads();                   // (B)
-        cur ^= 1;
+    if constexpr (DACT == 0) {
+        prefetch_x(split + 2 * G, sb);     // from here on: input quads of two tiles, grad_out quads of one in flight
+        __syncthreads();                   // (A)
+        int cur = 0;
+        for (int tile = split; tile < total_tiles; tile += 2 * G) {
+            commit_x(cur ^ 1, sa);         // tile + G, while the consumers multiply tile `tile` from image `cur`
+            prefetch_x(tile + 3 * G, sa);  // (past the end: zero-record descriptors, nothing is read)
+            commit_g(cur ^ 1, tile + G);
+            prefetch_g(tile + 2 * G);
+            __syncthreads();               // (B)
+            cur ^= 1;
+            if (tile + G >= total_tiles) break;
+            commit_x(cur ^ 1, sb);         // tile + 2 G
+            prefetch_x(tile + 4 * G, sb);
+            commit_g(cur ^ 1, tile + 2 * G);
+            prefetch_g(tile + 3 * G);
+            __syncthreads();               // (B)
+            cur ^= 1;
+        }
+    } else {
+        __syncthreads();                   // (A)
+        int cur = 0;
+        for (int tile = split; tile < total_tiles; tile += G) {
+            commit_x(cur ^ 1, sa);         // tile + G
+            prefetch_x(tile + 2 * G, sa);
+            commit_g(cur ^ 1, tile + G);
+            prefetch_g(tile + 2 * G);
+            __syncthreads();               // (B)
+            cur ^= 1;
+        }
     }
     x_slot.record(amax_x);
     g_slot.record(amax_g);

@@ -373,9 +373,9 @@ def test_fp16_backward_kernels_vs_cpu(B, Cin, H, W, Cout, act, xs, gs):
             os.environ.pop("EBFI_WGRAD_TR", None)
         else:
             os.environ["EBFI_WGRAD_TR"] = prev_env
-    # both gradients took the fp16 kernels: the weight gradient the pixel-major form (transposing LDS reads) when the layer has
-    # no activation to fold, the pair-word form otherwise
-    assert prof.get("conv_wgrad_f16_tr" if (act == 0 and force_tr) else "conv_wgrad_f16_ws") == 1 and prof.get("conv_fwd_f16_ws") == 1, prof
+    # both gradients took the fp16 kernels: the weight gradient in its pixel-major form (transposing LDS reads; with act != 0 it
+    # folds act'(y) and writes grad * act' for the data gradient) or, switched, in the pair-word form
+    assert prof.get("conv_wgrad_f16_tr" if force_tr else "conv_wgrad_f16_ws") == 1 and prof.get("conv_fwd_f16_ws") == 1, prof
     assert "conv_wgrad_x3_ws" not in prof and "conv_fwd_bf16x3_ws/dgrad" not in prof
     assert _rel(xd.grad, xr.grad) < 1e-3 and _rel(w.grad, wr.grad) < 1e-3 and _rel(b.grad, br.grad) < 1e-5
     assert int(book.guard[0].item()) == 0                   # calibrated scales: nothing left the range
