@@ -3287,7 +3287,12 @@ extern "C" int ebfi_conv2d_backward_weight_f16g(const void *input, const void *g
                                                 size_t workspace_bytes, void *stream) {
     if (!input || !grad_output || !grad_weight) return fail(EBFI_ERR_ARG, "conv2d_backward_weight_f16g: null argument");
     if (ksize != 3) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_weight_f16g: k=%d", ksize);
-    if (Cin_per_group % 64 != 0) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_weight_f16g: %d input channels per group (multiples of 64)", Cin_per_group);
+    // input channels: multiples of 64 for the pair-word kernel; the pixel-major kernel zero-fills a partial 64-channel block
+    // (loads past the sample's last channel read 0, columns past Cin are not stored), which serves the 32 / 48-channel layers
+    // of the detail branch -- at some wasted matrix work, which is not what bounds these launches
+    const bool ragged_ci = Cin_per_group % 64 != 0;
+    if (ragged_ci && (groups != 1 || Cin_per_group < 16))
+        return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_weight_f16g: %d input channels per group", Cin_per_group);
     if (act < 0 || act > 2 || (act != ACT_NONE && !saved_output)) return fail(EBFI_ERR_ARG, "conv2d_backward_weight_f16g: activation / saved_output");
     if (groups < 1 || Cout % groups != 0 || (groups > 1 && (Cout / groups) % 64 != 0))
         return fail(EBFI_ERR_ARG, "conv2d_backward_weight_f16g: %d output channels in %d groups", Cout, groups);
@@ -3338,6 +3343,9 @@ extern "C" int ebfi_conv2d_backward_weight_f16g(const void *input, const void *g
 #undef EBFI_LAUNCH_WTR
         if (int rc = check_launch("conv_wgrad_f16_tr")) return rc;
     } else {
+        if (ragged_ci)
+            return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_weight_f16g: %d input channels need the pixel-major kernel (3x3, pad 1, W %% 4 == 0, "
+                                              "16-byte aligned tensors)", Cin_per_group);
         using C = WCfg<3, 1, 32>;
         const size_t lds = (size_t)2 * (32 * GS + 33 * C::PS) * sizeof(unsigned);
         const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, WTY) * ceil_div(g.Wo, C::WTX);

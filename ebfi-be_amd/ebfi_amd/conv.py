@@ -230,7 +230,9 @@ class SiteConvBiasAct(Function):
         book = f16scale.active_book()
         B, Cin, H, W, M, ks, _, pad = geo
         f16 = book is not None and ks == 3 and pad == 1
-        f16_w = f16 and Cin % 64 == 0
+        # (partial 64-channel blocks -- the 32 / 48-channel layers of the detail branch -- go through the pixel-major kernel, which
+        # needs quad-aligned rows; below 32 channels the zero-filled half of the block would be most of the work)
+        f16_w = f16 and (Cin % 64 == 0 or (Cin >= 32 and W % 4 == 0 and os.environ.get("EBFI_WGRAD_TR", "1") != "0"))
         f16_x = f16 and W % 4 == 0 and Cin >= 48 and site.tr16_ptr() is not None
         with torch.cuda.device_of(x):
             st = N.stream_ptr(x.device)
