@@ -31,16 +31,31 @@ __device__ __forceinline__ float block_sum(float v, float *red) {      // 256 th
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(256) void plane_mean_kernel(const float *__restrict__ x, float *__restrict__ mean, int64_t N4) {
+// Round 3: the two per-plane reductions ran ONE workgroup per (b, c) plane -- 128 workgroups streaming 128-384 KB each on the
+// largest gates (0.4 TB/s, 48 / 129 us).  A plane is now cut into `S` slices (grid = S x planes, like the apply kernels);
+// the slice sums land in a scratch area and are added in slice order by a tiny finalising kernel (forward) / by
+// se_bwd_small (backward): same fixed-order determinism, ten times the workgroups.  The scratch is the head of a tensor the
+// NEXT kernel of the gate overwrites anyway (`out` forward, `grad_x` backward: planes * S <= planes * N floats).
+__global__ __launch_bounds__(256) void plane_mean_kernel(const float *__restrict__ x, float *__restrict__ part, int64_t N4) {
     __shared__ float red[4];
-    const f4 *p = reinterpret_cast<const f4 *>(x) + (int64_t)blockIdx.x * N4;
+    const int plane = blockIdx.y, S = gridDim.x;
+    const f4 *p = reinterpret_cast<const f4 *>(x) + (int64_t)plane * N4;
     float s = 0.f;
-    for (int64_t i = threadIdx.x; i < N4; i += 256) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N4; i += (int64_t)S * 256) {
         const f4 v = p[i];
         s += (v.x + v.y) + (v.z + v.w);
     }
     s = block_sum(s, red);
-    if (threadIdx.x == 0) mean[blockIdx.x] = s / (float)(N4 * 4);
+    if (threadIdx.x == 0) part[(int64_t)plane * S + blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void plane_mean_finish_kernel(const float *__restrict__ part, float *__restrict__ mean, int planes,
+                                                                int S, float inv_n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= planes) return;
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += part[(int64_t)i * S + k];
+    mean[i] = s * inv_n;
 }
 
 __device__ __forceinline__ float gate_of(const float *__restrict__ mean, const float *__restrict__ W, const float *__restrict__ bias,
@@ -83,16 +98,17 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const float *__restr
                                                             const float *__restrict__ x, float *__restrict__ ggate, int64_t N4,
                                                             int act, float slope) {
     __shared__ float red[4];
-    const int64_t base = (int64_t)blockIdx.x * N4;
+    const int plane = blockIdx.y, S = gridDim.x;
+    const int64_t base = (int64_t)plane * N4;
     const f4 *pg = reinterpret_cast<const f4 *>(gout) + base, *po = reinterpret_cast<const f4 *>(out) + base;
     const f4 *px = reinterpret_cast<const f4 *>(x) + base;
     float s = 0.f;
-    for (int64_t i = threadIdx.x; i < N4; i += 256) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N4; i += (int64_t)S * 256) {
         const f4 g = act_mask(pg[i], po[i], act, slope), v = px[i];
         s += (g.x * v.x + g.y * v.y) + (g.z * v.z + g.w * v.w);
     }
     s = block_sum(s, red);
-    if (threadIdx.x == 0) ggate[blockIdx.x] = s;
+    if (threadIdx.x == 0) ggate[(int64_t)plane * S + blockIdx.x] = s;      // slice sums; se_bwd_small adds them in order
 }
 
 // one workgroup: gz[b,c] = ggate*gate*(1-gate) -> grad_W[c,k] = sum_b gz[b,c] mean[b,k], grad_b[c] = sum_b gz[b,c],
@@ -100,11 +116,13 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const float *__restr
 __global__ __launch_bounds__(256) void se_bwd_small_kernel(const float *__restrict__ ggate, const float *__restrict__ gate,
                                                            const float *__restrict__ mean, const float *__restrict__ W,
                                                            float *__restrict__ gW, float *__restrict__ gb, float *__restrict__ gmean,
-                                                           int B, int C) {
+                                                           int B, int C, int S) {
     __shared__ float gz[4096];
     for (int i = threadIdx.x; i < B * C; i += 256) {
         const float s = gate[i];
-        gz[i] = ggate[i] * s * (1.f - s);
+        float gg = 0.f;
+        for (int k = 0; k < S; ++k) gg += ggate[(int64_t)i * S + k];          // slice sums of se_bwd_reduce, fixed order
+        gz[i] = gg * s * (1.f - s);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < C * C; i += 256) {
@@ -166,7 +184,10 @@ extern "C" int ebfi_se_gate_forward(const float *x, const float *weight, const f
     hipStream_t st = static_cast<hipStream_t>(stream);
     {
         ProfScope ps("se_gate_fwd", st, 0.0, 4.0 * B * C * (double)N * (res ? 4 : 3));
-        hipLaunchKernelGGL(plane_mean_kernel, dim3((unsigned)(B * C)), dim3(256), 0, st, x, mean, N / 4);
+        const unsigned S = slices(N / 4);
+        hipLaunchKernelGGL(plane_mean_kernel, dim3(S, (unsigned)(B * C)), dim3(256), 0, st, x, out, N / 4);   // slice sums -> head of `out`
+        hipLaunchKernelGGL(plane_mean_finish_kernel, dim3((unsigned)((B * C + 255) / 256)), dim3(256), 0, st, out, mean, B * C, (int)S,
+                           1.f / (float)N);
         hipLaunchKernelGGL(se_apply_fwd_kernel, dim3(slices(N / 4), (unsigned)(B * C)), dim3(256), 0, st, x, mean, weight, bias, res,
                            out, gate, C, N / 4, act, slope);
     }
@@ -184,12 +205,16 @@ extern "C" int ebfi_se_gate_backward(const float *grad_out, const float *out, co
     if (int rc = check("se_gate_backward", B, C, N)) return rc;
     if (B == 0) return EBFI_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    float *ggate = workspace, *gmean = workspace + (size_t)B * C;
+    float *gmean = workspace + (size_t)B * C;      // (workspace[0 .. B*C) is no longer used: the slice sums live in grad_x)
     const float *o = out ? out : grad_out;      // act == 0: `out` is not read through the mask
     {
         ProfScope ps("se_gate_bwd", st, 0.0, 4.0 * B * C * (double)N * (grad_res ? 7 : 6));
-        hipLaunchKernelGGL(se_bwd_reduce_kernel, dim3((unsigned)(B * C)), dim3(256), 0, st, grad_out, o, x, ggate, N / 4, act, slope);
-        hipLaunchKernelGGL(se_bwd_small_kernel, dim3(1), dim3(256), 0, st, ggate, gate, mean, weight, grad_weight, grad_bias, gmean, B, C);
+        const unsigned S = slices(N / 4);
+        // slice sums into the head of grad_x (B*C*S <= B*C*N floats; se_bwd_apply overwrites it afterwards); grad_x must not
+        // alias grad_out / out / x, which the callers guarantee (freshly allocated)
+        hipLaunchKernelGGL(se_bwd_reduce_kernel, dim3(S, (unsigned)(B * C)), dim3(256), 0, st, grad_out, o, x, grad_x, N / 4, act, slope);
+        hipLaunchKernelGGL(se_bwd_small_kernel, dim3(1), dim3(256), 0, st, grad_x, gate, mean, weight, grad_weight, grad_bias, gmean, B, C,
+                           (int)S);
         hipLaunchKernelGGL(se_bwd_apply_kernel, dim3(slices(N / 4), (unsigned)(B * C)), dim3(256), 0, st, grad_out, o, gate, gmean,
                            grad_x, grad_res, N / 4, act, slope);
     }

@@ -318,7 +318,9 @@ int ebfi_gather_sum(const float *src, const int32_t *idx, float *out, int64_t n_
  * x, res, out: [B*C planes][N] contiguous fp32 (a [B,C,D,H,W] tensor as it stands), N % 4 == 0, B*C <= 4096;
  * weight [C,C] (the 1x1x1 conv), bias [C] or NULL; act: 0 none, 1 LeakyReLU(slope) (slope 0 = ReLU).
  * forward writes mean [B*C] and gate [B*C] for the backward; backward workspace: 2*B*C floats; grad_res / grad_bias may
- * be NULL; `out` may be NULL when act == 0.  Deterministic (fixed-order reductions). */
+ * be NULL; `out` may be NULL when act == 0 (backward).  Deterministic (fixed-order reductions).  The head of `out` (forward) and of
+ * `grad_x` (backward) serves as scratch for the slice sums of the plane reductions before the tensor itself is written: neither
+ * may alias an input. */
 int ebfi_se_gate_forward(const float *x, const float *weight, const float *bias, const float *res, float *out, float *mean,
                          float *gate, int B, int C, int64_t N, int act, float slope, void *stream);
 int ebfi_se_gate_backward(const float *grad_out, const float *out, const float *x, const float *weight, const float *gate,

@@ -623,7 +623,9 @@ def test_se_gate_kernels_vs_torch_cpu():
     import torch.nn.functional as F
     from ebfi_amd.model import SEGating
     torch.manual_seed(23)
-    for (B, C, H, W, res, act) in [(2, 16, 8, 12, True, 0.0), (3, 24, 6, 10, False, 0.2), (1, 8, 5, 8, False, None), (2, 64, 4, 4, True, 0.0)]:
+    # (the 64 x 96 and 128 x 128 planes are cut into 2 / 4 slices by the sliced plane reductions of round 3)
+    for (B, C, H, W, res, act) in [(2, 16, 8, 12, True, 0.0), (3, 24, 6, 10, False, 0.2), (1, 8, 5, 8, False, None), (2, 64, 4, 4, True, 0.0),
+                                   (2, 16, 64, 96, True, 0.0), (1, 16, 128, 128, False, 0.2)]:
         gate = SEGating(C)
         with torch.no_grad():
             gate.attn_layer[0].weight.copy_(torch.randn_like(gate.attn_layer[0].weight) * 0.5)
