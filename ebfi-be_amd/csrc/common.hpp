@@ -16,6 +16,12 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 // hipGetLastError() after a launch -> EBFI_OK / EBFI_ERR_LAUNCH (with message)
 int check_launch(const char *what);
 
+// Development switches (EBFI_CONV_*, EBFI_WGRAD_*: kernel selection for A/B runs and tests) are honoured ONLY when the process
+// was started with EBFI_DEV=1 (looked up once): a production process never changes kernels, split counts or reduction order
+// because of a stray environment variable, and pays no getenv per launch (round-2 advisory).  The switch itself is read on
+// every call, so a test can flip it between launches.
+const char *dev_getenv(const char *name);
+
 // Raises a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) to at least `bytes` on the CURRENT
 // device, once per (kernel, device), thread-safe; EBFI_OK or EBFI_ERR_LAUNCH with the HIP error text.
 int ensure_dynamic_lds(const void *kernel, int bytes);

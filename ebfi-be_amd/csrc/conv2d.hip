@@ -2119,11 +2119,11 @@ int pick_wtx_x3(int) { return 32; }
 // than the second resident workgroup hides).
 // wave-specialised form (conv_wgrad_x3_ws): every 3x3 layer; EBFI_WGRAD_WS=0 restores the uniform-wave kernels (A/B runs)
 bool wgrad_x3_ws(const ConvGeom &g, int ks) {   // 64-channel input blocks: layers with other channel counts keep the 32-channel form
-    const char *e = getenv("EBFI_WGRAD_WS");
+    const char *e = dev_getenv("EBFI_WGRAD_WS");
     return ks == 3 && g.Cin % 64 == 0 && !(e && e[0] == '0');
 }
 bool wgrad_x3_small_wg(const ConvGeom &g, int ks) {
-    const bool off = getenv("EBFI_WGRAD_BIGWG") != nullptr;            // development switch (A/B runs)
+    const bool off = dev_getenv("EBFI_WGRAD_BIGWG") != nullptr;            // development switch (A/B runs)
     return !off && !wgrad_x3_ws(g, ks) && ks == 3 && g.Cin % 32 == 0 && g.Cout <= 256;
 }
 
@@ -2482,7 +2482,7 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
     const double flops = 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS;
     // 32 output channels per workgroup when 64 would leave more than half of the CUs without one (small feature maps of the
     // detail branch): twice the workgroups, each with half the matrix work per staged chunk
-    const bool few = x3 && tiles * ceil_div(g.Cout, 64) <= 128 && getenv("EBFI_CONV_NO_MT1") == nullptr;
+    const bool few = x3 && tiles * ceil_div(g.Cout, 64) <= 128 && dev_getenv("EBFI_CONV_NO_MT1") == nullptr;
     const int mt = (g.Cout <= 32 || few) ? 1 : 2;
     dim3 grid((unsigned)tiles, (unsigned)ceil_div(g.Cout, 32 * mt));
     if (x3) {
@@ -2490,12 +2490,12 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
         const size_t lds = (size_t)2 * (2 * PSX * 32 + 2 * KS * KS * 32 * mt * 32) + KB_LDS_BYTES;   // two buffers of unpadded hi/lo images
         // 16-byte input quads: rows must keep quads aligned, same-padding only; used where they pay (see the kernel's header)
         const bool vec4 = g.W % 4 == 0 && g.pad == KS / 2 && aligned16(x) && (!dact_y || aligned16(dact_y));
-        const char *ws_env = getenv("EBFI_CONV_WS");
+        const char *ws_env = dev_getenv("EBFI_CONV_WS");
         const bool extra = epi.addend != nullptr || epi.mask_y != nullptr;
         // wave-specialised form (conv_fwd_bf16x3_ws): every 3x3 layer the quad-staging producers can serve (64-channel blocks, no
         // folded activation derivative); EBFI_CONV_WS=0 / 1 = never / only the long layers (development switch, A/B runs)
         const bool ws_long = ceil_div(g.Cout, 64) >= 8 || K16 >= 512;
-        const bool ws_extra_ok = !extra || getenv("EBFI_CONV_WS_NOEXTRA") == nullptr;
+        const bool ws_extra_ok = !extra || dev_getenv("EBFI_CONV_WS_NOEXTRA") == nullptr;
         const bool use_ws = KS == 3 && mt == 2 && vec4 && dact == ACT_NONE && ws_extra_ok && !(ws_env && ws_env[0] == '0') &&
                             (ws_long || !(ws_env && ws_env[0] == '1'));
         if (use_ws) name = transposed ? "conv_fwd_bf16x3_ws/dgrad" : "conv_fwd_bf16x3_ws/fwd";
@@ -2512,14 +2512,14 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
         if (vec == 4) EBFI_LAUNCH_X3V(MT_, DA_, 4);                                                                      \
         else EBFI_LAUNCH_X3V(MT_, DA_, 1);                                                                               \
     } while (0)
-        const char *vec_env = getenv("EBFI_CONV_VEC");     // development switch (tools/kbench): 1 = dword loads, 4 = quad loads
+        const char *vec_env = dev_getenv("EBFI_CONV_VEC");     // development switch (tools/kbench): 1 = dword loads, 4 = quad loads
         const int vec = !vec4 ? 1 : (vec_env ? atoi(vec_env) : (dact != ACT_NONE ? 4 : 1));
         // the persistent form (3x3, dword loads, no folded derivative): one round of workgroups, each walking
         // ceil(tiles / gx) pixel tiles of its output-channel block
         const int64_t co_blocks = ceil_div(g.Cout, 32 * mt);
         int64_t gx = 256 / co_blocks;
         if (gx < 1) gx = 1;
-        if (gx > tiles || getenv("EBFI_CONV_NOPERSIST")) gx = tiles;
+        if (gx > tiles || dev_getenv("EBFI_CONV_NOPERSIST")) gx = tiles;
         const dim3 pgrid((unsigned)gx, (unsigned)co_blocks);
         if constexpr (KS == 3) {
             if (use_ws) {
@@ -3316,7 +3316,7 @@ extern "C" int ebfi_conv2d_backward_weight_f16g(const void *input, const void *g
     // 72 us on the 64 / 128-channel layers although it was faster in isolation; after the later changes of the round -- operand
     // scales and their running maxima on separate cache lines, channel blocks placed per XCD -- it runs 54-63 us inside the
     // step as well: 18.95 -> 18.45 ms per step with it on every eligible layer.)
-    const char *tr_env = getenv("EBFI_WGRAD_TR");
+    const char *tr_env = dev_getenv("EBFI_WGRAD_TR");
     const int64_t tr_tiles = (int64_t)g.B * ceil_div(g.Ho, TRH) * ceil_div(g.Wo, TRW);
     const bool tr_pays = !(tr_env && tr_env[0] == '0');
     const bool tr_ok = pad == 1 && W % 4 == 0 && aligned16(input) && aligned16(grad_output) && tr_pays &&

@@ -487,11 +487,15 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_f32(const float *__restri
             const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rgo, pb + (unsigned)co * (unsigned)g.HWo * 4u, 0, 0));
             s2 += v * v;
         }
+        // (fmaxf drops NaN operands: a NaN / Inf column must poison the bound explicitly, or the integer box below would
+        // launder it into a finite sum)
+        const int bad = __syncthreads_or(!(s2 <= 3.0e38f));
         gmax2 = wg_max256(s2, sCG);
+        if (bad) gmax2 = __builtin_nanf("");
     }
     for (int chunk = 0; chunk < g.nchunks; ++chunk) {
         const Chunk ck = get_chunk(g, chunk);
-        const bool box_on = bx.use && ck.cb <= BOX_CH;
+        bool box_on = bx.use && ck.cb <= BOX_CH;
         __syncthreads();                   // previous chunk's flush has read the box
         float fx_scale = 1.f, fx_inv = 1.f;
         if (box_on) {
@@ -560,6 +564,11 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_f32(const float *__restri
                 e = min(max(30 - e, -120), 120);
                 fx_scale = ldexpf(1.f, e);
                 fx_inv = ldexpf(1.f, -e);
+            } else if (!(bound == 0.f)) {
+                // NaN / Inf in grad_output, the weights or the masks (or a bound beyond fp32): the integer box would turn them
+                // into finite garbage (__float2int_rn maps NaN to 0 and saturates Inf).  This chunk scatters with plain float
+                // global atomics instead, which propagate non-finite values like the reference's col2im does (round-2 advisory).
+                box_on = false;
             }
         }
         const bool first_sub = (chunk % g.nsub) == 0;   // first channel sub-block of this group

@@ -111,6 +111,13 @@ ProfScope::~ProfScope() {
 
 }  // namespace ebfi
 
+namespace ebfi {
+const char *dev_getenv(const char *name) {
+    static const bool dev = [] { const char *e = getenv("EBFI_DEV"); return e != nullptr && e[0] == '1'; }();
+    return dev ? getenv(name) : nullptr;
+}
+}  // namespace ebfi
+
 using namespace ebfi;
 
 extern "C" {

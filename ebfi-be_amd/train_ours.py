@@ -188,6 +188,10 @@ def main():
         if scheduler is not None and it % st["lr_change_rate"] == 0 and it != 0 and lr_now >= st["lr_min"]:   # :335-338
             scheduler.step()
         it += 1
+    if rank == 0 and eng.book is not None:
+        # fp16 backward (ebfi_amd.f16scale): optimiser steps skipped because an operand left the fp16 range (expected: 0)
+        print("fp16 backward: %d of %d optimiser steps skipped by the overflow guard, %d operand scale slots"
+              % (eng.book.skipped_steps(), st["iterations"] - start, len(eng.book.index)), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -11,6 +11,10 @@ for p in (ROOT, PKG):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# the library honours its development switches (EBFI_WGRAD_TR, EBFI_CONV_*: kernel selection) only in a process started with
+# EBFI_DEV=1; some tests flip them to cover both forms of a kernel
+os.environ.setdefault("EBFI_DEV", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -199,3 +199,17 @@ def test_dcn_forward_split_precision_product_vs_oracle():
         assert _rel(plain.cpu(), ref) < 1e-5
         assert "dcn_fwd_bf16x3" in N.prof_collect()
         assert _rel(out.cpu(), ref) < 1e-4
+
+
+def test_non_finite_grad_output_propagates_through_grad_input():
+    """Round-2 advisory: the fixed-point LDS box of dcn_bwd_data must not launder NaN / Inf in grad_output into finite
+    numbers (__float2int_rn(NaN) == 0).  With a non-finite a-priori bound the chunk falls back to float global atomics: the
+    touched cells of grad_input are then non-finite, exactly the cells the reference's atomicAdd col2im would poison."""
+    from ebfi_amd.dcn import dcn_v2_backward
+    x, off, msk, w, b, g = _inputs(B=1, C=8, H=16, W=16, Co=8, k=3, s=1, p=1, d=1, dg=1, seed=5, off_scale=0.5)
+    g[0, 3, 7, 9] = float("nan")
+    gi = dcn_v2_backward(*[v.cuda() for v in (x, w, b, off, msk, g)], (1, 1), (1, 1), (1, 1), 1)[0].cpu()
+    ref = ref_ops.dcn_backward(x, w, b, off, msk, g, 1, 1, 1, 1)[0]
+    bad, bad_ref = ~torch.isfinite(gi), ~torch.isfinite(ref)
+    assert bad_ref.any() and torch.equal(bad, bad_ref)
+    assert _rel(gi[~bad], ref[~bad_ref]) < 5e-5

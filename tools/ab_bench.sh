@@ -6,7 +6,7 @@ mkdir -p gpurun_out/ab
 for round in 1 2; do
 for spec in "$@"; do
   name="${spec%%=*}"; envs="${spec#*=}"
-  env $envs timeout -k 10 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra-legs --no-ops > gpurun_out/ab/$name.$round.json 2> gpurun_out/ab/$name.$round.err || { echo "$name failed"; tail -3 gpurun_out/ab/$name.$round.err; continue; }
+  env EBFI_DEV=1 $envs timeout -k 10 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra-legs --no-ops > gpurun_out/ab/$name.$round.json 2> gpurun_out/ab/$name.$round.err || { echo "$name failed"; tail -3 gpurun_out/ab/$name.$round.err; continue; }
   python3 - "$name" "$round" <<'PY'
 import json,sys
 d=json.load(open("gpurun_out/ab/%s.%s.json"%(sys.argv[1],sys.argv[2])))

@@ -5,6 +5,7 @@ usage: python tools/f16bench.py [Cin Cout [H W B]] ...   (default: the step's sh
 import os
 import sys
 
+os.environ.setdefault("EBFI_DEV", "1")      # this tool flips the library's development switches
 import torch
 
 LAST = {}
