@@ -283,12 +283,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    untimed = {}
+
     def timed_run(tag):
         """W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize (max over ranks);
         afterwards the same K steps once more, eagerly, with the library's hipEvent pairs switched on, for the
         per-kernel table (a hipGraph replay cannot carry per-kernel event pairs, and the pairs cost a little time,
         so they stay out of the timed region)."""
-        for i in range(args.warmup):
+        # the engine's first steps are not the steady state: with the fp16 backward it takes `calibration_steps` eager steps
+        # (operand scales measured just in time) and captures the graph on the next one.  If W is too small to cover
+        # them, extra untimed steps are added so that the timed region never holds a capture (reported as untimed_steps).
+        settle = 0
+        if eng.use_graph:
+            cal = max(0, eng.calibration_steps - eng._steps_run) if (eng.book is not None and eng.precision == "bf16x3") else 0
+            capture = 0 if any(k[0] == eng.precision for k in eng._graphs) else 1
+            settle = max(0, cal + capture - args.warmup)
+        untimed[tag] = args.warmup + settle
+        for i in range(args.warmup + settle):
             eng.train_step(*batch)
             torch.cuda.synchronize(device)
             note("%s warm-up step %d done" % (tag, i))
@@ -337,6 +348,7 @@ def main():
 
     # replicas must still be identical after the timed steps (same init, every rank applied the same averaged gradient):
     # every rank contributes a checksum of its parameters, rank 0 compares them bit for bit
+    skipped = eng.book.skipped_steps() if eng.book is not None else None      # fp16 backward: steps the overflow guard skipped
     flat = eng.optimizer.flat.detach().double()
     check = torch.stack([flat.sum(), flat.square().sum()]).to("cpu" if rehearsal or world == 1 else device)
     checks = [check]
@@ -376,6 +388,9 @@ def main():
                                                 "tests/test_gpu_model.py::test_benchmarked_step_vs_oracle)" if eng.book is not None else ""),
                                      "bf16": "fp32 tensors and accumulation; conv operands rounded once to bf16"}[args.precision],
                        "launch": "hipGraph replay of fwd+loss+bwd+grad packing; all-reduce and Adam eager" if eng.use_graph else "eager",
+                       "untimed_steps": untimed[args.precision],
+                       "fp16_overflow_guard": None if eng.book is None else
+                       {"optimiser_steps_skipped": skipped, "operand_scale_slots": len(eng.book.index)},
                        "rehearsal_single_device_gloo": rehearsal},
             "roofline": roofline,
             "kernels": per_kernel,

@@ -13,8 +13,9 @@
 // layers.  Every operand is therefore multiplied by a POWER OF TWO on its way into LDS (exact in fp32) and the accumulator
 // is multiplied by the inverse product on its way out.  The scale of an operand lives in a device slot
 // {scale, running |max|}: the staging code records |max| of what it reads (it touches every element anyway), and one tiny
-// kernel per step (ebfi_f16_scales_finish) turns the maxima into the next step's scales (max * scale in [128, 256): 7
-// binades of headroom above, 22 below before fp16 loses precision) and raises a flag if a product could have overflowed
+// kernel per step (ebfi_f16_scales_finish) turns the maxima into the next step's scales (max * scale in [2, 4): 14 binades
+// of headroom above; below, fp16 is normal for 15 more and the MFMA takes subnormal operands -- measured on a 64 -> 64 layer,
+// the weight gradient's error stays at 2.7e-4 until max * scale drops under 2^-10) and raises a flag if a value could have overflowed
 // -- delayed scaling, as used for fp8 training; the first use of a slot is calibrated just in time by the host side
 // (ebfi_amd/f16scale.py).
 
@@ -26,11 +27,18 @@ __device__ __forceinline__ unsigned pack_f16(float a, float b) {   // v_cvt_pk_f
     return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, f16x2));
 }
 
+// fp32 -> fp16 conversions of this wave saturate at +-65504 instead of producing inf (MODE.FP16_OVFL; true inf / NaN inputs
+// stay what they are).  A scale that is too large for this step's data is caught by f16_scales_finish_kernel from the
+// recorded maximum either way; saturating keeps the step's wrong gradients FINITE, so the maxima recorded further down the
+// backward chain stay usable and every scale is repaired by that one finish launch instead of one layer per step.
+__device__ __forceinline__ void saturate_fp16_conversions() { __builtin_amdgcn_s_setreg(1 | (23 << 6), 1); }
+
 // Scale slot: 64 floats (256 bytes); [0] = scale (power of two), [32] = running |max| of the fp32 values staged through it
 // (float bits, ordered as unsigned for non-negative floats).  The two words sit in different 128-byte lines on purpose: the
 // atomic that raises the maximum executes at the memory side and drops its line from L2 -- next to the scale, which every
 // workgroup reads, that turned the 30 000-workgroup pack launch into a queue on one line (0.44 ms for 5.5 M elements).
 constexpr int SLOT_STRIDE = 64, SLOT_AMAX = 32;
+constexpr int F16_TARGET_EXP = 2;          // next scale: |max| * scale in [2^(F16_TARGET_EXP-1), 2^F16_TARGET_EXP) (f16scale.TARGET_EXP)
 struct ScaleSlot {
     float *p;
     __device__ __forceinline__ float scale() const { return p ? p[0] : 1.f; }
@@ -62,6 +70,7 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
                                                          const float *__restrict__ bias, float *__restrict__ out, ConvGeom g, int K16,
                                                          int act, float slope, EpiExtra epi, int tiles_total, ScaleSlot in_slot,
                                                          const float *__restrict__ w_slot) {
+    saturate_fp16_conversions();
     constexpr int KS = 3, KK = 9, MT = 2, RW = 2;              // RW: output rows per consumer wave
     constexpr int IH = TYB - 1 + KS, IW = TX - 1 + KS, PS = IH * IW, COS = 32 * MT;
     constexpr int NCW = TYB / RW, PT = 256;
@@ -300,6 +309,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_ws(const float *__restrict
                                                          const float *__restrict__ yact, float *__restrict__ slab,
                                                          float *__restrict__ gpre_out, ConvGeom g, float dslope, int total_tiles,
                                                          int need_bias, ScaleSlot x_slot, ScaleSlot g_slot) {
+    saturate_fp16_conversions();
     using C = WCfg<3, 1, 32>;
     constexpr int KS = 3, KK = 9, WTX = C::WTX, IH = C::IH, IW = C::IW;
     constexpr int IWP = 32, EXC = IW - IWP, CIB = 64, CP = CIB / 2, PS = C::PS, IWS = C::IWS;
@@ -544,7 +554,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_ws(const float *__restrict
 // ------------------------------------------------------------------------------------------------
 // Delayed scaling bookkeeping over slots 0 .. n-1 (SLOT_STRIDE floats each: scale at [0], |max| seen since the last call at [32]).  For every slot that saw
 // data: flag[0] |= 1 when the data was not finite or max * scale could have left the fp16 range (the step's gradients are
-// then suspect: the optimiser launch skips the update), the next scale puts max into [128, 256), the maximum is cleared.
+// then suspect: the optimiser launch skips the update), the next scale puts max into [2, 4) (F16_TARGET_EXP), the maximum is cleared.
 __global__ __launch_bounds__(256) void f16_scales_finish_kernel(float *__restrict__ slots, int n, int *__restrict__ flag) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -559,7 +569,7 @@ __global__ __launch_bounds__(256) void f16_scales_finish_kernel(float *__restric
     if (a <= 3.0e38f) {
         int e;
         (void)frexpf(a, &e);               // a = m * 2^e, m in [0.5, 1)
-        slot[0] = ldexpf(1.f, 8 - e);
+        slot[0] = ldexpf(1.f, F16_TARGET_EXP - e);
     }
     slot[SLOT_AMAX] = 0.f;
 }
@@ -570,6 +580,7 @@ __global__ __launch_bounds__(256) void f16_scales_finish_kernel(float *__restric
 __global__ __launch_bounds__(256) void pack_table_f16_kernel(const float *__restrict__ src, const int32_t *__restrict__ table,
                                                              int64_t n, _Float16 *__restrict__ out,
                                                              const int32_t *__restrict__ block_slot, float *__restrict__ slots) {
+    saturate_fp16_conversions();
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float *slot = slots + (int64_t)SLOT_STRIDE * block_slot[blockIdx.x];
     const int32_t t = e < n ? table[e] : -1;
@@ -623,6 +634,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict
                                                          const float *__restrict__ yact, float *__restrict__ gpre_out,
                                                          float *__restrict__ slab, ConvGeom g, float dslope, int total_tiles,
                                                          int need_bias, ScaleSlot x_slot, ScaleSlot g_slot) {
+    saturate_fp16_conversions();
     constexpr int KK = 9, PT = 256, NQ = 4;
     constexpr int NXI = TRXR * TRXQ * 8, NXK = (NXI + PT - 1) / PT;          // input items (row, quad, 8-channel group): 480, 2 per thread
     static_assert(NXK == 2 && TRH * (TRW / 4) * 8 == PT, "one grad_out item and two input items per producer thread");

@@ -89,6 +89,12 @@ class Engine:
         # forward+backward on loss / accu_step; the all-reduce and the optimiser step happen on every accu_step-th call
         self.accu_step = max(1, int(accu_step))
         self._micro = 0
+        # fp16 backward: the first optimiser steps of a run measure every operand scale just in time (eager launches).  The
+        # x0.1 initialisation leaves activations at 1e-18 in the deep stacks; the first Adam update (every weight and bias
+        # moves by lr) lifts them to 1e-4 -- fourteen decades in one step, which no one-step-old scale survives.  From the
+        # third step on magnitudes move by a few percent per step and the delayed scales (f16scale) take over.
+        self.calibration_steps = 2
+        self._steps_run = 0
         self._accum = None
         # graph=True: forward + loss + backward + gradient packing are captured once into a hipGraph (per input shape,
         # precision and loss phase) and replayed; the all-reduce and the optimiser step stay eager (train_step_graph).
@@ -148,6 +154,8 @@ class Engine:
 
     def _fwd_bwd(self, frame, event, t, gtex, target):
         with self._autocast(), self._bank(), self._book() as book:
+            if book is not None and self._steps_run < self.calibration_steps:
+                book.calibrated.clear()             # (measure every operand of this pass again, see __init__)
             if book is not None and self._micro == 0:
                 book.begin_step()                   # clear the overflow guard of this optimiser step
             sharp_pre, sharp = self.model(frame, event, t, gtex)
@@ -180,12 +188,14 @@ class Engine:
                 dist.all_reduce(guard[0:1], op=dist.ReduceOp.MAX)
         self.optimizer.step(self.bucket.flat, guard=guard)
         self.iteration += 1
+        self._steps_run += 1
         return True
 
     def train_step(self, frame, event, t, gtex, target):
         """One forward+backward on this rank's batch (plus, every `accu_step`-th call, the gradient all-reduce and the
         optimiser step); returns the (unreduced) loss tensor, already divided by accu_step like the reference's."""
-        if self.use_graph:
+        calibrating = self.book is not None and self.precision == "bf16x3" and self._steps_run < self.calibration_steps
+        if self.use_graph and not calibrating:
             return self.train_step_graph(frame, event, t, gtex, target)
         self.bucket.zero()
         loss = self._fwd_bwd(frame, event, t, gtex, target)

@@ -7,14 +7,20 @@ Every operand tensor of those kernels therefore has a SLOT of two device floats 
 
   * the kernel multiplies what it stages by `scale` (a power of two: exact in fp32) and raises `|max|` atomically,
   * `finish()` -- one tiny launch after the backward pass, captured with the step's graph -- sets every slot's next scale so
-    that |max| * scale lies in [128, 256) (7 binades of headroom to fp16's 65504, 22 below before precision is lost),
+    that |max| * scale lies in [2, 4) (14 binades of headroom to fp16's 65504; below, fp16 keeps 11 bits down to 2^-14 and
+    the matrix cores take subnormal operands: measured, the result's error is flat until |max| * scale < 2^-10),
     clears the maxima and raises the GUARD flag when a value was not finite or could have overflowed; the guarded Adam
     launch then skips the update of that step (guard[1] counts such steps),
   * the FIRST use of a slot is calibrated just in time from the tensor itself (`calibrate`: torch reductions on the launch
-    stream, no host synchronisation) -- that is the first eager pass of a run, before any graph is captured.
+    stream, no host synchronisation) -- that is the first eager pass of a run, before any graph is captured.  The engine
+    repeats that for every slot during the first `Engine.calibration_steps` (2) optimiser steps of a run: from the x0.1
+    initialisation the first Adam update moves activations by fourteen decades (biases 0 -> 1e-4 against 1e-18 signals),
+    which no one-step-old scale survives (measured with tools/scaletrace.py: steps 1-4 skipped without it, none with it),
+  * the kernels convert with MODE.FP16_OVFL set: a value past the range saturates at 65504 instead of becoming inf, so one
+    stale scale does not turn every maximum recorded further down the backward chain into inf (a repair per layer per step).
 
-Gradient magnitudes move by a few percent from step to step, so a scale that is one step old is as good as an exact one:
-the same recipe fp8 training uses, with far more headroom.
+After those first steps gradient magnitudes move by a few percent from step to step, so a scale that is one step old is as
+good as an exact one: the same recipe fp8 training uses, with far more headroom.
 """
 import contextlib
 
@@ -23,7 +29,7 @@ import torch
 from . import _native as N
 
 _ACTIVE = None
-TARGET_EXP = 8                      # |max| * scale in [2^(TARGET_EXP-1), 2^TARGET_EXP)
+TARGET_EXP = 2                      # |max| * scale in [2^(TARGET_EXP-1), 2^TARGET_EXP)
 SLOT_STRIDE, SLOT_AMAX = 64, 32     # floats per slot; offset of the running |max| (csrc/conv2d_f16.inc.hpp: separate cache lines)
 
 

@@ -238,7 +238,7 @@ int ebfi_kernelconv_fac_fused_x3(const void *input, const void *packed, size_t p
  * 64 floats (256 bytes): slot[0] = scale, slot[32] = running |max| of the values staged through it (separate cache lines);
  * kernels apply slot[0] and atomically raise slot[32]; slot i of a book starts at slots + 64 i;
  * ebfi_f16_scales_finish (once per step, after the backward pass) turns the maxima of all `n` slots into the next step's
- * scales (|max| * scale in [128, 256)), clears them, and sets flag[0] when a value was not finite or |max| * scale could
+ * scales (|max| * scale in [2, 4)), clears them, and sets flag[0] when a value was not finite or |max| * scale could
  * have left the fp16 range.  A new slot is initialised by the caller (ebfi_amd/f16scale.py calibrates it just in time).
  *   ebfi_pack_table_f16      fp16 weight images from the index table of ebfi_pack_table_bf16 (hi entries); images start on
  *                            256-element boundaries, elements [256 k, 256 k + 256) are scaled by slot block_slot[k]

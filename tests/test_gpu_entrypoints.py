@@ -81,13 +81,16 @@ def test_graph_replay_step_equals_eager_step():
     engines = [Engine(cfg, device="cuda", seed=7, graph=g, precision="bf16x3") for g in (False, True)]
     engines[1].model.load_state_dict(engines[0].model.state_dict())
     assert all(e.bank is not None and rc_fused.fusable(e.model.ResidualControl) for e in engines)
-    for it in range(4):
+    for it in range(6):                          # (fp16 backward: two eager calibration steps, the capture, three replays)
         batch = synthetic_batch(2, 64, 64, device="cuda", seed=100 + it)
         losses = [e.train_step(*batch) for e in engines]
         assert torch.allclose(losses[0], losses[1], rtol=1e-5, atol=0), (it, losses)
     assert len(engines[1]._graphs) == 1 and engines[1].bucket.views_intact()
+    assert all(e.book is not None and e.book.skipped_steps() == 0 for e in engines)
     for (n, a), b in zip(engines[0].model.named_parameters(), engines[1].model.parameters()):
-        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), n
+        # (Adam normalises the gradient: where it is rounding-sized the two runs' atomics-ordered sums move a parameter by a
+        #  fraction of lr = 1e-4 per step; a missed update would be 1e-4)
+        assert torch.allclose(a, b, rtol=1e-3, atol=1e-5), n
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs on the node (the round's GPU box has one)")

@@ -361,6 +361,28 @@ def test_full_size_modes_agree_and_batch_is_independent():
         assert _rel(res[mode][0][3:4], ref_s) < TOL and _rel(res[mode][1][3:4], ref_f) < TOL, mode
 
 
+def test_fp16_backward_takes_every_step_from_the_reference_initialisation():
+    """The reference's x0.1 initialisation (model_util.py:16-36) leaves the deep stacks' activations at 1e-18; the first Adam
+    update lifts them to 1e-4.  A one-step-old fp16 operand scale does not survive that jump (four optimiser steps were
+    skipped by the overflow guard before the engine measured the first two steps' scales just in time): from the default
+    initialisation, with a fresh batch every step, no step may be skipped -- eagerly and with the captured graph -- and the
+    two launch modes must agree."""
+    from ebfi_amd.engine import DEFAULT_MODEL_ARGS, Engine, synthetic_batch
+    losses = {}
+    for graph in (False, True):
+        eng = Engine(DEFAULT_MODEL_ARGS, device="cuda", precision="bf16x3", graph=graph, seed=9, lr=1e-4)
+        assert eng.book is not None and eng.calibration_steps == 2
+        out = []
+        for it in range(7):
+            batch = synthetic_batch(2, 128, 128, device="cuda", seed=500 + it, on_device=True)
+            out.append(eng.train_step(*batch).item())
+        assert eng.book.skipped_steps() == 0, (graph, eng.book.skipped_steps())
+        assert float(eng.optimizer.inner.state[eng.optimizer.flat]["step"]) == 7.0
+        assert len(eng._graphs) == (1 if graph else 0)
+        losses[graph] = out
+    assert np.allclose(losses[False], losses[True], rtol=1e-5), losses
+
+
 def test_benchmarked_step_vs_oracle():
     """The exact step bench.py times -- default widths, split-precision convs, weight bank, fused ResidualControl node,
     pre-activation FAC gradient, the whole forward + loss + backward replayed from a hipGraph -- against the CPU oracle
@@ -371,6 +393,8 @@ def test_benchmarked_step_vs_oracle():
     from ebfi_amd import rc_fused
     from ebfi_amd.engine import DEFAULT_MODEL_ARGS, Engine, synthetic_batch
     eng = Engine(DEFAULT_MODEL_ARGS, device="cuda", precision="bf16x3", graph=True, seed=4)
+    eng.calibration_steps = 0                   # straight to the captured graph (its two eager warm-up passes calibrate the
+    #                                             fp16 operand scales): the step compared below is a REPLAY, what bench.py times
     gen = torch.Generator(device="cpu").manual_seed(11)
     with torch.no_grad():                       # (parameters are views of the optimiser's flat buffer: copy in place)
         for p in eng.model.parameters():
@@ -405,6 +429,7 @@ def test_benchmarked_step_vs_oracle():
         dev = [v.cuda() for v in batch]
         loss = eng.train_step(*dev)             # 2 eager warm-up passes, the capture, one replay, all-reduce (1 rank), Adam
         flat = eng.bucket.flat.detach().cpu().clone()      # the packed gradient Adam just consumed
+        assert eng.book is not None and int(eng.book.guard[0].item()) == 0 and eng.book.skipped_steps() == 0   # (fp16 range guard)
         loss2 = eng.train_step(*dev)            # a second replay of the same graph (parameters have moved)
     finally:
         rc_fused.residual_control, eng.bank.refresh = rc_orig, refresh_orig
