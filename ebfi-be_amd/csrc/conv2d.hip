@@ -558,10 +558,26 @@ constexpr int KB_NSTAMP = 32;
             g_kb_stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 * KB_NSTAMP + threadIdx.x] =                  \
                 reinterpret_cast<unsigned long long *>(smd + KB_LDS_OFF)[threadIdx.x];                                  \
     } while (0)
+// (for kernels whose wave roles leave through different exits: every stamping thread copies its own row, no barrier)
+#define KB_FLUSH_SELF()                                                                                                 \
+    do {                                                                                                                \
+        if (g_kb_stamps && (threadIdx.x == 0 || threadIdx.x == 256))                                                    \
+            for (int i_ = 0; i_ < KB_NSTAMP; ++i_)                                                                      \
+                g_kb_stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + (threadIdx.x >> 8)) * KB_NSTAMP + i_] = \
+                    reinterpret_cast<unsigned long long *>(smd + KB_LDS_OFF)[(threadIdx.x >> 8) * KB_NSTAMP + i_];      \
+    } while (0)
+#define KB_CLEAR_SELF()                                                                                                 \
+    do {                                                                                                                \
+        if (threadIdx.x == 0 || threadIdx.x == 256)                                                                     \
+            for (int i_ = 0; i_ < KB_NSTAMP; ++i_)                                                                      \
+                reinterpret_cast<unsigned long long *>(smd + KB_LDS_OFF)[(threadIdx.x >> 8) * KB_NSTAMP + i_] = 0ull;   \
+    } while (0)
 #else
 #define KB_LDS_BYTES 0
 #define KB_STAMP(i) do { } while (0)
 #define KB_FLUSH() do { } while (0)
+#define KB_FLUSH_SELF() do { } while (0)
+#define KB_CLEAR_SELF() do { } while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -3253,7 +3269,7 @@ extern "C" int ebfi_conv2d_packed_f16(const void *input, const void *packed16, s
     const int64_t tiles = (int64_t)B * ceil_div(g.Ho, TYB) * ceil_div(g.Wo, TX);
     if (tiles > 2147483647LL) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: too many tiles");
     constexpr int PSX = (TYB - 1 + 3) * (TX - 1 + 3);
-    const size_t lds = (size_t)2 * (PSX * 32 + 9 * 64 * 32);
+    const size_t lds = (size_t)2 * (PSX * 32 + 9 * 64 * 32) + KB_LDS_BYTES;
     const int64_t co_blocks = ceil_div(g.Cout, 64);
     int64_t gx = 256 / co_blocks;
     if (gx < 1) gx = 1;
@@ -3331,8 +3347,8 @@ extern "C" int ebfi_conv2d_backward_weight_f16g(const void *input, const void *g
                      conv_bytes_wgrad(g, 9, act != ACT_NONE, grad_preact_out != nullptr));
 #define EBFI_LAUNCH_WTR(DA_)                                                                                               \
     do {                                                                                                                   \
-        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_wgrad_f16_tr<DA_>), TR_LDS)) return rc_;       \
-        hipLaunchKernelGGL((conv_wgrad_f16_tr<DA_>), grid, dim3(512), TR_LDS, st, static_cast<const float *>(input),           \
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_wgrad_f16_tr<DA_>), TR_LDS + KB_LDS_BYTES)) return rc_;       \
+        hipLaunchKernelGGL((conv_wgrad_f16_tr<DA_>), grid, dim3(512), TR_LDS + KB_LDS_BYTES, st, static_cast<const float *>(input),           \
                            static_cast<const float *>(grad_output), static_cast<const float *>(saved_output),              \
                            static_cast<float *>(grad_preact_out), slab, g, slope, (int)tiles, grad_bias != nullptr ? 1 : 0,  \
                            xs, gs);                                                                                        \

@@ -96,6 +96,9 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
         tb = u / tiles_y; ty0 = tyi * TYB; tx0 = txi * TX;
     };
     const float sx = in_slot.scale();
+    [[maybe_unused]] constexpr int KB_LDS_OFF = 2 * BUFB;
+    KB_CLEAR_SELF();
+    KB_STAMP(0);
 
     if (wave < NCW) {
         // ------------------------------------------------------------------ consumers: output rows 2*wave, 2*wave + 1
@@ -142,10 +145,12 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
                         acc[r][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[set][m], bf[set][r][n], acc[r][m][n], 0, 0, 0);
         };
         __syncthreads();                   // (A) the first chunk is committed
+        KB_STAMP(1);
         int item = 0, tcur = blockIdx.x;
         for (int ti = 0; ti < ntiles_mine; ++ti, tcur += G) {
             for (int chunk = 0; chunk < nchunks; ++chunk, ++item) {
                 const char *base = smd + (item & 1) * BUFB;
+                if (item < 12) KB_STAMP(2 + 2 * item);
                 tap_read(base, 0, 0);
 #pragma unroll
                 for (int tap = 0; tap < KK; ++tap) {
@@ -154,8 +159,10 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
                     tap_mfma(tap & 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if (item < 12) KB_STAMP(3 + 2 * item);
                 __syncthreads();           // (B) this buffer has been read, the other one is complete
             }
+            KB_STAMP(30);
             int cb_, cy0, cx0;
             tile_coords(tcur, cb_, cy0, cx0);
             // (written out per row: as a loop the EXTRA variant was not unrolled, `acc[r]` became a runtime index and the whole
@@ -172,11 +179,14 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
 #pragma unroll
                         for (int e = 0; e < 16; ++e) acc[r][m][n][e] = 0.f;
         }
+        KB_STAMP(31);
+        KB_FLUSH_SELF();
         return;
     }
     // ---------------------------------------------------------------------- producers
     // 16-byte quads of 4 consecutive pixels x 8 channels (as conv_fwd_bf16x3_ws) and the chunk's weight pieces; two register
     // stages, so the loads of items i+2 and i+3 are in flight while item i+1 is converted and written.
+    KB_STAMP(20);
     const int ptid = tid - 64 * NCW;
     const unsigned img_bytes = (unsigned)KK * (unsigned)g.Cout * (unsigned)K16 * 2u;
     const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(wp), 0, img_bytes, 0x00020000);
@@ -192,6 +202,7 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
         it_qr[k] = (id >> 1) / NQ;
         it_qq[k] = (id >> 1) - it_qr[k] * NQ;
     }
+    KB_STAMP(21);
     unsigned w_off[NWB];
     int w_dst[NWB];
 #pragma unroll
@@ -272,21 +283,35 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
         for (int it = 0; it < NWB; ++it)
             if (ptid + it * PT < WPIECES) *reinterpret_cast<u32x4 *>(base + w_dst[it]) = s.rw[it];
     };
+    // Order of the start-up (in-kernel stamps, tools/kbench f16): the loads are issued at the rate the memory system accepts them
+    // (60 KB per workgroup and chunk: issuing two chunks took 5.7 us), so nothing but item 0's commit may stand between the
+    // first loads and barrier (A) -- the consumers multiply item 0 while the later chunks are being requested.
+    KB_STAMP(22);
     pf_setup();
-    prefetch(sa);
-    commit(0, sa);                         // item 0
-    prefetch(sa);                          // item 1
-    prefetch(sb);                          // item 2: two chunks of loads in flight from here on
+    KB_STAMP(23);
+    prefetch(sa);                          // item 0
+    KB_STAMP(1);
+    prefetch(sb);                          // item 1 (requested before item 0 is converted: its data arrives behind item 0's)
+    commit(0, sa);
+    KB_STAMP(2);
     __syncthreads();                       // (A)
+    prefetch(sa);                          // item 2: two chunks of loads in flight from here on
+    KB_STAMP(3);
     for (int item = 0; item < nitems; item += 2) {
-        commit((item + 1) & 1, sa);        // item + 1, while the consumers multiply item
-        prefetch(sa);                      // item + 3 (past the end: empty descriptors, nothing is read)
+        if (item < 12) KB_STAMP(4 + 2 * item);
+        commit((item + 1) & 1, sb);        // item + 1, while the consumers multiply item
+        if (item < 12) KB_STAMP(5 + 2 * item);
+        prefetch(sb);                      // item + 3 (past the end: empty descriptors, nothing is read)
         __syncthreads();                   // (B)
         if (item + 1 >= nitems) break;
-        commit(item & 1, sb);              // item + 2
-        prefetch(sb);                      // item + 4
+        if (item < 12) KB_STAMP(6 + 2 * item);
+        commit(item & 1, sa);              // item + 2
+        if (item < 12) KB_STAMP(7 + 2 * item);
+        prefetch(sa);                      // item + 4
         __syncthreads();                   // (B)
     }
+    KB_STAMP(31);
+    KB_FLUSH_SELF();
     // (halo positions are read by several workgroups, padded / dead lanes contribute 0: the maximum is unaffected)
     in_slot.record(amax);
 }
@@ -669,6 +694,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict
     const int64_t wsz = (int64_t)g.Cout * g.Cin * KK;
     float *my = slab + (int64_t)split * (wsz + g.Cout);
     const float sx = x_slot.scale(), sg = g_slot.scale();
+    [[maybe_unused]] char *smd = smt;
+    [[maybe_unused]] constexpr int KB_LDS_OFF = TR_LDS;
+    KB_CLEAR_SELF();
+    KB_STAMP(0);
 
     if (wave < NQ) {
         // ------------------------------------------------------------------ consumers
@@ -705,9 +734,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict
         for (int j = 0; j < 4; ++j) boff[j] = col_off(nq + NQ * j);
         boff[4] = col_off(xt);
         __syncthreads();                   // (A) the first tile is committed
+        KB_STAMP(1);
         int cur = 0;
+        [[maybe_unused]] int kb_i = 0;
         for (int tile = split; tile < total_tiles; tile += G) {
             const char *base = smt + cur * TR_BUFB;
+            if (kb_i < 12) KB_STAMP(2 + 2 * kb_i);
 #pragma unroll
             for (int ks = 0; ks < TRH * 2; ++ks) {
                 const int y = ks >> 1, px0 = (ks & 1) * 16;
@@ -725,9 +757,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict
                         acc[j][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b[j], acc[j][m], 0, 0, 0);
                 accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(xm ? a[1] : a[0], b[4], accx, 0, 0, 0);
             }
+            if (kb_i < 12) KB_STAMP(3 + 2 * kb_i);
+            ++kb_i;
             __syncthreads();               // (B) this image has been read, the other one is complete
             cur ^= 1;
         }
+        KB_STAMP(29);
         const float oscale = 1.f / (sx * sg);
         const __amdgpu_buffer_rsrc_t rsl = make_rsrc(my, (unsigned)wsz * 4u);   // rows co >= Cout fall past the slab: dropped
         // slab layout of THIS kernel: [co][tap][ci] -- a block's lanes are consecutive input channels of one tap, so the channel
@@ -746,7 +781,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict
 #pragma unroll
             for (int m = 0; m < 2; ++m) store_block(acc[j][m], m, nq + NQ * j);
         store_block(accx, xm, xt);
+        KB_STAMP(30);
         __syncthreads();                   // (C) the producers' bias partials are in LDS
+        KB_STAMP(31);
+        KB_FLUSH_SELF();
         if (need_bias && ci_blk == 0 && wave == 0) {
             const float *scr = reinterpret_cast<const float *>(smt + 2 * TR_BUFB);
             const float v = ((scr[lane] + scr[64 + lane]) + scr[128 + lane]) + scr[192 + lane];
@@ -869,33 +907,49 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict
                 }
             }
     };
+    // Start-up order as in conv_fwd_f16_ws: only the first tile's commit between the first loads and barrier (A) (the three
+    // prefetches that used to stand there took 9 us to issue: the consumers started 18.7 us into a 44 us kernel).
     prefetch_x(split, sa);
     prefetch_g(split);
-    commit_x(0, sa);
-    commit_g(0, split);
-    prefetch_x(split + G, sa);
-    prefetch_g(split + G);
+    KB_STAMP(1);
     if constexpr (DACT == 0) {
-        prefetch_x(split + 2 * G, sb);     // from here on: input quads of two tiles, grad_out quads of one in flight
+        prefetch_x(split + G, sb);         // (requested before tile 0 is converted: arrives behind it)
+        commit_x(0, sa);
+        commit_g(0, split);
+        KB_STAMP(2);
         __syncthreads();                   // (A)
+        prefetch_g(split + G);
+        prefetch_x(split + 2 * G, sa);     // from here on: input quads of two tiles, grad_out quads of one in flight
+        KB_STAMP(3);
         int cur = 0;
+        [[maybe_unused]] int kb_i = 0;
         for (int tile = split; tile < total_tiles; tile += 2 * G) {
-            commit_x(cur ^ 1, sa);         // tile + G, while the consumers multiply tile `tile` from image `cur`
-            prefetch_x(tile + 3 * G, sa);  // (past the end: zero-record descriptors, nothing is read)
+            if (kb_i < 6) KB_STAMP(4 + 4 * kb_i);
+            commit_x(cur ^ 1, sb);         // tile + G, while the consumers multiply tile `tile` from image `cur`
+            prefetch_x(tile + 3 * G, sb);  // (past the end: zero-record descriptors, nothing is read)
             commit_g(cur ^ 1, tile + G);
             prefetch_g(tile + 2 * G);
+            if (kb_i < 6) KB_STAMP(5 + 4 * kb_i);
             __syncthreads();               // (B)
             cur ^= 1;
             if (tile + G >= total_tiles) break;
-            commit_x(cur ^ 1, sb);         // tile + 2 G
-            prefetch_x(tile + 4 * G, sb);
+            if (kb_i < 6) KB_STAMP(6 + 4 * kb_i);
+            commit_x(cur ^ 1, sa);         // tile + 2 G
+            prefetch_x(tile + 4 * G, sa);
             commit_g(cur ^ 1, tile + 2 * G);
             prefetch_g(tile + 3 * G);
+            if (kb_i < 6) KB_STAMP(7 + 4 * kb_i);
+            ++kb_i;
             __syncthreads();               // (B)
             cur ^= 1;
         }
     } else {
+        commit_x(0, sa);
+        commit_g(0, split);
+        KB_STAMP(2);
         __syncthreads();                   // (A)
+        prefetch_x(split + G, sa);
+        prefetch_g(split + G);
         int cur = 0;
         for (int tile = split; tile < total_tiles; tile += G) {
             commit_x(cur ^ 1, sa);         // tile + G
@@ -921,5 +975,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict
             if ((lane >> 3) == 0) scr[(wave - NQ) * 64 + 8 * chg + e] = v;
         }
     }
+    KB_STAMP(30);
     __syncthreads();                       // (C)
+    KB_STAMP(31);
+    KB_FLUSH_SELF();
 }

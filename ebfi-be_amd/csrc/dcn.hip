@@ -231,6 +231,54 @@ __device__ __forceinline__ void sample_cols_buf(__amdgpu_buffer_rsrc_t rx, unsig
     }
 }
 
+// Forward sampling with pre-formed corner coefficients.  The two corners of a row are fetched as ONE 8-byte pair at column
+// c = clamp(w0, 0, W-2) (make_tap); which pair element plays the low / high column corner depends only on the edge case:
+//   0 <= w0 <= W-2: (x, y) = (low, high)      w0 == -1: x = high, low is outside      w0 == W-1: y = low, high is outside
+// so the sample is cA * a.x + cB * a.y + cC * b.x + cD * b.y with the bilinear weights (and the modulation mask) folded
+// into cA .. cD once per (pixel, tap).  Rows outside the image get an out-of-range buffer offset (reads 0); a sample outside
+// (-1, H) x (-1, W) has all coefficients 0 (dcn_v2_im2col_cuda.cu:180).
+struct TapCoef {
+    float cA, cB, cC, cD;
+    unsigned o0, o1;        // byte offsets of the pair in the low / high row inside a channel plane (0x80000000 = outside)
+};
+__device__ __forceinline__ TapCoef make_tap_coef(float h, float w, float mask, int H, int W) {
+    TapCoef t;
+    const bool valid = (h > -1.f) && (w > -1.f) && (h < (float)H) && (w < (float)W);
+    h = valid ? h : 0.f;                    // (a NaN / far-off position must give an exact 0, not NaN * 0)
+    w = valid ? w : 0.f;
+    const float fh = floorf(h), fw = floorf(w);
+    const int h0 = (int)fh, w0 = (int)fw;
+    const float lh = h - fh, lw = w - fw;
+    const float hh = 1.f - lh, hw = 1.f - lw;
+    const float m = valid ? mask : 0.f;
+    const float w1 = hh * hw * m, w2 = hh * lw * m, w3 = lh * hw * m, w4 = lh * lw * m;
+    const bool lo_edge = w0 < 0, hi_edge = w0 > W - 2;
+    t.cA = lo_edge ? w2 : (hi_edge ? 0.f : w1);
+    t.cB = lo_edge ? 0.f : (hi_edge ? w1 : w2);
+    t.cC = lo_edge ? w4 : (hi_edge ? 0.f : w3);
+    t.cD = lo_edge ? 0.f : (hi_edge ? w3 : w4);
+    const int c = lo_edge ? 0 : (hi_edge ? W - 2 : w0);
+    t.o0 = (valid && h0 >= 0) ? (unsigned)(h0 * W + c) * 4u : 0x80000000u;
+    t.o1 = (valid && h0 + 1 <= H - 1) ? (unsigned)((h0 + 1) * W + c) * 4u : 0x80000000u;
+    return t;
+}
+template <int NCH, bool SPLIT>
+__device__ __forceinline__ void sample_coef(__amdgpu_buffer_rsrc_t rx, unsigned chan_byte, unsigned plane_bytes, const TapCoef &t,
+                                            float *col, int col_stride) {
+    u32x2 a[NCH], b[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        a[c] = __builtin_amdgcn_raw_buffer_load_b64(rx, t.o0 + chan_byte + (unsigned)c * plane_bytes, 0, 0);
+        b[c] = __builtin_amdgcn_raw_buffer_load_b64(rx, t.o1 + chan_byte + (unsigned)c * plane_bytes, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const float s = t.cA * __uint_as_float(a[c].x) + t.cB * __uint_as_float(a[c].y) + t.cC * __uint_as_float(b[c].x) +
+                        t.cD * __uint_as_float(b[c].y);
+        col[c * col_stride] = col_word<SPLIT>(s);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 // X3: the 64 x (cb*kk) x 64 product on the bf16 matrix cores in split precision (operands as bf16 hi + lo pairs, three
 // MFMAs per product, ~1e-5 of the exact kernel; see conv2d.hip).  LDS then holds the pair words and 16-row k-steps need
@@ -292,28 +340,36 @@ __global__ __launch_bounds__(256, X3 ? 3 : 4) void dcn_fwd_f32(const float *__re
         for (int it = 0; it < NWT; ++it)
             rwv[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, w_off[it] + wb, 0, 0));
         __syncthreads();   // previous chunk's MFMA reads are done
-        // columns: a thread keeps its pixel and walks (tap, channel-half) items strided over the 4 waves;
-        // the offsets / mask of the next item are fetched while the current one is gathered
+        // columns: a thread keeps its pixel; the chunk's cb * kk (channel, tap) samples are cut into four equal runs in
+        // tap-major order, one per wave (18 each at cb = 8, kk = 9: three taps touched per wave).  Per (pixel, tap) the four
+        // corner COEFFICIENTS are formed once -- bilinear weight x modulation mask x which element of the fetched pair plays
+        // which corner -- so that a channel costs two 8-byte gathers and four FMAs (the walk is VALU-bound: it used to form
+        // the corners with eight selects per channel and the tap geometry twice per tap; 272 -> see DESIGN section 7).
         {
-            const int half_n = (ck.cb + 1) >> 1;               // channels of the first half
-            const int nitems = 2 * g.kk;
+            const int R = ck.cb * g.kk;
+            const int i1 = (R * (wave + 1)) >> 2;
+            int idx = (R * wave) >> 2;
             TapPos tp = {0.f, 0.f, 0.f};
-            if (p_ok && wave < nitems) tp = tap_pos_hw(g, roff, rmsk, ck.grp, wave >> 1, p4, ho, wo);
-            for (int item = wave; item < nitems; item += 4) {
-                const int tap = item >> 1, c_lo = (item & 1) ? half_n : 0;
-                const int n = (item & 1) ? ck.cb - half_n : half_n;
+            if (p_ok && idx < i1) tp = tap_pos_hw(g, roff, rmsk, ck.grp, idx / ck.cb, p4, ho, wo);
+            while (idx < i1) {
+                const int tap = idx / ck.cb, c0 = idx - tap * ck.cb;
+                const int n = min(ck.cb - c0, i1 - idx);
                 TapPos tp_next = {0.f, 0.f, 0.f};
-                if (p_ok && item + 4 < nitems) tp_next = tap_pos_hw(g, roff, rmsk, ck.grp, (item + 4) >> 1, p4, ho, wo);
-                float *col = sCol + (c_lo * g.kk + tap) * NP + px;
-                if (p_ok && n > 0) {
-                    const Tap t = make_tap(tp.h, tp.w, g.H, g.W);
-                    const unsigned chan_byte = (unsigned)(ck.cbase + c_lo) * plane_bytes;
-                    if (n == 4) sample_cols_buf<4, X3>(rxs, chan_byte, plane_bytes, t, tp.mask, col, g.kk * NP, 4);
-                    else sample_cols_buf<0, X3>(rxs, chan_byte, plane_bytes, t, tp.mask, col, g.kk * NP, n);
+                if (p_ok && idx + n < i1) tp_next = tap_pos_hw(g, roff, rmsk, ck.grp, tap + 1, p4, ho, wo);
+                float *col = sCol + (c0 * g.kk + tap) * NP + px;
+                const int cstride = g.kk * NP;
+                if (p_ok) {
+                    const TapCoef t = make_tap_coef(tp.h, tp.w, tp.mask, g.H, g.W);
+                    unsigned cb_ = (unsigned)(ck.cbase + c0) * plane_bytes;
+                    int c = 0;
+                    for (; c + 4 <= n; c += 4, cb_ += 4u * plane_bytes) sample_coef<4, X3>(rxs, cb_, plane_bytes, t, col + c * cstride, cstride);
+                    for (; c + 2 <= n; c += 2, cb_ += 2u * plane_bytes) sample_coef<2, X3>(rxs, cb_, plane_bytes, t, col + c * cstride, cstride);
+                    for (; c < n; ++c, cb_ += plane_bytes) sample_coef<1, X3>(rxs, cb_, plane_bytes, t, col + c * cstride, cstride);
                 } else {
-                    for (int c = 0; c < n; ++c) col[c * g.kk * NP] = 0.f;
+                    for (int c = 0; c < n; ++c) col[c * cstride] = 0.f;
                 }
                 tp = tp_next;
+                idx += n;
             }
         }
         if constexpr (X3) {   // rows up to the next multiple of 16 take part in the last k-step

@@ -91,24 +91,28 @@ static void time_variants(std::vector<Variant> &vs, int rounds, int reps) {
 static void report_stamps(unsigned long long *d_stamps, size_t nwg, const char *what) {
     std::vector<unsigned long long> h(nwg * 2 * KB_NSTAMP);
     CK(hipMemcpy(h.data(), d_stamps, h.size() * 8, hipMemcpyDeviceToHost));
-    printf("  phase stamps of %s (cycles of s_memtime, mean over %zu workgroups; wave 0 | wave 4)\n", what, nwg);
+    printf("  phase stamps of %s (cycles of s_memtime at 100 MHz, mean over %zu workgroups; wave 0 | wave 4; each wave's own stamps)\n", what, nwg);
     for (int i = 1; i < KB_NSTAMP; ++i) {
         double d[2] = {0, 0}, s[2] = {0, 0};
-        size_t cnt = 0;
-        for (size_t w = 0; w < nwg; ++w) {
-            bool ok = true;
-            for (int k = 0; k < 2; ++k) ok = ok && h[(w * 2 + k) * KB_NSTAMP + i] && h[(w * 2 + k) * KB_NSTAMP];
-            if (!ok) continue;
-            ++cnt;
+        size_t cnt[2] = {0, 0};
+        for (size_t w = 0; w < nwg; ++w)
             for (int k = 0; k < 2; ++k) {
+                const unsigned long long *row = &h[(w * 2 + k) * KB_NSTAMP];
+                if (!row[i] || !row[0]) continue;
+                ++cnt[k];
                 int prev = i - 1;
-                while (prev > 0 && !h[(w * 2 + k) * KB_NSTAMP + prev]) --prev;
-                d[k] += (double)(h[(w * 2 + k) * KB_NSTAMP + i] - h[(w * 2 + k) * KB_NSTAMP + prev]);
-                s[k] += (double)(h[(w * 2 + k) * KB_NSTAMP + i] - h[(w * 2 + k) * KB_NSTAMP]);
+                while (prev > 0 && !row[prev]) --prev;
+                d[k] += (double)(row[i] - row[prev]);
+                s[k] += (double)(row[i] - row[0]);
             }
+        if (!cnt[0] && !cnt[1]) continue;
+        printf("    stamp %2d:", i);
+        for (int k = 0; k < 2; ++k) {
+            if (cnt[k]) printf("  +%7.0f (since start %8.0f)", d[k] / cnt[k], s[k] / cnt[k]);
+            else printf("  %8s %24s", "", "");
+            if (k == 0) printf(" |");
         }
-        if (!cnt) continue;
-        printf("    stamp %2d: +%8.0f | +%8.0f    since start %8.0f | %8.0f\n", i, d[0] / cnt, d[1] / cnt, s[0] / cnt, s[1] / cnt);
+        printf("\n");
     }
 }
 #endif
@@ -184,8 +188,67 @@ int main(int argc, char **argv) {
         ebfi_conv2d_backward_weight(x, g, y_ref, gw, gb, B, Cin, H, W, Cout, 3, 1, 1, 0, 0.f, wgs, wgb, EBFI_F32_BF16X3MMA, nullptr);
         CK(hipDeviceSynchronize());
         printf("  bf16x3 wgrad vs exact fp32: max rel %.3e\n", max_rel(gw, gw_ref, nw));
+    } else if (mode == "f16") {
+        // the fp16 backward kernels of the training step: data gradient (conv_fwd_f16_ws on a transposed image: here simply Cout ->
+        // Cin channels with arbitrary weights, the timing does not depend on them) and the pixel-major weight gradient
+        const int K16 = (Cout + 15) / 16 * 16;
+        const size_t img_bytes = (size_t)9 * Cin * K16 * 2;
+        std::vector<_Float16> himg(img_bytes / 2);
+        for (size_t i = 0; i < himg.size(); ++i) himg[i] = (_Float16)(0.01f * (float)((int)(i * 2654435761u >> 24) - 128));
+        void *img;
+        CK(hipMalloc(&img, img_bytes));
+        CK(hipMemcpy(img, himg.data(), img_bytes, hipMemcpyHostToDevice));
+        // KBENCH_COLD=n: rotate over n independent operand sets (n x 100 MB at the default shape) so that no launch finds its
+        // operands in the 256 MB Infinity Cache -- what the kernels see inside a training step
+        const int ncold = getenv("KBENCH_COLD") ? std::max(1, atoi(getenv("KBENCH_COLD"))) : 1;
+        std::vector<float *> xs{x}, gs{g}, gxs{gx};
+        for (int i = 1; i < ncold; ++i) {
+            xs.push_back(dev_random(nx, 10 + i, 1.f));
+            gs.push_back(dev_random(ny, 40 + i, 1.f));
+            float *t;
+            CK(hipMalloc(&t, nx * 4));
+            gxs.push_back(t);
+        }
+        int rot_d = 0, rot_w = 0;
+        auto dg = [&] { const int i = rot_d++ % ncold; return ebfi_conv2d_packed_f16(gs[i], img, img_bytes, nullptr, gxs[i], B, Cout, H, W, Cin, 3, 1, 1, 0, 0.f, nullptr, nullptr, 0, 0.f, nullptr, nullptr, nullptr); };
+        auto wg = [&] { const int i = rot_w++ % ncold; return ebfi_conv2d_backward_weight_f16g(xs[i], gs[i], nullptr, gw, gb, nullptr, B, Cin, H, W, Cout, 3, 1, 1, 0, 0.f, nullptr, nullptr, wgs, wgb, nullptr); };
+        printf("  operand sets in rotation: %d\n", ncold);
+        if (dg()) { fprintf(stderr, "%s\n", ebfi_last_error()); return 3; }
+        if (wg()) { fprintf(stderr, "%s\n", ebfi_last_error()); return 3; }
+        std::vector<Variant> vs;
+        vs.push_back({"dgrad f16 (conv_fwd_f16_ws)", dg, {}});
+        vs.push_back({"wgrad f16 tr + reduce", wg, {}});
+        // the two are independent given grad_out: on two streams one kernel's ramp / tail can overlap the other's steady state
+        hipStream_t s2;
+        hipEvent_t ev_fork, ev_join;
+        CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        CK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        CK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        auto wg_s2 = [&] { const int i = rot_w++ % ncold; return ebfi_conv2d_backward_weight_f16g(xs[i], gs[i], nullptr, gw, gb, nullptr, B, Cin, H, W, Cout, 3, 1, 1, 0, 0.f, nullptr, nullptr, wgs, wgb, s2); };
+        vs.push_back({"dgrad + wgrad, one stream", [&] { int rc = dg(); return rc ? rc : wg(); }, {}});
+        vs.push_back({"dgrad | wgrad, two streams", [&] {
+            CK(hipEventRecord(ev_fork, nullptr));
+            CK(hipStreamWaitEvent(s2, ev_fork, 0));
+            int rc = wg_s2();
+            if (rc) return rc;
+            rc = dg();
+            CK(hipEventRecord(ev_join, s2));
+            CK(hipStreamWaitEvent(nullptr, ev_join, 0));
+            return rc; }, {}});
+        time_variants(vs, 7, 20);
+#ifdef EBFI_KBENCH
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_kb_stamps), &d_stamps, sizeof(d_stamps)));
+        dg();
+        CK(hipDeviceSynchronize());
+        report_stamps(d_stamps, std::min((size_t)256, nwg_max), "conv_fwd_f16_ws as data gradient (wave 0 = consumer | wave 4 = producer)");
+        CK(hipMemset(d_stamps, 0, nwg_max * 2 * KB_NSTAMP * 8));
+        wg();
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_kb_stamps), &null_stamps, sizeof(null_stamps)));
+        report_stamps(d_stamps, std::min((size_t)256, nwg_max), "conv_wgrad_f16_tr (wave 0 = consumer | wave 4 = producer)");
+#endif
     } else {
-        fprintf(stderr, "usage: kbench fwd|wgrad [Cin Cout H W B]\n");
+        fprintf(stderr, "usage: kbench fwd|wgrad|f16 [Cin Cout H W B]\n");
         return 1;
     }
     return 0;
