@@ -126,6 +126,14 @@ class Engine:
             self.book = f16scale.ScaleBook(self.device)
             self.bank.attach_scale_book(self.book)
 
+    @property
+    def settled(self):
+        """True once the steps that are not the steady state are over: the just-in-time calibration steps of the fp16 backward
+        and, with graph=True, the capture.  (Throughput loggers start their clock here.)"""
+        if self.book is not None and self.precision == "bf16x3" and self._steps_run < self.calibration_steps:
+            return False
+        return not self.use_graph or bool(self._graphs)
+
     @contextlib.contextmanager
     def _autocast(self):
         """precision 'bf16' = bf16 matrix-core operands for the 3x3 / 1x1 convs (fp32 storage and

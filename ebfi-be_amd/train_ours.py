@@ -154,8 +154,9 @@ def main():
     TB = int(config["model"]["args"]["TB"])
     out_dir = os.path.join(tr.get("output_path", "./output"), "models", config.get("experiment", "Ours"), args.runid)
 
-    # throughput is counted from the end of the FIRST iteration of this run (which pays module load, allocator growth and,
-    # with --graph, the capture): what is logged is the steady-state rate, whole job (all ranks)
+    # throughput is counted from the end of the first iteration after which the engine is in its steady state (the first ones
+    # pay module load, allocator growth, the just-in-time calibration of the fp16 operand scales and, with --graph, the
+    # capture: Engine.settled): what is logged is the steady-state rate, whole job (all ranks)
     t0, frames, it = None, 0, start
     make = synthetic_batch_from_raw_events if args.raw_events else synthetic_batch
     while it < st["iterations"]:
@@ -176,7 +177,7 @@ def main():
             rate = frames / (time.perf_counter() - t0) if t0 is not None and frames else float("nan")
             print("Iteration: %d/%d train_loss: %.4e learning rate: %.4e  %.1f frames/s"
                   % (it, st["iterations"], loss.item(), lr_now, rate), flush=True)
-        if t0 is None:
+        if t0 is None and eng.settled:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
         # periodic checkpoints as train_ours.py:331-333 (saved BEFORE this iteration's scheduler step, like there), plus one
