@@ -13,6 +13,16 @@ import threading
 PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # .../ebfi-be_amd
 REPO_ROOT = os.path.dirname(PKG_ROOT)
 # EBFI_LIB_PATH: development switch for same-box A/B runs of two builds of the library
+# Development switches (EBFI_NO_*, EBFI_WGRAD_TR, ... -- A/B measurements and tests): honoured only in a process started with
+# EBFI_DEV=1, like the library's own (csrc/common.hpp dev_getenv), so that a stray variable cannot change which kernels a
+# production run, one of its ranks or one of its graph captures takes.
+_DEV = os.environ.get("EBFI_DEV") == "1"
+
+
+def dev_env(name, default=None):
+    return os.environ.get(name, default) if _DEV else default
+
+
 LIB_PATH = os.environ.get("EBFI_LIB_PATH") or os.path.join(PKG_ROOT, "lib", "libebfi_hip.so")
 HEADER = os.path.join(REPO_ROOT, "include", "ebfi_hip.h")
 BUILD_SCRIPT = os.path.join(PKG_ROOT, "csrc", "build.sh")

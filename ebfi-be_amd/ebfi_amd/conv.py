@@ -48,7 +48,7 @@ def _x3_ok(k, stride, rows=None, mode=None):
     """rows: output rows of the product (Cout forward, Cin for the data gradient): 7x7 runs in split precision up to 16.
     mode: the compute mode to decide for (None = the current process-wide one)."""
     return (mode or _COMPUTE) == "bf16x3" and stride == 1 and (k in (1, 3) or (k == 7 and rows is not None and rows <= 16 and
-                                                                               os.environ.get("EBFI_NO_CONV7X3") is None))
+                                                                               N.dev_env("EBFI_NO_CONV7X3") is None))
 
 
 def _bf16_ws(lib, geo, device):
@@ -232,7 +232,7 @@ class SiteConvBiasAct(Function):
         f16 = book is not None and ks == 3 and pad == 1
         # (partial 64-channel blocks -- the 32 / 48-channel layers of the detail branch -- go through the pixel-major kernel, which
         # needs quad-aligned rows; below 32 channels the zero-filled half of the block would be most of the work)
-        f16_w = f16 and (Cin % 64 == 0 or (Cin >= 32 and W % 4 == 0 and os.environ.get("EBFI_WGRAD_TR", "1") != "0"))
+        f16_w = f16 and (Cin % 64 == 0 or (Cin >= 32 and W % 4 == 0 and N.dev_env("EBFI_WGRAD_TR", "1") != "0"))
         f16_x = f16 and W % 4 == 0 and Cin >= 48 and site.tr16_ptr() is not None
         with torch.cuda.device_of(x):
             st = N.stream_ptr(x.device)

@@ -162,14 +162,13 @@ class FlatAdam:
         """The update as ONE bandwidth-bound launch of libebfi_hip.so (csrc/optim.hip) on the state tensors of the inner
         torch.optim.Adam (which keeps owning hyper-parameters, state and checkpoint layout).  CPU tensors, weight decay,
         amsgrad or maximize take torch's own step."""
-        import os
+        from . import _native as N
         grp = self.inner.param_groups[0]
         if not (self.flat.is_cuda and self.flat.dtype == torch.float32 and flat_grad.dtype == torch.float32 and
                 flat_grad.is_contiguous() and not grp.get("amsgrad") and not grp.get("maximize") and
                 float(grp.get("weight_decay", 0.0)) == 0.0 and not torch.is_tensor(grp["lr"]) and
-                os.environ.get("EBFI_NO_NATIVE_ADAM") is None):
+                N.dev_env("EBFI_NO_NATIVE_ADAM") is None):
             return False
-        from . import _native as N
         st = self.inner.state[self.flat]
         if not st:
             st["step"] = torch.zeros((), dtype=torch.float32, device=self.flat.device)

@@ -113,14 +113,14 @@ class Engine:
         # MFMA operand images of every conv weight, refreshed by one launch per step instead of one per conv call
         # (ebfi_amd.weightbank); training reads the optimiser's flat parameter buffer, inference keeps its own copy
         self.bank = None
-        import os
-        if self.device.type == "cuda" and os.environ.get("EBFI_NO_BANK", "0") != "1":     # (switch for A/B measurements)
+        from . import _native as N
+        if self.device.type == "cuda" and N.dev_env("EBFI_NO_BANK", "0") != "1":     # (switch for A/B measurements)
             from . import weightbank
             self.bank = weightbank.build_for(self.model, flat=self.optimizer.flat.data, params=self.optimizer.params) if train \
                 else weightbank.build_for(self.model, inference=True)
         self.book = None
         if backward_f16 is None:
-            backward_f16 = os.environ.get("EBFI_NO_F16_BWD", "0") != "1"
+            backward_f16 = N.dev_env("EBFI_NO_F16_BWD", "0") != "1"
         if train and self.bank is not None and precision == "bf16x3" and backward_f16:
             from . import f16scale
             self.book = f16scale.ScaleBook(self.device)

@@ -207,7 +207,7 @@ def se_gate(x, attn_conv, res=None, act=0, slope=0.0):
     B, C = x.shape[0], x.shape[1]
     n = x.numel() // max(B * C, 1)
     import os
-    if os.environ.get("EBFI_NO_SEGATE", "0") != "1" and \
+    if N.dev_env("EBFI_NO_SEGATE", "0") != "1" and \
             x.is_cuda and x.dtype == torch.float32 and n % 4 == 0 and B * C <= 4096 and attn_conv.in_channels == attn_conv.out_channels == C \
             and (res is None or res.shape == x.shape) and not torch.is_autocast_enabled():
         return _SEGate.apply(x, attn_conv.weight, attn_conv.bias, res, int(act), float(slope))

@@ -145,6 +145,6 @@ def ed_head(ev, bl, gn):
     import os
     if not (ev.is_cuda and ev.dtype == torch.float32 and bl.dtype == torch.float32 and ev.dim() == 4 and ev.shape == bl.shape and
             (ev.shape[2] * ev.shape[3]) % 4 == 0 and gn.weight is not None and gn.bias is not None and ev.shape[1] <= 1024 and
-            ev.shape[1] == gn.num_channels and not torch.is_autocast_enabled() and os.environ.get("EBFI_NO_EDHEAD") is None):
+            ev.shape[1] == gn.num_channels and not torch.is_autocast_enabled() and N.dev_env("EBFI_NO_EDHEAD") is None):
         return None
     return _EDHead.apply(ev, bl, gn.weight, gn.bias, gn.num_groups, gn.eps)

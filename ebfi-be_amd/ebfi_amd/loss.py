@@ -80,7 +80,7 @@ class _LapLoss(torch.autograd.Function):
         m = 1 << (_LapLoss.LEVELS - 1)
         ok = lambda t: t.is_cuda and t.dtype == torch.float32 and t.shape == a.shape
         return a.dim() == 4 and ok(a) and ok(target) and (b is None or ok(b)) and H % m == 0 and W % m == 0 and \
-            2 * H // m >= 3 and 2 * W // m >= 3 and not target.requires_grad and os.environ.get("EBFI_NO_LAPLOSS") is None
+            2 * H // m >= 3 and 2 * W // m >= 3 and not target.requires_grad and N.dev_env("EBFI_NO_LAPLOSS") is None
 
     @staticmethod
     def forward(ctx, a, b, target, coef_a, coef_b):

@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _native as N
 from . import conv, fold3d, fused, norm
 from .blur import Frame2DCP, Frame2Lap
 from .fac import KernelConv2D
@@ -215,7 +216,7 @@ class Modification(BaseModel):
         if torch.is_grad_enabled() and (cat.requires_grad or any(p.requires_grad for p in self.KernelConv.parameters())):
             return None
         if conv.get_compute_dtype() != "bf16x3" or not cat.is_cuda or cat.dtype != torch.float32 or cat.shape[-1] % 4 != 0 or \
-                os.environ.get("EBFI_NO_FAC_FUSION", "0") == "1":
+                N.dev_env("EBFI_NO_FAC_FUSION", "0") == "1":
             return None
         site = weightbank.lookup(self.KernelConv.conv2d.weight, "facrows")
         if site is None:
@@ -231,7 +232,7 @@ class Modification(BaseModel):
             return FrameTensor * ev1 + self.Conv2(ev1)
         fuse = self.KernelConv.native(cat)
         import os
-        if fuse is not None and fuse[0] == conv.ACT_LEAKY and ev.is_cuda and os.environ.get("EBFI_NO_PREACT", "0") != "1":
+        if fuse is not None and fuse[0] == conv.ACT_LEAKY and ev.is_cuda and N.dev_env("EBFI_NO_PREACT", "0") != "1":
             # the 1600-channel filter tensor has one consumer, the FAC op: its backward returns the gradient of the filters'
             # PRE-activation (kernel > 0 ? g : slope*g), so the 128 -> 1600 conv's weight / data gradient neither re-read the
             # 839 MB saved output for act' nor write / read a grad*act' side tensor of that size
