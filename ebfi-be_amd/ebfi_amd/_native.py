@@ -28,7 +28,7 @@ HEADER = os.path.join(REPO_ROOT, "include", "ebfi_hip.h")
 BUILD_SCRIPT = os.path.join(PKG_ROOT, "csrc", "build.sh")
 
 EBFI_F32, EBFI_BF16, EBFI_F32_BF16MMA, EBFI_F32_BF16X3MMA = 0, 1, 2, 3
-ABI_VERSION = 3          # include/ebfi_hip.h EBFI_ABI_VERSION
+ABI_VERSION = 4          # include/ebfi_hip.h EBFI_ABI_VERSION
 
 
 class EbfiNativeError(RuntimeError):
@@ -83,7 +83,8 @@ SIGNATURES = {
     "ebfi_prodmean_forward": (_i, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "ebfi_prodmean_backward": (_i, [_vp] * 5 + [_i64, _i64, _vp]),
     "ebfi_gather_sum": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
-    "ebfi_se_gate_forward": (_i, [_vp] * 7 + [_i, _i, _i64, _i, _c.c_float, _vp]),
+    "ebfi_se_gate_workspace": (_c.c_size_t, [_i, _i, _i64]),
+    "ebfi_se_gate_forward": (_i, [_vp] * 8 + [_i, _i, _i64, _i, _c.c_float, _vp]),
     "ebfi_se_gate_backward": (_i, [_vp] * 11 + [_i, _i, _i64, _i, _c.c_float, _vp]),
     "ebfi_groupnorm_workspace": (_sz, [_i, _i]),
     "ebfi_groupnorm_forward": (_i, [_vp] * 6 + [_i, _i, _i64, _i, _c.c_float, _vp, _sz, _vp]),

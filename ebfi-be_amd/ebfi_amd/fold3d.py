@@ -163,7 +163,7 @@ def conv_transpose3d_d2(x, m):
 
 
 class _SEGate(torch.autograd.Function):
-    """act(x * sigmoid(W mean(x) + b) (+ res)) as two launches forward, three backward (csrc/segate.hip)."""
+    """act(x * sigmoid(W mean(x) + b) (+ res)) as two launches forward, two backward (csrc/segate.hip)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, res, act, slope):
@@ -175,9 +175,10 @@ class _SEGate(torch.autograd.Function):
         out = torch.empty_like(x)
         mean = torch.empty(B * C, dtype=x.dtype, device=x.device)
         gate = torch.empty(B * C, dtype=x.dtype, device=x.device)
+        ws = torch.empty(max(int(N.lib().ebfi_se_gate_workspace(B, C, n)), 1), dtype=x.dtype, device=x.device)
         with torch.cuda.device_of(x):
-            rc = N.lib().ebfi_se_gate_forward(N.ptr(x), N.ptr(w2), N.ptr(bias), N.ptr(res), N.ptr(out), N.ptr(mean), N.ptr(gate), B, C,
-                                              n, act, slope, N.stream_ptr(x.device))
+            rc = N.lib().ebfi_se_gate_forward(N.ptr(x), N.ptr(w2), N.ptr(bias), N.ptr(res), N.ptr(out), N.ptr(mean), N.ptr(gate),
+                                              N.ptr(ws), B, C, n, act, slope, N.stream_ptr(x.device))
         N.check(rc, "ebfi_se_gate_forward")
         ctx.cfg = (B, C, n, act, slope, res is not None, bias is not None, weight.shape)
         ctx.save_for_backward(x, w2, gate, mean, out if act != 0 else None)
@@ -192,7 +193,7 @@ class _SEGate(torch.autograd.Function):
         gres = torch.empty_like(x) if has_res else None
         gw = torch.empty_like(w2)
         gb = torch.empty(C, dtype=x.dtype, device=x.device) if has_bias else None
-        ws = torch.empty(2 * B * C, dtype=x.dtype, device=x.device)
+        ws = torch.empty(max(int(N.lib().ebfi_se_gate_workspace(B, C, n)), 1), dtype=x.dtype, device=x.device)
         with torch.cuda.device_of(x):
             rc = N.lib().ebfi_se_gate_backward(N.ptr(g), N.ptr(out), N.ptr(x), N.ptr(w2), N.ptr(gate), N.ptr(mean), N.ptr(gx), N.ptr(gres),
                                                N.ptr(gw), N.ptr(gb), N.ptr(ws), B, C, n, act, slope, N.stream_ptr(x.device))

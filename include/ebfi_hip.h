@@ -46,8 +46,9 @@ extern "C" {
 #endif
 
 /* 3: round 2/3 additions (ebfi_ed_head_*, ebfi_laploss_*, ebfi_se_gate_*, ebfi_adam_step, ebfi_pack_table_bf16,
- * ebfi_conv2d_packed_x3, the fused KernelConv -> FAC forward, ...).  Bumped whenever an entry point is added or changed. */
-#define EBFI_ABI_VERSION 3
+ * ebfi_conv2d_packed_x3, the fused KernelConv -> FAC forward, ...).  4: ebfi_se_gate_forward takes a workspace
+ * (ebfi_se_gate_workspace).  Bumped whenever an entry point is added or changed. */
+#define EBFI_ABI_VERSION 4
 
 typedef enum {
     EBFI_OK = 0,
@@ -317,12 +318,12 @@ int ebfi_gather_sum(const float *src, const int32_t *idx, float *out, int64_t n_
  * SEGating (models/model_misc/resnet_3D.py:89-105) fused with what follows it: out = act(x * sigmoid(W mean(x) + b) (+ res)).
  * x, res, out: [B*C planes][N] contiguous fp32 (a [B,C,D,H,W] tensor as it stands), N % 4 == 0, B*C <= 4096;
  * weight [C,C] (the 1x1x1 conv), bias [C] or NULL; act: 0 none, 1 LeakyReLU(slope) (slope 0 = ReLU).
- * forward writes mean [B*C] and gate [B*C] for the backward; backward workspace: 2*B*C floats; grad_res / grad_bias may
- * be NULL; `out` may be NULL when act == 0 (backward).  Deterministic (fixed-order reductions).  The head of `out` (forward) and of
- * `grad_x` (backward) serves as scratch for the slice sums of the plane reductions before the tensor itself is written: neither
- * may alias an input. */
+ * forward writes mean [B*C] and gate [B*C] for the backward; both directions take a workspace of
+ * ebfi_se_gate_workspace(B, C, N) floats (slice sums of the plane reductions); grad_res / grad_bias may be NULL; `out` may be
+ * NULL when act == 0 (backward).  Two launches each way, deterministic (fixed-order reductions). */
+size_t ebfi_se_gate_workspace(int B, int C, int64_t N);
 int ebfi_se_gate_forward(const float *x, const float *weight, const float *bias, const float *res, float *out, float *mean,
-                         float *gate, int B, int C, int64_t N, int act, float slope, void *stream);
+                         float *gate, float *workspace, int B, int C, int64_t N, int act, float slope, void *stream);
 int ebfi_se_gate_backward(const float *grad_out, const float *out, const float *x, const float *weight, const float *gate,
                           const float *mean, float *grad_x, float *grad_res, float *grad_weight, float *grad_bias,
                           float *workspace, int B, int C, int64_t N, int act, float slope, void *stream);

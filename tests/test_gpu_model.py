@@ -650,7 +650,9 @@ def test_se_gate_kernels_vs_torch_cpu():
     torch.manual_seed(23)
     # (the 64 x 96 and 128 x 128 planes are cut into 2 / 4 slices by the sliced plane reductions of round 3)
     for (B, C, H, W, res, act) in [(2, 16, 8, 12, True, 0.0), (3, 24, 6, 10, False, 0.2), (1, 8, 5, 8, False, None), (2, 64, 4, 4, True, 0.0),
-                                   (2, 16, 64, 96, True, 0.0), (1, 16, 128, 128, False, 0.2)]:
+                                   (2, 16, 64, 96, True, 0.0), (1, 16, 128, 128, False, 0.2),
+                                   (70, 8, 4, 4, False, None),       # more than 64 samples: grad_W / grad_b accumulated in rounds
+                                   (2, 288, 2, 2, True, 0.0)]:       # more channels than threads in the gate prologue
         gate = SEGating(C)
         with torch.no_grad():
             gate.attn_layer[0].weight.copy_(torch.randn_like(gate.attn_layer[0].weight) * 0.5)

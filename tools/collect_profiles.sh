@@ -13,7 +13,7 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p
 find $OUT/prof -name "*kernel_trace*" -delete; find $OUT/prof -name "*.csv" | head
 echo "[3b] timeline of graph-replayed steps"
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o g -- python3 tools/graphprof.py --steps 12 > $OUT/graphprof.log 2>&1
-f=$(find $OUT/trace -name "*kernel_trace.csv" | head -1); python3 tools/trace_summary.py $f 0.5 > $OUT/graph_replay_timeline.txt; rm -rf $OUT/trace; head -5 $OUT/graph_replay_timeline.txt
+f=$(find $OUT/trace -name "*kernel_trace.csv" | head -1); python3 tools/trace_summary.py $f auto > $OUT/graph_replay_timeline.txt; rm -rf $OUT/trace; head -5 $OUT/graph_replay_timeline.txt
 echo "[4] PMC passes (eager launches), FETCH_SIZE then WRITE_SIZE"
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs --no-graph > /dev/null 2> $OUT/pmc_$C.err

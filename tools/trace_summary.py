@@ -2,7 +2,7 @@
 """Timeline summary of a rocprofv3 --kernel-trace CSV (development): for the replayed steps of tools/graphprof.py, how much
 of the wall time has >= 1 kernel running, how much is gaps, how much overlap there is, and per kernel the exclusive time
 (time during which it was the only kernel running) next to its summed duration.
-usage: trace_summary.py <kernel_trace.csv> [skip_fraction]"""
+usage: trace_summary.py <kernel_trace.csv> [skip_fraction | auto]   (auto: everything after the last device pause > 2 ms)"""
 import csv
 import collections
 import re
@@ -22,8 +22,17 @@ def main():
     for r in csv.DictReader(open(sys.argv[1])):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
     rows.sort()
-    skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.3
-    rows = rows[int(len(rows) * skip):]
+    skip = sys.argv[2] if len(sys.argv) > 2 else "0.3"
+    if skip == "auto":
+        # the replayed steps follow the last long pause of the device (the graph capture: tens of ms without a kernel)
+        cut, end = 0, rows[0][1]
+        for i, (s, e, n) in enumerate(rows):
+            if s - end > 2_000_000:
+                cut = i
+            end = max(end, e)
+        rows = rows[cut:]
+    else:
+        rows = rows[int(len(rows) * float(skip)):]
     t0, t1 = rows[0][0], max(r[1] for r in rows)
     events = []
     for s, e, n in rows:
