@@ -250,8 +250,14 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
 #pragma unroll
             for (int c = 0; c < 8; ++c) s.rq[k][c] = __builtin_amdgcn_raw_buffer_load_b128(r, pf_off[k] + cb + (unsigned)c * plane_bytes, 0, 0);
         const unsigned wb = (unsigned)__builtin_amdgcn_readfirstlane(pf_chunk) * (unsigned)(CKB * 2);
+#ifndef KB_NO_WLOAD      // (timing ablation of tools/kbench only: results are wrong without the weight pieces)
 #pragma unroll
         for (int it = 0; it < NWB; ++it) s.rw[it] = __builtin_amdgcn_raw_buffer_load_b128(rwt, w_off[it] + wb, 0, 0);
+#else
+#pragma unroll
+        for (int it = 0; it < NWB; ++it) s.rw[it] = u32x4{0u, 0u, 0u, 0u};
+        (void)wb;
+#endif
         if (++pf_chunk == nchunks) {
             pf_chunk = 0;
             pf_tile += G;
