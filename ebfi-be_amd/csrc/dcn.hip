@@ -203,6 +203,21 @@ __device__ __forceinline__ TapPos tap_pos_hw(const Geom &g, __amdgpu_buffer_rsrc
     return r;
 }
 
+// the same with the tap given as (row i, column j) of the kernel window: the forward walk steps (tap, i, j) incrementally in
+// scalar registers -- `tap / kw` and `idx / cb` per item were vector integer divisions, 40 of an item's 65 set-up instructions
+__device__ __forceinline__ TapPos tap_pos_ij(const Geom &g, __amdgpu_buffer_rsrc_t roff, __amdgpu_buffer_rsrc_t rmsk, int grp,
+                                             int tap, int i, int j, unsigned p4, int ho, int wo) {
+    const unsigned plane = (unsigned)g.HWo * 4u;
+    const unsigned ob = (unsigned)(grp * 2 * g.kk + 2 * tap) * plane + p4;
+    const float dy = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(roff, ob, 0, 0));
+    const float dx = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(roff, ob + plane, 0, 0));
+    TapPos r;
+    r.mask = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rmsk, (unsigned)(grp * g.kk + tap) * plane + p4, 0, 0));
+    r.h = (float)(ho * g.sh - g.ph + i * g.dh) + dy;
+    r.w = (float)(wo * g.sw - g.pw + j * g.dw) + dx;
+    return r;
+}
+
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 template <int NCH, bool SPLIT>
 __device__ __forceinline__ void sample_cols_buf(__amdgpu_buffer_rsrc_t rx, unsigned chan_byte, unsigned plane_bytes, const Tap &t,
@@ -290,7 +305,8 @@ __global__ __launch_bounds__(256, X3 ? 3 : 4) void dcn_fwd_f32(const float *__re
     constexpr int ROWS = X3 ? KCP : KC + 2;
     __shared__ float sW[ROWS * WSTR];   // [kl][co]
     __shared__ float sCol[ROWS * NP];   // [kl][px]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave-uniform on purpose: run bounds, taps and their (i, j) stay scalar)
     const int b = blockIdx.x / g.tiles_per_img;
     const int p0 = (blockIdx.x - b * g.tiles_per_img) * NP;
     const int co_base = blockIdx.y * 64;
@@ -349,13 +365,16 @@ __global__ __launch_bounds__(256, X3 ? 3 : 4) void dcn_fwd_f32(const float *__re
             const int R = ck.cb * g.kk;
             const int i1 = (R * (wave + 1)) >> 2;
             int idx = (R * wave) >> 2;
+            int tap = idx / ck.cb, c0 = idx - tap * ck.cb;            // one scalar division per chunk; stepped from here on
+            int ti = tap / g.kw, tj = tap - ti * g.kw;
             TapPos tp = {0.f, 0.f, 0.f};
-            if (p_ok && idx < i1) tp = tap_pos_hw(g, roff, rmsk, ck.grp, idx / ck.cb, p4, ho, wo);
+            if (p_ok && idx < i1) tp = tap_pos_ij(g, roff, rmsk, ck.grp, tap, ti, tj, p4, ho, wo);
             while (idx < i1) {
-                const int tap = idx / ck.cb, c0 = idx - tap * ck.cb;
                 const int n = min(ck.cb - c0, i1 - idx);
+                int ni = ti, nj = tj + 1;
+                if (nj == g.kw) { nj = 0; ++ni; }
                 TapPos tp_next = {0.f, 0.f, 0.f};
-                if (p_ok && idx + n < i1) tp_next = tap_pos_hw(g, roff, rmsk, ck.grp, tap + 1, p4, ho, wo);
+                if (p_ok && idx + n < i1) tp_next = tap_pos_ij(g, roff, rmsk, ck.grp, tap + 1, ni, nj, p4, ho, wo);
                 float *col = sCol + (c0 * g.kk + tap) * NP + px;
                 const int cstride = g.kk * NP;
                 if (p_ok) {
@@ -370,6 +389,8 @@ __global__ __launch_bounds__(256, X3 ? 3 : 4) void dcn_fwd_f32(const float *__re
                 }
                 tp = tp_next;
                 idx += n;
+                c0 = 0;                                              // (a run continues at channel 0 of the next tap)
+                ++tap; ti = ni; tj = nj;
             }
         }
         if constexpr (X3) {   // rows up to the next multiple of 16 take part in the last k-step
