@@ -280,11 +280,14 @@ __device__ __forceinline__ TapCoef make_tap_coef(float h, float w, float mask, i
 template <int NCH, bool SPLIT>
 __device__ __forceinline__ void sample_coef(__amdgpu_buffer_rsrc_t rx, unsigned chan_byte, unsigned plane_bytes, const TapCoef &t,
                                             float *col, int col_stride) {
+    // the channel offset is wave-uniform (the walk's run bounds are scalar): it rides in the instruction's scalar offset, the
+    // lane offset stays the pair's position inside a plane (out of range = 0x80000000: still past the extent with any channel)
     u32x2 a[NCH], b[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        a[c] = __builtin_amdgcn_raw_buffer_load_b64(rx, t.o0 + chan_byte + (unsigned)c * plane_bytes, 0, 0);
-        b[c] = __builtin_amdgcn_raw_buffer_load_b64(rx, t.o1 + chan_byte + (unsigned)c * plane_bytes, 0, 0);
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)(chan_byte + (unsigned)c * plane_bytes));
+        a[c] = __builtin_amdgcn_raw_buffer_load_b64(rx, t.o0, so, 0);
+        b[c] = __builtin_amdgcn_raw_buffer_load_b64(rx, t.o1, so, 0);
     }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
