@@ -213,3 +213,21 @@ def test_non_finite_grad_output_propagates_through_grad_input():
     bad, bad_ref = ~torch.isfinite(gi), ~torch.isfinite(ref)
     assert bad_ref.any() and torch.equal(bad, bad_ref)
     assert _rel(gi[~bad], ref[~bad_ref]) < 5e-5
+
+
+def test_forward_with_non_finite_and_far_offsets_matches_the_reference_rule():
+    """dcn_v2_im2col_cuda.cu:176-186: a sample contributes only if -1 < h < H and -1 < w < W -- a NaN, infinite or far-away
+    sampling position compares false and contributes an exact 0, whatever the mask.  The forward kernel folds bilinear weight,
+    mask and corner selection into four coefficients per (pixel, tap): they must be exactly 0 there (not NaN * 0)."""
+    from ebfi_amd.dcn import dcn_v2_conv
+    cfg = dict(B=1, C=16, H=12, W=20, Co=8, k=3, s=1, p=1, d=1, dg=2)
+    x, off, msk, w, b, _ = _inputs(**cfg, seed=11)
+    flat = off.view(-1)
+    idx = torch.randperm(flat.numel(), generator=torch.Generator().manual_seed(5))[:200]
+    vals = torch.tensor([float("nan"), float("inf"), -float("inf"), 1e9, -1e9, 3e38, 25.0, -25.0])
+    flat[idx] = vals[torch.arange(200) % len(vals)]
+    ref = ref_ops.dcn_forward(x, w, b, off, msk, 1, 1, 1, 2)
+    assert torch.isfinite(ref).all()
+    out = dcn_v2_conv(x.cuda(), off.cuda(), msk.cuda(), w.cuda(), b.cuda(), 1, 1, 1, 2)
+    assert torch.isfinite(out).all()
+    assert _rel(out.cpu(), ref) < 2e-5
