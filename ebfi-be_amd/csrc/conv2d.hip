@@ -538,6 +538,17 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16(const float *__restrict__ x
 // slice per CU instead of two): one workgroup of 8 waves per CU.
 constexpr int TYB = 8, NTB = 512;
 
+// Workgroup ids are dealt round-robin over the 8 XCDs, each with its own L2 (MI355X_MICROARCH.md, workgroup dispatch; used for
+// speed only).  Neighbouring pixel tiles share halo rows and partial cache lines: with tile = workgroup id they sat on different
+// XCDs and every L2 fetched its own copy from the fabric (rocprofv3 FETCH_SIZE, calibrated on tools/bwprobe.hip: 1.75-2.3x the
+// algorithmic bytes).  xcd_tile() permutes the tile index so that the ids congruent mod 8 -- one XCD -- cover one CONTIGUOUS
+// eighth of the tile sequence (at B = 8: one image each).  Bijective on [0, T) for every T; callers apply it only when the
+// grid's x extent is a multiple of 8 (otherwise id % 8 is not the XCD of the workgroup).
+__device__ __forceinline__ int xcd_tile(int t, int T) {
+    const int q = T >> 3, r = T & 7, x = t & 7, j = t >> 3;
+    return x * q + min(x, r) + j;
+}
+
 // In-kernel phase stamps: compiled in by tools/kbench.hip only (-DEBFI_KBENCH); the product build has no stamp code.
 #ifdef EBFI_KBENCH
 // stamps go to a small LDS area behind the operand buffers (a global store per stamp would sit in the wave's vmcnt queue and
@@ -619,7 +630,8 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_db(const float *__restric
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = (g.Wo + TX - 1) / TX, tiles_y = (g.Ho + TYB - 1) / TYB;
-    int t = blockIdx.x;
+    const bool xcd_map = (gridDim.x & 7) == 0;             // (see xcd_tile: neighbouring tiles on one XCD)
+    int t = xcd_map ? xcd_tile(blockIdx.x, tiles_total) : blockIdx.x;
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const int b = t / tiles_y;
@@ -831,7 +843,7 @@ __global__ __launch_bounds__(NTB) void conv_fwd_bf16x3_db(const float *__restric
         // a 4-chunk tile) are paid once per workgroup instead of once per tile.
         const int grp = co_base / (g.Cout / g.groups);
         auto tile_coords = [&](int tt, int &tb, int &ty0, int &tx0) {
-            int u = tt;
+            int u = xcd_map ? xcd_tile(tt, tiles_total) : tt;      // (neighbouring tiles on one XCD: shared halo lines hit its L2)
             const int txi = u % tiles_x; u /= tiles_x;
             const int tyi = u % tiles_y;
             tb = u / tiles_y; ty0 = tyi * TYB; tx0 = txi * TX;
@@ -2265,8 +2277,9 @@ __global__ __launch_bounds__(NTWS) void conv_fwd_bf16x3_ws(const float *__restri
     int ntiles_mine = 0;
     for (int t = blockIdx.x; t < tiles_total; t += G) ++ntiles_mine;
     const int nitems = ntiles_mine * nchunks;
+    const bool xcd_map = (gridDim.x & 7) == 0;
     auto tile_coords = [&](int tt, int &tb, int &ty0, int &tx0) {
-        int u = tt;
+        int u = xcd_map ? xcd_tile(tt, tiles_total) : tt;          // (neighbouring tiles on one XCD: shared halo lines hit its L2)
         const int txi = u % tiles_x; u /= tiles_x;
         const int tyi = u % tiles_y;
         tb = u / tiles_y; ty0 = tyi * TYB; tx0 = txi * TX;

@@ -89,8 +89,9 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
     int ntiles_mine = 0;
     for (int t = blockIdx.x; t < tiles_total; t += G) ++ntiles_mine;
     const int nitems = ntiles_mine * nchunks;
+    const bool xcd_map = (gridDim.x & 7) == 0;
     auto tile_coords = [&](int tt, int &tb, int &ty0, int &tx0) {
-        int u = tt;
+        int u = xcd_map ? xcd_tile(tt, tiles_total) : tt;          // (neighbouring tiles on one XCD: shared halo lines hit its L2)
         const int txi = u % tiles_x; u /= tiles_x;
         const int tyi = u % tiles_y;
         tb = u / tiles_y; ty0 = tyi * TYB; tx0 = txi * TX;
@@ -823,8 +824,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict
 #pragma unroll
     for (int e = 0; e < 8; ++e) bacc[e] = 0.f;
     float amax_g = 0.f, amax_x = 0.f;
+    // (splits congruent mod 8 run on one XCD when gridDim.x is a multiple of 8 -- see the placement above -- so their tiles
+    // split, split + G, .. are mapped onto one contiguous eighth of the tile sequence: shared halo lines hit that XCD's L2)
+    const bool xcd_map = (gridDim.x & 7) == 0;
     auto tile_coords = [&](int tile, int &b, int &y0, int &x0) {
-        int t = tile;
+        int t = (xcd_map && tile < total_tiles) ? xcd_tile(tile, total_tiles) : tile;
         const int tx = t % tiles_x; t /= tiles_x;
         const int ty = t % tiles_y;
         b = t / tiles_y; y0 = ty * TRH; x0 = tx * TRW;
