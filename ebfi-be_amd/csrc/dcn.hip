@@ -310,8 +310,16 @@ __global__ __launch_bounds__(256, X3 ? 3 : 4) void dcn_fwd_f32(const float *__re
     __shared__ float sCol[ROWS * NP];   // [kl][px]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave-uniform on purpose: run bounds, taps and their (i, j) stay scalar)
-    const int b = blockIdx.x / g.tiles_per_img;
-    const int p0 = (blockIdx.x - b * g.tiles_per_img) * NP;
+    // workgroup ids go round-robin over the 8 XCDs: with tile = id every XCD's 4 MB L2 saw the gathers of ALL samples (33.5 MB
+    // of input at B = 8); ids congruent mod 8 now cover one contiguous eighth of the tiles -- one sample per XCD at B = 8, whose
+    // 4.2 MB of planes its L2 can keep (same permutation as xcd_tile in conv2d.hip; speed only)
+    int tile = blockIdx.x;
+    if ((gridDim.x & 7) == 0) {
+        const int T = gridDim.x, q = T >> 3;
+        tile = (tile & 7) * q + (tile >> 3);
+    }
+    const int b = tile / g.tiles_per_img;
+    const int p0 = (tile - b * g.tiles_per_img) * NP;
     const int co_base = blockIdx.y * 64;
     const int mt = wave >> 1, nt = wave & 1;
     const bool tile_live = co_base + mt * 32 < g.Co;
