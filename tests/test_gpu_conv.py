@@ -337,6 +337,9 @@ def _banked_layer(Cin, Cout, scale_w=1.0):
     (1, 64, 16, 64, 128, 1, 1e-12, 1e-20),     # magnitudes far below fp16's range: what the x0.1 initialisation produces
     (1, 64, 8, 64, 64, 0, 3e4, 1e6),           # ... and far above it (no activation: at |y| ~ 1e5 the fp32 forward's last bits
                                                #     decide the sign of y ~ 0, a kink of the test, not of the kernels)
+    (3, 64, 342, 160, 64, 0, 1.0, 1.0),        # 387 forward / 1290 weight-gradient tiles on 256 persistent workgroups: the
+                                               #     XCD-contiguous tile permutation (xcd_tile) with a remainder (T % 8 != 0);
+                                               #     no activation: among 10 M outputs a few |y| < 1e-5 flip the LeakyReLU mask
 ])
 def test_fp16_backward_kernels_vs_cpu(B, Cin, H, W, Cout, act, xs, gs):
     """csrc/conv2d_f16.inc.hpp through the autograd node the model uses (conv.SiteConvBiasAct with a scale book active): data
@@ -356,7 +359,8 @@ def test_fp16_backward_kernels_vs_cpu(B, Cin, H, W, Cout, act, xs, gs):
     x = torch.randn(B, Cin, H, W) * xs
     g = torch.randn(B, Cout, H, W) * gs
     xr, wr, br = x.clone().requires_grad_(), w.detach().cpu().clone().requires_grad_(), b.detach().cpu().clone().requires_grad_()
-    _ref(xr, wr, br, 1, 1, act, 0.01).backward(g)
+    yr = _ref(xr, wr, br, 1, 1, act, 0.01)
+    yr.backward(g)
     xd = x.cuda().requires_grad_()
     conv.set_compute_dtype("bf16x3")
     try:
@@ -380,6 +384,7 @@ def test_fp16_backward_kernels_vs_cpu(B, Cin, H, W, Cout, act, xs, gs):
     assert prof.get("conv_wgrad_f16_tr" if force_tr else "conv_wgrad_f16_ws") == 1, prof
     assert prof.get("conv_fwd_f16_ws", 0) == (1 if Cin >= 48 else 0), prof      # (narrower data gradients keep the 32-channel split-precision form)
     assert "conv_wgrad_x3_ws" not in prof and "conv_fwd_bf16x3_ws/dgrad" not in prof
+    assert _rel(y.detach(), yr.detach()) < 1e-4             # (the split-precision forward: every tile written exactly once)
     assert _rel(xd.grad, xr.grad) < 1e-3 and _rel(w.grad, wr.grad) < 1e-3 and _rel(b.grad, br.grad) < 1e-5
     assert int(book.guard[0].item()) == 0                   # calibrated scales: nothing left the range
     # the maxima recorded by the kernels became the next scales: |max| * scale in [2, 4)
