@@ -17,6 +17,8 @@ fields the line carries
   fp32_exact_mode  the same step with every conv on the exact fp32 matrix cores (second leg of the same run)
   ops              FAC fwd/bwd, DCNv2 fwd/bwd and the composite DCNv2+FAC forward (the north_star target, >= 0.30 of the HBM
                    roofline) at B=8, 128x128 features, timed in the same process (N=1 only)
+  inference        BASELINE configs 2 (B=4 256x256, fp32 and bf16x3) and 5 (B=8 720x1280): frames/s, peak memory, and the roofline
+                   of the fused KernelConv -> FAC kernel (N=1 only)
   cpu_baseline     the CPU oracle (oracle/model_ref.py + loss_ref.py, a port of the reference path) timed on this box's
                    host cores on a bounded sample (rank 0, N=1 only)
 """
@@ -236,6 +238,77 @@ def ops_block(device, iters=20):
     return out
 
 
+def inference_block(device):
+    """BASELINE.json configs 2 and 5 (inference through the reference's per-timestamp loop, infer_ours.py:113-118) in THIS
+    process: B=4 256x256 with the exact fp32 kernels and in the default split-precision mode, and B=8 720x1280 (HD).  One
+    timed clip = the timestamp-independent prefix once + `num_ts` replays of the per-timestamp hipGraph
+    (ebfi_amd.engine.ClipInterpolator); O(1)-gain random weights (the x0.1 initialisation outputs the constant 0.5).  The
+    roofline entry is the fused KernelConv(128->1600) -> FAC kernel, the dominant launch of these configs, timed with the
+    library's hipEvent pairs during one extra eager (no-graph) timestamp."""
+    from ebfi_amd import _native as N
+    from ebfi_amd.engine import DEFAULT_MODEL_ARGS, ClipInterpolator, synthetic_batch
+    from ebfi_amd.model import EVFIAutoEx
+    torch.manual_seed(123)
+    model = EVFIAutoEx(**DEFAULT_MODEL_ARGS).to(device).eval()
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() > 1:
+                p.copy_(torch.randn_like(p) * (1.2 / p[0].numel() ** 0.5))
+            else:
+                p.add_(0.05 * torch.randn_like(p))
+    out = {"note": "inference, one clip = prefix (feature extractors + exposure decision) once + num_ts per-timestamp hipGraph "
+                   "replays; frames/s = B * num_ts / wall time of the clip"}
+    legs = [("config2_fp32", 4, 256, 256, "fp32", 8), ("config2_bf16x3", 4, 256, 256, "bf16x3", 16),
+            ("config5_hd_bf16x3", 8, 720, 1280, "bf16x3", 4)]
+    for tag, B, h, w, prec, num_ts in legs:
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats(device)
+        interp = ClipInterpolator(model, precision=prec, graph=True, hoist=True)
+        frame, event, _, gtex, _ = synthetic_batch(B, h, w, TB, device=device, seed=123)
+        stamps = [i / float(num_ts) for i in range(num_ts)]
+        interp(frame, event, gtex, stamps[:1])                 # untimed: allocator, capture
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        res = interp(frame, event, gtex, stamps)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        entry = {"B": B, "height": h, "width": w, "precision": prec, "num_ts": num_ts, "frames_per_s": round(B * num_ts / dt, 2),
+                 "ms_per_timestamp": round(1e3 * dt / num_ts, 3), "peak_memory_GB": round(torch.cuda.max_memory_allocated(device) / 1e9, 2),
+                 "output_mean": round(float(res.mean().item()), 5), "finite": bool(torch.isfinite(res).all().item())}
+        if prec == "bf16x3":
+            eager = ClipInterpolator(model, precision=prec, graph=False, hoist=True)
+            eager(frame, event, gtex, stamps[:1])
+            torch.cuda.synchronize(device)
+            N.prof_reset()
+            N.prof_enable(True)
+            eager(frame, event, gtex, stamps[:2])
+            torch.cuda.synchronize(device)
+            N.prof_enable(False)
+            k = N.prof_collect()
+            per_kernel, _ = kernel_table(k, 1.0, 2)
+            top = sorted(per_kernel.items(), key=lambda kv: -kv[1]["total_ms"])[:5]
+            entry["top_kernels_ms_per_timestamp"] = {n: round(v["total_ms"] / 2, 4) for n, v in top}
+            fused = k.get("conv_fwd_bf16x3_ws/kernelconv_fac")
+            if fused and fused[0]:
+                n, ms, flops, nbytes = fused
+                secs = ms * 1e-3
+                t_mfma, t_hbm = 3 * flops / (BF16_MFMA_PEAK_TFS * 1e12), nbytes / (HBM_PEAK_GBS * 1e9)
+                entry["kernelconv_fac_fused"] = {
+                    "kernel": "conv_fwd_bf16x3_ws/kernelconv_fac", "launches": n, "avg_ms": round(ms / n, 4),
+                    "bound": "mfma" if t_mfma >= t_hbm else "hbm", "algorithmic_flops_per_launch": flops / n,
+                    "algorithmic_bytes_per_launch": nbytes / n, "achieved": round(flops / secs / 1e12, 2), "peak": BF16_MFMA_PEAK_TFS,
+                    "unit": "TFLOP/s", "frac": round(flops / secs / 1e12 / BF16_MFMA_PEAK_TFS, 4),
+                    "executed": round(3 * flops / secs / 1e12, 2), "frac_executed": round(3 * flops / secs / 1e12 / BF16_MFMA_PEAK_TFS, 4),
+                    "GBps": round(nbytes / secs / 1e9, 1), "frac_hbm": round(nbytes / secs / 1e9 / HBM_PEAK_GBS, 4)}
+            del eager
+        out[tag] = entry
+        note("inference %s: %.1f frames/s, peak %.1f GB" % (tag, entry["frames_per_s"], entry["peak_memory_GB"]))
+        del interp, frame, event, res
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -248,6 +321,10 @@ def main():
                     help="launch every kernel of the step eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ops", action="store_true", help="skip the FAC / DCNv2 op block (north_star target figure)")
+    ap.add_argument("--no-inference", action="store_true", help="skip the inference block (BASELINE configs 2 and 5)")
+    ap.add_argument("--strict-graph", action="store_true",
+                    help="exit non-zero when the hipGraph capture of the step failed and the engine fell back to eager launches "
+                         "(default: report it as config.graph_capture_failed and in config.launch)")
     ap.add_argument("--no-bf16-leg", "--no-extra-legs", dest="no_extra_legs", action="store_true",
                     help="skip the secondary measurement of the same step in the exact-fp32 mode")
     args = ap.parse_args()
@@ -359,6 +436,15 @@ def main():
     if any(c != checks[0] for c in checks):
         raise SystemExit("bench.py: replicas diverged, per-rank parameter checksums %r" % (checks,))
 
+    # a capture that could not be taken silently costs ~20 % of the step: every rank reports, the line carries the flag
+    capture_failed, capture_err = bool(eng.graph_capture_failed), eng.graph_capture_error
+    if world > 1:
+        flag = torch.tensor([1.0 if capture_failed else 0.0], device="cpu" if rehearsal else device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        capture_failed = bool(flag.item() > 0)
+    if capture_failed:
+        note("WARNING: hipGraph capture failed (%s): the timed region ran eager launches" % (capture_err or "on another rank"))
+
     if rank == 0:
         per_kernel, roofline = kernel_table(kernels, prof_elapsed, args.steps)
         if roofline is not None:
@@ -387,7 +473,9 @@ def main():
                                                 "delayed power-of-two operand scales (packed gradient within 5e-3 of the oracle's: "
                                                 "tests/test_gpu_model.py::test_benchmarked_step_vs_oracle)" if eng.book is not None else ""),
                                      "bf16": "fp32 tensors and accumulation; conv operands rounded once to bf16"}[args.precision],
-                       "launch": "hipGraph replay of fwd+loss+bwd+grad packing; all-reduce and Adam eager" if eng.use_graph else "eager",
+                       "launch": "hipGraph replay of fwd+loss+bwd+grad packing; all-reduce and Adam eager" if eng.use_graph else
+                       ("eager (hipGraph capture FAILED on at least one rank: %s)" % capture_err if capture_failed else "eager"),
+                       "graph_capture_failed": capture_failed,
                        "untimed_steps": untimed[args.precision],
                        "fp16_overflow_guard": None if eng.book is None else
                        {"optimiser_steps_skipped": skipped, "operand_scale_slots": len(eng.book.index)},
@@ -402,6 +490,9 @@ def main():
             torch.cuda.empty_cache()
             out["ops"] = ops_block(device)
             out["dcn_fac_forward_frac_hbm"] = out["ops"]["dcn_fac_forward"]["frac_hbm"]
+        if world == 1 and not args.no_inference:
+            note("inference block: configs 2 (B=4 256x256) and 5 (B=8 720x1280) ...")
+            out["inference"] = inference_block(device)
         if world == 1 and not args.no_cpu_baseline:
             note("cpu baseline (oracle on host cores) ...")
             out["cpu_baseline"] = cpu_baseline(dict(DEFAULT_MODEL_ARGS))
@@ -412,6 +503,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if args.strict_graph and capture_failed:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

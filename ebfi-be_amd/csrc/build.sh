@@ -7,6 +7,10 @@ OUT="$HERE/../lib"
 # EBFI_LIB_PATH); the defaults are the in-tree product library
 OUTLIB="${EBFI_LIB_OUT:-$OUT/libebfi_hip.so}"
 OBJ="${EBFI_OBJ_DIR:-$HERE/obj}"
+if [ -n "${EBFI_EXTRA_FLAGS:-}" ] && { [ -z "${EBFI_LIB_OUT:-}" ] || [ -z "${EBFI_OBJ_DIR:-}" ]; }; then
+    echo "build.sh: EBFI_EXTRA_FLAGS changes the kernels: build into a separate file (set EBFI_LIB_OUT and EBFI_OBJ_DIR)" >&2
+    exit 2
+fi
 mkdir -p "$OUT" "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -munsafe-fp-atomics ${EBFI_EXTRA_FLAGS:-}"

@@ -7,6 +7,7 @@
 #include <cstdio>
 
 #include "../../include/ebfi_hip.h"
+#include "ablate_guard.hpp"
 
 namespace ebfi {
 

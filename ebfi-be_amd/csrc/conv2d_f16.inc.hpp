@@ -601,7 +601,9 @@ __global__ __launch_bounds__(256) void f16_scales_finish_kernel(float *__restric
     if (a <= 3.0e38f) {
         int e;
         (void)frexpf(a, &e);               // a = m * 2^e, m in [0.5, 1)
-        slot[0] = ldexpf(1.f, F16_TARGET_EXP - e);
+        // (clamped like the host-side calibration, f16scale.calibrate: a recorded |max| below ~2^-125 must not turn the
+        // next scale into +inf -- the x0.1 initialisation does produce 1e-29 gradients)
+        slot[0] = ldexpf(1.f, min(F16_TARGET_EXP - e, 120));
     }
     slot[SLOT_AMAX] = 0.f;
 }
@@ -618,11 +620,13 @@ __global__ __launch_bounds__(256) void pack_table_f16_kernel(const float *__rest
     const int32_t t = e < n ? table[e] : -1;
     const float v = t >= 0 ? src[t & 0x3fffffff] : 0.f;
     if (e < n) out[e] = (_Float16)(v * slot[0]);
-    float m = fabsf(v);
+    // |max| over the wave on the float BITS (non-negative floats order like unsigned integers, and a NaN weight -- which
+    // fmaxf would drop -- stays the largest value and reaches the slot: the finish launch then raises the guard)
+    unsigned m = __float_as_uint(fabsf(v));
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
-    if ((threadIdx.x & 63) == 0 && m > __builtin_nontemporal_load(slot + SLOT_AMAX))
-        atomicMax(reinterpret_cast<unsigned *>(slot + SLOT_AMAX), __float_as_uint(m));
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d, 64));
+    if ((threadIdx.x & 63) == 0 && !(__uint_as_float(m) <= __builtin_nontemporal_load(slot + SLOT_AMAX)))
+        atomicMax(reinterpret_cast<unsigned *>(slot + SLOT_AMAX), m);
 }
 
 // ------------------------------------------------------------------------------------------------

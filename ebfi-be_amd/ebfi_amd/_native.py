@@ -12,7 +12,6 @@ import threading
 
 PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # .../ebfi-be_amd
 REPO_ROOT = os.path.dirname(PKG_ROOT)
-# EBFI_LIB_PATH: development switch for same-box A/B runs of two builds of the library
 # Development switches (EBFI_NO_*, EBFI_WGRAD_TR, ... -- A/B measurements and tests): honoured only in a process started with
 # EBFI_DEV=1, like the library's own (csrc/common.hpp dev_getenv), so that a stray variable cannot change which kernels a
 # production run, one of its ranks or one of its graph captures takes.
@@ -23,12 +22,15 @@ def dev_env(name, default=None):
     return os.environ.get(name, default) if _DEV else default
 
 
-LIB_PATH = os.environ.get("EBFI_LIB_PATH") or os.path.join(PKG_ROOT, "lib", "libebfi_hip.so")
+# EBFI_LIB_PATH (a second build of the library for same-box A/B runs, tools/ab_bench.sh) is a development switch like the
+# others: ignored unless EBFI_DEV=1.  The ABI version of whatever is loaded must match in every case -- an older build whose
+# entry points changed signature would be called with shifted arguments (round-3 advisory).
+LIB_PATH = dev_env("EBFI_LIB_PATH") or os.path.join(PKG_ROOT, "lib", "libebfi_hip.so")
 HEADER = os.path.join(REPO_ROOT, "include", "ebfi_hip.h")
 BUILD_SCRIPT = os.path.join(PKG_ROOT, "csrc", "build.sh")
 
-EBFI_F32, EBFI_BF16, EBFI_F32_BF16MMA, EBFI_F32_BF16X3MMA = 0, 1, 2, 3
-ABI_VERSION = 4          # include/ebfi_hip.h EBFI_ABI_VERSION
+EBFI_F32, EBFI_F32_BF16MMA, EBFI_F32_BF16X3MMA = 0, 2, 3
+ABI_VERSION = 5          # include/ebfi_hip.h EBFI_ABI_VERSION
 
 
 class EbfiNativeError(RuntimeError):
@@ -147,15 +149,10 @@ def lib():
             try:
                 fn = getattr(h, name)
             except AttributeError as e:
-                if os.environ.get("EBFI_LIB_PATH"):     # an older build under A/B (tools/ab_bench.sh): say what stays unbound
-                    import sys
-                    print("ebfi_amd._native: %s (EBFI_LIB_PATH) does not export %s; calls to it will fail"
-                          % (LIB_PATH, name), file=sys.stderr)
-                    continue
                 raise EbfiNativeError("%s does not export %s" % (LIB_PATH, name)) from e
             fn.restype = res
             fn.argtypes = args
-        if h.ebfi_abi_version() != ABI_VERSION and not os.environ.get("EBFI_LIB_PATH"):
+        if h.ebfi_abi_version() != ABI_VERSION:
             raise EbfiNativeError("ABI version mismatch: library %d, binding %d" % (h.ebfi_abi_version(), ABI_VERSION))
         _lib = h
     return _lib
@@ -185,9 +182,7 @@ def dtype_code(t):
     import torch
     if t.dtype == torch.float32:
         return EBFI_F32
-    if t.dtype == torch.bfloat16:
-        return EBFI_BF16
-    raise EbfiNativeError("unsupported dtype %s (float32 / bfloat16 only)" % t.dtype)
+    raise EbfiNativeError("unsupported dtype %s (the ops take float32 tensors, like the reference's)" % t.dtype)
 
 
 def require_gpu(*tensors):

@@ -232,7 +232,10 @@ class SiteConvBiasAct(Function):
         f16 = book is not None and ks == 3 and pad == 1
         # (partial 64-channel blocks -- the 32 / 48-channel layers of the detail branch -- go through the pixel-major kernel, which
         # needs quad-aligned rows; below 32 channels the zero-filled half of the block would be most of the work)
-        f16_w = f16 and (Cin % 64 == 0 or (Cin >= 32 and W % 4 == 0 and N.dev_env("EBFI_WGRAD_TR", "1") != "0"))
+        # (the pixel-major kernel -- the only one for ragged Cin -- stages 16-byte quads: operands that are unaligned views
+        # take the split-precision kernel instead of failing with EBFI_ERR_UNSUPPORTED)
+        al16 = all(t is None or t.data_ptr() % 16 == 0 for t in (x, gout, y))
+        f16_w = f16 and (Cin % 64 == 0 or (Cin >= 32 and W % 4 == 0 and al16 and N.dev_env("EBFI_WGRAD_TR", "1") != "0"))
         f16_x = f16 and W % 4 == 0 and Cin >= 48 and site.tr16_ptr() is not None
         with torch.cuda.device_of(x):
             st = N.stream_ptr(x.device)

@@ -21,6 +21,20 @@ def is_distributed():
 
 
 @torch.no_grad()
+def sync_guard(guard):
+    """Overflow guard of the fp16 backward (ebfi_amd.f16scale: int32[2] = [flag of this step, skipped steps]): every rank must
+    take -- or skip -- the same update, so the flag is MAX-reduced over ranks before the guarded optimiser launch reads it."""
+    if guard is not None and is_distributed():
+        if guard.is_cuda and dist.get_backend() == "gloo":     # (rehearsal fabric: reduce through the host)
+            host = guard[0:1].cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MAX)
+            guard[0:1].copy_(host)
+        else:
+            dist.all_reduce(guard[0:1], op=dist.ReduceOp.MAX)
+    return guard
+
+
+@torch.no_grad()
 def reduce_tensor(input_tensor, average=True):
     """myutils/utils.py:80-92: barrier + all_reduce(SUM) (+ / world); identity on one rank."""
     if not (dist.is_available() and dist.is_initialized()):

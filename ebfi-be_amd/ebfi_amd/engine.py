@@ -100,6 +100,7 @@ class Engine:
         # precision and loss phase) and replayed; the all-reduce and the optimiser step stay eager (train_step_graph).
         self.use_graph = bool(graph) and self.device.type == "cuda"
         self._graphs = {}
+        self.graph_capture_failed, self.graph_capture_error = False, None    # set when a capture fell back to eager launches
         if train:
             self.model.train()
             self.loss = TrainLoss(self.model_args.get("DetailEnabled", True)).to(self.device)
@@ -164,14 +165,20 @@ class Engine:
         with self._autocast(), self._bank(), self._book() as book:
             if book is not None and self._steps_run < self.calibration_steps:
                 book.calibrated.clear()             # (measure every operand of this pass again, see __init__)
-            if book is not None and self._micro == 0:
-                book.begin_step()                   # clear the overflow guard of this optimiser step
             sharp_pre, sharp = self.model(frame, event, t, gtex)
             loss = self.loss(sharp_pre.float(), sharp.float(), target, self.iteration, self.accu_step)
             loss.backward()
             if book is not None:
                 book.finish()                       # next step's operand scales from this pass's maxima; guard on overflow
         return loss.detach()
+
+    def _begin_micro_step(self):
+        """Clears the fp16 overflow guard at the start of an accumulation window -- EAGERLY, never inside the captured
+        region: a graph replays whatever `_micro` was at capture time, so a clear baked into it would wipe the flag a
+        previous micro-step of the same window raised (round-3 advisory); the guard therefore stays an OR over the window
+        and is only cleared here, before the window's first forward."""
+        if self.book is not None and self.precision == "bf16x3" and self._micro == 0:
+            self.book.begin_step()
 
     def _finish_micro_step(self, flat):
         """`flat`: this call's packed gradient (of loss / accu_step).  Sums the calls of one accumulation window in place
@@ -189,11 +196,8 @@ class Engine:
         self.bucket.reduce_mean_packed()
         guard = None
         if self.book is not None and self.precision == "bf16x3":
-            guard = self.book.guard
-            from .dp import is_distributed
-            if is_distributed():                    # every rank must take (or skip) the same update
-                import torch.distributed as dist
-                dist.all_reduce(guard[0:1], op=dist.ReduceOp.MAX)
+            from .dp import sync_guard
+            guard = sync_guard(self.book.guard)     # every rank must take (or skip) the same update
         self.optimizer.step(self.bucket.flat, guard=guard)
         self.iteration += 1
         self._steps_run += 1
@@ -205,6 +209,7 @@ class Engine:
         calibrating = self.book is not None and self.precision == "bf16x3" and self._steps_run < self.calibration_steps
         if self.use_graph and not calibrating:
             return self.train_step_graph(frame, event, t, gtex, target)
+        self._begin_micro_step()
         self.bucket.zero()
         loss = self._fwd_bwd(frame, event, t, gtex, target)
         self._finish_micro_step(self.bucket.gather())
@@ -243,11 +248,13 @@ class Engine:
                 print("ebfi_amd.engine: hipGraph capture failed (%s); continuing with eager launches" % str(err).splitlines()[0],
                       file=sys.stderr, flush=True)
                 self.use_graph = False
+                self.graph_capture_failed, self.graph_capture_error = True, str(err).splitlines()[0]
                 torch.cuda.synchronize(self.device)
                 return self.train_step(frame, event, t, gtex, target)
             entry = (graph, static_in, loss, flat, [p.grad for p in self.bucket.params])
             self._graphs[key] = entry
         graph, static_in, loss, flat, grads = entry
+        self._begin_micro_step()
         for s, v in zip(static_in, inputs):
             if s.data_ptr() != v.data_ptr():
                 s.copy_(v)
@@ -262,3 +269,84 @@ class Engine:
     def infer(self, frame, event, t, gtex=None):
         with self._autocast(), self._bank():
             return self.model(frame, event, t, gtex)[-1]
+
+
+class ClipInterpolator:
+    """Inference over the latent timestamps of a clip (reference loop infer_ours.py:113-118: the same Frame / Event / GTEx for
+    every timestamp, only T changes): the timestamp-independent prefix of the network (`EVFIAutoEx.encode`: both feature
+    extractors, Frame2Lap + ExposureDecision) runs ONCE per clip, the per-timestamp rest (`decode`) is captured into a hipGraph
+    per input shape and replayed with a new T.  Outputs are bit-identical to calling the model once per timestamp
+    (tests/test_gpu_model.py::test_hoisted_inference_is_bit_identical).  precision 'bf16x3' packs the conv weight images once
+    (inference weight bank, incl. the fused KernelConv -> FAC layout)."""
+
+    def __init__(self, model, precision="bf16x3", graph=True, hoist=True):
+        self.model = model.eval()
+        self.precision, self.graph, self.hoist = precision, bool(graph), bool(hoist)
+        self.bank = None
+        if precision == "bf16x3" and next(model.parameters()).is_cuda:
+            from . import weightbank
+            self.bank = weightbank.build_for(model, inference=True)
+            self.bank.refresh()
+        self._captured = {}
+
+    @contextlib.contextmanager
+    def _ctx(self):
+        from . import conv
+        prev = conv.get_compute_dtype()
+        conv.set_compute_dtype(self.precision)
+        try:
+            with (self.bank.active() if self.bank is not None else contextlib.nullcontext()):
+                yield
+        finally:
+            conv.set_compute_dtype(prev)
+
+    def refresh_weights(self):
+        if self.bank is not None:
+            self.bank.refresh()
+
+    def _step(self, state, frame, event, gtex, t):
+        return self.model.decode(state, t)[-1] if self.hoist else self.model(frame, event, t, gtex)[-1]
+
+    @torch.no_grad()
+    def __call__(self, frame, event, gtex, timestamps):
+        """timestamps: iterable of floats (or [B,1] tensors) -> [B, len(timestamps), 3, H, W] (the `Final` output)."""
+        with self._ctx():
+            state = self.model.encode(frame, event, gtex) if self.hoist else None
+            B, dev = frame.shape[0], frame.device
+            outs = []
+            if not self.graph or dev.type != "cuda":
+                for ts in timestamps:
+                    t = ts if torch.is_tensor(ts) else torch.full((B, 1), float(ts), device=dev)
+                    outs.append(self._step(state, frame, event, gtex, t))
+                return torch.stack(outs, 1)
+            key = (tuple(frame.shape), tuple(event.shape), gtex is not None)
+            ent = self._captured.get(key)
+            if ent is None:
+                # static inputs of the captured graph: the prefix's outputs (hoisted) or the raw inputs, plus T
+                st_in = [v.clone() if torch.is_tensor(v) else v for v in state] if self.hoist else \
+                    [frame.clone(), event.clone(), None if gtex is None else gtex.clone()]
+                t_static = torch.zeros(B, 1, device=dev)
+                call = (lambda: self.model.decode(tuple(st_in), t_static)[-1]) if self.hoist else \
+                    (lambda: self.model(st_in[0], st_in[1], t_static, st_in[2])[-1])
+                side = torch.cuda.Stream(dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    call()                                  # warm-up off the capturing stream (allocator, lazy inits)
+                torch.cuda.current_stream(dev).wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    out_static = call()
+                ent = self._captured[key] = (g, st_in, t_static, out_static)
+            g, st_in, t_static, out_static = ent
+            src = state if self.hoist else (frame, event, gtex)
+            for dst, v in zip(st_in, src):
+                if torch.is_tensor(dst):
+                    dst.copy_(v)
+            for ts in timestamps:
+                if torch.is_tensor(ts):
+                    t_static.copy_(ts)
+                else:
+                    t_static.fill_(float(ts))
+                g.replay()
+                outs.append(out_static.clone())
+            return torch.stack(outs, 1)

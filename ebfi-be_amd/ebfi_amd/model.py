@@ -490,7 +490,11 @@ class EVFIAutoEx(BaseModel):
             return torch.full((Frame.size(0), 1), float(self.FixEx), dtype=Frame.dtype, device=Frame.device)
         return self.ExposureDecision(Event, self._blurry_level(Frame))
 
-    def forward(self, Frame, Event, T, GTEx=None):
+    def encode(self, Frame, Event, GTEx=None):
+        """The part of forward() that does not depend on the latent timestamp T: pad to a multiple of 8, both feature
+        extractors and the exposure estimate (Frame2Lap + ExposureDecision).  The reference's inference and training loops
+        call the model once per timestamp with IDENTICAL Frame / Event (infer_ours.py:113-118, train_ours.py:237-251);
+        `decode(state, T)` finishes a forward from this state, and forward() is exactly decode(encode(...), T)."""
         H, W = Frame.size()[-2:]
         cropper = CropSize(W, H, {"h": 8, "w": 8}) if (H % 8 or W % 8) else None
         if cropper is not None:
@@ -500,6 +504,10 @@ class EVFIAutoEx(BaseModel):
         frame_feat = self.FrameFeatExtract(Frame)
         event_feat = self.EventFeatExtract(Event)
         ex = self._exposure(Frame, Event, GTEx)
+        return Frame, frame_feat, event_feat, ex, cropper
+
+    def decode(self, state, T):
+        Frame, frame_feat, event_feat, ex, cropper = state
         event_feat = self.ResidualControl(event_feat, ex, T)
         Sharp = self._reconstruct(self.Modification(frame_feat, event_feat))
         Final = Sharp + self.Detail(img0=Frame, img1=Sharp) if self.DetailEnabled else Sharp
@@ -508,3 +516,6 @@ class EVFIAutoEx(BaseModel):
             Sharp = cropper.crop(Sharp).contiguous()
             Final = cropper.crop(Final).contiguous() if self.DetailEnabled else Sharp
         return Sharp, Final
+
+    def forward(self, Frame, Event, T, GTEx=None):
+        return self.decode(self.encode(Frame, Event, GTEx), T)

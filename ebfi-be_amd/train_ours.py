@@ -11,8 +11,9 @@ and the checkpoint layout {model:{name,states}, lr_scheduler:{name,states}, opti
 trainer:{training_mode, iteration, monitor_best}} (train_ours.py:621-671) with --resume / --reset as in
 _resume_checkpoint (:673-716): training continues at trainer.iteration + 1.
 Unlike the reference (whose fwd+bwd sits inside model.no_sync()) gradients ARE averaged across ranks every optimiser
-step (one flat RCCL all-reduce).  Data: synthetic batches; the HDF5 pipeline, TensorBoard, validation
-and early stopping of the reference are out of scope.
+step (one flat RCCL all-reduce).  Data: synthetic batches or, with --data, recorded clips through
+ebfi_amd.clipdata (the tensor contract of dataloader/h5dataset.py:283-295 from .npz clips, or .h5 when h5py is installed);
+TensorBoard, validation and early stopping of the reference are out of scope.
 
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train_ours.py -c config/train_ours.yml -id run
     python train_ours.py -c config/train_ours.yml -id run --iterations 20
@@ -117,6 +118,32 @@ def resume_checkpoint(path, eng, scheduler, config, reset=False, map_location="c
     return start
 
 
+def real_data_passes(path, config, B, TB, device, rank, world, seed):
+    """Endless stream of (Frame, Event, T, GTEx, LatentF) passes from recorded clips (ebfi_amd.clipdata): the dataset keys
+    are the reference's (config train_dataloader.dataset, train_ours.yml:115-150); defaults = its shipped values."""
+    from ebfi_amd import clipdata
+    ds_cfg = ((config.get("train_dataloader") or {}).get("dataset") or {})
+    aug = ds_cfg.get("data_augment") or {}
+    crop, mode = None, "random"
+    if aug.get("enabled", False):
+        if (aug.get("random_crop") or {}).get("enabled"):
+            crop, mode = aug["random_crop"]["size"], "random"
+        elif (aug.get("center_crop") or {}).get("enabled"):
+            crop, mode = aug["center_crop"]["size"], "center"
+    ds = clipdata.ClipDataset(path, time_bins=int(ds_cfg.get("time_bins", TB)),
+                              frames_per_period=int(ds_cfg.get("NumFramePerPeriod", 16)),
+                              frames_per_blurry=int(ds_cfg.get("NumFramePerBlurry", 16)),
+                              exposure_method=ds_cfg.get("ExposureMethod", "Custom"),
+                              exposure_time=ds_cfg.get("ExposureTime", [9, 10, 11, 12, 13, 14, 15]),
+                              crop=crop, crop_mode=mode, flips=bool((aug.get("flip") or {}).get("enabled", False)) and
+                              aug.get("enabled", False), device=device, seed=seed)
+    if len(ds) < B * world:
+        raise SystemExit("--data: %d periods in %s, need at least batch_size x world = %d" % (len(ds), path, B * world))
+    for batch in clipdata.batches(ds, B, rank=rank, world=world, seed=seed):
+        for inputs in clipdata.model_inputs(batch):
+            yield inputs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("-c", "--config", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "config", "train_ours.yml"))
@@ -131,6 +158,13 @@ def main():
     ap.add_argument("--host-data", action="store_true",
                     help="draw every synthetic batch on the host (bit-identical across machines, ~0.5 s per B=8 256x256 batch) "
                          "instead of with the device generator (default: the data path must not be slower than the 20 ms step)")
+    ap.add_argument("--no-f16-backward", action="store_true",
+                    help="bf16x3 precision: keep the data / weight gradients on the split-precision kernels (3 MFMAs per product) "
+                         "instead of the fp16 single-product ones with delayed operand scales (ebfi_amd.f16scale)")
+    ap.add_argument("--data", default=None,
+                    help="recorded clips instead of synthetic batches: a directory of .npz clips (or .h5 in the reference's layout "
+                         "when h5py is installed), a datalist .txt, or one clip file (ebfi_amd.clipdata); the dataset section of "
+                         "the config (train_dataloader.dataset, reference keys) sets periods / exposure / crop")
     ap.add_argument("--raw-events", action="store_true",
                     help="build the event tensor from synthetic raw event lists with the device events_to_stack kernel "
                          "(the reference's data path, h5dataset.py:327-352) instead of drawing voxel counts directly")
@@ -147,7 +181,8 @@ def main():
 
     eng = Engine(config["model"]["args"], device=device, precision=args.precision, lr=float(oargs.get("lr", 1e-4)),
                  betas=tuple(oargs.get("betas", (0.9, 0.999))), seed=args.seed,      # same init on every rank
-                 graph=args.graph or bool(tr.get("graph", False)), accu_step=st["accu_step"])
+                 graph=args.graph or bool(tr.get("graph", False)), accu_step=st["accu_step"],
+                 backward_f16=False if args.no_f16_backward else None)
     scheduler = build_lr_scheduler(config, eng.optimizer.inner)
     start = resume_checkpoint(args.resume, eng, scheduler, config, reset=args.reset, map_location=device) if args.resume else 0
     B, H, W = int(tr.get("batch_size", 8)), int(tr.get("height", 256)), int(tr.get("width", 256))
@@ -159,12 +194,17 @@ def main():
     # capture: Engine.settled): what is logged is the steady-state rate, whole job (all ranks)
     t0, frames, it = None, 0, start
     make = synthetic_batch_from_raw_events if args.raw_events else synthetic_batch
+    real = real_data_passes(args.data, config, B, TB, device, rank, world, args.seed) if args.data else None
     while it < st["iterations"]:
         for micro in range(st["accu_step"]):
-            # one fresh synthetic batch per pass, different on every rank (seed + rank, like the reference); drawn by the
-            # device generator unless --host-data: the host draw alone would cap the loop at ~15 frames/s
-            batch = make(B, H, W, TB, device=device, seed=args.seed + 1000 * (it * st["accu_step"] + micro), rank=rank,
-                         on_device=not args.host_data)
+            if real is not None:
+                # one pass per latent frame of the loaded periods, in the reference's order (train_ours.py:226-251)
+                batch = next(real)
+            else:
+                # one fresh synthetic batch per pass, different on every rank (seed + rank, like the reference); drawn by the
+                # device generator unless --host-data: the host draw alone would cap the loop at ~15 frames/s
+                batch = make(B, H, W, TB, device=device, seed=args.seed + 1000 * (it * st["accu_step"] + micro), rank=rank,
+                             on_device=not args.host_data)
             loss = eng.train_step(*batch)
             if t0 is not None:
                 frames += B * world

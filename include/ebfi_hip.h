@@ -9,8 +9,9 @@
  *     failure on the calling thread.
  *   - launches are asynchronous on `stream`; the library keeps no global mutable state besides the
  *     optional profiler (ebfi_prof_*), so distinct streams/threads may call concurrently.
- *   - dtype: element type of all floating tensors of the call (EBFI_F32 / EBFI_BF16, fp32
- *     accumulation either way).  Shapes/strides are in ELEMENTS, NCHW order of the LOGICAL dims
+ *   - dtype: every floating tensor of a call is fp32 in memory (EBFI_F32), like the reference's ops; the
+ *     other ebfi_dtype values select the matrix-core OPERAND precision of the convolution kernels
+ *     (fp32 accumulation always).  Shapes/strides are in ELEMENTS, NCHW order of the LOGICAL dims
  *     (a channels-last tensor is passed with its real strides).
  *
  * Reference interfaces replaced (paths relative to the reference repo):
@@ -47,8 +48,9 @@ extern "C" {
 
 /* 3: round 2/3 additions (ebfi_ed_head_*, ebfi_laploss_*, ebfi_se_gate_*, ebfi_adam_step, ebfi_pack_table_bf16,
  * ebfi_conv2d_packed_x3, the fused KernelConv -> FAC forward, ...).  4: ebfi_se_gate_forward takes a workspace
- * (ebfi_se_gate_workspace).  Bumped whenever an entry point is added or changed. */
-#define EBFI_ABI_VERSION 4
+ * (ebfi_se_gate_workspace).  5 (round 4): the never-implemented EBFI_BF16 storage value left ebfi_dtype; fp16 filter storage
+ * and the fused-gradient entry points of the KernelConv -> FAC training path.  Bumped whenever an entry point is added or changed. */
+#define EBFI_ABI_VERSION 5
 
 typedef enum {
     EBFI_OK = 0,
@@ -60,7 +62,8 @@ typedef enum {
 
 /* EBFI_F32_BF16MMA: fp32 tensors, operands rounded to bf16 for the matrix cores, fp32 accumulation
  * (accepted by ebfi_conv2d_backward_weight; the forward / data-gradient have *_bf16mma entry points) */
-typedef enum { EBFI_F32 = 0, EBFI_BF16 = 1, EBFI_F32_BF16MMA = 2, EBFI_F32_BF16X3MMA = 3 } ebfi_dtype;
+/* (value 1 was a bf16-storage mode that no entry point ever implemented: removed in ABI 5, the number stays unused) */
+typedef enum { EBFI_F32 = 0, EBFI_F32_BF16MMA = 2, EBFI_F32_BF16X3MMA = 3 } ebfi_dtype;
 
 int ebfi_abi_version(void);
 const char *ebfi_last_error(void);

@@ -330,7 +330,8 @@ def _banked_layer(Cin, Cout, scale_w=1.0):
 
 @pytest.mark.parametrize("B,Cin,H,W,Cout,act,xs,gs", [
     (2, 64, 16, 64, 64, 1, 1.0, 1.0),          # ResidualControl shape, whole tiles
-    (1, 128, 13, 36, 64, 1, 1.0, 1.0),         # ragged tiles, two input-channel blocks
+    (1, 128, 13, 38, 64, 1, 1.0, 1.0),         # ragged tiles, two input-channel blocks; rows that do not split into 16-byte
+                                               #     quads: the pair-word weight gradient and the split-precision data gradient
     (2, 64, 20, 36, 200, 0, 1.0, 1.0),         # Cout not a multiple of 64, no activation
     (2, 48, 16, 32, 32, 1, 1.0, 1.0),          # a folded detail-branch layer: partial 64-channel input block (zero-filled)
     (1, 32, 32, 32, 48, 0, 1.0, 1.0),          # ... 32 input channels: weight gradient fp16, data gradient split precision
@@ -348,12 +349,9 @@ def test_fp16_backward_kernels_vs_cpu(B, Cin, H, W, Cout, act, xs, gs):
     just-in-time calibrated scales move them into fp16's range (cases 4, 5 would be all-zero / all-inf without)."""
     from ebfi_amd import _native as N
     from ebfi_amd import conv
-    import os
-    # the pixel-major weight-gradient kernel is the default for activation-free layers; its development switch (read per launch)
-    # selects the pair-word kernel for some of the cases so that both forms stay covered
-    force_tr = H >= 16
-    prev_env = os.environ.get("EBFI_WGRAD_TR")
-    os.environ["EBFI_WGRAD_TR"] = "1" if force_tr else "0"
+    # the pixel-major weight-gradient kernel serves every layer whose rows split into 16-byte quads; the pair-word kernel
+    # takes the others (product rule of ebfi_conv2d_backward_weight_f16g: no development switch involved)
+    force_tr = W % 4 == 0
     torch.manual_seed(B * 7 + Cin + Cout + H)
     w, b, bank, book = _banked_layer(Cin, Cout)
     x = torch.randn(B, Cin, H, W) * xs
@@ -375,15 +373,12 @@ def test_fp16_backward_kernels_vs_cpu(B, Cin, H, W, Cout, act, xs, gs):
         prof = {k: v[0] for k, v in N.prof_collect().items() if v[0] > 0}
     finally:
         conv.set_compute_dtype("fp32")
-        if prev_env is None:
-            os.environ.pop("EBFI_WGRAD_TR", None)
-        else:
-            os.environ["EBFI_WGRAD_TR"] = prev_env
     # both gradients took the fp16 kernels: the weight gradient in its pixel-major form (transposing LDS reads; with act != 0 it
     # folds act'(y) and writes grad * act' for the data gradient) or, switched, in the pair-word form
     assert prof.get("conv_wgrad_f16_tr" if force_tr else "conv_wgrad_f16_ws") == 1, prof
-    assert prof.get("conv_fwd_f16_ws", 0) == (1 if Cin >= 48 else 0), prof      # (narrower data gradients keep the 32-channel split-precision form)
-    assert "conv_wgrad_x3_ws" not in prof and "conv_fwd_bf16x3_ws/dgrad" not in prof
+    assert prof.get("conv_fwd_f16_ws", 0) == (1 if Cin >= 48 and W % 4 == 0 else 0), prof   # (narrower data gradients, and rows
+    #                                                                       without quads, keep the split-precision form)
+    assert "conv_wgrad_x3_ws" not in prof and ("conv_fwd_bf16x3_ws/dgrad" not in prof or W % 4 != 0)
     assert _rel(y.detach(), yr.detach()) < 1e-4             # (the split-precision forward: every tile written exactly once)
     assert _rel(xd.grad, xr.grad) < 1e-3 and _rel(w.grad, wr.grad) < 1e-3 and _rel(b.grad, br.grad) < 1e-5
     assert int(book.guard[0].item()) == 0                   # calibrated scales: nothing left the range

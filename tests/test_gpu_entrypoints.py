@@ -109,3 +109,104 @@ def test_bench_two_gpus_rccl():
     assert d["n_gpus"] == 2 and d["config"]["collective_backend"] == "nccl"
     assert d["config"]["replica_param_checksum"]["ranks_identical"] is True
     assert "hipGraph replay" in d["config"]["launch"]
+
+
+def test_hoisted_inference_is_bit_identical():
+    """ClipInterpolator (what infer_ours.py runs): the timestamp-independent prefix computed once per clip + the per-timestamp
+    rest replayed from a hipGraph gives, bit for bit, what calling the model once per timestamp gives (reference loop
+    infer_ours.py:113-118) -- in both conv modes, with and without the graph, on a size that needs the pad / crop path."""
+    from ebfi_amd import conv
+    from ebfi_amd.engine import ClipInterpolator, synthetic_batch
+    from ebfi_amd.model import EVFIAutoEx
+    from ebfi_amd.engine import DEFAULT_MODEL_ARGS
+    torch.manual_seed(5)
+    cfg = dict(DEFAULT_MODEL_ARGS, step=2, channels=[8, 8, 16, 16])
+    model = EVFIAutoEx(**cfg).cuda().eval()
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() > 1:
+                p.copy_(torch.randn_like(p) * (1.2 / p[0].numel() ** 0.5))
+    stamps = [0.0, 0.25, 0.8125]
+    for (h, w) in ((64, 64), (60, 76)):
+        frame, event, _, gtex, _ = synthetic_batch(2, h, w, 16, device="cuda", seed=3)
+        for prec in ("bf16x3", "fp32"):
+            plain = ClipInterpolator(model, precision=prec, graph=False, hoist=False)
+            ref = plain(frame, event, gtex, stamps)
+            assert ref.shape == (2, 3, 3, h, w) and ref.std() > 1e-3
+            # the un-hoisted eager path IS the module call of the reference loop
+            conv.set_compute_dtype(prec)
+            try:
+                with torch.no_grad(), (plain.bank.active() if plain.bank is not None else torch.no_grad()):
+                    direct = model(frame, event, torch.full((2, 1), stamps[1], device="cuda"), gtex)[-1]
+            finally:
+                conv.set_compute_dtype("fp32")
+            assert torch.equal(direct, ref[:, 1])
+            for graph in (False, True):
+                got = ClipInterpolator(model, precision=prec, graph=graph, hoist=True)(frame, event, gtex, stamps)
+                assert torch.equal(got, ref), (prec, graph, (got - ref).abs().max().item())
+    # a second clip through the SAME captured graph picks up its own prefix
+    interp = ClipInterpolator(model, precision="bf16x3", graph=True, hoist=True)
+    a = synthetic_batch(2, 64, 64, 16, device="cuda", seed=3)
+    b = synthetic_batch(2, 64, 64, 16, device="cuda", seed=4)
+    ra, rb, ra2 = (interp(v[0], v[1], v[3], stamps) for v in (a, b, a))
+    assert torch.equal(ra, ra2) and not torch.equal(ra, rb) and len(interp._captured) == 1
+
+
+def test_overflow_in_first_micro_step_of_a_graph_window_skips_the_update():
+    """Gradient accumulation + hipGraph replay + fp16 backward (round-3 advisory): the overflow guard must stay raised over the
+    whole accumulation window.  The clear used to sit inside the captured region, so the replay of micro-step 1 wiped the
+    flag micro-step 0 had raised and Adam applied saturated gradients.  Now the window's first call clears it eagerly: an
+    overflow forced in micro-step 0 (event counts scaled by 1e6: the staged activations leave their one-step-old scales) skips
+    the window's update -- parameters, moments, step count untouched, the skip counted -- and the next window goes through."""
+    from ebfi_amd.engine import Engine, synthetic_batch
+    cfg = dict(step=2, channels=[8, 8, 16, 16])
+    eng = Engine(cfg, device="cuda", seed=7, graph=True, precision="bf16x3", accu_step=2)
+    with torch.no_grad():
+        for p in eng.model.parameters():
+            if p.dim() > 1:
+                p.copy_(torch.randn_like(p) * (1.2 / p[0].numel() ** 0.5))
+    mk = lambda s: list(synthetic_batch(2, 64, 64, device="cuda", seed=s))
+    for it in range(8):                                   # 4 windows: 2 calibration steps (eager), capture, one replayed window
+        eng.train_step(*mk(100 + it))
+    assert eng.iteration == 4 and len(eng._graphs) == 1 and eng.book.skipped_steps() == 0
+    st = eng.optimizer.inner.state[eng.optimizer.flat]
+    before = (eng.optimizer.flat.detach().clone(), st["exp_avg"].clone(), float(st["step"]))
+    bad = mk(200)
+    bad[1] = bad[1] * 1e6                                 # event counts x1e6 in micro-step 0: every activation the weight
+    #                                                       gradients stage outgrows its one-step-old fp16 scale by 2^20
+    eng.train_step(*bad)
+    assert int(eng.book.guard[0].item()) == 1             # raised by micro-step 0 ...
+    eng.train_step(*mk(201))                              # ... micro-step 1 is clean and replays the same graph
+    assert eng.book.skipped_steps() == 1 and eng.iteration == 5
+    assert torch.equal(before[0], eng.optimizer.flat.detach()) and torch.equal(before[1], st["exp_avg"])
+    assert float(st["step"]) == before[2]
+    for it in range(4):                                   # the scales have followed / recovered: the next windows update again
+        eng.train_step(*mk(300 + it))
+    assert eng.book.skipped_steps() <= 2 and not torch.equal(before[0], eng.optimizer.flat.detach())
+    assert torch.isfinite(eng.optimizer.flat).all()
+
+
+@pytest.mark.parametrize("native", [True, False])
+def test_guarded_adam_skip_leaves_state_untouched(native, monkeypatch):
+    """guard[0] != 0: parameters, both moments and the step counter stay as they are and guard[1] counts the skip -- in the
+    native launch (ebfi_adam_step_guarded) and in the host-side check in front of torch's own step (the path taken for
+    options the native kernel does not cover)."""
+    from ebfi_amd.dp import FlatAdam
+    torch.manual_seed(1)
+    params = [torch.nn.Parameter(torch.randn(300, 7).cuda()), torch.nn.Parameter(torch.randn(11).cuda())]
+    opt = FlatAdam(params, lr=1e-2)
+    if not native:
+        monkeypatch.setattr(FlatAdam, "_native_step", lambda self, g, guard=None: False)
+    guard = torch.zeros(2, dtype=torch.int32, device="cuda")
+    g = torch.randn(opt.flat.numel(), device="cuda")
+    opt.step(g, guard=guard)                              # a clean step first (creates the state)
+    st = opt.inner.state[opt.flat]
+    snap = (opt.flat.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(), float(st["step"]))
+    guard[0] = 1
+    opt.step(torch.full_like(g, 65504.0), guard=guard)
+    torch.cuda.synchronize()
+    assert torch.equal(snap[0], opt.flat.detach()) and torch.equal(snap[1], st["exp_avg"]) and torch.equal(snap[2], st["exp_avg_sq"])
+    assert float(st["step"]) == snap[3] == 1.0 and guard.tolist() == [1, 1]
+    guard[0] = 0
+    opt.step(g, guard=guard)
+    assert float(st["step"]) == 2.0 and guard.tolist() == [0, 1] and not torch.equal(snap[0], opt.flat.detach())

@@ -123,6 +123,54 @@ def test_flat_bucket_allreduce_equals_large_batch_math(tmp_path):
     assert torch.allclose(ga, g / 2, atol=1e-5)
 
 
+def _guard_worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ebfi_amd.dp import FlatAdam, FlatGradBucket, broadcast_parameters, sync_guard
+    torch.manual_seed(100 + rank)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(4, 2, 1))
+    broadcast_parameters(net, 0)
+    bucket, opt = FlatGradBucket(net), FlatAdam(list(net.parameters()), lr=1e-2)
+    guard = torch.zeros(2, dtype=torch.int32)           # f16scale.ScaleBook.guard: [flag of this step, skipped steps]
+    snaps = []
+    for step, raise_on in enumerate((None, 1, None)):   # step 1: ONLY rank 1 sees an overflow
+        torch.manual_seed(7 + step)
+        data = torch.randn(4, 3, 8, 8)
+        bucket.zero()
+        net(data[rank * 2:(rank + 1) * 2]).pow(2).sum().backward()
+        bucket.gather()
+        guard[0] = 1 if raise_on == rank else 0         # (what f16_scales_finish does on the rank whose operand overflowed)
+        bucket.reduce_mean_packed()
+        opt.step(bucket.flat, guard=sync_guard(guard))  # Engine._finish_micro_step's order
+        st = opt.inner.state.get(opt.flat, {})
+        snaps.append((opt.flat.detach().clone(), int(guard[0]), int(guard[1]),
+                      st["exp_avg"].clone() if st else None, float(st["step"]) if st else 0.0))
+    torch.save(snaps, os.path.join(outdir, "g%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overflow_guard_raised_on_one_rank_skips_the_update_on_every_rank(tmp_path):
+    """Data parallelism with the fp16 backward: the guard flag is MAX-reduced (dp.sync_guard) before the guarded optimiser
+    step, so a flag raised on ONE rank skips the update on BOTH (parameters, moments and step count untouched, the skip
+    counted) and the replicas stay bit-identical; the next clean step updates both."""
+    ctx = mp.get_context("spawn")
+    port = 29500 + ((os.getpid() + 137) % 500)
+    procs = [ctx.Process(target=_guard_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    a, b = (torch.load(os.path.join(str(tmp_path), "g%d.pt" % r)) for r in range(2))
+    for sa, sb in zip(a, b):
+        assert torch.equal(sa[0], sb[0]) and sa[1:3] == sb[1:3] and sa[4] == sb[4]      # replicas in lock-step at every step
+    (w0, f0, n0, m0, t0), (w1, f1, n1, m1, t1), (w2, f2, n2, m2, t2) = a
+    assert (f0, n0, t0) == (0, 0, 1.0) and (f1, n1, t1) == (1, 1, 1.0) and (f2, n2, t2) == (0, 1, 2.0)
+    assert torch.equal(w0, w1) and torch.equal(m0, m1)      # the flagged step changed nothing on either rank
+    assert not torch.equal(w1, w2) and not torch.equal(m1, m2)
+
+
 def test_flat_bucket_single_process():
     from ebfi_amd.dp import FlatGradBucket
     net = torch.nn.Linear(3, 2)

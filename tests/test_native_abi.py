@@ -31,10 +31,10 @@ def test_library_exports_every_declared_symbol(built_lib):
 
 def test_library_loads_and_reports_version(built_lib):
     lib = N.lib()
-    # the binding, the header and the library agree on the ABI generation (4 since the second half of round 3)
+    # the binding, the header and the library agree on the ABI generation (5 since round 4)
     header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "ebfi_hip.h")).read()
-    assert "#define EBFI_ABI_VERSION 4" in header
-    assert lib.ebfi_abi_version() == 4 == N.ABI_VERSION
+    assert "#define EBFI_ABI_VERSION 5" in header
+    assert lib.ebfi_abi_version() == 5 == N.ABI_VERSION
     assert lib.ebfi_events_workspace(16) == (2 * 16 + 1) * 8
     # workspace query is pure host arithmetic: 512 slabs max, here 2*ceil(16/64)=2 tiles -> 2 slabs
     need = lib.ebfi_dcn_backward_workspace(2, 2, 4, 4, 2, 3, 3, 1, 1, 1, 1, 1, 1, 1, 0)
@@ -49,7 +49,7 @@ def test_argument_errors_do_not_touch_the_gpu(built_lib):
     rc = lib.ebfi_dcn_forward(*([ctypes.c_void_p(8)] * 6), 1, 3, 4, 4, 2, 3, 3, 1, 1, 1, 1, 1, 1, 2, 0, None)
     assert rc == -1 and b"divisible" in lib.ebfi_last_error()
     rc = lib.ebfi_dcn_forward(*([ctypes.c_void_p(8)] * 6), 1, 2, 4, 4, 2, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, None)
-    assert rc == -3    # bf16 not implemented yet -> loud, not silent
+    assert rc == -3    # a dtype code other than EBFI_F32 -> loud, not silent
 
 
 def test_ops_refuse_cpu_tensors():

@@ -3,6 +3,6 @@
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 mkdir -p "$HERE/bin"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-function -munsafe-fp-atomics -DEBFI_KBENCH ${KBENCH_FLAGS:-} \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-function -munsafe-fp-atomics -DEBFI_KBENCH -DEBFI_ABLATE ${KBENCH_FLAGS:-} \
     "$HERE/kbench.hip" "$HERE/../ebfi-be_amd/csrc/runtime.hip" -o "$HERE/bin/kbench"
 echo "built $HERE/bin/kbench"
