@@ -197,7 +197,8 @@ class ClipDataset:
 
     def assemble(self, sharp, blur, stack, duty):
         dev = stack.device
-        rel_ts = torch.arange(self.P, dtype=torch.float32, device=dev) / self.P
+        rel_ts = (torch.arange(self.P) / self.P).to(dev)      # integer tensor / int on the HOST, like GetTimestamp (a device
+        #                                                       division may differ in the last bit)
         return {"SeqLatentF": sharp[None, None].contiguous(), "SeqBlurryF": blur[None, None].contiguous(),
                 "SeqHREv": stack[None].contiguous(), "RelativeLatentTs": rel_ts[None, None],
                 "SeqExposureDuty": torch.tensor([[[duty]]], dtype=torch.float32, device=dev)}
