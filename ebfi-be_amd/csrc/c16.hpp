@@ -1,0 +1,65 @@
+// fp16 operand storage of the backward pass (round 4): helpers shared by conv2d.hip and fuse.hip.
+//
+// Layout "c16": a tensor [B, C, H, W] (C a multiple of 16) kept as fp16 [B][C/16][H][W][16] -- blocks of 16 channels,
+// pixel-major inside a block, the 16 channels of a pixel in 32 contiguous bytes -- multiplied by the power-of-two scale of
+// its slot.  It is the STAGING layout of both backward kernels: the data gradient (conv_fwd_f16_ws) walks 16-channel chunks
+// whose LDS image is [position][16 ch], the weight gradient (conv_wgrad_f16_tr) keeps [pixel][64 ch] images = four blocks;
+// either way a tile row is one contiguous run of 32-byte positions, so the producers are plain 16-byte copies (no
+// conversion, half the bytes of the fp32 NCHW planes, a quarter of the vector-memory instructions).  The tensors are written
+// in this form by whoever produces them: the epilogues of the forward / data-gradient kernels (store_out_tile), the fused
+// ResidualControl stages (fuse.hip) or the standalone conversion (to_c16_kernel).  The WRITER applies the slot's scale and
+// records |max|; readers only need the scale.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ebfi {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {   // v_cvt_pk_f16_f32: round to nearest even, a in the low half
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, f16x2));
+}
+
+// fp32 -> fp16 conversions of this wave saturate at +-65504 instead of producing inf (MODE.FP16_OVFL; true inf / NaN inputs
+// stay what they are).  A scale that is too large for this step's data is caught by f16_scales_finish_kernel from the
+// recorded maximum either way; saturating keeps the step's wrong gradients FINITE, so the maxima recorded further down the
+// backward chain stay usable and every scale is repaired by that one finish launch instead of one layer per step.
+__device__ __forceinline__ void saturate_fp16_conversions() { __builtin_amdgcn_s_setreg(1 | (23 << 6), 1); }
+
+// Scale slot: 64 floats (256 bytes); [0] = scale (power of two), [32] = running |max| of the fp32 values staged through it
+// (float bits, ordered as unsigned for non-negative floats).  The two words sit in different 128-byte lines on purpose: the
+// atomic that raises the maximum executes at the memory side and drops its line from L2 -- next to the scale, which every
+// workgroup reads, that turned the 30 000-workgroup pack launch into a queue on one line (0.44 ms for 5.5 M elements).
+constexpr int SLOT_STRIDE = 64, SLOT_AMAX = 32;
+constexpr int F16_TARGET_EXP = 2;          // next scale: |max| * scale in [2^(F16_TARGET_EXP-1), 2^F16_TARGET_EXP) (f16scale.TARGET_EXP)
+struct ScaleSlot {
+    float *p;
+    __device__ __forceinline__ float scale() const { return p ? p[0] : 1.f; }
+    __device__ __forceinline__ void record(float wave_max_candidate) const {
+        // one atomic per wave: butterfly over the 64 lanes, lane 0 publishes (NaN / Inf propagate as large unsigned values)
+        float m = wave_max_candidate;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+        // (many workgroups report into one word: only a value above the one already there needs the atomic -- NaN compares
+        // false and goes through)
+        if (p && (threadIdx.x & 63) == 0 && !(m <= __builtin_nontemporal_load(p + SLOT_AMAX)))
+            atomicMax(reinterpret_cast<unsigned *>(p + SLOT_AMAX), __float_as_uint(m));
+    }
+};
+
+
+typedef unsigned u32x4_c16 __attribute__((ext_vector_type(4)));
+
+// One pixel's 16 channels of a c16 block from the two lane halves of a 32x32 MFMA accumulator: lane (h = lane >> 5) holds
+// channels 4h..4h+3 (a0, a1 = packed pairs) and 8+4h..8+4h+3 (b0, b1) of pixel (lane & 31).  v_permlane32_swap exchanges the
+// upper half of one register with the lower half of another, after which the lower lanes hold channels 0..7 and the upper
+// lanes channels 8..15 of their pixel, each as 16 contiguous bytes: one 16-byte store per lane, 1 KB contiguous per wave.
+__device__ __forceinline__ u32x4_c16 c16_gather_halves(unsigned a0, unsigned a1, unsigned b0, unsigned b1) {
+    const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+    return u32x4_c16{s0[0], s1[0], s0[1], s1[1]};
+}
+
+}  // namespace ebfi

@@ -22,6 +22,7 @@
 //       operand fetch), accumulates a 64 x (64*KK) block in registers and writes ONE partial slab;
 //       `conv_wgrad_reduce_f32` sums slabs in fixed order => deterministic grad_weight / grad_bias.
 #include "common.hpp"
+#include "c16.hpp"
 
 using namespace ebfi;
 
@@ -46,6 +47,11 @@ struct EpiExtra {
     const float *mask_y;
     int mask_act;
     float mask_slope;
+    // round 4: the output additionally (or, with a NULL fp32 output, only) as a scaled fp16 image in the c16 layout (c16.hpp)
+    // for the backward kernels that will stage it: out16 [B][Cout/16][Ho][Wo][16], multiplied by slot16[0]; |max| of the
+    // unscaled values is recorded into slot16 (one atomic per wave and launch).  Cout must be a multiple of 16.
+    _Float16 *out16 = nullptr;
+    float *slot16 = nullptr;
 };
 
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
@@ -96,57 +102,91 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, unsigned byte_o
 template <int MT, bool EXTRA = false>
 __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const float *__restrict__ bias, const f32x16 (&acc)[MT][2],
                                                const ConvGeom &g, int b, int co_base, int yo, int x0, int lane, int act,
-                                               float slope, EpiExtra ex = EpiExtra{nullptr, nullptr, 0, 0.f}, float oscale = 1.f) {
+                                               float slope, EpiExtra ex = EpiExtra{nullptr, nullptr, 0, 0.f}, float oscale = 1.f,
+                                               float *amax16 = nullptr) {
     // oscale: the accumulators are oscale-times too small (operands were scaled by powers of two: conv2d_f16.inc.hpp); 1 otherwise
+    // amax16 (with ex.out16): running |max| of what this wave wrote into the fp16 image (recorded by the caller at the end)
     const int HWo = g.Ho * g.Wo;
     const unsigned plane = (unsigned)HWo * 4u;
-    const __amdgpu_buffer_rsrc_t ro = make_rsrc(out + (int64_t)b * g.Cout * HWo, (unsigned)g.Cout * plane);
-    const __amdgpu_buffer_rsrc_t rb = make_rsrc(bias ? bias : out, bias ? (unsigned)g.Cout * 4u : 0u);
+    const bool has32 = out != nullptr;
+    const float *anyp = bias ? bias : (out ? out : reinterpret_cast<const float *>(ex.slot16));     // base of the empty descriptors
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(has32 ? out + (int64_t)b * g.Cout * HWo : anyp, has32 ? (unsigned)g.Cout * plane : 0u);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(bias ? bias : anyp, bias ? (unsigned)g.Cout * 4u : 0u);
     // the extras: descriptors over the same sample of tensors shaped like the output (absent: empty descriptor, reads 0)
-    const __amdgpu_buffer_rsrc_t ra = make_rsrc((EXTRA && ex.addend) ? ex.addend + (int64_t)b * g.Cout * HWo : out,
-                                                (EXTRA && ex.addend) ? (unsigned)g.Cout * plane : 0u);
-    const __amdgpu_buffer_rsrc_t rm = make_rsrc((EXTRA && ex.mask_y) ? ex.mask_y + (int64_t)b * g.Cout * HWo : out,
-                                                (EXTRA && ex.mask_y) ? (unsigned)g.Cout * plane : 0u);
+    const bool has_a = EXTRA && ex.addend != nullptr, has_m = EXTRA && ex.mask_y != nullptr, has16 = EXTRA && ex.out16 != nullptr;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(has_a ? ex.addend + (int64_t)b * g.Cout * HWo : anyp, has_a ? (unsigned)g.Cout * plane : 0u);
+    const __amdgpu_buffer_rsrc_t rm = make_rsrc(has_m ? ex.mask_y + (int64_t)b * g.Cout * HWo : anyp, has_m ? (unsigned)g.Cout * plane : 0u);
+    const int cb16 = g.Cout >> 4;                                  // 16-channel blocks of the fp16 image
+    const __amdgpu_buffer_rsrc_t r16 = __builtin_amdgcn_make_buffer_rsrc(
+        has16 ? ex.out16 + (int64_t)b * cb16 * HWo * 16 : const_cast<_Float16 *>(reinterpret_cast<const _Float16 *>(anyp)), 0,
+        has16 ? (unsigned)cb16 * (unsigned)HWo * 32u : 0u, 0x00020000);
+    const float s16 = has16 ? ex.slot16[0] : 1.f;
+    float am = 0.f;
     const int h = lane >> 5, l31 = lane & 31;
-    float bv[MT][16];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) bv[m][r] = buf_ld(rb, (unsigned)(co_base + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 4u);
     auto emit = [&](auto actf) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m) {
+            float bvm[16];                 // (per 32-row tile: both tiles' biases up front cost 16 more live registers -- spills)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bvm[r] = buf_ld(rb, (unsigned)(co_base + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 4u);
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const int xo = x0 + n * 32 + l31;
-                const unsigned base = (yo < g.Ho && xo < g.Wo && co_base + m * 32 + 4 * h < g.Cout)
+                const bool px_ok = yo < g.Ho && xo < g.Wo;
+                const unsigned base = (px_ok && co_base + m * 32 + 4 * h < g.Cout)
                                           ? (unsigned)(co_base + m * 32 + 4 * h) * plane + (unsigned)(yo * g.Wo + xo) * 4u : SENT;
+                float v[16];
                 if constexpr (EXTRA) {
                     float av[16], mv[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        av[r] = buf_ld(ra, base + (unsigned)((r & 3) + 8 * (r >> 2)) * plane);
-                        mv[r] = buf_ld(rm, base + (unsigned)((r & 3) + 8 * (r >> 2)) * plane);
+                    for (int r = 0; r < 16; ++r) av[r] = 0.f, mv[r] = 0.f;
+                    if (has_a) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) av[r] = buf_ld(ra, base + (unsigned)((r & 3) + 8 * (r >> 2)) * plane);
                     }
-                    const bool leaky = ex.mask_act == ACT_LEAKY, sig = ex.mask_act == ACT_SIGMOID, has_m = ex.mask_y != nullptr;
+                    if (has_m) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mv[r] = buf_ld(rm, base + (unsigned)((r & 3) + 8 * (r >> 2)) * plane);
+                    }
+                    const bool leaky = ex.mask_act == ACT_LEAKY, sig = ex.mask_act == ACT_SIGMOID;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        float v = actf(acc[m][n][r] * oscale + bv[m][r] + av[r]);
+                        const float t = actf(acc[m][n][r] * oscale + bvm[r] + av[r]);
                         const float d = leaky ? (mv[r] > 0.f ? 1.f : ex.mask_slope) : (sig ? mv[r] * (1.f - mv[r]) : 1.f);
-                        v = has_m ? v * d : v;
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, base + (unsigned)((r & 3) + 8 * (r >> 2)) * plane, 0, 0);
+                        v[r] = has_m ? t * d : t;
                     }
                 } else {
 #pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = actf(acc[m][n][r] * oscale + bvm[r]);
+                }
+                if (has32) {
+#pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(actf(acc[m][n][r] * oscale + bv[m][r])), ro,
-                                                              base + (unsigned)((r & 3) + 8 * (r >> 2)) * plane, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ro, base + (unsigned)((r & 3) + 8 * (r >> 2)) * plane, 0, 0);
+                }
+                if constexpr (EXTRA) {
+                    if (has16) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const float *u = v + 8 * j;             // rows 16 j + {4h..4h+3, 8+4h..8+4h+3} of the 32-row tile
+                            float mx = fmaxf(fmaxf(fmaxf(fabsf(u[0]), fabsf(u[1])), fmaxf(fabsf(u[2]), fabsf(u[3]))),
+                                             fmaxf(fmaxf(fabsf(u[4]), fabsf(u[5])), fmaxf(fabsf(u[6]), fabsf(u[7]))));
+                            am = fmaxf(am, mx);
+                            const u32x4_c16 q = c16_gather_halves(pack_f16(u[0] * s16, u[1] * s16), pack_f16(u[2] * s16, u[3] * s16),
+                                                                  pack_f16(u[4] * s16, u[5] * s16), pack_f16(u[6] * s16, u[7] * s16));
+                            const int cblk = ((co_base + m * 32) >> 4) + j;
+                            const unsigned o16 = (px_ok && cblk < cb16) ? ((unsigned)cblk * (unsigned)HWo + (unsigned)(yo * g.Wo + xo)) * 32u + (unsigned)h * 16u : SENT;
+                            __builtin_amdgcn_raw_buffer_store_b128(q, r16, o16, 0, 0);
+                        }
+                    }
                 }
             }
+        }
     };
     if (act == ACT_LEAKY) emit([slope](float v) { return v > 0.f ? v : v * slope; });
     else if (act == ACT_SIGMOID) emit([](float v) { return 1.f / (1.f + __expf(-v)); });
     else emit([](float v) { return v; });
+    if (amax16) *amax16 = fmaxf(*amax16, am);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2302,6 +2342,8 @@ __global__ __launch_bounds__(NTWS) void conv_fwd_bf16x3_ws(const float *__restri
         for (int tap = 0; tap < KK; ++tap)
             fbits |= (unsigned)((((pbase + (tap / KS) * IW + (tap % KS)) >> 3) & 1) ^ hsel) << tap;
         bf16x8 ah[2][MT], al[2][MT], bh[2][2], bl[2][2];
+        [[maybe_unused]] float amax16 = 0.f;
+        if constexpr (EXTRA) saturate_fp16_conversions();       // (the fp16 side image of the epilogue: MODE.FP16_OVFL, see c16.hpp)
         auto tap_read = [&](const char *base, int tap, int set) {
             const int ky = tap / KS, kx = tap - ky * KS;
             const char *bp = base + pbase * 32 + (int)(((fbits >> tap) & 1u) << 4) + (ky * IW + kx) * 32;
@@ -2356,13 +2398,16 @@ __global__ __launch_bounds__(NTWS) void conv_fwd_bf16x3_ws(const float *__restri
             int cb_, cy0, cx0;
             tile_coords(tcur, cb_, cy0, cx0);
             if constexpr (FAC) fac_epilogue_tile<MT>(out, bias, acc, g, fac, cb_, co_base, cy0 + wave, cx0, lane, slope);
-            else store_out_tile<MT, EXTRA>(out, bias, acc, g, cb_, co_base, cy0 + wave, cx0, lane, act, slope, epi);
+            else store_out_tile<MT, EXTRA>(out, bias, acc, g, cb_, co_base, cy0 + wave, cx0, lane, act, slope, epi, 1.f, &amax16);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+        }
+        if constexpr (EXTRA) {
+            if (epi.out16 != nullptr) ScaleSlot{epi.slot16}.record(amax16);      // |max| of the fp16 side image this wave wrote
         }
         return;
     }
@@ -2511,7 +2556,8 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
     const double flops = 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * KS * KS;
     // 32 output channels per workgroup when 64 would leave more than half of the CUs without one (small feature maps of the
     // detail branch): twice the workgroups, each with half the matrix work per staged chunk
-    const bool few = x3 && tiles * ceil_div(g.Cout, 64) <= 128 && dev_getenv("EBFI_CONV_NO_MT1") == nullptr;
+    // (a requested fp16 side image pins the 64-channel wave-specialised form: its epilogue is the one that writes it)
+    const bool few = x3 && epi.out16 == nullptr && tiles * ceil_div(g.Cout, 64) <= 128 && dev_getenv("EBFI_CONV_NO_MT1") == nullptr;
     const int mt = (g.Cout <= 32 || few) ? 1 : 2;
     dim3 grid((unsigned)tiles, (unsigned)ceil_div(g.Cout, 32 * mt));
     if (x3) {
@@ -2520,13 +2566,16 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
         // 16-byte input quads: rows must keep quads aligned, same-padding only; used where they pay (see the kernel's header)
         const bool vec4 = g.W % 4 == 0 && g.pad == KS / 2 && aligned16(x) && (!dact_y || aligned16(dact_y));
         const char *ws_env = dev_getenv("EBFI_CONV_WS");
-        const bool extra = epi.addend != nullptr || epi.mask_y != nullptr;
+        const bool extra = epi.addend != nullptr || epi.mask_y != nullptr || epi.out16 != nullptr;
         // wave-specialised form (conv_fwd_bf16x3_ws): every 3x3 layer the quad-staging producers can serve (64-channel blocks, no
         // folded activation derivative); EBFI_CONV_WS=0 / 1 = never / only the long layers (development switch, A/B runs)
         const bool ws_long = ceil_div(g.Cout, 64) >= 8 || K16 >= 512;
         const bool ws_extra_ok = !extra || dev_getenv("EBFI_CONV_WS_NOEXTRA") == nullptr;
         const bool use_ws = KS == 3 && mt == 2 && vec4 && dact == ACT_NONE && ws_extra_ok && !(ws_env && ws_env[0] == '0') &&
                             (ws_long || !(ws_env && ws_env[0] == '1'));
+        if (epi.out16 != nullptr && !use_ws)
+            return fail(EBFI_ERR_UNSUPPORTED, "conv2d: the fp16 side image is written by the wave-specialised 3x3 kernel only "
+                        "(W %% 4 == 0, same padding, more than 32 output channels, 16-byte aligned input)");
         if (use_ws) name = transposed ? "conv_fwd_bf16x3_ws/dgrad" : "conv_fwd_bf16x3_ws/fwd";
         ProfScope ps(name, st, flops, conv_bytes_fwd(g, KS * KS, dact != 0));
 #define EBFI_LAUNCH_X3V(MT_, DA_, VEC_)                                                                                   \
@@ -3189,11 +3238,29 @@ extern "C" int ebfi_conv2d_backward_weight_ex(const void *input, const void *gra
 // are ALREADY packed (weight bank), optionally grouped, with the epilogue extras of EpiExtra; and the matching grouped
 // weight gradient on pre-activation gradients.  The data gradient of a layer is this same forward convolution over its
 // gradient with the transposed images, so one entry point serves both directions.
+extern "C" int ebfi_conv2d_packed_x3_c16(const void *input, const void *packed, size_t packed_bytes, const void *bias, void *output,
+                                         int B, int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups, int act,
+                                         float slope, const void *addend, const void *mask_y, int mask_act, float mask_slope,
+                                         void *out16, void *slot16, void *stream);
 extern "C" int ebfi_conv2d_packed_x3(const void *input, const void *packed, size_t packed_bytes, const void *bias, void *output,
                                      int B, int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups, int act,
                                      float slope, const void *addend, const void *mask_y, int mask_act, float mask_slope,
                                      void *stream) {
+    return ebfi_conv2d_packed_x3_c16(input, packed, packed_bytes, bias, output, B, Cin_per_group, H, W, Cout, ksize, pad, groups, act,
+                                     slope, addend, mask_y, mask_act, mask_slope, nullptr, nullptr, stream);
+}
+
+// Same, plus the output as a scaled fp16 image in the c16 layout (c16.hpp; out16 [B][Cout/16][Ho][Wo][16], scale and |max|
+// record in slot16): what the fp16 weight gradient of the NEXT layer stages.  3x3 layers on the wave-specialised kernel only
+// (quad-aligned rows, 64-channel blocks); anything else is refused rather than silently skipping the side image.
+extern "C" int ebfi_conv2d_packed_x3_c16(const void *input, const void *packed, size_t packed_bytes, const void *bias, void *output,
+                                         int B, int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups, int act,
+                                         float slope, const void *addend, const void *mask_y, int mask_act, float mask_slope,
+                                         void *out16, void *slot16, void *stream) {
     if (!input || !packed || !output) return fail(EBFI_ERR_ARG, "conv2d_packed_x3: null argument");
+    if ((out16 != nullptr) != (slot16 != nullptr)) return fail(EBFI_ERR_ARG, "conv2d_packed_x3: out16 and slot16 come together");
+    if (out16 && (Cout % 16 != 0 || ksize != 3 || !aligned16(out16)))
+        return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_x3: the fp16 side image needs a 3x3 layer with Cout %% 16 == 0 (Cout = %d)", Cout);
     if (act < 0 || act > 2 || mask_act < 0 || mask_act > 2) return fail(EBFI_ERR_ARG, "conv2d_packed_x3: unknown activation");
     if (ksize != 1 && ksize != 3) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_x3: k=%d", ksize);
     if (groups < 1 || Cout % groups != 0 || (groups > 1 && (Cout / groups) % 64 != 0))
@@ -3205,7 +3272,8 @@ extern "C" int ebfi_conv2d_packed_x3(const void *input, const void *packed, size
     g.groups = groups;
     if (B == 0) return EBFI_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const EpiExtra epi{static_cast<const float *>(addend), static_cast<const float *>(mask_y), mask_act, mask_slope};
+    const EpiExtra epi{static_cast<const float *>(addend), static_cast<const float *>(mask_y), mask_act, mask_slope,
+                       static_cast<_Float16 *>(out16), static_cast<float *>(slot16)};
     const float *x = static_cast<const float *>(input), *bs = static_cast<const float *>(bias);
     float *o = static_cast<float *>(output);
     void *ws = const_cast<void *>(packed);
@@ -3257,20 +3325,42 @@ extern "C" int ebfi_kernelconv_fac_fused_x3(const void *input, const void *packe
 // fp16 single-product forms for the BACKWARD pass of the training step (conv2d_f16.inc.hpp): the data gradient as a
 // convolution of the (pre-activation) gradient with packed fp16 TRANSPOSED weight images, and the weight gradient, both
 // with power-of-two operand scales kept in device slots {scale, running |max|}.
+extern "C" int ebfi_conv2d_packed_f16_c16(const void *input, int input_is_c16, const void *packed16, size_t packed_bytes,
+                                          const void *bias, void *output, int B, int Cin_per_group, int H, int W, int Cout, int ksize,
+                                          int pad, int groups, int act, float slope, const void *addend, const void *mask_y,
+                                          int mask_act, float mask_slope, void *in_slot, const void *w_slot, void *out16,
+                                          void *slot16, void *stream);
 extern "C" int ebfi_conv2d_packed_f16(const void *input, const void *packed16, size_t packed_bytes, const void *bias, void *output,
                                       int B, int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups, int act,
                                       float slope, const void *addend, const void *mask_y, int mask_act, float mask_slope,
                                       void *in_slot, const void *w_slot, void *stream) {
-    if (!input || !packed16 || !output) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: null argument");
+    if (!output) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: null argument");
+    return ebfi_conv2d_packed_f16_c16(input, 0, packed16, packed_bytes, bias, output, B, Cin_per_group, H, W, Cout, ksize, pad, groups,
+                                      act, slope, addend, mask_y, mask_act, mask_slope, in_slot, w_slot, nullptr, nullptr, stream);
+}
+
+// Same with fp16 operand STORAGE (round 4, c16.hpp): input_is_c16 != 0: `input` is the scaled fp16 image
+// [B][groups*Cin/16][H][W][16] of the tensor, written by its producer with in_slot's scale (Cin_per_group % 16 == 0);
+// out16 / slot16: the output as such an image for the next backward kernel -- in addition to `output`, or alone (output NULL).
+extern "C" int ebfi_conv2d_packed_f16_c16(const void *input, int input_is_c16, const void *packed16, size_t packed_bytes,
+                                          const void *bias, void *output, int B, int Cin_per_group, int H, int W, int Cout, int ksize,
+                                          int pad, int groups, int act, float slope, const void *addend, const void *mask_y,
+                                          int mask_act, float mask_slope, void *in_slot, const void *w_slot, void *out16,
+                                          void *slot16, void *stream) {
+    if (!input || !packed16 || (!output && !out16)) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: null argument");
+    if ((out16 != nullptr) != (slot16 != nullptr)) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: out16 and slot16 come together");
+    if (out16 && (Cout % 16 != 0 || !aligned16(out16))) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_f16: fp16 output image needs Cout %% 16 == 0");
+    if (input_is_c16 && (Cin_per_group % 16 != 0 || !in_slot))
+        return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_f16: an fp16 input image needs Cin %% 16 == 0 and its scale slot");
     if (act < 0 || act > 2 || mask_act < 0 || mask_act > 2) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: unknown activation");
     if (ksize != 3 || pad != 1) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_f16: 3x3 same-padded convolutions only (k=%d pad=%d)", ksize, pad);
     if (groups < 1 || Cout % groups != 0 || (groups > 1 && (Cout / groups) % 64 != 0))
         return fail(EBFI_ERR_ARG, "conv2d_packed_f16: %d output channels in %d groups (groups need multiples of 64 channels)", Cout, groups);
-    if (W % 4 != 0 || !aligned16(input))
+    if ((!input_is_c16 && W % 4 != 0) || !aligned16(input))
         return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_f16: needs W %% 4 == 0 and a 16-byte aligned input (W = %d)", W);
     ConvGeom g;
     if (int rc = make_geom(g, B, Cin_per_group, H, W, Cout, ksize, 1, pad)) return rc;
-    if ((int64_t)groups * (Cin_per_group + 64) * H * W * 4 >= (1LL << 31) - (1LL << 26))
+    if ((int64_t)groups * (Cin_per_group + 64) * H * W * 4 >= (1LL << 31) - (1LL << 26) || (int64_t)(Cout + 64) * H * W * 4 >= (1LL << 31) - (1LL << 26))
         return fail(EBFI_ERR_ARG, "conv2d_packed_f16: one sample exceeds the 2 GiB reach of 32-bit buffer offsets");
     g.groups = groups;
     const int K16 = (g.Cin + 15) / 16 * 16;
@@ -3278,7 +3368,8 @@ extern "C" int ebfi_conv2d_packed_f16(const void *input, const void *packed16, s
     if (packed_bytes < need) return fail(EBFI_ERR_WORKSPACE, "conv2d_packed_f16: packed image %zu bytes < required %zu", packed_bytes, need);
     if (B == 0) return EBFI_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const EpiExtra epi{static_cast<const float *>(addend), static_cast<const float *>(mask_y), mask_act, mask_slope};
+    const EpiExtra epi{static_cast<const float *>(addend), static_cast<const float *>(mask_y), mask_act, mask_slope,
+                       static_cast<_Float16 *>(out16), static_cast<float *>(slot16)};
     const int64_t tiles = (int64_t)B * ceil_div(g.Ho, TYB) * ceil_div(g.Wo, TX);
     if (tiles > 2147483647LL) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: too many tiles");
     constexpr int PSX = (TYB - 1 + 3) * (TX - 1 + 3);
@@ -3288,22 +3379,28 @@ extern "C" int ebfi_conv2d_packed_f16(const void *input, const void *packed16, s
     if (gx < 1) gx = 1;
     if (gx > tiles) gx = tiles;
     const dim3 grid((unsigned)gx, (unsigned)co_blocks);
-    const bool extra = epi.addend != nullptr || epi.mask_y != nullptr;
+    const bool extra = epi.addend != nullptr || epi.mask_y != nullptr || epi.out16 != nullptr;
     const double flops = 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * 9;
-    ProfScope ps("conv_fwd_f16_ws", st, flops, conv_bytes_fwd(g, 9, false));
+    // algorithmic bytes: input + output in the element size they are stored in (fp16 images: 2 bytes) + the packed weights
+    const double px = (double)g.B * g.Ho * g.Wo;
+    const double io_bytes = px * g.groups * g.Cin * (input_is_c16 ? 2.0 : 4.0) + px * g.Cout * ((output ? 4.0 : 0.0) + (out16 ? 2.0 : 0.0)) +
+                            px * g.Cout * ((addend ? 4.0 : 0.0) + (mask_y ? 4.0 : 0.0)) + 2.0 * 9 * (double)g.Cout * g.Cin;
+    ProfScope ps("conv_fwd_f16_ws", st, flops, io_bytes);
     const ScaleSlot isl{static_cast<float *>(in_slot)};
     const float *x = static_cast<const float *>(input), *bs = static_cast<const float *>(bias);
     const _Float16 *wp = static_cast<const _Float16 *>(packed16);
     float *o = static_cast<float *>(output);
-    if (extra) {
-        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_f16_ws<true>), 160 * 1024)) return rc_;
-        hipLaunchKernelGGL((conv_fwd_f16_ws<true>), grid, dim3(NTF16), lds, st, x, wp, bs, o, g, K16, act, slope, epi, (int)tiles, isl,
-                           static_cast<const float *>(w_slot));
-    } else {
-        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_f16_ws<false>), 160 * 1024)) return rc_;
-        hipLaunchKernelGGL((conv_fwd_f16_ws<false>), grid, dim3(NTF16), lds, st, x, wp, bs, o, g, K16, act, slope, epi, (int)tiles, isl,
-                           static_cast<const float *>(w_slot));
-    }
+#define EBFI_LAUNCH_F16WS(EX_, IN_)                                                                                      \
+    do {                                                                                                                 \
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_f16_ws<EX_, IN_>), 160 * 1024)) return rc_; \
+        hipLaunchKernelGGL((conv_fwd_f16_ws<EX_, IN_>), grid, dim3(NTF16), lds, st, x, wp, bs, o, g, K16, act, slope, epi,   \
+                           (int)tiles, isl, static_cast<const float *>(w_slot));                                        \
+    } while (0)
+    if (extra && input_is_c16) EBFI_LAUNCH_F16WS(true, true);
+    else if (extra) EBFI_LAUNCH_F16WS(true, false);
+    else if (input_is_c16) EBFI_LAUNCH_F16WS(false, true);
+    else EBFI_LAUNCH_F16WS(false, false);
+#undef EBFI_LAUNCH_F16WS
     return check_launch("conv_fwd_f16_ws");
 }
 
@@ -3402,6 +3499,59 @@ extern "C" int ebfi_conv2d_backward_weight_f16g(const void *input, const void *g
         ProfScope ps("conv_wgrad_reduce_f32", st);
         hipLaunchKernelGGL(conv_wgrad_reduce_f32, dim3((unsigned)ceil_div(n_total, 64)), dim3(256), 0, st, slab, nsplit, n_weight,
                            n_total, static_cast<float *>(grad_weight), static_cast<float *>(grad_bias), tr_ok ? Cin_per_group : 0, 9);
+    }
+    return check_launch("conv_wgrad_reduce_f32");
+}
+
+// Weight / bias gradient of a (grouped) 3x3 same-padded convolution from the fp16 c16 images (c16.hpp) of its input and of
+// its PRE-activation gradient: input16 [B][groups*Cin/16][H][W][16] scaled by x_slot[0], grad16 [B][Cout/16][H][W][16] scaled
+// by g_slot[0] (both written, and their |max| recorded, by the kernels that produced the tensors).  Same slabs, same
+// deterministic reduction and the same workspace size as ebfi_conv2d_backward_weight_f16g.
+extern "C" int ebfi_conv2d_backward_weight_f16c(const void *input16, const void *grad16, void *grad_weight, void *grad_bias, int B,
+                                                int Cin_per_group, int H, int W, int Cout, int groups, const void *x_slot,
+                                                const void *g_slot, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!input16 || !grad16 || !grad_weight || !x_slot || !g_slot) return fail(EBFI_ERR_ARG, "conv2d_backward_weight_f16c: null argument");
+    if (Cin_per_group % 16 != 0 || Cout % 16 != 0 || Cin_per_group < 16)
+        return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_weight_f16c: channel counts must be multiples of 16 (%d -> %d)", Cin_per_group, Cout);
+    if (groups < 1 || Cout % groups != 0 || (groups > 1 && ((Cout / groups) % 64 != 0 || Cin_per_group % 64 != 0)))
+        return fail(EBFI_ERR_ARG, "conv2d_backward_weight_f16c: %d output channels in %d groups", Cout, groups);
+    if (!aligned16(input16) || !aligned16(grad16)) return fail(EBFI_ERR_ARG, "conv2d_backward_weight_f16c: images must be 16-byte aligned");
+    ConvGeom g;
+    if (int rc = make_geom(g, B, Cin_per_group, H, W, Cout, 3, 1, 1)) return rc;
+    g.groups = groups;
+    if ((int64_t)(groups * Cin_per_group + 64) * H * W * 2 >= (1LL << 31) - (1LL << 26) || (int64_t)(Cout + 64) * H * W * 2 >= (1LL << 31) - (1LL << 26))
+        return fail(EBFI_ERR_ARG, "conv2d_backward_weight_f16c: one sample exceeds the 2 GiB reach of 32-bit buffer offsets");
+    const size_t need = ebfi_conv2d_backward_weight_workspace(B, Cin_per_group, H, W, Cout, 3, 1, 1, EBFI_F32);
+    if (!workspace || workspace_bytes < need)
+        return fail(EBFI_ERR_WORKSPACE, "conv2d_backward_weight_f16c: workspace %zu bytes < required %zu", workspace_bytes, need);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t n_weight = (int64_t)Cout * Cin_per_group * 9, n_total = n_weight + Cout;
+    if (B == 0) {
+        (void)hipMemsetAsync(grad_weight, 0, (size_t)n_weight * sizeof(float), st);
+        if (grad_bias) (void)hipMemsetAsync(grad_bias, 0, (size_t)Cout * sizeof(float), st);
+        return EBFI_OK;
+    }
+    float *slab = static_cast<float *>(workspace);
+    int nsplit = wgrad_x3_splits(g, 3);
+    const int64_t tiles = (int64_t)g.B * ceil_div(g.Ho, TRH) * ceil_div(g.Wo, TRW);
+    if (tiles > 2147483647LL) return fail(EBFI_ERR_ARG, "conv2d_backward_weight_f16c: too many tiles");
+    if (nsplit > tiles) nsplit = (int)tiles;
+    dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, 64));
+    const ScaleSlot xs{const_cast<float *>(static_cast<const float *>(x_slot))}, gs{const_cast<float *>(static_cast<const float *>(g_slot))};
+    {
+        const double px = (double)g.B * g.Ho * g.Wo;
+        ProfScope ps("conv_wgrad_f16_tr", st, 2.0 * px * (double)g.Cout * g.Cin * 9,
+                     2.0 * px * (g.groups * g.Cin + g.Cout) + 4.0 * (double)n_total);
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_wgrad_f16_tr<ACT_NONE, true>), TR_LDS + KB_LDS_BYTES)) return rc_;
+        hipLaunchKernelGGL((conv_wgrad_f16_tr<ACT_NONE, true>), grid, dim3(512), TR_LDS + KB_LDS_BYTES, st,
+                           static_cast<const float *>(input16), static_cast<const float *>(grad16), static_cast<const float *>(nullptr),
+                           static_cast<float *>(nullptr), slab, g, 0.f, (int)tiles, grad_bias != nullptr ? 1 : 0, xs, gs);
+        if (int rc = check_launch("conv_wgrad_f16_tr")) return rc;
+    }
+    {
+        ProfScope ps("conv_wgrad_reduce_f32", st);
+        hipLaunchKernelGGL(conv_wgrad_reduce_f32, dim3((unsigned)ceil_div(n_total, 64)), dim3(256), 0, st, slab, nsplit, n_weight,
+                           n_total, static_cast<float *>(grad_weight), static_cast<float *>(grad_bias), Cin_per_group, 9);
     }
     return check_launch("conv_wgrad_reduce_f32");
 }

@@ -19,40 +19,8 @@
 // -- delayed scaling, as used for fp8 training; the first use of a slot is calibrated just in time by the host side
 // (ebfi_amd/f16scale.py).
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ unsigned pack_f16(float a, float b) {   // v_cvt_pk_f16_f32: round to nearest even, a in the low half
-    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, f16x2));
-}
-
-// fp32 -> fp16 conversions of this wave saturate at +-65504 instead of producing inf (MODE.FP16_OVFL; true inf / NaN inputs
-// stay what they are).  A scale that is too large for this step's data is caught by f16_scales_finish_kernel from the
-// recorded maximum either way; saturating keeps the step's wrong gradients FINITE, so the maxima recorded further down the
-// backward chain stay usable and every scale is repaired by that one finish launch instead of one layer per step.
-__device__ __forceinline__ void saturate_fp16_conversions() { __builtin_amdgcn_s_setreg(1 | (23 << 6), 1); }
-
-// Scale slot: 64 floats (256 bytes); [0] = scale (power of two), [32] = running |max| of the fp32 values staged through it
-// (float bits, ordered as unsigned for non-negative floats).  The two words sit in different 128-byte lines on purpose: the
-// atomic that raises the maximum executes at the memory side and drops its line from L2 -- next to the scale, which every
-// workgroup reads, that turned the 30 000-workgroup pack launch into a queue on one line (0.44 ms for 5.5 M elements).
-constexpr int SLOT_STRIDE = 64, SLOT_AMAX = 32;
-constexpr int F16_TARGET_EXP = 2;          // next scale: |max| * scale in [2^(F16_TARGET_EXP-1), 2^F16_TARGET_EXP) (f16scale.TARGET_EXP)
-struct ScaleSlot {
-    float *p;
-    __device__ __forceinline__ float scale() const { return p ? p[0] : 1.f; }
-    __device__ __forceinline__ void record(float wave_max_candidate) const {
-        // one atomic per wave: butterfly over the 64 lanes, lane 0 publishes (NaN / Inf propagate as large unsigned values)
-        float m = wave_max_candidate;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
-        // (many workgroups report into one word: only a value above the one already there needs the atomic -- NaN compares
-        // false and goes through)
-        if (p && (threadIdx.x & 63) == 0 && !(m <= __builtin_nontemporal_load(p + SLOT_AMAX)))
-            atomicMax(reinterpret_cast<unsigned *>(p + SLOT_AMAX), __float_as_uint(m));
-    }
-};
+// (f16 vector types, pack_f16, saturate_fp16_conversions and ScaleSlot live in c16.hpp: the split-precision forward kernels
+// and the fused stages write fp16 side images too)
 
 // ------------------------------------------------------------------------------------------------
 // conv_fwd_f16_ws: the wave-specialised 3x3 forward / data gradient (64 output channels per workgroup, 8 rows x 64 px
@@ -65,7 +33,11 @@ struct ScaleSlot {
 //   wp      fp16 image [tap][Cout][K16], already scaled by w_slot[0] (the pack launch applied and recorded it)
 //   out     act(acc / (in_scale * w_scale) + bias + addend) * act'(mask_y)
 constexpr int NTF16 = 512;
-template <bool EXTRA>
+//   IN16 (round 4): x is NOT fp32 NCHW but the scaled fp16 image of the tensor in the c16 layout (c16.hpp), written by its
+//           producer with in_slot's scale: the staging becomes a plain 16-byte copy (6 loads + 6 LDS stores per thread and
+//           chunk instead of 24 + 8 conversions + 12), half the bytes; in_slot is only read here (the writer recorded |max|)
+//   epi.out16: the output additionally / only (out == NULL) as a c16 fp16 image for the next backward kernel
+template <bool EXTRA, bool IN16 = false>
 __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict__ x, const _Float16 *__restrict__ wp,
                                                          const float *__restrict__ bias, float *__restrict__ out, ConvGeom g, int K16,
                                                          int act, float slope, EpiExtra epi, int tiles_total, ScaleSlot in_slot,
@@ -113,6 +85,7 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[r][m][n][e] = 0.f;
         const float oscale = 1.f / (sx * (w_slot ? w_slot[0] : 1.f));
+        [[maybe_unused]] float amax16 = 0.f;
         const int hsel = lane >> 5, l31 = lane & 31;
         const int a_lane = INB + l31 * 32 + ((hsel ^ ((l31 >> 3) & 1)) << 4);
         const int pbase = RW * wave * IW + l31;
@@ -169,8 +142,8 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
             // (written out per row: as a loop the EXTRA variant was not unrolled, `acc[r]` became a runtime index and the whole
             // accumulator array moved to scratch memory -- 410 instead of 45 us per launch)
             static_assert(RW == 2, "epilogue is written out for two rows");
-            store_out_tile<MT, EXTRA>(out, bias, acc[0], g, cb_, co_base, cy0 + RW * wave, cx0, lane, act, slope, epi, oscale);
-            store_out_tile<MT, EXTRA>(out, bias, acc[1], g, cb_, co_base, cy0 + RW * wave + 1, cx0, lane, act, slope, epi, oscale);
+            store_out_tile<MT, EXTRA>(out, bias, acc[0], g, cb_, co_base, cy0 + RW * wave, cx0, lane, act, slope, epi, oscale, &amax16);
+            store_out_tile<MT, EXTRA>(out, bias, acc[1], g, cb_, co_base, cy0 + RW * wave + 1, cx0, lane, act, slope, epi, oscale, &amax16);
 #pragma unroll
             for (int r = 0; r < RW; ++r)
 #pragma unroll
@@ -182,6 +155,9 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
         }
         KB_STAMP(31);
         KB_FLUSH_SELF();
+        if constexpr (EXTRA) {
+            if (epi.out16 != nullptr) ScaleSlot{epi.slot16}.record(amax16);
+        }
         return;
     }
     // ---------------------------------------------------------------------- producers
@@ -191,6 +167,105 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
     const int ptid = tid - 64 * NCW;
     const unsigned img_bytes = (unsigned)KK * (unsigned)g.Cout * (unsigned)K16 * 2u;
     const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(wp), 0, img_bytes, 0x00020000);
+    if constexpr (IN16) {
+        // ---- fp16 c16 input: piece id -> (tile row, tile column, 8-channel half); the chunk's block of a position is 32
+        // contiguous bytes, a tile row 66 x 32 = 2112 contiguous bytes: consecutive lanes copy consecutive 16-byte pieces
+        constexpr int NPIECE = PS * 2, NPK = (NPIECE + PT - 1) / PT;
+        const int p_half = ptid & 1;                                  // (PT is even: the half is the same for every k)
+        int p_row[NPK], p_col[NPK], p_dst[NPK];
+#pragma unroll
+        for (int k = 0; k < NPK; ++k) {
+            const int pos = (ptid + k * PT) >> 1;
+            p_row[k] = pos / IW;
+            p_col[k] = pos - p_row[k] * IW;
+            p_dst[k] = pos * 32 + ((p_half ^ ((pos >> 3) & 1)) << 4);
+        }
+        unsigned w_off[NWB];
+        int w_dst[NWB];
+#pragma unroll
+        for (int it = 0; it < NWB; ++it) {
+            const int j = ptid + it * PT;
+            const int row = j >> 1, half = j & 1;
+            const int tap = row / COS, co = row - tap * COS;
+            w_off[it] = j < WPIECES ? (unsigned)(((tap * g.Cout + co_base + co) * K16 + half * 8) * 2) : SENT;
+            w_dst[it] = INB + row * 32 + ((half ^ ((row >> 3) & 1)) << 4);
+        }
+        struct Stage16 {
+            u32x4 rq[NPK];
+            u32x4 rw[NWB];
+        };
+        Stage16 sa, sb, sc;                    // THREE chunks of loads in flight (10 registers of payload per chunk and thread)
+        const unsigned blk_bytes = (unsigned)HW * 32u;                // one 16-channel block of one sample
+        const _Float16 *x16 = reinterpret_cast<const _Float16 *>(x);
+        const int cbg = g.Cin >> 4;                                   // 16-channel blocks per group (= chunks)
+        int pf_tile = blockIdx.x, pf_chunk = 0;
+        unsigned pf_off[NPK];
+        const _Float16 *pf_src = x16;
+        unsigned pf_bytes = 0u;
+        auto pf_setup = [&]() {
+            const bool live = pf_tile < tiles_total;
+            int tb, ty0, tx0;
+            tile_coords(live ? pf_tile : 0, tb, ty0, tx0);
+#pragma unroll
+            for (int k = 0; k < NPK; ++k) {
+                const int yy = ty0 - g.pad + p_row[k], xx = tx0 - g.pad + p_col[k];
+                const bool ok = live && ptid + k * PT < NPIECE && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+                pf_off[k] = ok ? (unsigned)(yy * g.W + xx) * 32u + (unsigned)p_half * 16u : SENT;
+            }
+            pf_src = x16 + ((int64_t)tb * g.groups + grp) * cbg * HW * 16;
+            pf_bytes = live ? (unsigned)cbg * blk_bytes : 0u;
+        };
+        auto prefetch = [&](Stage16 &s) {
+            const uint64_t pa = reinterpret_cast<uint64_t>(pf_src);
+            const uint64_t pu = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(pa >> 32)) << 32) |
+                                (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)pa);
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<_Float16 *>(pu), 0, (unsigned)__builtin_amdgcn_readfirstlane(pf_bytes), 0x00020000);
+            const unsigned cb = (unsigned)__builtin_amdgcn_readfirstlane(pf_chunk) * blk_bytes;
+#pragma unroll
+            for (int k = 0; k < NPK; ++k) s.rq[k] = __builtin_amdgcn_raw_buffer_load_b128(r, pf_off[k] + cb, 0, 0);
+            const unsigned wb = (unsigned)__builtin_amdgcn_readfirstlane(pf_chunk) * (unsigned)(CKB * 2);
+#pragma unroll
+            for (int it = 0; it < NWB; ++it) s.rw[it] = __builtin_amdgcn_raw_buffer_load_b128(rwt, w_off[it] + wb, 0, 0);
+            if (++pf_chunk == nchunks) {
+                pf_chunk = 0;
+                pf_tile += G;
+                pf_setup();
+            }
+        };
+        auto commit = [&](int buf, Stage16 &s) {
+            char *base = smd + buf * BUFB;
+#pragma unroll
+            for (int k = 0; k < NPK; ++k)
+                if (ptid + k * PT < NPIECE) *reinterpret_cast<u32x4 *>(base + p_dst[k]) = s.rq[k];
+#pragma unroll
+            for (int it = 0; it < NWB; ++it)
+                if (ptid + it * PT < WPIECES) *reinterpret_cast<u32x4 *>(base + w_dst[it]) = s.rw[it];
+        };
+        pf_setup();
+        prefetch(sa);                          // item 0
+        prefetch(sb);                          // item 1
+        prefetch(sc);                          // item 2
+        commit(0, sa);
+        __syncthreads();                       // (A)
+        prefetch(sa);                          // item 3
+        // steady state: before barrier (B) of item i the producers commit item i + 1 and request item i + 4; the stages rotate
+        // sb -> sc -> sa (written out three times: a runtime stage index would move the registers to scratch)
+        for (int item = 0; item < nitems; item += 3) {
+            commit((item + 1) & 1, sb);
+            prefetch(sb);
+            __syncthreads();                   // (B) item
+            if (item + 1 >= nitems) break;
+            commit(item & 1, sc);
+            prefetch(sc);
+            __syncthreads();                   // (B) item + 1
+            if (item + 2 >= nitems) break;
+            commit((item + 1) & 1, sa);
+            prefetch(sa);
+            __syncthreads();                   // (B) item + 2
+        }
+        return;
+    }
     constexpr int SH = (4 - (KS / 2) % 4) % 4;
     constexpr int NQ = (IW + SH + 3) / 4;
     constexpr int NITEM = IH * NQ * 2;
@@ -665,7 +740,10 @@ constexpr int TR_LDS = 2 * TR_BUFB + 4 * 64 * 4;                             // 
 // DACT != 0: grad_out is multiplied by act'(saved output) on the way in (the layer's own activation folded, as in the other
 // weight-gradient kernels) and, with gpre_out, the product is written out for the data gradient; the saved-output quads take
 // the registers of the second input stage, so this form keeps ONE tile of input loads in flight.
-template <int DACT>
+// IN16 (round 4, DACT == 0 only): x and gout are the scaled fp16 images of the two tensors in the c16 layout (c16.hpp): a
+// [pixel][64 ch] LDS image is four 16-channel blocks whose tile rows are contiguous runs, so the producers copy 16-byte
+// pieces (7 + 4 loads per thread and tile instead of 16 + 8 plus the conversions) and move half the bytes.
+template <int DACT, bool IN16 = false>
 __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict__ x, const float *__restrict__ gout,
                                                          const float *__restrict__ yact, float *__restrict__ gpre_out,
                                                          float *__restrict__ slab, ConvGeom g, float dslope, int total_tiles,
@@ -805,6 +883,136 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict
     }
     // ---------------------------------------------------------------------- producers
     const int ptid = tid - 64 * NQ;
+    if constexpr (IN16) {
+        static_assert(DACT == 0, "fp16 c16 operands: pre-activation gradients only");
+        // input image: rows 0..5, stored columns 1..34 of the 36 (the two outer ones are never read), 4 blocks, 2 halves
+        constexpr int XCOLS = TRW + 2, NXP = 4 * TRXR * XCOLS * 2, NXK16 = (NXP + PT - 1) / PT;      // 1632 pieces, 7 per thread
+        constexpr int NGK16 = 4;                                                               // 4 x 128 px x 2 = 1024 grad_out pieces
+        const _Float16 *x16 = reinterpret_cast<const _Float16 *>(x), *g16 = reinterpret_cast<const _Float16 *>(gout);
+        const int p_half = ptid & 1;
+        int xb[NXK16], xr[NXK16], xc[NXK16], xd[NXK16];
+#pragma unroll
+        for (int k = 0; k < NXK16; ++k) {
+            int id = (ptid + k * PT) >> 1;
+            xc[k] = id % XCOLS; id /= XCOLS;
+            xr[k] = id % TRXR;
+            xb[k] = id / TRXR;                                       // 0..3 (>= 4: past the end)
+            const int pos = xr[k] * TRXW + xc[k] + 1;
+            xd[k] = pos * 128 + (((2 * xb[k] + p_half) ^ (((pos >> 1) & 1) << 2)) << 4);
+        }
+        // grad_out pieces: id = ptid + k * 256 -> half = ptid & 1, pixel (ptid >> 1) & 31, row (ptid >> 6), block k
+        const int gp_x = (ptid >> 1) & 31, gp_y = ptid >> 6;
+        const int gpix = gp_y * TRW + gp_x;
+        int gd[NGK16];
+#pragma unroll
+        for (int k = 0; k < NGK16; ++k) gd[k] = TR_XB + gpix * 128 + (((2 * k + p_half) ^ (((gpix >> 1) & 1) << 2)) << 4);
+        const int cbx = g.Cin >> 4, cbo = g.Cout >> 4;               // 16-channel blocks per group (input) / of grad_out
+        const int cbx_rem = (g.Cin + 15) / 16 - (ci_base >> 4);      // blocks of this workgroup's 64-channel block that exist
+        const unsigned xblk = (unsigned)HW * 32u, gblk = (unsigned)HWo * 32u;
+        const unsigned xs_bytes = (unsigned)((g.Cin + 15) / 16) * xblk, gs_bytes = (unsigned)cbo * gblk;
+        (void)cbx;
+        struct S16 {
+            u32x4 rx[NXK16];
+            u32x4 rg[NGK16];
+        };
+        S16 sa, sb, sc;
+        float bacc[NGK16][8];
+#pragma unroll
+        for (int k = 0; k < NGK16; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bacc[k][e] = 0.f;
+        const bool xcd_map = (gridDim.x & 7) == 0;
+        auto tile_coords = [&](int tile, int &b, int &y0, int &x0) {
+            int t = (xcd_map && tile < total_tiles) ? xcd_tile(tile, total_tiles) : tile;
+            const int tx = t % tiles_x; t /= tiles_x;
+            const int ty = t % tiles_y;
+            b = t / tiles_y; y0 = ty * TRH; x0 = tx * TRW;
+        };
+        auto prefetch = [&](int tile, S16 &s) {
+            int b, y0, x0;
+            tile_coords(tile, b, y0, x0);
+            const bool live = tile < total_tiles;
+            const int bb = live ? b : 0;
+            const __amdgpu_buffer_rsrc_t rxi = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<_Float16 *>(x16) + ((int64_t)bb * g.groups + grp) * ((g.Cin + 15) / 16) * HW * 16, 0, live ? xs_bytes : 0u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rgo = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<_Float16 *>(g16) + (int64_t)bb * cbo * HWo * 16, 0, live ? gs_bytes : 0u, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < NXK16; ++k) {
+                const int yy = y0 - 1 + xr[k], xx = x0 - 1 + xc[k];
+                const bool ok = ptid + k * PT < NXP && xb[k] < cbx_rem && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+                const unsigned o = ok ? (unsigned)((ci_base >> 4) + xb[k]) * xblk + (unsigned)(yy * g.W + xx) * 32u + (unsigned)p_half * 16u : SENT;
+                s.rx[k] = __builtin_amdgcn_raw_buffer_load_b128(rxi, o, 0, 0);
+            }
+            const int gy = y0 + gp_y, gx = x0 + gp_x;
+            const bool gok = gy < g.Ho && gx < g.Wo;
+#pragma unroll
+            for (int k = 0; k < NGK16; ++k) {
+                const int cb = (co_base >> 4) + k;
+                const unsigned o = (gok && cb < cbo) ? (unsigned)cb * gblk + (unsigned)(gy * g.Wo + gx) * 32u + (unsigned)p_half * 16u : SENT;
+                s.rg[k] = __builtin_amdgcn_raw_buffer_load_b128(rgo, o, 0, 0);
+            }
+        };
+        const float inv_sg = 1.f / sg;
+        auto commit = [&](int buf, S16 &s) {
+            char *img = smt + buf * TR_BUFB;
+#pragma unroll
+            for (int k = 0; k < NXK16; ++k)
+                if (ptid + k * PT < NXP) *reinterpret_cast<u32x4 *>(img + xd[k]) = s.rx[k];
+#pragma unroll
+            for (int k = 0; k < NGK16; ++k) {
+                *reinterpret_cast<u32x4 *>(img + gd[k]) = s.rg[k];
+                if (need_bias && ci_blk == 0) {                      // bias gradient: plain sums of the (scaled) grad_out values
+                    const f16x8 hv = __builtin_bit_cast(f16x8, s.rg[k]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bacc[k][e] += (float)hv[e];
+                }
+            }
+        };
+        // the two outer stored columns (0 and 35) of the input image are never read; zero-filled positions come from the loads
+        prefetch(split, sa);
+        prefetch(split + G, sb);
+        prefetch(split + 2 * G, sc);
+        commit(0, sa);
+        __syncthreads();                   // (A)
+        prefetch(split + 3 * G, sa);
+        int cur = 0;
+        for (int tile = split; tile < total_tiles; tile += 3 * G) {
+            commit(cur ^ 1, sb);           // tile + G
+            prefetch(tile + 4 * G, sb);
+            __syncthreads();               // (B)
+            cur ^= 1;
+            if (tile + G >= total_tiles) break;
+            commit(cur ^ 1, sc);           // tile + 2 G
+            prefetch(tile + 5 * G, sc);
+            __syncthreads();               // (B)
+            cur ^= 1;
+            if (tile + 2 * G >= total_tiles) break;
+            commit(cur ^ 1, sa);           // tile + 3 G
+            prefetch(tile + 6 * G, sa);
+            __syncthreads();               // (B)
+            cur ^= 1;
+        }
+        if (need_bias && ci_blk == 0) {
+            // channel 16 k + 8 half + e: summed over the lanes that share `half` (lane bits 1..5 = pixel), then the four waves
+            // (= tile rows) go through LDS to the consumers, which add them in a fixed order after barrier (C)
+            float *scr = reinterpret_cast<float *>(smt + 2 * TR_BUFB);
+#pragma unroll
+            for (int k = 0; k < NGK16; ++k)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = bacc[k][e];
+                    v += __shfl_xor(v, 2, 64);
+                    v += __shfl_xor(v, 4, 64);
+                    v += __shfl_xor(v, 8, 64);
+                    v += __shfl_xor(v, 16, 64);
+                    v += __shfl_xor(v, 32, 64);
+                    if ((lane >> 1) == 0) scr[(wave - NQ) * 64 + 16 * k + 8 * p_half + e] = v * inv_sg;
+                }
+        }
+        __syncthreads();                   // (C)
+        return;
+    }
     const unsigned go_bytes = (unsigned)g.Cout * (unsigned)HWo * 4u, x_bytes = (unsigned)g.Cin * (unsigned)HW * 4u;
     const unsigned xplane = (unsigned)HW * 4u, gplane = (unsigned)HWo * 4u;
     // item geometry (fixed per thread): 8-channel group `chg`; grad_out item (row gy, quad gq); input items (row, quad)

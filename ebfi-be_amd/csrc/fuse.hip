@@ -5,6 +5,7 @@
 //     by_ex = Conv1(ex) * Conv3(x) + x ;  by_t = Conv2(t) * Conv4(x) + x ;  cat([by_ex, by_t], 1)
 // with a0 = Conv3(x), a1 = Conv4(x) [B,C,H,W] and the per-sample channel scales s0 = Conv1(ex), s1 = Conv2(t) [B,C].
 #include "common.hpp"
+#include "c16.hpp"
 
 using namespace ebfi;
 
@@ -133,6 +134,162 @@ __global__ __launch_bounds__(256) void prodmean_bwd_kernel(const float *__restri
     reinterpret_cast<f4 *>(gb)[i] = u * k;
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp16 operand storage (round 4, c16.hpp): the fused stages write the tensors the backward convolutions will stage as scaled
+// fp16 images [B][C/16][HW][16] themselves.  A thread owns 4 consecutive pixels of 8 channels (one half of a 16-channel
+// block): eight 16-byte plane loads in, four 16-byte pieces (pixel, 8 channels) out.
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void c16_store_quad(_Float16 *__restrict__ dst, int64_t piece0, const f4 (&v)[8], float s, float &amax) {
+    // dst + piece0 * 8 halves: the piece of the FIRST pixel; the next pixels follow every 32 bytes (= 2 pieces)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        u4 q;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const float a = v[e][j], b = v[e + 1][j];
+            amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));
+            q[e >> 1] = pack_f16(a * s, b * s);
+        }
+        *reinterpret_cast<u4 *>(dst + (piece0 + 2 * j) * 8) = q;
+    }
+}
+
+// fp32 [B, C, HW] -> c16 image (optionally times the LeakyReLU derivative of `mask_y`: the pre-activation gradient of a layer
+// whose output is mask_y).  One thread per (b, 8-channel group, pixel quad).
+__global__ __launch_bounds__(256) void to_c16_kernel(const float *__restrict__ src, const float *__restrict__ mask_y, float mask_slope,
+                                                     _Float16 *__restrict__ dst, float *__restrict__ slot, int C, int64_t HW4,
+                                                     int64_t total) {
+    saturate_fp16_conversions();
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float amax = 0.f;
+    if (i < total) {
+        const int64_t q = i % HW4, bg = i / HW4;                  // bg = b * (C / 8) + channel group
+        const int64_t G8 = C / 8, b = bg / G8, cg = bg - b * G8;
+        const f4 *p = reinterpret_cast<const f4 *>(src) + (b * C + cg * 8) * HW4 + q;
+        f4 v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = p[e * HW4];
+        if (mask_y) {
+            const f4 *m = reinterpret_cast<const f4 *>(mask_y) + (b * C + cg * 8) * HW4 + q;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const f4 y = m[e * HW4];
+                v[e].x *= y.x > 0.f ? 1.f : mask_slope; v[e].y *= y.y > 0.f ? 1.f : mask_slope;
+                v[e].z *= y.z > 0.f ? 1.f : mask_slope; v[e].w *= y.w > 0.f ? 1.f : mask_slope;
+            }
+        }
+        // block cg / 2 of sample b, pixel 4 q, half cg & 1
+        const int64_t piece0 = ((b * (C / 16) + cg / 2) * (HW4 * 4) + 4 * q) * 2 + (cg & 1);
+        c16_store_quad(dst, piece0, v, slot[0], amax);
+    }
+    ScaleSlot{slot}.record(amax);
+}
+
+// src_fwd_kernel with the output additionally as a c16 image (the input of the weight gradient of the layer that follows)
+__global__ __launch_bounds__(256) void src_fwd_c16_kernel(const float *__restrict__ a0, const float *__restrict__ s0,
+                                                          const float *__restrict__ a1, const float *__restrict__ s1,
+                                                          const float *__restrict__ x, float *__restrict__ out,
+                                                          _Float16 *__restrict__ out16, float *__restrict__ slot, int C, int64_t HW4,
+                                                          int64_t total, int64_t a_bs4) {
+    saturate_fp16_conversions();
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float amax = 0.f;
+    if (i < total) {
+        const int64_t q = i % HW4, bg = i / HW4;                  // bg = b * (2C / 8) + output channel group
+        const int64_t G8 = 2 * C / 8, b = bg / G8, cg = bg - b * G8;
+        const int64_t co = cg * 8;                                // first output channel of the group (never straddles C: C % 8 == 0)
+        const bool second = co >= C;
+        const int64_t c = second ? co - C : co;
+        const f4 *pa = reinterpret_cast<const f4 *>(second ? a1 : a0) + b * a_bs4 + c * HW4 + q;
+        const f4 *px = reinterpret_cast<const f4 *>(x) + (b * C + c) * HW4 + q;
+        const float *ps = (second ? s1 : s0) + b * C + c;
+        f4 v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = pa[e * HW4] * ps[e] + px[e * HW4];
+        f4 *o = reinterpret_cast<f4 *>(out) + (b * 2 * C + co) * HW4 + q;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e * HW4] = v[e];
+        const int64_t piece0 = ((b * (2 * C / 16) + cg / 2) * (HW4 * 4) + 4 * q) * 2 + (cg & 1);
+        c16_store_quad(out16, piece0, v, slot[0], amax);
+    }
+    ScaleSlot{slot}.record(amax);
+}
+
+// src_bwd_kernel writing grad_a0 | grad_a1 (the pre-activation gradient of the two second layers) as ONE c16 image of 2C
+// channels instead of two fp32 tensors.  A workgroup owns 8 channels of one sample and one of `nslice` pixel slices; the
+// per-channel sums of grad*a (the gradients of the scales) leave as per-slice partials [nslice][B][C], summed in slice order by
+// the caller (fixed order: deterministic).
+__global__ __launch_bounds__(256) void src_bwd_c16_kernel(const float *__restrict__ gout, const float *__restrict__ a0,
+                                                          const float *__restrict__ s0, const float *__restrict__ a1,
+                                                          const float *__restrict__ s1, _Float16 *__restrict__ ga16,
+                                                          float *__restrict__ slot, float *__restrict__ gx, float *__restrict__ gs0p,
+                                                          float *__restrict__ gs1p, int B, int C, int64_t HW4, int64_t a_bs4,
+                                                          int nslice, float mask_slope) {
+    saturate_fp16_conversions();
+    __shared__ float red[4][16];
+    const int G8 = C / 8;
+    const int slice = blockIdx.x % nslice, bg = blockIdx.x / nslice;
+    const int b = bg / G8, cg = bg - b * G8, c = cg * 8;
+    const int64_t q0 = HW4 * slice / nslice, q1 = HW4 * (slice + 1) / nslice;
+    float k0[8], k1[8], d0[8], d1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) k0[e] = s0[b * C + c + e], k1[e] = s1[b * C + c + e], d0[e] = 0.f, d1[e] = 0.f;
+    const float sc = slot[0];
+    float amax = 0.f;
+    auto dm = [&](const f4 &v) {
+        f4 m;
+        m.x = v.x > 0.f ? 1.f : mask_slope; m.y = v.y > 0.f ? 1.f : mask_slope;
+        m.z = v.z > 0.f ? 1.f : mask_slope; m.w = v.w > 0.f ? 1.f : mask_slope;
+        return m;
+    };
+    const f4 *g0 = reinterpret_cast<const f4 *>(gout) + ((int64_t)b * 2 * C + c) * HW4;
+    const f4 *g1 = reinterpret_cast<const f4 *>(gout) + ((int64_t)b * 2 * C + C + c) * HW4;
+    const f4 *p0 = reinterpret_cast<const f4 *>(a0) + (int64_t)b * a_bs4 + (int64_t)c * HW4;
+    const f4 *p1 = reinterpret_cast<const f4 *>(a1) + (int64_t)b * a_bs4 + (int64_t)c * HW4;
+    f4 *ox = reinterpret_cast<f4 *>(gx) + ((int64_t)b * C + c) * HW4;
+    const int64_t blk0 = ((int64_t)b * (2 * C / 16) + cg / 2) * (HW4 * 4), blk1 = ((int64_t)b * (2 * C / 16) + (C + c) / 16) * (HW4 * 4);
+    for (int64_t q = q0 + threadIdx.x; q < q1; q += 256) {
+        f4 u0[8], u1[8], w[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) u0[e] = g0[e * HW4 + q], u1[e] = g1[e * HW4 + q];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ox[e * HW4 + q] = u0[e] + u1[e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const f4 v = p0[e * HW4 + q];
+            d0[e] += (u0[e].x * v.x + u0[e].y * v.y) + (u0[e].z * v.z + u0[e].w * v.w);
+            w[e] = u0[e] * k0[e] * dm(v);
+        }
+        c16_store_quad(ga16, (blk0 + 4 * q) * 2 + (cg & 1), w, sc, amax);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const f4 v = p1[e * HW4 + q];
+            d1[e] += (u1[e].x * v.x + u1[e].y * v.y) + (u1[e].z * v.z + u1[e].w * v.w);
+            w[e] = u1[e] * k1[e] * dm(v);
+        }
+        c16_store_quad(ga16, (blk1 + 4 * q) * 2 + (((C + c) >> 3) & 1), w, sc, amax);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            d0[e] += __shfl_xor(d0[e], d, 64);
+            d1[e] += __shfl_xor(d1[e], d, 64);
+        }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[threadIdx.x >> 6][e] = d0[e], red[threadIdx.x >> 6][8 + e] = d1[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        float *dst = threadIdx.x < 8 ? gs0p : gs1p;
+        dst[((int64_t)slice * B + b) * C + c + (threadIdx.x & 7)] = v;
+    }
+    ScaleSlot{slot}.record(amax);
+}
+
 int check_planes(const char *who, int B, int C, int64_t HW) {
     if (B < 0 || C <= 0 || HW <= 0) return fail(EBFI_ERR_ARG, "%s: bad dimensions", who);
     if (HW % 4 != 0) return fail(EBFI_ERR_UNSUPPORTED, "%s: H*W must be a multiple of 4 (got %lld)", who, (long long)HW);
@@ -202,6 +359,67 @@ extern "C" int ebfi_scale_residual_cat_backward_ex(const float *grad_out, const 
         ProfScope ps("scale_residual_cat_bwd", st, 0.0, 28.0 * B * C * (double)HW);
         hipLaunchKernelGGL(src_bwd_kernel, dim3((unsigned)(B * C)), dim3(256), 0, st, grad_out, a0, s0, a1, s1, grad_a0, grad_a1,
                            grad_x, grad_s0, grad_s1, C, HW / 4, a_batch_stride / 4, grad_a_batch_stride / 4, mask_leaky, mask_slope);
+    }
+    return check_launch("scale_residual_cat_bwd");
+}
+
+// fp16 c16 images (include/ebfi_hip.h, csrc/c16.hpp) ---------------------------------------------------------------
+extern "C" int ebfi_to_c16(const float *src, const float *mask_y, float mask_slope, void *dst16, void *slot, int B, int C, int64_t HW,
+                           void *stream) {
+    if (!src || !dst16 || !slot) return fail(EBFI_ERR_ARG, "to_c16: null argument");
+    if (C % 16 != 0) return fail(EBFI_ERR_UNSUPPORTED, "to_c16: %d channels (multiples of 16)", C);
+    if (int rc = check_planes("to_c16", B, C, HW)) return rc;
+    if (!aligned16(src) || !aligned16(dst16) || (mask_y && !aligned16(mask_y))) return fail(EBFI_ERR_ARG, "to_c16: 16-byte aligned tensors");
+    if (B == 0) return EBFI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)B * (C / 8) * (HW / 4);
+    {
+        ProfScope ps("to_c16", st, 0.0, (mask_y ? 10.0 : 6.0) * B * C * (double)HW);
+        hipLaunchKernelGGL(to_c16_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, src, mask_y, mask_slope,
+                           static_cast<_Float16 *>(dst16), static_cast<float *>(slot), C, HW / 4, total);
+    }
+    return check_launch("to_c16");
+}
+
+extern "C" int ebfi_scale_residual_cat_forward_c16(const float *a0, const float *s0, const float *a1, const float *s1, const float *x,
+                                                   float *out, void *out16, void *slot, int B, int C, int64_t HW,
+                                                   int64_t a_batch_stride, void *stream) {
+    if (!a0 || !s0 || !a1 || !s1 || !x || !out || !out16 || !slot) return fail(EBFI_ERR_ARG, "scale_residual_cat_forward_c16: null argument");
+    if (a_batch_stride % 4 != 0 || a_batch_stride < (int64_t)C * HW) return fail(EBFI_ERR_ARG, "scale_residual_cat_forward_c16: batch stride");
+    if (C % 8 != 0) return fail(EBFI_ERR_UNSUPPORTED, "scale_residual_cat_forward_c16: %d channels (multiples of 8)", C);
+    if (int rc = check_planes("scale_residual_cat_forward_c16", B, C, HW)) return rc;
+    if (B == 0) return EBFI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)B * (2 * C / 8) * (HW / 4);
+    {
+        ProfScope ps("scale_residual_cat_fwd", st, 0.0, 24.0 * B * C * (double)HW);
+        hipLaunchKernelGGL(src_fwd_c16_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, a0, s0, a1, s1, x, out,
+                           static_cast<_Float16 *>(out16), static_cast<float *>(slot), C, HW / 4, total, a_batch_stride / 4);
+    }
+    return check_launch("scale_residual_cat_fwd");
+}
+
+extern "C" int ebfi_scale_residual_cat_backward_slices(void) { return 8; }
+
+// grad_a16: c16 image of [grad_a0 | grad_a1] (2C channels) times the LeakyReLU(mask_slope) derivative of a0 / a1, scaled by
+// slot[0]; grad_x [B,C,HW] fp32; grad_s0_part / grad_s1_part [ebfi_scale_residual_cat_backward_slices()][B][C] partial sums
+extern "C" int ebfi_scale_residual_cat_backward_c16(const float *grad_out, const float *a0, const float *s0, const float *a1,
+                                                    const float *s1, void *grad_a16, void *slot, float *grad_x, float *grad_s0_part,
+                                                    float *grad_s1_part, int B, int C, int64_t HW, int64_t a_batch_stride,
+                                                    float mask_slope, void *stream) {
+    if (!grad_out || !a0 || !s0 || !a1 || !s1 || !grad_a16 || !slot || !grad_x || !grad_s0_part || !grad_s1_part)
+        return fail(EBFI_ERR_ARG, "scale_residual_cat_backward_c16: null argument");
+    if (a_batch_stride % 4 != 0 || a_batch_stride < (int64_t)C * HW) return fail(EBFI_ERR_ARG, "scale_residual_cat_backward_c16: batch stride");
+    if (C % 16 != 0) return fail(EBFI_ERR_UNSUPPORTED, "scale_residual_cat_backward_c16: %d channels (multiples of 16)", C);
+    if (int rc = check_planes("scale_residual_cat_backward_c16", B, C, HW)) return rc;
+    if (B == 0) return EBFI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nslice = ebfi_scale_residual_cat_backward_slices();
+    {
+        ProfScope ps("scale_residual_cat_bwd", st, 0.0, 24.0 * B * C * (double)HW);
+        hipLaunchKernelGGL(src_bwd_c16_kernel, dim3((unsigned)(B * (C / 8) * nslice)), dim3(256), 0, st, grad_out, a0, s0, a1, s1,
+                           static_cast<_Float16 *>(grad_a16), static_cast<float *>(slot), grad_x, grad_s0_part, grad_s1_part, B, C,
+                           HW / 4, a_batch_stride / 4, nslice, mask_slope);
     }
     return check_launch("scale_residual_cat_bwd");
 }

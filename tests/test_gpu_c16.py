@@ -1,0 +1,177 @@
+"""fp16 operand storage (csrc/c16.hpp): every writer and reader of the c16 images against plain torch and against the fp32-input
+forms of the same kernels.  Same fp16 operands in the same MFMA order: the image-reading kernels must reproduce the
+fp32-reading ones BIT FOR BIT; the images themselves must equal fp16(value * scale) of the fp32 tensors exactly."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from ebfi_amd import _native as N  # noqa: E402
+
+
+def _ref_image(x, scale):
+    B, C, H, W = x.shape
+    return (x * scale).half().reshape(B, C // 16, 16, H, W).permute(0, 1, 3, 4, 2).contiguous()
+
+
+def _banked(cin, cout, groups=1):
+    from ebfi_amd import f16scale, weightbank
+    w = torch.nn.Parameter((torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5).cuda())
+    b = torch.nn.Parameter((torch.randn(cout) * 0.1).cuda())
+    bank = weightbank.WeightBank([w, b])
+    site = bank.register(w, b, "id", groups=groups)
+    book = f16scale.ScaleBook("cuda")
+    bank.attach_scale_book(book)
+    bank.refresh()
+    return w, b, bank, book, site
+
+
+@pytest.mark.parametrize("B,C,H,W,masked", [(2, 64, 16, 64, False), (1, 128, 13, 36, True), (3, 16, 8, 4, False)])
+def test_to_c16_matches_torch(B, C, H, W, masked):
+    from ebfi_amd import c16, f16scale
+    torch.manual_seed(B + C)
+    book = f16scale.ScaleBook("cuda")
+    i = book.slot("t")
+    book.slots[f16scale.SLOT_STRIDE * i] = 0.25
+    x = (torch.randn(B, C, H, W) * 3).cuda()
+    y = torch.randn(B, C, H, W).cuda()
+    img = c16.to_c16(x, book.ptr(i), y if masked else None, 0.01)
+    ref = x * torch.where(y > 0, 1.0, 0.01) if masked else x
+    assert torch.equal(img, _ref_image(ref, 0.25))
+    assert book.amax(i) == ref.abs().max().item()
+    assert torch.equal(c16.from_c16(img, 0.25), (ref * 0.25).half().float() / 0.25)
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,groups", [(2, 64, 16, 64, 128, 1), (1, 64, 13, 36, 128, 2), (3, 128, 20, 132, 64, 1)])
+def test_forward_conv_writes_the_image_of_its_output(B, Cin, H, W, Cout, groups):
+    from ebfi_amd import c16, f16scale
+    torch.manual_seed(1)
+    w, b, bank, book, site = _banked(Cin, Cout, groups)
+    i = book.slot("out")
+    book.slots[f16scale.SLOT_STRIDE * i] = 2.0
+    x = torch.randn(B, groups * Cin, H, W).cuda()
+    out = torch.empty(B, Cout, H, W, device="cuda")
+    img = c16.empty(B, Cout, H, W, "cuda").fill_(7.0)
+    plain = torch.empty_like(out)
+    lib = N.lib()
+    st = N.stream_ptr(x.device)
+    args = (N.ptr(x), site.fwd_ptr(), site.fwd_bytes, N.ptr(site.bias()))
+    geo = (B, Cin, H, W, Cout, 3, 1, groups, 1, 0.01, N.ptr(None), N.ptr(None), 0, 0.0)
+    N.check(lib.ebfi_conv2d_packed_x3(*args, N.ptr(plain), *geo, st), "x3")
+    N.check(lib.ebfi_conv2d_packed_x3_c16(*args, N.ptr(out), *geo, N.ptr(img), book.ptr(i), st), "x3_c16")
+    assert torch.equal(out, plain)                               # the fp32 output is unchanged by the side image
+    assert torch.equal(img, _ref_image(out, 2.0))
+    assert book.amax(i) == out.abs().max().item()
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,groups,extras", [
+    (2, 64, 16, 64, 128, 1, False), (1, 64, 13, 36, 128, 2, True), (2, 128, 24, 68, 64, 1, True), (3, 64, 342, 160, 64, 1, False)])
+def test_data_gradient_reads_and_writes_images(B, Cin, H, W, Cout, groups, extras):
+    """ebfi_conv2d_packed_f16_c16 (the data gradient as a convolution with the transposed fp16 images): fp16-image input vs
+    fp32 input bit for bit; fp16-image output == fp16(fp32 output * scale); a NULL fp32 output writes only the image."""
+    from ebfi_amd import c16, f16scale
+    torch.manual_seed(2)
+    # `site` as the TRANSPOSED images of a layer Cout <- Cin: the data gradient maps Cout-channel gradients to Cin channels
+    w, b, bank, book, site = _banked(Cout // groups if groups > 1 else Cout, Cin * groups if groups > 1 else Cin, groups)
+    # (the registered layer maps (groups * site.K) -> site.M; its data gradient reads site.M channels and writes groups * site.K)
+    gch, och = site.M, site.K * groups
+    g = torch.randn(B, gch, H, W).cuda() * 3e-3
+    si, so = book.slot("g"), book.slot("o")
+    book.calibrate(si, g)
+    book.slots[f16scale.SLOT_STRIDE * so] = 64.0
+    g16 = c16.to_c16(g, book.ptr(si))
+    addend = torch.randn(B, och, H, W).cuda() * 1e-3 if extras else None
+    mask = torch.randn(B, och, H, W).cuda() if extras else None
+    lib, st = N.lib(), N.stream_ptr(g.device)
+
+    def run(inp, is16, out, out16):
+        rc = lib.ebfi_conv2d_packed_f16_c16(N.ptr(inp), is16, site.tr16_ptr(), site.tr16_bytes, N.ptr(None), N.ptr(out), B,
+                                            gch // groups, H, W, och, 3, 1, groups, 0, 0.0, N.ptr(addend), N.ptr(mask),
+                                            1 if extras else 0, 0.01 if extras else 0.0, book.ptr(si), site.w_slot_ptr(),
+                                            N.ptr(out16), book.ptr(so) if out16 is not None else N.ptr(None), st)
+        N.check(rc, "ebfi_conv2d_packed_f16_c16")
+    ref32 = torch.empty(B, och, H, W, device="cuda")
+    run(g, 0, ref32, None)
+    a32 = torch.empty_like(ref32)
+    run(g16, 1, a32, None)
+    assert torch.equal(a32, ref32)
+    b32, b16 = torch.empty_like(ref32), c16.empty(B, och, H, W, "cuda")
+    run(g16, 1, b32, b16)
+    assert torch.equal(b32, ref32) and torch.equal(b16, _ref_image(ref32, 64.0))
+    only16 = c16.empty(B, och, H, W, "cuda")
+    run(g16, 1, None, only16)
+    assert torch.equal(only16, b16)
+    assert book.amax(so) == ref32.abs().max().item()
+    # against fp32 math (loose: fp16 operands)
+    wt = w.detach()
+    ref = torch.nn.functional.conv_transpose2d(g.cpu(), wt.cpu(), None, 1, 1, groups=groups) if True else None
+    if extras:
+        ref = (ref + addend.cpu()) * torch.where(mask.cpu() > 0, 1.0, 0.01)
+    assert ((ref32.cpu() - ref).abs().max() / ref.abs().max()).item() < 2e-3
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,groups", [(2, 64, 16, 64, 64, 1), (1, 64, 13, 36, 128, 2), (2, 128, 20, 68, 200 // 8 * 8, 1),
+                                                   (2, 48, 16, 32, 32, 1), (3, 64, 342, 160, 64, 1)])
+def test_weight_gradient_from_images(B, Cin, H, W, Cout, groups):
+    """ebfi_conv2d_backward_weight_f16c vs ebfi_conv2d_backward_weight_f16g on the same tensors: the same fp16 operands in the
+    same order -> grad_weight bit for bit; grad_bias from the fp16-rounded gradient (1e-3)."""
+    from ebfi_amd import c16, f16scale
+    torch.manual_seed(3)
+    Cout = (Cout + 15) // 16 * 16
+    x = torch.randn(B, groups * Cin, H, W).cuda() * 0.3
+    g = torch.randn(B, Cout, H, W).cuda() * 2e-2
+    book = f16scale.ScaleBook("cuda")
+    sx, sg = book.slot("x"), book.slot("g")
+    book.calibrate(sx, x)
+    book.calibrate(sg, g)
+    lib, st = N.lib(), N.stream_ptr(x.device)
+    need = int(lib.ebfi_conv2d_backward_weight_workspace(B, Cin, H, W, Cout, 3, 1, 1, N.EBFI_F32))
+    ws = torch.empty(max(need, 4), dtype=torch.uint8, device="cuda")
+    gw_a, gb_a = torch.empty(Cout, Cin, 3, 3, device="cuda"), torch.empty(Cout, device="cuda")
+    rc = lib.ebfi_conv2d_backward_weight_f16g(N.ptr(x), N.ptr(g), N.ptr(None), N.ptr(gw_a), N.ptr(gb_a), N.ptr(None), B, Cin, H, W, Cout,
+                                              3, 1, groups, 0, 0.0, book.ptr(sx), book.ptr(sg), N.ptr(ws), need, st)
+    N.check(rc, "f16g")
+    x16, g16 = c16.to_c16(x, book.ptr(sx)), c16.to_c16(g, book.ptr(sg))
+    gw_b, gb_b = torch.empty_like(gw_a), torch.empty_like(gb_a)
+    rc = lib.ebfi_conv2d_backward_weight_f16c(N.ptr(x16), N.ptr(g16), N.ptr(gw_b), N.ptr(gb_b), B, Cin, H, W, Cout, groups,
+                                              book.ptr(sx), book.ptr(sg), N.ptr(ws), need, st)
+    N.check(rc, "f16c")
+    assert torch.equal(gw_a, gw_b)
+    assert ((gb_a - gb_b).abs().max() / gb_a.abs().max()).item() < 1e-3
+    ref_b = g.sum((0, 2, 3))
+    assert ((gb_b - ref_b).abs().max() / ref_b.abs().max()).item() < 1e-3
+
+
+def test_fused_residual_control_stages_write_images():
+    from ebfi_amd import c16, f16scale
+    torch.manual_seed(4)
+    B, C, H, W = 2, 64, 16, 32
+    HW = H * W
+    a = torch.randn(B, 2 * C, H, W).cuda()
+    s0, s1 = torch.randn(B, C).cuda(), torch.randn(B, C).cuda()
+    x = torch.randn(B, C, H, W).cuda()
+    book = f16scale.ScaleBook("cuda")
+    so, sg = book.slot("c"), book.slot("ga")
+    book.slots[f16scale.SLOT_STRIDE * so] = 4.0
+    book.slots[f16scale.SLOT_STRIDE * sg] = 512.0
+    lib, st = N.lib(), N.stream_ptr(a.device)
+    a1p = N._vp(a.data_ptr() + 4 * C * HW)
+    out, out16 = torch.empty(B, 2 * C, H, W, device="cuda"), c16.empty(B, 2 * C, H, W, "cuda")
+    N.check(lib.ebfi_scale_residual_cat_forward_c16(N.ptr(a), N.ptr(s0), a1p, N.ptr(s1), N.ptr(x), N.ptr(out), N.ptr(out16), book.ptr(so),
+                                                    B, C, HW, 2 * C * HW, st), "fwd_c16")
+    ref = torch.empty_like(out)
+    N.check(lib.ebfi_scale_residual_cat_forward_ex(N.ptr(a), N.ptr(s0), a1p, N.ptr(s1), N.ptr(x), N.ptr(ref), B, C, HW, 2 * C * HW, st), "fwd")
+    assert torch.equal(out, ref) and torch.equal(out16, _ref_image(ref, 4.0)) and book.amax(so) == ref.abs().max().item()
+    # backward
+    gc = torch.randn(B, 2 * C, H, W).cuda() * 1e-2
+    ga = torch.empty(B, 2 * C, H, W, device="cuda")
+    gx, gs0, gs1 = torch.empty(B, C, H, W, device="cuda"), torch.empty(B, C, device="cuda"), torch.empty(B, C, device="cuda")
+    N.check(lib.ebfi_scale_residual_cat_backward_ex(N.ptr(gc), N.ptr(a), N.ptr(s0), a1p, N.ptr(s1), N.ptr(ga), N._vp(ga.data_ptr() + 4 * C * HW),
+                                                    N.ptr(gx), N.ptr(gs0), N.ptr(gs1), B, C, HW, 2 * C * HW, 2 * C * HW, 1, 0.01, st), "bwd")
+    S = int(lib.ebfi_scale_residual_cat_backward_slices())
+    ga16 = c16.empty(B, 2 * C, H, W, "cuda")
+    gx2, p0, p1 = torch.empty_like(gx), torch.empty(S, B, C, device="cuda"), torch.empty(S, B, C, device="cuda")
+    N.check(lib.ebfi_scale_residual_cat_backward_c16(N.ptr(gc), N.ptr(a), N.ptr(s0), a1p, N.ptr(s1), N.ptr(ga16), book.ptr(sg), N.ptr(gx2),
+                                                     N.ptr(p0), N.ptr(p1), B, C, HW, 2 * C * HW, 0.01, st), "bwd_c16")
+    assert torch.equal(gx2, gx) and torch.equal(ga16, _ref_image(ga, 512.0)) and book.amax(sg) == ga.abs().max().item()
+    assert torch.allclose(p0.sum(0), gs0, rtol=1e-5, atol=1e-7) and torch.allclose(p1.sum(0), gs1, rtol=1e-5, atol=1e-7)
