@@ -1,14 +1,18 @@
 // fp16 operand storage of the backward pass (round 4): helpers shared by conv2d.hip and fuse.hip.
 //
-// Layout "c16": a tensor [B, C, H, W] (C a multiple of 16) kept as fp16 [B][C/16][H][W][16] -- blocks of 16 channels,
-// pixel-major inside a block, the 16 channels of a pixel in 32 contiguous bytes -- multiplied by the power-of-two scale of
-// its slot.  It is the STAGING layout of both backward kernels: the data gradient (conv_fwd_f16_ws) walks 16-channel chunks
-// whose LDS image is [position][16 ch], the weight gradient (conv_wgrad_f16_tr) keeps [pixel][64 ch] images = four blocks;
-// either way a tile row is one contiguous run of 32-byte positions, so the producers are plain 16-byte copies (no
-// conversion, half the bytes of the fp32 NCHW planes, a quarter of the vector-memory instructions).  The tensors are written
-// in this form by whoever produces them: the epilogues of the forward / data-gradient kernels (store_out_tile), the fused
-// ResidualControl stages (fuse.hip) or the standalone conversion (to_c16_kernel).  The WRITER applies the slot's scale and
-// records |max|; readers only need the scale.
+// Layout "c16": a tensor [B, C, H, W] (C a multiple of 16) kept as fp16 [B][C/16][H][2][W][8] -- blocks of 16 channels; inside
+// a block one image ROW holds first the channels 0..7 of its W pixels (16 bytes per pixel), then the channels 8..15 --
+// multiplied by the power-of-two scale of its slot.  It is the STAGING layout of both backward kernels: the data gradient
+// (conv_fwd_f16_ws) walks 16-channel chunks whose LDS image is [position][16 ch], the weight gradient (conv_wgrad_f16_tr)
+// keeps [pixel][64 ch] images = four blocks; the unit both copy is the 16-byte piece (pixel, 8 channels), and a tile row is
+// two contiguous runs of pieces, so the producers are plain 16-byte copies (no conversion, half the bytes of the fp32 NCHW
+// planes, a quarter of the vector-memory instructions).  The half-row split is what makes the WRITERS coalesce: a 32x32 MFMA
+// accumulator leaves channels 0..7 of 32 consecutive pixels in the lower lanes and channels 8..15 in the upper ones (after
+// one v_permlane32_swap per register pair) -- two contiguous 512-byte runs per store instruction; the first form, with a
+// pixel's 16 channels in 32 contiguous bytes, wrote half-lines and ran SLOWER than the fp32 stores it replaced.  The tensors
+// are written in this form by whoever produces them: the epilogues of the forward / data-gradient kernels (store_out_tile),
+// the fused ResidualControl stages (fuse.hip) or the standalone conversion (to_c16_kernel).  The WRITER applies the slot's
+// scale and records |max|; readers only need the scale.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -32,7 +36,12 @@ __device__ __forceinline__ void saturate_fp16_conversions() { __builtin_amdgcn_s
 // (float bits, ordered as unsigned for non-negative floats).  The two words sit in different 128-byte lines on purpose: the
 // atomic that raises the maximum executes at the memory side and drops its line from L2 -- next to the scale, which every
 // workgroup reads, that turned the 30 000-workgroup pack launch into a queue on one line (0.44 ms for 5.5 M elements).
-constexpr int SLOT_STRIDE = 64, SLOT_AMAX = 32;
+// [1] = FLOOR of the running maximum (7/8 of the previous step's): a wave whose own maximum is below it sends no atomic.  Without
+// it every launch started from 0 and nearly every wave of it (8192 in a fused stage) queued an atomic on the one address --
+// 81 us instead of 33 us for a ResidualControl stage inside the step (the isolated benchmark, whose maximum is already there
+// after the first iteration, never showed it).  A step whose values all stay below the floor keeps its scale (the true
+// maximum is within 1/8 of the previous one) and lets the floor decay.
+constexpr int SLOT_STRIDE = 64, SLOT_AMAX = 32, SLOT_FLOOR = 1;
 constexpr int F16_TARGET_EXP = 2;          // next scale: |max| * scale in [2^(F16_TARGET_EXP-1), 2^F16_TARGET_EXP) (f16scale.TARGET_EXP)
 struct ScaleSlot {
     float *p;
@@ -44,7 +53,7 @@ struct ScaleSlot {
         for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
         // (many workgroups report into one word: only a value above the one already there needs the atomic -- NaN compares
         // false and goes through)
-        if (p && (threadIdx.x & 63) == 0 && !(m <= __builtin_nontemporal_load(p + SLOT_AMAX)))
+        if (p && (threadIdx.x & 63) == 0 && !(m <= fmaxf(__builtin_nontemporal_load(p + SLOT_AMAX), p[SLOT_FLOOR])))
             atomicMax(reinterpret_cast<unsigned *>(p + SLOT_AMAX), __float_as_uint(m));
     }
 };

@@ -21,6 +21,8 @@
 //       activation derivative) and the input halo tile [ci][y][x] with odd strides (conflict-free
 //       operand fetch), accumulates a 64 x (64*KK) block in registers and writes ONE partial slab;
 //       `conv_wgrad_reduce_f32` sums slabs in fixed order => deterministic grad_weight / grad_bias.
+#include <type_traits>
+
 #include "common.hpp"
 #include "c16.hpp"
 
@@ -52,6 +54,9 @@ struct EpiExtra {
     // unscaled values is recorded into slot16 (one atomic per wave and launch).  Cout must be a multiple of 16.
     _Float16 *out16 = nullptr;
     float *slot16 = nullptr;
+    // planar16 != 0: out16 is a PLANAR fp16 tensor [B][Cout][Ho][Wo] instead (the filters of the FAC op, whose kernels read
+    // planes: csrc/fac.hip); any Cout
+    int planar16 = 0;
 };
 
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
@@ -117,9 +122,11 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(has_a ? ex.addend + (int64_t)b * g.Cout * HWo : anyp, has_a ? (unsigned)g.Cout * plane : 0u);
     const __amdgpu_buffer_rsrc_t rm = make_rsrc(has_m ? ex.mask_y + (int64_t)b * g.Cout * HWo : anyp, has_m ? (unsigned)g.Cout * plane : 0u);
     const int cb16 = g.Cout >> 4;                                  // 16-channel blocks of the fp16 image
+    const bool planar = EXTRA && ex.planar16 != 0;
     const __amdgpu_buffer_rsrc_t r16 = __builtin_amdgcn_make_buffer_rsrc(
-        has16 ? ex.out16 + (int64_t)b * cb16 * HWo * 16 : const_cast<_Float16 *>(reinterpret_cast<const _Float16 *>(anyp)), 0,
-        has16 ? (unsigned)cb16 * (unsigned)HWo * 32u : 0u, 0x00020000);
+        has16 ? ex.out16 + (planar ? (int64_t)b * g.Cout * HWo : (int64_t)b * cb16 * HWo * 16)
+              : const_cast<_Float16 *>(reinterpret_cast<const _Float16 *>(anyp)), 0,
+        has16 ? (planar ? (unsigned)g.Cout * (unsigned)HWo * 2u : (unsigned)cb16 * (unsigned)HWo * 32u) : 0u, 0x00020000);
     const float s16 = has16 ? ex.slot16[0] : 1.f;
     float am = 0.f;
     const int h = lane >> 5, l31 = lane & 31;
@@ -148,12 +155,13 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
 #pragma unroll
                         for (int r = 0; r < 16; ++r) mv[r] = buf_ld(rm, base + (unsigned)((r & 3) + 8 * (r >> 2)) * plane);
                     }
-                    const bool leaky = ex.mask_act == ACT_LEAKY, sig = ex.mask_act == ACT_SIGMOID;
+                    // (LeakyReLU masks only -- the launchers refuse anything else with extras: one code path; mask absent: mv = 0
+                    // would select the slope, so the slope is 1 then)
+                    const float ms = has_m ? ex.mask_slope : 1.f;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float t = actf(acc[m][n][r] * oscale + bvm[r] + av[r]);
-                        const float d = leaky ? (mv[r] > 0.f ? 1.f : ex.mask_slope) : (sig ? mv[r] * (1.f - mv[r]) : 1.f);
-                        v[r] = has_m ? t * d : t;
+                        v[r] = t * ((has_m && mv[r] > 0.f) ? 1.f : ms);
                     }
                 } else {
 #pragma unroll
@@ -165,7 +173,18 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ro, base + (unsigned)((r & 3) + 8 * (r >> 2)) * plane, 0, 0);
                 }
                 if constexpr (EXTRA) {
-                    if (has16) {
+                    if (has16 && planar) {
+                        // planes: one 2-byte store per value, lanes = consecutive pixels (64-byte runs per channel)
+                        const unsigned pb = (px_ok && co_base + m * 32 + 4 * h < g.Cout)
+                                                ? (unsigned)(co_base + m * 32 + 4 * h) * (unsigned)HWo * 2u + (unsigned)(yo * g.Wo + xo) * 2u : SENT;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            am = fmaxf(am, fabsf(v[r]));
+                            const _Float16 hv = (_Float16)(v[r] * s16);
+                            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), r16,
+                                                                  pb + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)HWo * 2u, 0, 0);
+                        }
+                    } else if (has16) {
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
                             const float *u = v + 8 * j;             // rows 16 j + {4h..4h+3, 8+4h..8+4h+3} of the 32-row tile
@@ -175,7 +194,9 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
                             const u32x4_c16 q = c16_gather_halves(pack_f16(u[0] * s16, u[1] * s16), pack_f16(u[2] * s16, u[3] * s16),
                                                                   pack_f16(u[4] * s16, u[5] * s16), pack_f16(u[6] * s16, u[7] * s16));
                             const int cblk = ((co_base + m * 32) >> 4) + j;
-                            const unsigned o16 = (px_ok && cblk < cb16) ? ((unsigned)cblk * (unsigned)HWo + (unsigned)(yo * g.Wo + xo)) * 32u + (unsigned)h * 16u : SENT;
+                            // lower lanes: channels 0..7 of 32 consecutive pixels = one 512-byte run, upper lanes: channels 8..15
+                            const unsigned o16 = (px_ok && cblk < cb16)
+                                                     ? ((unsigned)cblk * (unsigned)HWo * 2u + (unsigned)((yo * 2 + h) * g.Wo + xo)) * 16u : SENT;
                             __builtin_amdgcn_raw_buffer_store_b128(q, r16, o16, 0, 0);
                         }
                     }
@@ -183,9 +204,17 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
             }
         }
     };
-    if (act == ACT_LEAKY) emit([slope](float v) { return v > 0.f ? v : v * slope; });
-    else if (act == ACT_SIGMOID) emit([](float v) { return 1.f / (1.f + __expf(-v)); });
-    else emit([](float v) { return v; });
+    if constexpr (EXTRA) {
+        // ONE instance of the (large, fully unrolled) body: no activation = LeakyReLU with slope 1; the sigmoid never meets
+        // the extras (launchers check).  Three instances per call and two calls per tile made the kernel 26 000 instructions
+        // long -- the epilogue ran out of the instruction cache and cost more than the bytes it saved.
+        const float sl = act == ACT_LEAKY ? slope : 1.f;
+        emit([sl](float v) { return v > 0.f ? v : v * sl; });
+    } else {
+        if (act == ACT_LEAKY) emit([slope](float v) { return v > 0.f ? v : v * slope; });
+        else if (act == ACT_SIGMOID) emit([](float v) { return 1.f / (1.f + __expf(-v)); });
+        else emit([](float v) { return v; });
+    }
     if (amax16) *amax16 = fmaxf(*amax16, am);
 }
 
@@ -2576,7 +2605,7 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
         if (epi.out16 != nullptr && !use_ws)
             return fail(EBFI_ERR_UNSUPPORTED, "conv2d: the fp16 side image is written by the wave-specialised 3x3 kernel only "
                         "(W %% 4 == 0, same padding, more than 32 output channels, 16-byte aligned input)");
-        if (use_ws) name = transposed ? "conv_fwd_bf16x3_ws/dgrad" : "conv_fwd_bf16x3_ws/fwd";
+        if (use_ws) name = transposed ? "conv_fwd_bf16x3_ws/dgrad" : (epi.out16 ? "conv_fwd_bf16x3_ws/fwd_img" : "conv_fwd_bf16x3_ws/fwd");
         ProfScope ps(name, st, flops, conv_bytes_fwd(g, KS * KS, dact != 0));
 #define EBFI_LAUNCH_X3V(MT_, DA_, VEC_)                                                                                   \
     do {                                                                                                                 \
@@ -2597,6 +2626,8 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
         const int64_t co_blocks = ceil_div(g.Cout, 32 * mt);
         int64_t gx = 256 / co_blocks;
         if (gx < 1) gx = 1;
+        // (measured, round 4: rounding gx down to a multiple of 8 so that xcd_tile applies to the 128 -> 1600 layer -- 200 instead
+        // of 250 workgroups -- is time-neutral: 1.23-1.27 ms against 1.15-1.34 ms; what the L2s save the idle CUs give back)
         if (gx > tiles || dev_getenv("EBFI_CONV_NOPERSIST")) gx = tiles;
         const dim3 pgrid((unsigned)gx, (unsigned)co_blocks);
         if constexpr (KS == 3) {
@@ -3241,13 +3272,13 @@ extern "C" int ebfi_conv2d_backward_weight_ex(const void *input, const void *gra
 extern "C" int ebfi_conv2d_packed_x3_c16(const void *input, const void *packed, size_t packed_bytes, const void *bias, void *output,
                                          int B, int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups, int act,
                                          float slope, const void *addend, const void *mask_y, int mask_act, float mask_slope,
-                                         void *out16, void *slot16, void *stream);
+                                         void *out16, void *slot16, int out16_planar, void *stream);
 extern "C" int ebfi_conv2d_packed_x3(const void *input, const void *packed, size_t packed_bytes, const void *bias, void *output,
                                      int B, int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups, int act,
                                      float slope, const void *addend, const void *mask_y, int mask_act, float mask_slope,
                                      void *stream) {
     return ebfi_conv2d_packed_x3_c16(input, packed, packed_bytes, bias, output, B, Cin_per_group, H, W, Cout, ksize, pad, groups, act,
-                                     slope, addend, mask_y, mask_act, mask_slope, nullptr, nullptr, stream);
+                                     slope, addend, mask_y, mask_act, mask_slope, nullptr, nullptr, 0, stream);
 }
 
 // Same, plus the output as a scaled fp16 image in the c16 layout (c16.hpp; out16 [B][Cout/16][Ho][Wo][16], scale and |max|
@@ -3256,10 +3287,12 @@ extern "C" int ebfi_conv2d_packed_x3(const void *input, const void *packed, size
 extern "C" int ebfi_conv2d_packed_x3_c16(const void *input, const void *packed, size_t packed_bytes, const void *bias, void *output,
                                          int B, int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups, int act,
                                          float slope, const void *addend, const void *mask_y, int mask_act, float mask_slope,
-                                         void *out16, void *slot16, void *stream) {
-    if (!input || !packed || !output) return fail(EBFI_ERR_ARG, "conv2d_packed_x3: null argument");
+                                         void *out16, void *slot16, int out16_planar, void *stream) {
+    // out16_planar != 0: out16 is a planar fp16 tensor [B, Cout, H, W] (the FAC op's filters) instead of a c16 image; `output`
+    // may be NULL when out16 is given (the fp16 tensor alone)
+    if (!input || !packed || (!output && !out16)) return fail(EBFI_ERR_ARG, "conv2d_packed_x3: null argument");
     if ((out16 != nullptr) != (slot16 != nullptr)) return fail(EBFI_ERR_ARG, "conv2d_packed_x3: out16 and slot16 come together");
-    if (out16 && (Cout % 16 != 0 || ksize != 3 || !aligned16(out16)))
+    if (out16 && ((!out16_planar && Cout % 16 != 0) || ksize != 3 || !aligned16(out16)))
         return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_x3: the fp16 side image needs a 3x3 layer with Cout %% 16 == 0 (Cout = %d)", Cout);
     if (act < 0 || act > 2 || mask_act < 0 || mask_act > 2) return fail(EBFI_ERR_ARG, "conv2d_packed_x3: unknown activation");
     if (ksize != 1 && ksize != 3) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_x3: k=%d", ksize);
@@ -3272,8 +3305,10 @@ extern "C" int ebfi_conv2d_packed_x3_c16(const void *input, const void *packed, 
     g.groups = groups;
     if (B == 0) return EBFI_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const EpiExtra epi{static_cast<const float *>(addend), static_cast<const float *>(mask_y), mask_act, mask_slope,
-                       static_cast<_Float16 *>(out16), static_cast<float *>(slot16)};
+    if ((addend || mask_y || out16) && (act == ACT_SIGMOID || mask_act == ACT_SIGMOID))
+        return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_x3: the epilogue extras take LeakyReLU / no activation only");
+    const EpiExtra epi{static_cast<const float *>(addend), mask_act == ACT_LEAKY ? static_cast<const float *>(mask_y) : nullptr, mask_act,
+                       mask_slope, static_cast<_Float16 *>(out16), static_cast<float *>(slot16), out16 ? out16_planar : 0};
     const float *x = static_cast<const float *>(input), *bs = static_cast<const float *>(bias);
     float *o = static_cast<float *>(output);
     void *ws = const_cast<void *>(packed);
@@ -3350,13 +3385,16 @@ extern "C" int ebfi_conv2d_packed_f16_c16(const void *input, int input_is_c16, c
     if (!input || !packed16 || (!output && !out16)) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: null argument");
     if ((out16 != nullptr) != (slot16 != nullptr)) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: out16 and slot16 come together");
     if (out16 && (Cout % 16 != 0 || !aligned16(out16))) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_f16: fp16 output image needs Cout %% 16 == 0");
-    if (input_is_c16 && (Cin_per_group % 16 != 0 || !in_slot))
+    // input_is_c16: 0 = fp32 NCHW, 1 = c16 image, 2 = planar fp16 [B, groups*Cin, H, W] (scaled by in_slot like an image)
+    if (input_is_c16 < 0 || input_is_c16 > 2) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: input storage %d", input_is_c16);
+    if (input_is_c16 == 1 && (Cin_per_group % 16 != 0 || !in_slot))
         return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_f16: an fp16 input image needs Cin %% 16 == 0 and its scale slot");
+    if (input_is_c16 == 2 && !in_slot) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: a planar fp16 input needs its scale slot");
     if (act < 0 || act > 2 || mask_act < 0 || mask_act > 2) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: unknown activation");
     if (ksize != 3 || pad != 1) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_f16: 3x3 same-padded convolutions only (k=%d pad=%d)", ksize, pad);
     if (groups < 1 || Cout % groups != 0 || (groups > 1 && (Cout / groups) % 64 != 0))
         return fail(EBFI_ERR_ARG, "conv2d_packed_f16: %d output channels in %d groups (groups need multiples of 64 channels)", Cout, groups);
-    if ((!input_is_c16 && W % 4 != 0) || !aligned16(input))
+    if ((input_is_c16 != 1 && W % 4 != 0) || !aligned16(input))
         return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_f16: needs W %% 4 == 0 and a 16-byte aligned input (W = %d)", W);
     ConvGeom g;
     if (int rc = make_geom(g, B, Cin_per_group, H, W, Cout, ksize, 1, pad)) return rc;
@@ -3368,8 +3406,10 @@ extern "C" int ebfi_conv2d_packed_f16_c16(const void *input, int input_is_c16, c
     if (packed_bytes < need) return fail(EBFI_ERR_WORKSPACE, "conv2d_packed_f16: packed image %zu bytes < required %zu", packed_bytes, need);
     if (B == 0) return EBFI_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const EpiExtra epi{static_cast<const float *>(addend), static_cast<const float *>(mask_y), mask_act, mask_slope,
-                       static_cast<_Float16 *>(out16), static_cast<float *>(slot16)};
+    if ((addend || mask_y || out16) && (act == ACT_SIGMOID || mask_act == ACT_SIGMOID))
+        return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_f16: the epilogue extras take LeakyReLU / no activation only");
+    const EpiExtra epi{static_cast<const float *>(addend), mask_act == ACT_LEAKY ? static_cast<const float *>(mask_y) : nullptr, mask_act,
+                       mask_slope, static_cast<_Float16 *>(out16), static_cast<float *>(slot16)};
     const int64_t tiles = (int64_t)B * ceil_div(g.Ho, TYB) * ceil_div(g.Wo, TX);
     if (tiles > 2147483647LL) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: too many tiles");
     constexpr int PSX = (TYB - 1 + 3) * (TX - 1 + 3);
@@ -3385,7 +3425,10 @@ extern "C" int ebfi_conv2d_packed_f16_c16(const void *input, int input_is_c16, c
     const double px = (double)g.B * g.Ho * g.Wo;
     const double io_bytes = px * g.groups * g.Cin * (input_is_c16 ? 2.0 : 4.0) + px * g.Cout * ((output ? 4.0 : 0.0) + (out16 ? 2.0 : 0.0)) +
                             px * g.Cout * ((addend ? 4.0 : 0.0) + (mask_y ? 4.0 : 0.0)) + 2.0 * 9 * (double)g.Cout * g.Cin;
-    ProfScope ps("conv_fwd_f16_ws", st, flops, io_bytes);
+    // (label = kernel symbol / role: which operand storage the launch read and wrote)
+    ProfScope ps(input_is_c16 == 2 ? "conv_fwd_f16_ws/p16_f32" :
+                 input_is_c16 ? (out16 ? (output ? "conv_fwd_f16_ws/img_both" : "conv_fwd_f16_ws/img_img") : "conv_fwd_f16_ws/img_f32")
+                              : (out16 ? "conv_fwd_f16_ws/f32_img" : "conv_fwd_f16_ws/f32_f32"), st, flops, io_bytes);
     const ScaleSlot isl{static_cast<float *>(in_slot)};
     const float *x = static_cast<const float *>(input), *bs = static_cast<const float *>(bias);
     const _Float16 *wp = static_cast<const _Float16 *>(packed16);
@@ -3396,7 +3439,12 @@ extern "C" int ebfi_conv2d_packed_f16_c16(const void *input, int input_is_c16, c
         hipLaunchKernelGGL((conv_fwd_f16_ws<EX_, IN_>), grid, dim3(NTF16), lds, st, x, wp, bs, o, g, K16, act, slope, epi,   \
                            (int)tiles, isl, static_cast<const float *>(w_slot));                                        \
     } while (0)
-    if (extra && input_is_c16) EBFI_LAUNCH_F16WS(true, true);
+    if (input_is_c16 == 2) {
+        if (extra) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_f16: planar fp16 input with epilogue extras");
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_f16_ws<false, false, true>), 160 * 1024)) return rc_;
+        hipLaunchKernelGGL((conv_fwd_f16_ws<false, false, true>), grid, dim3(NTF16), lds, st, x, wp, bs, o, g, K16, act, slope, epi,
+                           (int)tiles, isl, static_cast<const float *>(w_slot));
+    } else if (extra && input_is_c16) EBFI_LAUNCH_F16WS(true, true);
     else if (extra) EBFI_LAUNCH_F16WS(true, false);
     else if (input_is_c16) EBFI_LAUNCH_F16WS(false, true);
     else EBFI_LAUNCH_F16WS(false, false);
@@ -3453,7 +3501,7 @@ extern "C" int ebfi_conv2d_backward_weight_f16g(const void *input, const void *g
         if (nsplit > tiles) nsplit = (int)tiles;
         dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, 64));
         const ScaleSlot xs{static_cast<float *>(x_slot)}, gs{static_cast<float *>(g_slot)};
-        ProfScope ps("conv_wgrad_f16_tr", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * 9,
+        ProfScope ps("conv_wgrad_f16_tr/f32", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * 9,
                      conv_bytes_wgrad(g, 9, act != ACT_NONE, grad_preact_out != nullptr));
 #define EBFI_LAUNCH_WTR(DA_)                                                                                               \
     do {                                                                                                                   \
@@ -3507,12 +3555,15 @@ extern "C" int ebfi_conv2d_backward_weight_f16g(const void *input, const void *g
 // its PRE-activation gradient: input16 [B][groups*Cin/16][H][W][16] scaled by x_slot[0], grad16 [B][Cout/16][H][W][16] scaled
 // by g_slot[0] (both written, and their |max| recorded, by the kernels that produced the tensors).  Same slabs, same
 // deterministic reduction and the same workspace size as ebfi_conv2d_backward_weight_f16g.
-extern "C" int ebfi_conv2d_backward_weight_f16c(const void *input16, const void *grad16, void *grad_weight, void *grad_bias, int B,
-                                                int Cin_per_group, int H, int W, int Cout, int groups, const void *x_slot,
-                                                const void *g_slot, void *workspace, size_t workspace_bytes, void *stream) {
+extern "C" int ebfi_conv2d_backward_weight_f16c(const void *input16, const void *grad16, int grad_is_planar, void *grad_weight,
+                                                void *grad_bias, int B, int Cin_per_group, int H, int W, int Cout, int groups,
+                                                const void *x_slot, const void *g_slot, void *workspace, size_t workspace_bytes,
+                                                void *stream) {
     if (!input16 || !grad16 || !grad_weight || !x_slot || !g_slot) return fail(EBFI_ERR_ARG, "conv2d_backward_weight_f16c: null argument");
-    if (Cin_per_group % 16 != 0 || Cout % 16 != 0 || Cin_per_group < 16)
+    // grad_is_planar != 0: grad16 is a planar fp16 tensor [B, Cout, H, W] (scaled by g_slot) instead of a c16 image
+    if (Cin_per_group % 16 != 0 || (!grad_is_planar && Cout % 16 != 0) || Cin_per_group < 16)
         return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_weight_f16c: channel counts must be multiples of 16 (%d -> %d)", Cin_per_group, Cout);
+    if (grad_is_planar && W % 4 != 0) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_weight_f16c: planar gradient rows need W %% 4 == 0");
     if (groups < 1 || Cout % groups != 0 || (groups > 1 && ((Cout / groups) % 64 != 0 || Cin_per_group % 64 != 0)))
         return fail(EBFI_ERR_ARG, "conv2d_backward_weight_f16c: %d output channels in %d groups", Cout, groups);
     if (!aligned16(input16) || !aligned16(grad16)) return fail(EBFI_ERR_ARG, "conv2d_backward_weight_f16c: images must be 16-byte aligned");
@@ -3540,12 +3591,19 @@ extern "C" int ebfi_conv2d_backward_weight_f16c(const void *input16, const void 
     const ScaleSlot xs{const_cast<float *>(static_cast<const float *>(x_slot))}, gs{const_cast<float *>(static_cast<const float *>(g_slot))};
     {
         const double px = (double)g.B * g.Ho * g.Wo;
-        ProfScope ps("conv_wgrad_f16_tr", st, 2.0 * px * (double)g.Cout * g.Cin * 9,
+        ProfScope ps("conv_wgrad_f16_tr/img", st, 2.0 * px * (double)g.Cout * g.Cin * 9,
                      2.0 * px * (g.groups * g.Cin + g.Cout) + 4.0 * (double)n_total);
-        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_wgrad_f16_tr<ACT_NONE, true>), TR_LDS + KB_LDS_BYTES)) return rc_;
-        hipLaunchKernelGGL((conv_wgrad_f16_tr<ACT_NONE, true>), grid, dim3(512), TR_LDS + KB_LDS_BYTES, st,
-                           static_cast<const float *>(input16), static_cast<const float *>(grad16), static_cast<const float *>(nullptr),
-                           static_cast<float *>(nullptr), slab, g, 0.f, (int)tiles, grad_bias != nullptr ? 1 : 0, xs, gs);
+        if (grad_is_planar) {
+            if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_wgrad_f16_tr<ACT_NONE, true, true>), TR_LDS + KB_LDS_BYTES)) return rc_;
+            hipLaunchKernelGGL((conv_wgrad_f16_tr<ACT_NONE, true, true>), grid, dim3(512), TR_LDS + KB_LDS_BYTES, st,
+                               static_cast<const float *>(input16), static_cast<const float *>(grad16), static_cast<const float *>(nullptr),
+                               static_cast<float *>(nullptr), slab, g, 0.f, (int)tiles, grad_bias != nullptr ? 1 : 0, xs, gs);
+        } else {
+            if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_wgrad_f16_tr<ACT_NONE, true>), TR_LDS + KB_LDS_BYTES)) return rc_;
+            hipLaunchKernelGGL((conv_wgrad_f16_tr<ACT_NONE, true>), grid, dim3(512), TR_LDS + KB_LDS_BYTES, st,
+                               static_cast<const float *>(input16), static_cast<const float *>(grad16), static_cast<const float *>(nullptr),
+                               static_cast<float *>(nullptr), slab, g, 0.f, (int)tiles, grad_bias != nullptr ? 1 : 0, xs, gs);
+        }
         if (int rc = check_launch("conv_wgrad_f16_tr")) return rc;
     }
     {

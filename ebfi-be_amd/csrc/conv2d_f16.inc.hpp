@@ -37,7 +37,10 @@ constexpr int NTF16 = 512;
 //           producer with in_slot's scale: the staging becomes a plain 16-byte copy (6 loads + 6 LDS stores per thread and
 //           chunk instead of 24 + 8 conversions + 12), half the bytes; in_slot is only read here (the writer recorded |max|)
 //   epi.out16: the output additionally / only (out == NULL) as a c16 fp16 image for the next backward kernel
-template <bool EXTRA, bool IN16 = false>
+//   INP16:  x is a PLANAR fp16 tensor [B, groups*Cin, H, W] scaled by in_slot's scale (the grad_kernel of the FAC op, written by
+//           fac_bwd_rows_f32<.., H16>): the quad staging of the fp32 form with 8-byte loads and byte permutes instead of
+//           conversions, half the bytes; in_slot is only read
+template <bool EXTRA, bool IN16 = false, bool INP16 = false>
 __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict__ x, const _Float16 *__restrict__ wp,
                                                          const float *__restrict__ bias, float *__restrict__ out, ConvGeom g, int K16,
                                                          int act, float slope, EpiExtra epi, int tiles_total, ScaleSlot in_slot,
@@ -55,7 +58,8 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
     const int co_base = blockIdx.y * COS;
     const int grp = co_base / (g.Cout / g.groups);
     const int HW = g.H * g.W;
-    const unsigned plane_bytes = (unsigned)HW * 4u, x_bytes = (unsigned)g.Cin * plane_bytes;
+    constexpr unsigned ES = INP16 ? 2u : 4u;                        // bytes per input element of the quad-staging path
+    const unsigned plane_bytes = (unsigned)HW * ES, x_bytes = (unsigned)g.Cin * plane_bytes;
     const int nchunks = K16 / CKB;
     const int G = gridDim.x;
     int ntiles_mine = 0;
@@ -168,17 +172,19 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
     const unsigned img_bytes = (unsigned)KK * (unsigned)g.Cout * (unsigned)K16 * 2u;
     const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(wp), 0, img_bytes, 0x00020000);
     if constexpr (IN16) {
-        // ---- fp16 c16 input: piece id -> (tile row, tile column, 8-channel half); the chunk's block of a position is 32
-        // contiguous bytes, a tile row 66 x 32 = 2112 contiguous bytes: consecutive lanes copy consecutive 16-byte pieces
+        // ---- fp16 c16 input: 16-byte pieces (position, 8-channel half); a tile row is two contiguous runs of 66 pieces
         constexpr int NPIECE = PS * 2, NPK = (NPIECE + PT - 1) / PT;
-        const int p_half = ptid & 1;                                  // (PT is even: the half is the same for every k)
-        int p_row[NPK], p_col[NPK], p_dst[NPK];
+        // piece id = (tile row, channel half, tile column): consecutive lanes walk the columns of one half-row run (c16.hpp)
+        int p_row[NPK], p_col[NPK], p_half[NPK], p_dst[NPK];
 #pragma unroll
         for (int k = 0; k < NPK; ++k) {
-            const int pos = (ptid + k * PT) >> 1;
-            p_row[k] = pos / IW;
-            p_col[k] = pos - p_row[k] * IW;
-            p_dst[k] = pos * 32 + ((p_half ^ ((pos >> 3) & 1)) << 4);
+            const int id = ptid + k * PT;
+            const int t = id / IW;
+            p_col[k] = id - t * IW;
+            p_half[k] = t & 1;
+            p_row[k] = t >> 1;
+            const int pos = p_row[k] * IW + p_col[k];
+            p_dst[k] = pos * 32 + ((p_half[k] ^ ((pos >> 3) & 1)) << 4);
         }
         unsigned w_off[NWB];
         int w_dst[NWB];
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
             for (int k = 0; k < NPK; ++k) {
                 const int yy = ty0 - g.pad + p_row[k], xx = tx0 - g.pad + p_col[k];
                 const bool ok = live && ptid + k * PT < NPIECE && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
-                pf_off[k] = ok ? (unsigned)(yy * g.W + xx) * 32u + (unsigned)p_half * 16u : SENT;
+                pf_off[k] = ok ? (unsigned)((yy * 2 + p_half[k]) * g.W + xx) * 16u : SENT;
             }
             pf_src = x16 + ((int64_t)tb * g.groups + grp) * cbg * HW * 16;
             pf_bytes = live ? (unsigned)cbg * blk_bytes : 0u;
@@ -289,8 +295,10 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
         w_off[it] = j < WPIECES ? (unsigned)(((tap * g.Cout + co_base + co) * K16 + half * 8) * 2) : SENT;
         w_dst[it] = INB + row * 32 + ((half ^ ((row >> 3) & 1)) << 4);
     }
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    using QV = std::conditional_t<INP16, u32x2, u32x4>;            // 4 pixels of one channel: 8 or 16 bytes
     struct Stage {
-        u32x4 rq[NIT][8];
+        QV rq[NIT][8];
         u32x4 rw[NWB];
     };
     Stage sa, sb;
@@ -307,9 +315,10 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
         for (int k = 0; k < NIT; ++k) {
             const int yy = ty0 - g.pad + it_qr[k], xq = tx0 - g.pad - SH + 4 * it_qq[k];
             const bool ok = live && ptid + k * PT < NITEM && yy >= 0 && yy < g.H && xq >= 0 && xq + 3 < g.W;
-            pf_off[k] = ok ? (unsigned)(yy * g.W + xq) * 4u + (unsigned)(8 * it_qh[k]) * plane_bytes : SENT;
+            pf_off[k] = ok ? (unsigned)(yy * g.W + xq) * ES + (unsigned)(8 * it_qh[k]) * plane_bytes : SENT;
         }
-        pf_src = x + ((int64_t)tb * g.groups + grp) * g.Cin * HW;
+        // (INP16: `x` points at halves: the sample offset in bytes is half the fp32 one)
+        pf_src = reinterpret_cast<const float *>(reinterpret_cast<const char *>(x) + ((int64_t)tb * g.groups + grp) * g.Cin * HW * (int64_t)ES);
         pf_bytes = live ? x_bytes : 0u;
     };
     auto prefetch = [&](Stage &s) {
@@ -324,7 +333,10 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
 #pragma unroll
         for (int k = 0; k < NIT; ++k)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) s.rq[k][c] = __builtin_amdgcn_raw_buffer_load_b128(r, pf_off[k] + cb + (unsigned)c * plane_bytes, 0, 0);
+            for (int c = 0; c < 8; ++c) {
+                if constexpr (INP16) s.rq[k][c] = __builtin_amdgcn_raw_buffer_load_b64(r, pf_off[k] + cb + (unsigned)c * plane_bytes, 0, 0);
+                else s.rq[k][c] = __builtin_amdgcn_raw_buffer_load_b128(r, pf_off[k] + cb + (unsigned)c * plane_bytes, 0, 0);
+            }
         const unsigned wb = (unsigned)__builtin_amdgcn_readfirstlane(pf_chunk) * (unsigned)(CKB * 2);
 #ifndef KB_NO_WLOAD      // (timing ablation of tools/kbench only: results are wrong without the weight pieces)
 #pragma unroll
@@ -352,9 +364,14 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
                     u32x4 hv;
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
-                        const float v0 = __uint_as_float(s.rq[k][e][j]), v1 = __uint_as_float(s.rq[k][e + 1][j]);
-                        amax = fmaxf(amax, fmaxf(fabsf(v0), fabsf(v1)));
-                        hv[e >> 1] = pack_f16(v0 * sx, v1 * sx);
+                        if constexpr (INP16) {
+                            // half (j & 1) of dword (j >> 1) of channels e, e + 1 -> one word (e in the low half)
+                            hv[e >> 1] = __builtin_amdgcn_perm(s.rq[k][e + 1][j >> 1], s.rq[k][e][j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
+                        } else {
+                            const float v0 = __uint_as_float(s.rq[k][e][j]), v1 = __uint_as_float(s.rq[k][e + 1][j]);
+                            amax = fmaxf(amax, fmaxf(fabsf(v0), fabsf(v1)));
+                            hv[e >> 1] = pack_f16(v0 * sx, v1 * sx);
+                        }
                     }
                     const int pos = it_qr[k] * IW + c;
                     const int d = pos * 32 + ((it_qh[k] ^ ((pos >> 3) & 1)) << 4);
@@ -395,7 +412,7 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
     KB_STAMP(31);
     KB_FLUSH_SELF();
     // (halo positions are read by several workgroups, padded / dead lanes contribute 0: the maximum is unaffected)
-    in_slot.record(amax);
+    if constexpr (!INP16) in_slot.record(amax);       // (an fp16 input was recorded by its writer)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -667,9 +684,10 @@ __global__ __launch_bounds__(256) void f16_scales_finish_kernel(float *__restric
     if (i >= n) return;
     float *slot = slots + (int64_t)SLOT_STRIDE * i;
     const float a = slot[SLOT_AMAX], s = slot[0];
-    if (!(a > 0.f)) {                      // nothing staged through this slot (or all zeros): keep the scale
+    if (!(a > 0.f)) {                      // nothing staged through this slot, or nothing above the floor: keep the scale
         if (a != a) atomicOr(flag, 1);
         slot[SLOT_AMAX] = 0.f;
+        slot[SLOT_FLOOR] *= 0.5f;          // (decays fast: a tensor that shrank is measured again within a few steps)
         return;
     }
     if (!(a <= 3.0e38f) || a * s > 60000.f) atomicOr(flag, 1);
@@ -679,6 +697,9 @@ __global__ __launch_bounds__(256) void f16_scales_finish_kernel(float *__restric
         // (clamped like the host-side calibration, f16scale.calibrate: a recorded |max| below ~2^-125 must not turn the
         // next scale into +inf -- the x0.1 initialisation does produce 1e-29 gradients)
         slot[0] = ldexpf(1.f, min(F16_TARGET_EXP - e, 120));
+        slot[SLOT_FLOOR] = 0.875f * a;     // next step: only waves above 7/8 of this maximum report (c16.hpp)
+    } else {
+        slot[SLOT_FLOOR] = 0.f;
     }
     slot[SLOT_AMAX] = 0.f;
 }
@@ -700,7 +721,7 @@ __global__ __launch_bounds__(256) void pack_table_f16_kernel(const float *__rest
     unsigned m = __float_as_uint(fabsf(v));
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d, 64));
-    if ((threadIdx.x & 63) == 0 && !(__uint_as_float(m) <= __builtin_nontemporal_load(slot + SLOT_AMAX)))
+    if ((threadIdx.x & 63) == 0 && !(__uint_as_float(m) <= fmaxf(__builtin_nontemporal_load(slot + SLOT_AMAX), slot[SLOT_FLOOR])))
         atomicMax(reinterpret_cast<unsigned *>(slot + SLOT_AMAX), m);
 }
 
@@ -743,7 +764,10 @@ constexpr int TR_LDS = 2 * TR_BUFB + 4 * 64 * 4;                             // 
 // IN16 (round 4, DACT == 0 only): x and gout are the scaled fp16 images of the two tensors in the c16 layout (c16.hpp): a
 // [pixel][64 ch] LDS image is four 16-channel blocks whose tile rows are contiguous runs, so the producers copy 16-byte
 // pieces (7 + 4 loads per thread and tile instead of 16 + 8 plus the conversions) and move half the bytes.
-template <int DACT, bool IN16 = false>
+// GP16 (with IN16): grad_out is a PLANAR fp16 tensor [B, Cout, H, W] scaled by g_slot's scale instead of a c16 image (the
+// grad_kernel the FAC backward writes plane by plane): staged like the fp32 form -- eight 8-byte loads of 4 pixels per thread,
+// byte permutes into four (pixel, 8 channels) pieces.
+template <int DACT, bool IN16 = false, bool GP16 = false>
 __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict__ x, const float *__restrict__ gout,
                                                          const float *__restrict__ yact, float *__restrict__ gpre_out,
                                                          float *__restrict__ slab, ConvGeom g, float dslope, int total_tiles,
@@ -886,22 +910,24 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict
     if constexpr (IN16) {
         static_assert(DACT == 0, "fp16 c16 operands: pre-activation gradients only");
         // input image: rows 0..5, stored columns 1..34 of the 36 (the two outer ones are never read), 4 blocks, 2 halves
-        constexpr int XCOLS = TRW + 2, NXP = 4 * TRXR * XCOLS * 2, NXK16 = (NXP + PT - 1) / PT;      // 1632 pieces, 7 per thread
+        constexpr int XCOLS = TRW + 2, NXP = 4 * TRXR * 2 * XCOLS, NXK16 = (NXP + PT - 1) / PT;      // 1632 pieces, 7 per thread
         constexpr int NGK16 = 4;                                                               // 4 x 128 px x 2 = 1024 grad_out pieces
         const _Float16 *x16 = reinterpret_cast<const _Float16 *>(x), *g16 = reinterpret_cast<const _Float16 *>(gout);
-        const int p_half = ptid & 1;
-        int xb[NXK16], xr[NXK16], xc[NXK16], xd[NXK16];
+        // input pieces: id = (block, row, half, column); grad_out pieces: id = ptid + 256 k -> pixel ptid & 31, half (ptid >> 5) & 1,
+        // row ptid >> 6, block k: consecutive lanes walk the columns of one half-row run of the image (c16.hpp)
+        int xb[NXK16], xr[NXK16], xc[NXK16], xh[NXK16], xd[NXK16];
 #pragma unroll
         for (int k = 0; k < NXK16; ++k) {
-            int id = (ptid + k * PT) >> 1;
+            int id = ptid + k * PT;
             xc[k] = id % XCOLS; id /= XCOLS;
+            xh[k] = id & 1; id >>= 1;
             xr[k] = id % TRXR;
             xb[k] = id / TRXR;                                       // 0..3 (>= 4: past the end)
             const int pos = xr[k] * TRXW + xc[k] + 1;
-            xd[k] = pos * 128 + (((2 * xb[k] + p_half) ^ (((pos >> 1) & 1) << 2)) << 4);
+            xd[k] = pos * 128 + (((2 * xb[k] + xh[k]) ^ (((pos >> 1) & 1) << 2)) << 4);
         }
-        // grad_out pieces: id = ptid + k * 256 -> half = ptid & 1, pixel (ptid >> 1) & 31, row (ptid >> 6), block k
-        const int gp_x = (ptid >> 1) & 31, gp_y = ptid >> 6;
+        const int p_half = (ptid >> 5) & 1;
+        const int gp_x = ptid & 31, gp_y = ptid >> 6;
         const int gpix = gp_y * TRW + gp_x;
         int gd[NGK16];
 #pragma unroll
@@ -911,9 +937,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict
         const unsigned xblk = (unsigned)HW * 32u, gblk = (unsigned)HWo * 32u;
         const unsigned xs_bytes = (unsigned)((g.Cin + 15) / 16) * xblk, gs_bytes = (unsigned)cbo * gblk;
         (void)cbx;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         struct S16 {
             u32x4 rx[NXK16];
-            u32x4 rg[NGK16];
+            u32x4 rg[NGK16];                       // c16: four pieces; planar: eight 8-byte quads (4 pixels of channels 8 chg + e) as 4 x 16 B
         };
         S16 sa, sb, sc;
         float bacc[NGK16][8];
@@ -921,6 +948,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict
         for (int k = 0; k < NGK16; ++k)
 #pragma unroll
             for (int e = 0; e < 8; ++e) bacc[k][e] = 0.f;
+        // planar grad_out item of this thread: 8-channel group chg, tile row pg_y, quad pg_q (as the fp32 form)
+        const int chg = ptid & 7, pg_y = (ptid >> 3) >> 3, pg_q = (ptid >> 3) & 7;
+        const unsigned gplane16 = (unsigned)HWo * 2u;
         const bool xcd_map = (gridDim.x & 7) == 0;
         auto tile_coords = [&](int tile, int &b, int &y0, int &x0) {
             int t = (xcd_map && tile < total_tiles) ? xcd_tile(tile, total_tiles) : tile;
@@ -941,16 +971,29 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict
             for (int k = 0; k < NXK16; ++k) {
                 const int yy = y0 - 1 + xr[k], xx = x0 - 1 + xc[k];
                 const bool ok = ptid + k * PT < NXP && xb[k] < cbx_rem && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
-                const unsigned o = ok ? (unsigned)((ci_base >> 4) + xb[k]) * xblk + (unsigned)(yy * g.W + xx) * 32u + (unsigned)p_half * 16u : SENT;
+                const unsigned o = ok ? (unsigned)((ci_base >> 4) + xb[k]) * xblk + (unsigned)((yy * 2 + xh[k]) * g.W + xx) * 16u : SENT;
                 s.rx[k] = __builtin_amdgcn_raw_buffer_load_b128(rxi, o, 0, 0);
             }
-            const int gy = y0 + gp_y, gx = x0 + gp_x;
-            const bool gok = gy < g.Ho && gx < g.Wo;
+            if constexpr (GP16) {
+                const __amdgpu_buffer_rsrc_t rgp = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<_Float16 *>(g16) + (int64_t)bb * g.Cout * HWo, 0, live ? (unsigned)g.Cout * gplane16 : 0u, 0x00020000);
+                const int gy = y0 + pg_y, gx = x0 + 4 * pg_q;
+                const unsigned o = (gy < g.Ho && gx + 3 < g.Wo) ? (unsigned)(co_base + 8 * chg) * gplane16 + (unsigned)(gy * g.Wo + gx) * 2u : SENT;
 #pragma unroll
-            for (int k = 0; k < NGK16; ++k) {
-                const int cb = (co_base >> 4) + k;
-                const unsigned o = (gok && cb < cbo) ? (unsigned)cb * gblk + (unsigned)(gy * g.Wo + gx) * 32u + (unsigned)p_half * 16u : SENT;
-                s.rg[k] = __builtin_amdgcn_raw_buffer_load_b128(rgo, o, 0, 0);
+                for (int k = 0; k < NGK16; ++k) {          // channels 2k, 2k + 1 of the group in one register quad
+                    const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(rgp, o + (unsigned)(2 * k) * gplane16, 0, 0);
+                    const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(rgp, o + (unsigned)(2 * k + 1) * gplane16, 0, 0);
+                    s.rg[k] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                }
+            } else {
+                const int gy = y0 + gp_y, gx = x0 + gp_x;
+                const bool gok = gy < g.Ho && gx < g.Wo;
+#pragma unroll
+                for (int k = 0; k < NGK16; ++k) {
+                    const int cb = (co_base >> 4) + k;
+                    const unsigned o = (gok && cb < cbo) ? (unsigned)cb * gblk + (unsigned)((gy * 2 + p_half) * g.Wo + gx) * 16u : SENT;
+                    s.rg[k] = __builtin_amdgcn_raw_buffer_load_b128(rgo, o, 0, 0);
+                }
             }
         };
         const float inv_sg = 1.f / sg;
@@ -959,13 +1002,34 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict
 #pragma unroll
             for (int k = 0; k < NXK16; ++k)
                 if (ptid + k * PT < NXP) *reinterpret_cast<u32x4 *>(img + xd[k]) = s.rx[k];
+            if constexpr (GP16) {
+                // rg[k] = {ch 2k: px 0-1, px 2-3, ch 2k+1: px 0-1, px 2-3}; piece of pixel j = channels 8 chg .. 8 chg + 7
 #pragma unroll
-            for (int k = 0; k < NGK16; ++k) {
-                *reinterpret_cast<u32x4 *>(img + gd[k]) = s.rg[k];
-                if (need_bias && ci_blk == 0) {                      // bias gradient: plain sums of the (scaled) grad_out values
-                    const f16x8 hv = __builtin_bit_cast(f16x8, s.rg[k]);
+                for (int j = 0; j < 4; ++j) {
+                    u32x4 hv;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) bacc[k][e] += (float)hv[e];
+                    for (int k = 0; k < 4; ++k)
+                        hv[k] = __builtin_amdgcn_perm(s.rg[k][2 + (j >> 1)], s.rg[k][j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
+                    const int pix = pg_y * TRW + 4 * pg_q + j;
+                    *reinterpret_cast<u32x4 *>(img + TR_XB + pix * 128 + ((chg ^ (((pix >> 1) & 1) << 2)) << 4)) = hv;
+                }
+                if (need_bias && ci_blk == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const f16x8 hv = __builtin_bit_cast(f16x8, s.rg[k]);     // 4 pixels of channel 2k, then 4 of channel 2k + 1
+                        bacc[k][0] += ((float)hv[0] + (float)hv[1]) + ((float)hv[2] + (float)hv[3]);
+                        bacc[k][1] += ((float)hv[4] + (float)hv[5]) + ((float)hv[6] + (float)hv[7]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NGK16; ++k) {
+                    *reinterpret_cast<u32x4 *>(img + gd[k]) = s.rg[k];
+                    if (need_bias && ci_blk == 0) {                      // bias gradient: plain sums of the (scaled) grad_out values
+                        const f16x8 hv = __builtin_bit_cast(f16x8, s.rg[k]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) bacc[k][e] += (float)hv[e];
+                    }
                 }
             }
         };
@@ -993,8 +1057,26 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict
             __syncthreads();               // (B)
             cur ^= 1;
         }
+        if constexpr (GP16) {
+            if (need_bias && ci_blk == 0) {
+                // channel 8 chg + 2 k + i: summed over the 8 lanes-groups of a wave that share chg (lane bits 3..5), as the fp32 form
+                float *scr = reinterpret_cast<float *>(smt + 2 * TR_BUFB);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        float v = bacc[k][i];
+                        v += __shfl_xor(v, 8, 64);
+                        v += __shfl_xor(v, 16, 64);
+                        v += __shfl_xor(v, 32, 64);
+                        if ((lane >> 3) == 0) scr[(wave - NQ) * 64 + 8 * chg + 2 * k + i] = v * inv_sg;
+                    }
+            }
+            __syncthreads();               // (C)
+            return;
+        }
         if (need_bias && ci_blk == 0) {
-            // channel 16 k + 8 half + e: summed over the lanes that share `half` (lane bits 1..5 = pixel), then the four waves
+            // channel 16 k + 8 half + e: summed over the lanes that share `half` (lane bits 0..4 = pixel), then the four waves
             // (= tile rows) go through LDS to the consumers, which add them in a fixed order after barrier (C)
             float *scr = reinterpret_cast<float *>(smt + 2 * TR_BUFB);
 #pragma unroll
@@ -1002,12 +1084,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float v = bacc[k][e];
+                    v += __shfl_xor(v, 1, 64);
                     v += __shfl_xor(v, 2, 64);
                     v += __shfl_xor(v, 4, 64);
                     v += __shfl_xor(v, 8, 64);
                     v += __shfl_xor(v, 16, 64);
-                    v += __shfl_xor(v, 32, 64);
-                    if ((lane >> 1) == 0) scr[(wave - NQ) * 64 + 16 * k + 8 * p_half + e] = v * inv_sg;
+                    if ((lane & 31) == 0) scr[(wave - NQ) * 64 + 16 * k + 8 * p_half + e] = v * inv_sg;
                 }
         }
         __syncthreads();                   // (C)

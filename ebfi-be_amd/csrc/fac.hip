@@ -18,6 +18,7 @@
 //   generic   per-element kernels (any stride, any K, 64-bit indexing) for everything the fast
 //             paths do not cover; still HIP -- there is no CPU fallback.
 #include "common.hpp"
+#include "c16.hpp"
 
 using namespace ebfi;
 
@@ -33,6 +34,27 @@ __device__ __forceinline__ void st_stream4(float *p, f32x4 v) {
     __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p));
 }
 
+// fp16 filter / grad_kernel storage (round 4): the same PLANAR [B, C*K*K, Ho, Wo] tensors as halves, multiplied by the
+// power-of-two scale of a slot (c16.hpp ScaleSlot): 8-byte accesses of 4 pixels instead of 16-byte ones, half the bytes of
+// the op's two big streams.  `inv` undoes the scale on the way in.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 ld_stream4h(const _Float16 *p, float inv) {
+    // (one 64-bit scalar: hipcc 7.2 turns a non-temporal load of a 2 x 32-bit ext vector into a single dword load and hands the
+    // same word out twice -- the first version of this function returned pixels 0, 1, 0, 1)
+    const unsigned long long q64 = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(p));
+    const f16x2 a = __builtin_bit_cast(f16x2, (unsigned)q64), b = __builtin_bit_cast(f16x2, (unsigned)(q64 >> 32));
+    return f32x4{(float)a[0] * inv, (float)a[1] * inv, (float)b[0] * inv, (float)b[1] * inv};
+}
+__device__ __forceinline__ void st_stream4h(_Float16 *p, f32x4 v, float s) {
+    const unsigned long long q64 = (unsigned long long)pack_f16(v[0] * s, v[1] * s) | ((unsigned long long)pack_f16(v[2] * s, v[3] * s) << 32);
+    __builtin_nontemporal_store(q64, reinterpret_cast<unsigned long long *>(p));
+}
+template <bool H16>
+__device__ __forceinline__ f32x4 ld_filter4(const void *base, int64_t elem, float inv) {
+    if constexpr (H16) return ld_stream4h(static_cast<const _Float16 *>(base) + elem, inv);
+    else return ld_stream4(static_cast<const float *>(base) + elem);
+}
+
 struct Str4 {
     int64_t s0, s1, s2, s3;
 };
@@ -41,11 +63,11 @@ static inline Str4 str4(const int64_t *p) { return Str4{p[0], p[1], p[2], p[3]};
 // ------------------------------------------------------------------------------------------------
 // forward, vectorised tile kernel.  Requirements (checked by the launcher): innermost stride 1 for
 // all three tensors, Wo % 4 == 0, filter/output rows 16-byte aligned.
-template <int K, int TH, int TW>
+template <int K, int TH, int TW, bool H16 = false>
 __global__ __launch_bounds__(256) void fac_fwd_tile_f32(const float *__restrict__ in, Str4 is,
-                                                        const float *__restrict__ kern, Str4 ks,
+                                                        const void *__restrict__ kern, Str4 ks,
                                                         float *__restrict__ out, Str4 os, int C, int Ho,
-                                                        int Wo) {
+                                                        int Wo, const float *__restrict__ f_slot = nullptr) {
     static_assert(TH * (TW / 4) == 256, "tile must map onto 256 threads");
     constexpr int IH = TH + K - 1;
     constexpr int IW = TW + K - 1;
@@ -73,10 +95,11 @@ __global__ __launch_bounds__(256) void fac_fwd_tile_f32(const float *__restrict_
     const int y = y0 + ty, x = x0 + 4 * tx;
     if (y >= Ho || x >= Wo) return;
 
-    const float *kp = kern + (int64_t)b * ks.s0 + (int64_t)c * K * K * ks.s1 + (int64_t)y * ks.s2 + x;
+    const int64_t kp = (int64_t)b * ks.s0 + (int64_t)c * K * K * ks.s1 + (int64_t)y * ks.s2 + x;
+    const float finv = H16 ? 1.f / f_slot[0] : 1.f;
     f32x4 kv[K * K];
 #pragma unroll
-    for (int t = 0; t < K * K; ++t) kv[t] = ld_stream4(kp + (int64_t)t * ks.s1);
+    for (int t = 0; t < K * K; ++t) kv[t] = ld_filter4<H16>(kern, kp + (int64_t)t * ks.s1, finv);
 
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
@@ -125,13 +148,18 @@ __global__ void fac_fwd_generic_f32(const float *__restrict__ in, Str4 is, const
 // ------------------------------------------------------------------------------------------------
 // backward, fused row kernel (see file header).  K in {1,3,5}; innermost strides 1; Wo % 4 == 0;
 // filter / grad_kernel / grad_output rows 16-byte aligned.  TPR = lanes per row (power of two <= 64).
-template <int K, int TPR>
+template <int K, int TPR, bool H16 = false>
 __global__ __launch_bounds__(256) void fac_bwd_rows_f32(const float *__restrict__ in, Str4 is,
-                                                        const float *__restrict__ kern, Str4 ks,
+                                                        const void *__restrict__ kern, Str4 ks,
                                                         const float *__restrict__ gout, Str4 gs,
                                                         float *__restrict__ gin, Str4 gis,
-                                                        float *__restrict__ gkern, Str4 gks, int C, int Ho,
-                                                        int Wo, float kslope) {
+                                                        void *__restrict__ gkern, Str4 gks, int C, int Ho,
+                                                        int Wo, float kslope, const float *__restrict__ f_slot = nullptr,
+                                                        float *__restrict__ g_slot = nullptr) {
+    // H16: filters and grad_kernel are fp16 planes scaled by f_slot[0] / g_slot[0]; |max| of grad_kernel recorded into g_slot
+    if constexpr (H16) saturate_fp16_conversions();
+    const float finv = H16 ? 1.f / f_slot[0] : 1.f, gsc = (H16 && g_slot) ? g_slot[0] : 1.f;
+    [[maybe_unused]] float gk_amax = 0.f;
     // kslope: grad_kernel leaves multiplied by (kernel > 0 ? 1 : kslope) -- the derivative of the LeakyReLU that produced the
     // filters, so that the layer below receives the gradient of its PRE-activation (1.0 = plain grad_kernel, bit for bit)
     static_assert(K == 1 || K == 3 || K == 5, "carry scheme needs K-1 <= 4");
@@ -149,9 +177,10 @@ __global__ __launch_bounds__(256) void fac_bwd_rows_f32(const float *__restrict_
     const int nchunks = nx4 / TPR + 1;     // the lane right after the last loading lane writes the tail
 
     const float *inrow = in + (int64_t)b * is.s0 + (int64_t)c * is.s1 + (int64_t)Y * is.s2;
-    const float *kbase = kern + (int64_t)b * ks.s0 + (int64_t)c * K * K * ks.s1;
+    const int64_t kbase = (int64_t)b * ks.s0 + (int64_t)c * K * K * ks.s1;
     const float *gbase = gout + (int64_t)b * gs.s0 + (int64_t)c * gs.s1;
-    float *gkbase = gkern ? gkern + (int64_t)b * gks.s0 + (int64_t)c * K * K * gks.s1 : nullptr;
+    const bool has_gk = gkern != nullptr;
+    const int64_t gkbase = (int64_t)b * gks.s0 + (int64_t)c * K * K * gks.s1;
     float *ginrow = gin ? gin + (int64_t)b * gis.s0 + (int64_t)c * gis.s1 + (int64_t)Y * gis.s2 : nullptr;
 
     float carry[NU > 0 ? NU : 1];
@@ -167,7 +196,7 @@ __global__ __launch_bounds__(256) void fac_bwd_rows_f32(const float *__restrict_
         for (int j = 0; j < NS; ++j) s[j] = 0.f;
         if (active) {
             float inr[NS];
-            if (gkbase != nullptr) {
+            if (has_gk) {
 #pragma unroll
                 for (int j = 0; j < NS; ++j) inr[j] = inrow[x + j];   // x + j <= Wo - 4 + 3 + K - 1 < Wi
             }
@@ -179,11 +208,17 @@ __global__ __launch_bounds__(256) void fac_bwd_rows_f32(const float *__restrict_
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx) {
                     const int t = ky * K + kx;
-                    const f32x4 w = ld_stream4(kbase + (int64_t)t * ks.s1 + (int64_t)y * ks.s2 + x);
-                    if (gkbase != nullptr) {
+                    const f32x4 w = ld_filter4<H16>(kern, kbase + (int64_t)t * ks.s1 + (int64_t)y * ks.s2 + x, finv);
+                    if (has_gk) {
                         const f32x4 p = {inr[kx + 0] * g.x * (w.x > 0.f ? 1.f : kslope), inr[kx + 1] * g.y * (w.y > 0.f ? 1.f : kslope),
                                          inr[kx + 2] * g.z * (w.z > 0.f ? 1.f : kslope), inr[kx + 3] * g.w * (w.w > 0.f ? 1.f : kslope)};
-                        st_stream4(gkbase + (int64_t)t * gks.s1 + (int64_t)y * gks.s2 + x, p);
+                        const int64_t go_ = gkbase + (int64_t)t * gks.s1 + (int64_t)y * gks.s2 + x;
+                        if constexpr (H16) {
+                            gk_amax = fmaxf(gk_amax, fmaxf(fmaxf(fabsf(p[0]), fabsf(p[1])), fmaxf(fabsf(p[2]), fabsf(p[3]))));
+                            st_stream4h(static_cast<_Float16 *>(gkern) + go_, p, gsc);
+                        } else {
+                            st_stream4(static_cast<float *>(gkern) + go_, p);
+                        }
                     }
                     s[kx + 0] = fmaf(w.x, g.x, s[kx + 0]);
                     s[kx + 1] = fmaf(w.y, g.y, s[kx + 1]);
@@ -209,6 +244,9 @@ __global__ __launch_bounds__(256) void fac_bwd_rows_f32(const float *__restrict_
             for (int m = 0; m < 4; ++m)
                 if (x + m < Wi) ginrow[x + m] = o[m];
         }
+    }
+    if constexpr (H16) {
+        if (has_gk && g_slot) ScaleSlot{g_slot}.record(gk_amax);
     }
 }
 
@@ -272,40 +310,45 @@ int check_shapes(const int64_t *ish, const int64_t *ksh, int K, int64_t *B, int6
     return EBFI_OK;
 }
 
-template <int K>
-void launch_fwd_tile(hipStream_t st, const float *in, Str4 is, const float *kern, Str4 ks, float *out, Str4 os,
-                     int B, int C, int Ho, int Wo) {
-    const double bytes = 4.0 * B * C * (double)Ho * Wo * (1 + K * K + 1);   // in + K*K filter planes + out
+template <int K, bool H16 = false>
+void launch_fwd_tile(hipStream_t st, const float *in, Str4 is, const void *kern, Str4 ks, float *out, Str4 os,
+                     int B, int C, int Ho, int Wo, const float *f_slot = nullptr) {
+    const double bytes = B * C * (double)Ho * Wo * (4.0 + (H16 ? 2.0 : 4.0) * K * K + 4.0);   // in + K*K filter planes + out
+    const char *name = H16 ? "fac_fwd_tile_f32/p16" : "fac_fwd_tile_f32";
     if (Wo <= 64) {
         dim3 grid((unsigned)ceil_div(Wo, 64), (unsigned)ceil_div(Ho, 16), (unsigned)(B * C));
-        ProfScope ps("fac_fwd_tile_f32", st, 2.0 * B * C * (double)Ho * Wo * K * K, bytes);
-        hipLaunchKernelGGL((fac_fwd_tile_f32<K, 16, 64>), grid, dim3(256), 0, st, in, is, kern, ks, out, os, C, Ho, Wo);
+        ProfScope ps(name, st, 2.0 * B * C * (double)Ho * Wo * K * K, bytes);
+        hipLaunchKernelGGL((fac_fwd_tile_f32<K, 16, 64, H16>), grid, dim3(256), 0, st, in, is, kern, ks, out, os, C, Ho, Wo, f_slot);
     } else {
         dim3 grid((unsigned)ceil_div(Wo, 128), (unsigned)ceil_div(Ho, 8), (unsigned)(B * C));
-        ProfScope ps("fac_fwd_tile_f32", st, 2.0 * B * C * (double)Ho * Wo * K * K, bytes);
-        hipLaunchKernelGGL((fac_fwd_tile_f32<K, 8, 128>), grid, dim3(256), 0, st, in, is, kern, ks, out, os, C, Ho, Wo);
+        ProfScope ps(name, st, 2.0 * B * C * (double)Ho * Wo * K * K, bytes);
+        hipLaunchKernelGGL((fac_fwd_tile_f32<K, 8, 128, H16>), grid, dim3(256), 0, st, in, is, kern, ks, out, os, C, Ho, Wo, f_slot);
     }
 }
 
-template <int K, int TPR>
-void launch_bwd_rows_t(hipStream_t st, const float *in, Str4 is, const float *kern, Str4 ks, const float *go,
-                       Str4 gs, float *gin, Str4 gis, float *gk, Str4 gks, int B, int C, int Ho, int Wo, float kslope) {
+template <int K, int TPR, bool H16 = false>
+void launch_bwd_rows_t(hipStream_t st, const float *in, Str4 is, const void *kern, Str4 ks, const float *go,
+                       Str4 gs, float *gin, Str4 gis, void *gk, Str4 gks, int B, int C, int Ho, int Wo, float kslope,
+                       const float *f_slot = nullptr, float *g_slot = nullptr) {
     constexpr int ROWS = 4 * (64 / TPR);
     dim3 grid((unsigned)ceil_div(Ho + K - 1, ROWS), (unsigned)(B * C));
     const double px = (double)B * C * Ho * Wo;     // filters + gout + in read, grad_in + grad_kernel written
-    ProfScope ps("fac_bwd_rows_f32", st, 4.0 * px * K * K, 4.0 * px * (K * K + 1 + 1 + (gin ? 1 : 0) + (gk ? K * K : 0)));
-    hipLaunchKernelGGL((fac_bwd_rows_f32<K, TPR>), grid, dim3(256), 0, st, in, is, kern, ks, go, gs, gin, gis, gk, gks,
-                       C, Ho, Wo, kslope);
+    const double e = H16 ? 2.0 : 4.0;
+    ProfScope ps(H16 ? "fac_bwd_rows_f32/p16" : "fac_bwd_rows_f32", st, 4.0 * px * K * K,
+                 px * (e * K * K + 4.0 + 4.0 + (gin ? 4.0 : 0.0) + (gk ? e * K * K : 0.0)));
+    hipLaunchKernelGGL((fac_bwd_rows_f32<K, TPR, H16>), grid, dim3(256), 0, st, in, is, kern, ks, go, gs, gin, gis, gk, gks,
+                       C, Ho, Wo, kslope, f_slot, g_slot);
 }
 
-template <int K>
-void launch_bwd_rows(hipStream_t st, const float *in, Str4 is, const float *kern, Str4 ks, const float *go, Str4 gs,
-                     float *gin, Str4 gis, float *gk, Str4 gks, int B, int C, int Ho, int Wo, float kslope) {
+template <int K, bool H16 = false>
+void launch_bwd_rows(hipStream_t st, const float *in, Str4 is, const void *kern, Str4 ks, const float *go, Str4 gs,
+                     float *gin, Str4 gis, void *gk, Str4 gks, int B, int C, int Ho, int Wo, float kslope,
+                     const float *f_slot = nullptr, float *g_slot = nullptr) {
     const int nx4 = Wo / 4;
-    if (nx4 <= 8) launch_bwd_rows_t<K, 8>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo, kslope);
-    else if (nx4 <= 16) launch_bwd_rows_t<K, 16>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo, kslope);
-    else if (nx4 <= 32) launch_bwd_rows_t<K, 32>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo, kslope);
-    else launch_bwd_rows_t<K, 64>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo, kslope);
+    if (nx4 <= 8) launch_bwd_rows_t<K, 8, H16>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo, kslope, f_slot, g_slot);
+    else if (nx4 <= 16) launch_bwd_rows_t<K, 16, H16>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo, kslope, f_slot, g_slot);
+    else if (nx4 <= 32) launch_bwd_rows_t<K, 32, H16>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo, kslope, f_slot, g_slot);
+    else launch_bwd_rows_t<K, 64, H16>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo, kslope, f_slot, g_slot);
 }
 
 }  // namespace
@@ -416,4 +459,43 @@ extern "C" int ebfi_fac_backward_ex(const void *input, const int64_t input_shape
                            go, gs, gk, gks, total, (int)C, (int)Ho, (int)Wo, K, kern, ks, kslope);
     }
     return check_launch("fac_bwd_kernel_generic_f32");
+}
+
+// ------------------------------------------------------------------------------------------------ fp16 filter storage (round 4)
+// The FAC op with its two big tensors kept as fp16 PLANES scaled by the power-of-two of a scale slot (c16.hpp ScaleSlot,
+// ebfi_f16_scales_finish): filters16 / grad_kernel16 [B, C*K*K, Ho, Wo] halves, everything contiguous; input_pad
+// [B, C, Ho+K-1, Wo+K-1], output / grad_output [B, C, Ho, Wo], grad_input_pad like input_pad (fp32).  K = 5 (the model's),
+// Wo % 4 == 0.  grad_kernel16 leaves multiplied by the LeakyReLU(kernel_leaky_slope) derivative of the filters, times
+// g_slot[0], its |max| recorded into g_slot (the WRITER of an fp16 tensor records, c16.hpp).
+extern "C" int ebfi_fac_forward_p16(const float *input_pad, const void *filters16, const void *f_slot, float *output, int B, int C, int Ho,
+                                    int Wo, int K, void *stream) {
+    if (!input_pad || !filters16 || !f_slot || !output) return fail(EBFI_ERR_ARG, "fac_forward_p16: null argument");
+    if (K != 5 || Wo % 4 != 0 || B < 0 || C < 1 || Ho < 1 || Wo < 4 || (int64_t)B * C > 65535)
+        return fail(EBFI_ERR_UNSUPPORTED, "fac_forward_p16: K = 5, Wo %% 4 == 0, B*C <= 65535 (K=%d Wo=%d)", K, Wo);
+    if (!aligned16(filters16) || !aligned16(output)) return fail(EBFI_ERR_ARG, "fac_forward_p16: 16-byte aligned tensors");
+    if (B == 0) return EBFI_OK;
+    const int64_t Hi = Ho + K - 1, Wi = Wo + K - 1, HW = (int64_t)Ho * Wo;
+    const Str4 is{C * Hi * Wi, Hi * Wi, Wi, 1}, ks{(int64_t)C * K * K * HW, HW, Wo, 1}, os{C * HW, HW, Wo, 1};
+    launch_fwd_tile<5, true>(static_cast<hipStream_t>(stream), input_pad, is, filters16, ks, output, os, B, C, Ho, Wo,
+                             static_cast<const float *>(f_slot));
+    return check_launch("fac_fwd_tile_f32/p16");
+}
+
+extern "C" int ebfi_fac_backward_p16(const float *input_pad, const void *filters16, const void *f_slot, const float *grad_output,
+                                     float *grad_input_pad, void *grad_kernel16, void *g_slot, float kernel_leaky_slope, int B, int C,
+                                     int Ho, int Wo, int K, void *stream) {
+    if (!input_pad || !filters16 || !f_slot || !grad_output) return fail(EBFI_ERR_ARG, "fac_backward_p16: null argument");
+    if (grad_kernel16 && !g_slot) return fail(EBFI_ERR_ARG, "fac_backward_p16: grad_kernel16 needs its scale slot");
+    if (K != 5 || Wo % 4 != 0 || B < 0 || C < 1 || Ho < 1 || Wo < 4 || (int64_t)B * C > 65535)
+        return fail(EBFI_ERR_UNSUPPORTED, "fac_backward_p16: K = 5, Wo %% 4 == 0, B*C <= 65535 (K=%d Wo=%d)", K, Wo);
+    if (!aligned16(filters16) || !aligned16(grad_output) || (grad_kernel16 && !aligned16(grad_kernel16)))
+        return fail(EBFI_ERR_ARG, "fac_backward_p16: 16-byte aligned tensors");
+    if (!grad_input_pad && !grad_kernel16) return EBFI_OK;
+    if (B == 0) return EBFI_OK;
+    const int64_t Hi = Ho + K - 1, Wi = Wo + K - 1, HW = (int64_t)Ho * Wo;
+    const Str4 is{C * Hi * Wi, Hi * Wi, Wi, 1}, ks{(int64_t)C * K * K * HW, HW, Wo, 1}, gs{C * HW, HW, Wo, 1};
+    launch_bwd_rows<5, true>(static_cast<hipStream_t>(stream), input_pad, is, filters16, ks, grad_output, gs, grad_input_pad, is,
+                             grad_kernel16, ks, B, C, Ho, Wo, kernel_leaky_slope, static_cast<const float *>(f_slot),
+                             static_cast<float *>(g_slot));
+    return check_launch("fac_bwd_rows_f32/p16");
 }

@@ -141,7 +141,8 @@ __global__ __launch_bounds__(256) void prodmean_bwd_kernel(const float *__restri
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void c16_store_quad(_Float16 *__restrict__ dst, int64_t piece0, const f4 (&v)[8], float s, float &amax) {
-    // dst + piece0 * 8 halves: the piece of the FIRST pixel; the next pixels follow every 32 bytes (= 2 pieces)
+    // dst + piece0 * 8 halves: the piece of the FIRST pixel; the quad's four pixels lie in one image row (W % 4 == 0), so their
+    // pieces are 64 contiguous bytes -- and consecutive lanes own consecutive quads: every store instruction writes one run
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         u4 q;
@@ -151,15 +152,20 @@ __device__ __forceinline__ void c16_store_quad(_Float16 *__restrict__ dst, int64
             amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));
             q[e >> 1] = pack_f16(a * s, b * s);
         }
-        *reinterpret_cast<u4 *>(dst + (piece0 + 2 * j) * 8) = q;
+        *reinterpret_cast<u4 *>(dst + (piece0 + j) * 8) = q;
     }
+}
+// piece index of (block cb of a tensor with CB blocks per sample, sample b, flat pixel p = 4 q, channel half): image rows are W pieces
+__device__ __forceinline__ int64_t c16_piece(int64_t b, int64_t CB, int64_t cb, int64_t HW4, int64_t q, int W4, int half) {
+    const int64_t y = q / W4, xq = q - y * W4;
+    return ((b * CB + cb) * (HW4 * 4) * 2) + ((y * 2 + half) * W4 + xq) * 4;
 }
 
 // fp32 [B, C, HW] -> c16 image (optionally times the LeakyReLU derivative of `mask_y`: the pre-activation gradient of a layer
 // whose output is mask_y).  One thread per (b, 8-channel group, pixel quad).
 __global__ __launch_bounds__(256) void to_c16_kernel(const float *__restrict__ src, const float *__restrict__ mask_y, float mask_slope,
                                                      _Float16 *__restrict__ dst, float *__restrict__ slot, int C, int64_t HW4,
-                                                     int64_t total) {
+                                                     int W4, int64_t total) {
     saturate_fp16_conversions();
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float amax = 0.f;
@@ -179,9 +185,7 @@ __global__ __launch_bounds__(256) void to_c16_kernel(const float *__restrict__ s
                 v[e].z *= y.z > 0.f ? 1.f : mask_slope; v[e].w *= y.w > 0.f ? 1.f : mask_slope;
             }
         }
-        // block cg / 2 of sample b, pixel 4 q, half cg & 1
-        const int64_t piece0 = ((b * (C / 16) + cg / 2) * (HW4 * 4) + 4 * q) * 2 + (cg & 1);
-        c16_store_quad(dst, piece0, v, slot[0], amax);
+        c16_store_quad(dst, c16_piece(b, C / 16, cg / 2, HW4, q, W4, (int)(cg & 1)), v, slot[0], amax);
     }
     ScaleSlot{slot}.record(amax);
 }
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(256) void src_fwd_c16_kernel(const float *__restric
                                                           const float *__restrict__ a1, const float *__restrict__ s1,
                                                           const float *__restrict__ x, float *__restrict__ out,
                                                           _Float16 *__restrict__ out16, float *__restrict__ slot, int C, int64_t HW4,
-                                                          int64_t total, int64_t a_bs4) {
+                                                          int W4, int64_t total, int64_t a_bs4) {
     saturate_fp16_conversions();
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float amax = 0.f;
@@ -210,8 +214,7 @@ __global__ __launch_bounds__(256) void src_fwd_c16_kernel(const float *__restric
         f4 *o = reinterpret_cast<f4 *>(out) + (b * 2 * C + co) * HW4 + q;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e * HW4] = v[e];
-        const int64_t piece0 = ((b * (2 * C / 16) + cg / 2) * (HW4 * 4) + 4 * q) * 2 + (cg & 1);
-        c16_store_quad(out16, piece0, v, slot[0], amax);
+        c16_store_quad(out16, c16_piece(b, 2 * C / 16, cg / 2, HW4, q, W4, (int)(cg & 1)), v, slot[0], amax);
     }
     ScaleSlot{slot}.record(amax);
 }
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(256) void src_bwd_c16_kernel(const float *__restric
                                                           const float *__restrict__ s0, const float *__restrict__ a1,
                                                           const float *__restrict__ s1, _Float16 *__restrict__ ga16,
                                                           float *__restrict__ slot, float *__restrict__ gx, float *__restrict__ gs0p,
-                                                          float *__restrict__ gs1p, int B, int C, int64_t HW4, int64_t a_bs4,
+                                                          float *__restrict__ gs1p, int B, int C, int64_t HW4, int W4, int64_t a_bs4,
                                                           int nslice, float mask_slope) {
     saturate_fp16_conversions();
     __shared__ float red[4][16];
@@ -248,7 +251,6 @@ __global__ __launch_bounds__(256) void src_bwd_c16_kernel(const float *__restric
     const f4 *p0 = reinterpret_cast<const f4 *>(a0) + (int64_t)b * a_bs4 + (int64_t)c * HW4;
     const f4 *p1 = reinterpret_cast<const f4 *>(a1) + (int64_t)b * a_bs4 + (int64_t)c * HW4;
     f4 *ox = reinterpret_cast<f4 *>(gx) + ((int64_t)b * C + c) * HW4;
-    const int64_t blk0 = ((int64_t)b * (2 * C / 16) + cg / 2) * (HW4 * 4), blk1 = ((int64_t)b * (2 * C / 16) + (C + c) / 16) * (HW4 * 4);
     for (int64_t q = q0 + threadIdx.x; q < q1; q += 256) {
         f4 u0[8], u1[8], w[8];
 #pragma unroll
@@ -261,14 +263,14 @@ __global__ __launch_bounds__(256) void src_bwd_c16_kernel(const float *__restric
             d0[e] += (u0[e].x * v.x + u0[e].y * v.y) + (u0[e].z * v.z + u0[e].w * v.w);
             w[e] = u0[e] * k0[e] * dm(v);
         }
-        c16_store_quad(ga16, (blk0 + 4 * q) * 2 + (cg & 1), w, sc, amax);
+        c16_store_quad(ga16, c16_piece(b, 2 * C / 16, cg / 2, HW4, q, W4, cg & 1), w, sc, amax);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const f4 v = p1[e * HW4 + q];
             d1[e] += (u1[e].x * v.x + u1[e].y * v.y) + (u1[e].z * v.z + u1[e].w * v.w);
             w[e] = u1[e] * k1[e] * dm(v);
         }
-        c16_store_quad(ga16, (blk1 + 4 * q) * 2 + (((C + c) >> 3) & 1), w, sc, amax);
+        c16_store_quad(ga16, c16_piece(b, 2 * C / 16, (C + c) / 16, HW4, q, W4, ((C + c) >> 3) & 1), w, sc, amax);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e)
@@ -364,9 +366,11 @@ extern "C" int ebfi_scale_residual_cat_backward_ex(const float *grad_out, const 
 }
 
 // fp16 c16 images (include/ebfi_hip.h, csrc/c16.hpp) ---------------------------------------------------------------
-extern "C" int ebfi_to_c16(const float *src, const float *mask_y, float mask_slope, void *dst16, void *slot, int B, int C, int64_t HW,
+extern "C" int ebfi_to_c16(const float *src, const float *mask_y, float mask_slope, void *dst16, void *slot, int B, int C, int H, int W,
                            void *stream) {
+    const int64_t HW = (int64_t)H * W;
     if (!src || !dst16 || !slot) return fail(EBFI_ERR_ARG, "to_c16: null argument");
+    if (W % 4 != 0) return fail(EBFI_ERR_UNSUPPORTED, "to_c16: W %% 4 != 0 (W = %d)", W);
     if (C % 16 != 0) return fail(EBFI_ERR_UNSUPPORTED, "to_c16: %d channels (multiples of 16)", C);
     if (int rc = check_planes("to_c16", B, C, HW)) return rc;
     if (!aligned16(src) || !aligned16(dst16) || (mask_y && !aligned16(mask_y))) return fail(EBFI_ERR_ARG, "to_c16: 16-byte aligned tensors");
@@ -376,15 +380,17 @@ extern "C" int ebfi_to_c16(const float *src, const float *mask_y, float mask_slo
     {
         ProfScope ps("to_c16", st, 0.0, (mask_y ? 10.0 : 6.0) * B * C * (double)HW);
         hipLaunchKernelGGL(to_c16_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, src, mask_y, mask_slope,
-                           static_cast<_Float16 *>(dst16), static_cast<float *>(slot), C, HW / 4, total);
+                           static_cast<_Float16 *>(dst16), static_cast<float *>(slot), C, HW / 4, W / 4, total);
     }
     return check_launch("to_c16");
 }
 
 extern "C" int ebfi_scale_residual_cat_forward_c16(const float *a0, const float *s0, const float *a1, const float *s1, const float *x,
-                                                   float *out, void *out16, void *slot, int B, int C, int64_t HW,
+                                                   float *out, void *out16, void *slot, int B, int C, int H, int W,
                                                    int64_t a_batch_stride, void *stream) {
+    const int64_t HW = (int64_t)H * W;
     if (!a0 || !s0 || !a1 || !s1 || !x || !out || !out16 || !slot) return fail(EBFI_ERR_ARG, "scale_residual_cat_forward_c16: null argument");
+    if (W % 4 != 0) return fail(EBFI_ERR_UNSUPPORTED, "scale_residual_cat_forward_c16: W %% 4 != 0 (W = %d)", W);
     if (a_batch_stride % 4 != 0 || a_batch_stride < (int64_t)C * HW) return fail(EBFI_ERR_ARG, "scale_residual_cat_forward_c16: batch stride");
     if (C % 8 != 0) return fail(EBFI_ERR_UNSUPPORTED, "scale_residual_cat_forward_c16: %d channels (multiples of 8)", C);
     if (int rc = check_planes("scale_residual_cat_forward_c16", B, C, HW)) return rc;
@@ -394,7 +400,7 @@ extern "C" int ebfi_scale_residual_cat_forward_c16(const float *a0, const float 
     {
         ProfScope ps("scale_residual_cat_fwd", st, 0.0, 24.0 * B * C * (double)HW);
         hipLaunchKernelGGL(src_fwd_c16_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, a0, s0, a1, s1, x, out,
-                           static_cast<_Float16 *>(out16), static_cast<float *>(slot), C, HW / 4, total, a_batch_stride / 4);
+                           static_cast<_Float16 *>(out16), static_cast<float *>(slot), C, HW / 4, W / 4, total, a_batch_stride / 4);
     }
     return check_launch("scale_residual_cat_fwd");
 }
@@ -405,8 +411,10 @@ extern "C" int ebfi_scale_residual_cat_backward_slices(void) { return 8; }
 // slot[0]; grad_x [B,C,HW] fp32; grad_s0_part / grad_s1_part [ebfi_scale_residual_cat_backward_slices()][B][C] partial sums
 extern "C" int ebfi_scale_residual_cat_backward_c16(const float *grad_out, const float *a0, const float *s0, const float *a1,
                                                     const float *s1, void *grad_a16, void *slot, float *grad_x, float *grad_s0_part,
-                                                    float *grad_s1_part, int B, int C, int64_t HW, int64_t a_batch_stride,
+                                                    float *grad_s1_part, int B, int C, int H, int W, int64_t a_batch_stride,
                                                     float mask_slope, void *stream) {
+    const int64_t HW = (int64_t)H * W;
+    if (W % 4 != 0) return fail(EBFI_ERR_UNSUPPORTED, "scale_residual_cat_backward_c16: W %% 4 != 0 (W = %d)", W);
     if (!grad_out || !a0 || !s0 || !a1 || !s1 || !grad_a16 || !slot || !grad_x || !grad_s0_part || !grad_s1_part)
         return fail(EBFI_ERR_ARG, "scale_residual_cat_backward_c16: null argument");
     if (a_batch_stride % 4 != 0 || a_batch_stride < (int64_t)C * HW) return fail(EBFI_ERR_ARG, "scale_residual_cat_backward_c16: batch stride");
@@ -419,7 +427,7 @@ extern "C" int ebfi_scale_residual_cat_backward_c16(const float *grad_out, const
         ProfScope ps("scale_residual_cat_bwd", st, 0.0, 24.0 * B * C * (double)HW);
         hipLaunchKernelGGL(src_bwd_c16_kernel, dim3((unsigned)(B * (C / 8) * nslice)), dim3(256), 0, st, grad_out, a0, s0, a1, s1,
                            static_cast<_Float16 *>(grad_a16), static_cast<float *>(slot), grad_x, grad_s0_part, grad_s1_part, B, C,
-                           HW / 4, a_batch_stride / 4, nslice, mask_slope);
+                           HW / 4, W / 4, a_batch_stride / 4, nslice, mask_slope);
     }
     return check_launch("scale_residual_cat_bwd");
 }

@@ -71,14 +71,16 @@ SIGNATURES = {
     "ebfi_pack_table_f16": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "ebfi_conv2d_packed_f16": (_i, [_vp, _vp, _sz, _vp, _vp] + [_i] * 8 + [_i, _c.c_float, _vp, _vp, _i, _c.c_float, _vp, _vp, _vp]),
     "ebfi_conv2d_backward_weight_f16g": (_i, [_vp] * 6 + [_i] * 8 + [_i, _c.c_float, _vp, _vp, _vp, _sz, _vp]),
-    "ebfi_to_c16": (_i, [_vp, _vp, _c.c_float, _vp, _vp, _i, _i, _i64, _vp]),
-    "ebfi_conv2d_packed_x3_c16": (_i, [_vp, _vp, _sz, _vp, _vp] + [_i] * 8 + [_i, _c.c_float, _vp, _vp, _i, _c.c_float, _vp, _vp, _vp]),
+    "ebfi_to_c16": (_i, [_vp, _vp, _c.c_float, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ebfi_conv2d_packed_x3_c16": (_i, [_vp, _vp, _sz, _vp, _vp] + [_i] * 8 + [_i, _c.c_float, _vp, _vp, _i, _c.c_float, _vp, _vp, _i, _vp]),
     "ebfi_conv2d_packed_f16_c16": (_i, [_vp, _i, _vp, _sz, _vp, _vp] + [_i] * 8 + [_i, _c.c_float, _vp, _vp, _i, _c.c_float,
                                         _vp, _vp, _vp, _vp, _vp]),
-    "ebfi_conv2d_backward_weight_f16c": (_i, [_vp] * 4 + [_i] * 6 + [_vp, _vp, _vp, _sz, _vp]),
-    "ebfi_scale_residual_cat_forward_c16": (_i, [_vp] * 8 + [_i, _i, _i64, _i64, _vp]),
+    "ebfi_conv2d_backward_weight_f16c": (_i, [_vp, _vp, _i, _vp, _vp] + [_i] * 6 + [_vp, _vp, _vp, _sz, _vp]),
+    "ebfi_fac_forward_p16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ebfi_fac_backward_p16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_float, _i, _i, _i, _i, _i, _vp]),
+    "ebfi_scale_residual_cat_forward_c16": (_i, [_vp] * 8 + [_i, _i, _i, _i, _i64, _vp]),
     "ebfi_scale_residual_cat_backward_slices": (_i, []),
-    "ebfi_scale_residual_cat_backward_c16": (_i, [_vp] * 10 + [_i, _i, _i64, _i64, _c.c_float, _vp]),
+    "ebfi_scale_residual_cat_backward_c16": (_i, [_vp] * 10 + [_i, _i, _i, _i, _i64, _c.c_float, _vp]),
     "ebfi_kernelconv_fac_fused_x3": (_i, [_vp, _vp, _sz, _vp, _vp, _vp] + [_i] * 6 + [_c.c_float, _vp]),
     "ebfi_conv2d_packed_x3": (_i, [_vp, _vp, _sz, _vp, _vp] + [_i] * 8 + [_i, _c.c_float, _vp, _vp, _i, _c.c_float, _vp]),
     "ebfi_conv2d_backward_weight_x3g": (_i, [_vp] * 4 + [_i] * 8 + [_vp, _sz, _vp]),

@@ -1,7 +1,8 @@
 """fp16 operand storage of the backward pass: the "c16" images (csrc/c16.hpp, include/ebfi_hip.h).
 
-A tensor [B, C, H, W] (C % 16 == 0) is kept as fp16 [B, C/16, H, W, 16] times the power-of-two scale of its slot in the scale
-book (ebfi_amd.f16scale) -- the layout both fp16 backward kernels stage, so their producers copy 16-byte pieces instead of
+A tensor [B, C, H, W] (C % 16 == 0, W % 4 == 0) is kept as fp16 [B, C/16, H, 2, W, 8] (16-channel blocks; a row holds the
+channels 0..7 of its pixels, then the channels 8..15) times the power-of-two scale of its slot in the scale book
+(ebfi_amd.f16scale) -- the layout both fp16 backward kernels stage, so their producers copy 16-byte pieces instead of
 converting fp32 planes.  Images are WRITTEN by the kernels that produce the tensors (conv epilogues, the fused ResidualControl
 stages, `to_c16` for everything else); this module only allocates them and wraps the standalone conversion.
 """
@@ -13,7 +14,9 @@ from . import _native as N
 def empty(B, C, H, W, device):
     if C % 16 != 0:
         raise ValueError("c16 images hold multiples of 16 channels (got %d)" % C)
-    return torch.empty((B, C // 16, H, W, 16), dtype=torch.float16, device=device)
+    if W % 4 != 0:
+        raise ValueError("c16 images need rows of whole pixel quads (W = %d)" % W)
+    return torch.empty((B, C // 16, H, 2, W, 8), dtype=torch.float16, device=device)
 
 
 def to_c16(x, slot_ptr, mask_y=None, mask_slope=0.0, out=None):
@@ -27,12 +30,12 @@ def to_c16(x, slot_ptr, mask_y=None, mask_slope=0.0, out=None):
         return out
     with torch.cuda.device_of(x):
         rc = N.lib().ebfi_to_c16(N.ptr(x), N.ptr(mask_y.contiguous() if mask_y is not None else None), float(mask_slope),
-                                 N.ptr(out), slot_ptr, B, C, H * W, N.stream_ptr(x.device))
+                                 N.ptr(out), slot_ptr, B, C, H, W, N.stream_ptr(x.device))
     N.check(rc, "ebfi_to_c16")
     return out
 
 
 def from_c16(img, scale=1.0):
     """Image -> fp32 [B,C,H,W] / scale (tests and diagnostics; plain torch)."""
-    B, CB, H, W, _ = img.shape
-    return img.permute(0, 1, 4, 2, 3).reshape(B, CB * 16, H, W).float() / scale
+    B, CB, H, _, W, _ = img.shape
+    return img.permute(0, 1, 3, 5, 2, 4).reshape(B, CB * 16, H, W).float() / scale

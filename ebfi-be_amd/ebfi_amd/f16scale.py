@@ -30,7 +30,8 @@ from . import _native as N
 
 _ACTIVE = None
 TARGET_EXP = 2                      # |max| * scale in [2^(TARGET_EXP-1), 2^TARGET_EXP)
-SLOT_STRIDE, SLOT_AMAX = 64, 32     # floats per slot; offset of the running |max| (csrc/conv2d_f16.inc.hpp: separate cache lines)
+SLOT_STRIDE, SLOT_AMAX = 64, 32     # floats per slot; offset of the running |max| (csrc/c16.hpp: separate cache lines)
+SLOT_FLOOR = 1                      # floor of the running |max| (7/8 of the previous step's: waves below it send no atomic)
 
 
 def active_book():

@@ -126,6 +126,58 @@ def _dgrad(lib, st, g, site, out, B, cin_g, H, W, cout, groups, slope, addend=No
     _conv(lib, st, g, site.tr_ptr(), site.tr_bytes, None, out, B, cin_g, H, W, cout, groups, 0, slope, addend, mask)
 
 
+# ---- fp16 operand storage (ebfi_amd.c16, csrc/c16.hpp): the tensors the backward convolutions stage are written as scaled fp16
+# images by whoever produces them, the backward kernels copy 16-byte pieces instead of converting fp32 planes
+def _slot_keys(sites):
+    keys = []
+    for sa, sb, sc in sites:
+        keys += [(sa.key, "x"), (sa.key, "g"), (sb.key, "x"), (sb.key, "g"), (sc.key, "x"), (sc.key, "g")]
+    return keys
+
+
+def images_usable(book, sites, W):
+    """The image path needs every operand slot of the module calibrated (the layer-wise form below measures them just in time
+    on the first eager pass and during the engine's calibration steps) and rows that split into 16-byte quads."""
+    if N.dev_env("EBFI_NO_C16", "0") == "1":          # (development switch: same-box A/B of the two forms)
+        return False
+    if book is None or W % 4 != 0 or any(sa.tr16_ptr() is None or sb.tr16_ptr() is None or sc.tr16_ptr() is None for sa, sb, sc in sites):
+        return False
+    return all(book.index.get(k) in book.calibrated for k in _slot_keys(sites))
+
+
+def _conv16(lib, st, x, site, bias, out, B, cin_g, H, W, cout, groups, slope, out16, slot16):
+    """Split-precision forward convolution + LeakyReLU whose output also leaves as an fp16 image."""
+    rc = lib.ebfi_conv2d_packed_x3_c16(N.ptr(x), site.fwd_ptr(), site.fwd_bytes, N.ptr(bias), N.ptr(out), B, cin_g, H, W, cout, 3, 1,
+                                       groups, ACT, slope, N.ptr(None), N.ptr(None), 0, 0.0, N.ptr(out16),
+                                       slot16 if out16 is not None else N.ptr(None), 0, st)
+    N.check(rc, "ebfi_conv2d_packed_x3_c16")
+
+
+def _wgrad16(lib, st, x16, g16, B, cin_g, H, W, cout, groups, ws_cache, book, site):
+    gw = torch.empty((cout, cin_g, 3, 3), dtype=torch.float32, device=x16.device)
+    gb = torch.empty(cout, dtype=torch.float32, device=x16.device)
+    key = (cin_g, cout)
+    if key not in ws_cache:
+        need = int(lib.ebfi_conv2d_backward_weight_workspace(B, cin_g, H, W, cout, 3, 1, 1, N.EBFI_F32))
+        ws_cache[key] = (torch.empty(max(need, 4), dtype=torch.uint8, device=x16.device), need)
+    ws, need = ws_cache[key]
+    rc = lib.ebfi_conv2d_backward_weight_f16c(N.ptr(x16), N.ptr(g16), 0, N.ptr(gw), N.ptr(gb), B, cin_g, H, W, cout, groups,
+                                              book.ptr(book.slot((site.key, "x"))), book.ptr(book.slot((site.key, "g"))),
+                                              N.ptr(ws), need, st)
+    N.check(rc, "ebfi_conv2d_backward_weight_f16c")
+    return gw, gb
+
+
+def _dgrad16(lib, st, g16, site, B, cin_g, H, W, cout, groups, slope, book, out=None, out16=None, slot16=None, addend=None, mask=None):
+    """Data gradient of `site`'s layer from the IMAGE of its pre-activation gradient; the result as fp32 (`out`) and / or as
+    the image of the next pre-activation gradient (`out16`, scale slot `slot16`)."""
+    rc = lib.ebfi_conv2d_packed_f16_c16(N.ptr(g16), 1, site.tr16_ptr(), site.tr16_bytes, N.ptr(None), N.ptr(out), B, cin_g, H, W, cout,
+                                        3, 1, groups, 0, slope, N.ptr(addend), N.ptr(mask), ACT if mask is not None else 0,
+                                        slope if mask is not None else 0.0, book.ptr(book.slot((site.key, "g"))), site.w_slot_ptr(),
+                                        N.ptr(out16), slot16 if out16 is not None else N.ptr(None), 0, st)
+    N.check(rc, "ebfi_conv2d_packed_f16_c16")
+
+
 class ResidualControlFn(Function):
     """apply(data, s_ex [step,B,C], s_t [step,B,C], sites, slope, *params) -> x_step.
     params per round: W3a, b3a, W4a, b4a, W3b, b3b, W4b, b4b, W5, b5 (inputs only so that autograd routes their gradients)."""
@@ -141,6 +193,33 @@ class ResidualControlFn(Function):
         # inference (grad mode off at the call): nothing is kept -- at B=8 720x1280 the 12 rounds' intermediates are 40 GB
         keep = bool(sites_keep[1])
         sites = sites_keep[0]
+        from . import c16, f16scale
+        book = f16scale.active_book()
+        images = keep and images_usable(book, sites, W)
+        ctx.images = images
+        if images:
+            with torch.cuda.device_of(x):
+                st = N.stream_ptr(x.device)
+                new = lambda ch: torch.empty((B, ch, H, W), dtype=x.dtype, device=x.device)
+                img = lambda ch: c16.empty(B, ch, H, W, x.device)
+                sp = lambda site, role: book.ptr(book.slot((site.key, role)))
+                x16 = c16.to_c16(x, sp(sites[0][0], "x"))
+                for i, (sa, sb, sc) in enumerate(sites):
+                    ya, a, c, xn = new(2 * C), new(2 * C), new(2 * C), new(C)
+                    ya16, c16i = img(2 * C), img(2 * C)
+                    nxt = sites[i + 1][0] if i + 1 < len(sites) else None
+                    xn16 = img(C) if nxt is not None else None
+                    _conv16(lib, st, x, sa, sa.bias(), ya, B, C, H, W, 2 * C, 1, slope, ya16, sp(sb, "x"))
+                    _conv(lib, st, ya, sb.fwd_ptr(), sb.fwd_bytes, sb.bias(), a, B, C, H, W, 2 * C, 2, ACT, slope)
+                    rc = lib.ebfi_scale_residual_cat_forward_c16(N.ptr(a), N.ptr(s_ex[i]), N._vp(a.data_ptr() + 4 * C * HW), N.ptr(s_t[i]),
+                                                                 N.ptr(x), N.ptr(c), N.ptr(c16i), sp(sc, "x"), B, C, H, W, 2 * C * HW, st)
+                    N.check(rc, "ebfi_scale_residual_cat_forward_c16")
+                    _conv16(lib, st, c, sc, sc.bias(), xn, B, 2 * C, H, W, C, 1, slope, xn16, sp(nxt, "x") if nxt is not None else None)
+                    saved += [x, ya, a, x16, ya16, c16i]       # (c itself is not needed again: its image feeds the weight gradient)
+                    x, x16 = xn, xn16
+            ctx.sites, ctx.slope, ctx.dims = sites, slope, (B, C, H, W)
+            ctx.save_for_backward(s_ex, s_t, x, *saved)
+            return x
         with torch.cuda.device_of(x):
             st = N.stream_ptr(x.device)
             new = lambda ch: torch.empty((B, ch, H, W), dtype=x.dtype, device=x.device)
@@ -171,6 +250,49 @@ class ResidualControlFn(Function):
         gs_ex, gs_t = torch.empty_like(s_ex), torch.empty_like(s_t)
         pgrads = [None] * (10 * nstep)
         ws_cache = {}
+        if ctx.images:
+            from . import c16
+            if book is None:
+                raise RuntimeError("ResidualControl ran its forward with fp16 operand images: backward() must run inside the same "
+                                   "scale-book context (Engine._fwd_bwd)")
+            with torch.cuda.device_of(gout):
+                st = N.stream_ptr(gout.device)
+                dev = gout.device
+                new = lambda ch: torch.empty((B, ch, H, W), dtype=gout.dtype, device=dev)
+                img = lambda ch: c16.empty(B, ch, H, W, dev)
+                sp = lambda site, role: book.ptr(book.slot((site.key, role)))
+                S = int(lib.ebfi_scale_residual_cat_backward_slices())
+                parts = torch.empty((2, nstep, S, B, C), dtype=torch.float32, device=dev)
+                # image of the last round's pre-activation gradient (later rounds get theirs from the data gradient's epilogue)
+                g5 = c16.to_c16(gout.contiguous(), sp(sites[-1][2], "g"), xlast, slope)
+                gdata = None
+                for i in range(nstep - 1, -1, -1):
+                    sa, sb, sc = sites[i]
+                    x, ya, a, x16, ya16, c16i = saved[6 * i:6 * i + 6]
+                    gw5, gb5 = _wgrad16(lib, st, c16i, g5, B, 2 * C, H, W, C, 1, ws_cache, book, sc)
+                    gc = new(2 * C)
+                    _dgrad16(lib, st, g5, sc, B, C, H, W, 2 * C, 1, 0.0, book, out=gc)
+                    gb16, gxres = img(2 * C), new(C)
+                    rc = lib.ebfi_scale_residual_cat_backward_c16(
+                        N.ptr(gc), N.ptr(a), N.ptr(s_ex[i]), N._vp(a.data_ptr() + 4 * C * HW), N.ptr(s_t[i]), N.ptr(gb16), sp(sb, "g"),
+                        N.ptr(gxres), N.ptr(parts[0, i]), N.ptr(parts[1, i]), B, C, H, W, 2 * C * HW, slope, st)
+                    N.check(rc, "ebfi_scale_residual_cat_backward_c16")
+                    gwb, gbb = _wgrad16(lib, st, ya16, gb16, B, C, H, W, 2 * C, 2, ws_cache, book, sb)
+                    ga16 = img(2 * C)
+                    _dgrad16(lib, st, gb16, sb, B, C, H, W, 2 * C, 2, slope, book, out16=ga16, slot16=sp(sa, "g"), mask=ya)
+                    gwa, gba = _wgrad16(lib, st, x16, ga16, B, C, H, W, 2 * C, 1, ws_cache, book, sa)
+                    if i > 0:       # leaves as the image of the previous round's Conv5 pre-activation gradient
+                        g5 = img(C)
+                        _dgrad16(lib, st, ga16, sa, B, 2 * C, H, W, C, 1, slope, book, out16=g5, slot16=sp(sites[i - 1][2], "g"),
+                                 addend=gxres, mask=x)
+                    else:
+                        gdata = new(C)
+                        _dgrad16(lib, st, ga16, sa, B, 2 * C, H, W, C, 1, slope, book, out=gdata, addend=gxres)
+                    pgrads[10 * i:10 * i + 10] = [gwa[:C], gba[:C], gwa[C:], gba[C:], gwb[:C], gbb[:C], gwb[C:], gbb[C:], gw5, gb5]
+                sums = parts.sum(2)                    # per-slice partials of the scale gradients, in slice order
+                gs_ex, gs_t = sums[0], sums[1]
+            need = ctx.needs_input_grad
+            return (gdata if need[0] else None, gs_ex if need[1] else None, gs_t if need[2] else None, None, None) + tuple(pgrads)
         with torch.cuda.device_of(gout):
             st = N.stream_ptr(gout.device)
             new = lambda ch: torch.empty((B, ch, H, W), dtype=gout.dtype, device=gout.device)

@@ -263,41 +263,55 @@ int ebfi_conv2d_backward_weight_f16g(const void *input, const void *grad_output,
                                      float slope, void *x_slot, void *g_slot, void *workspace,
                                      size_t workspace_bytes, void *stream);
 /* ------------------------------------------------------------------ fp16 operand STORAGE of the backward pass (round 4)
- * Layout "c16": a tensor [B, C, H, W] (C % 16 == 0) as fp16 [B][C/16][H][W][16] -- 16-channel blocks, pixel-major inside a
- * block -- multiplied by the power-of-two scale in slot[0] of its scale slot (ebfi_f16_scales_finish).  It is the staging
+ * Layout "c16": a tensor [B, C, H, W] (C % 16 == 0, W % 4 == 0) as fp16 [B][C/16][H][2][W][8] -- 16-channel blocks; an image
+ * row holds the channels 0..7 of its W pixels, then the channels 8..15 -- multiplied by the power-of-two scale in slot[0] of
+ * its scale slot (ebfi_f16_scales_finish).  It is the staging
  * layout of both fp16 backward kernels: their producers copy 16-byte pieces instead of converting fp32 NCHW planes, half
  * the bytes.  The WRITER of an image applies the scale and records |max| into the slot; readers only read the scale.
  * Replaces, inside ResidualControl's backward chain (models/Ours/model_singleframe.py:115-136), the fp32 tensors autograd
  * would hand from layer to layer.
  *   ebfi_to_c16                        fp32 [B,C,HW] -> image (optionally times LeakyReLU'(mask_y): a pre-activation gradient)
  *   ebfi_conv2d_packed_x3_c16          ebfi_conv2d_packed_x3 writing its output also as an image (out16, slot16)
- *   ebfi_conv2d_packed_f16_c16         ebfi_conv2d_packed_f16 reading an image (input_is_c16, scale in in_slot) and / or
+ *   ebfi_conv2d_packed_f16_c16         ebfi_conv2d_packed_f16 reading an image (input_is_c16 = 1; 2 = planar fp16; scale in in_slot) and / or
  *                                      writing its output as one (out16 / slot16; `output` may then be NULL)
  *   ebfi_conv2d_backward_weight_f16c   weight / bias gradient from the images of the input and of the pre-activation gradient
  *   ebfi_scale_residual_cat_forward_c16 / _backward_c16   the fused ResidualControl stages writing images: forward out + out16;
  *                                      backward [grad_a0 | grad_a1] * LeakyReLU'(a) as ONE image of 2C channels, grad_x fp32,
  *                                      scale gradients as per-slice partial sums [slices][B][C] (summed in order by the caller) */
-int ebfi_to_c16(const float *src, const float *mask_y, float mask_slope, void *dst16, void *slot, int B, int C, int64_t HW,
+int ebfi_to_c16(const float *src, const float *mask_y, float mask_slope, void *dst16, void *slot, int B, int C, int H, int W,
                 void *stream);
 int ebfi_conv2d_packed_x3_c16(const void *input, const void *packed, size_t packed_bytes, const void *bias, void *output,
                               int B, int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups, int act,
                               float slope, const void *addend, const void *mask_y, int mask_act, float mask_slope,
-                              void *out16, void *slot16, void *stream);
+                              void *out16, void *slot16, int out16_planar, void *stream);
 int ebfi_conv2d_packed_f16_c16(const void *input, int input_is_c16, const void *packed16, size_t packed_bytes,
                                const void *bias, void *output, int B, int Cin_per_group, int H, int W, int Cout, int ksize,
                                int pad, int groups, int act, float slope, const void *addend, const void *mask_y,
                                int mask_act, float mask_slope, void *in_slot, const void *w_slot, void *out16,
                                void *slot16, void *stream);
-int ebfi_conv2d_backward_weight_f16c(const void *input16, const void *grad16, void *grad_weight, void *grad_bias, int B,
-                                     int Cin_per_group, int H, int W, int Cout, int groups, const void *x_slot,
-                                     const void *g_slot, void *workspace, size_t workspace_bytes, void *stream);
+int ebfi_conv2d_backward_weight_f16c(const void *input16, const void *grad16, int grad_is_planar, void *grad_weight,
+                                     void *grad_bias, int B, int Cin_per_group, int H, int W, int Cout, int groups,
+                                     const void *x_slot, const void *g_slot, void *workspace, size_t workspace_bytes,
+                                     void *stream);
+/* The 1600-channel tensors of the KernelConv -> FAC pair in the TRAINING step (reference
+ * models/Ours/model_singleframe.py:161-162, KernelConv2D_kernel.cu:25-150): the filters and grad_kernel as PLANAR fp16
+ * [B, C*K*K, Ho, Wo] scaled by a slot's power of two -- the layout the FAC kernels stream plane by plane.  The 128 -> 1600
+ * convolution writes the filters in that form (ebfi_conv2d_packed_x3_c16 with out16_planar, output NULL), the FAC forward /
+ * backward read them and the backward writes grad_kernel (times the LeakyReLU derivative) likewise; the weight / data
+ * gradient of the convolution stage the planes (ebfi_conv2d_backward_weight_f16c grad_is_planar, ebfi_conv2d_packed_f16_c16
+ * input_is_c16 = 2).  No fp32 [B, 1600, h, w] tensor is written or read. */
+int ebfi_fac_forward_p16(const float *input_pad, const void *filters16, const void *f_slot, float *output, int B, int C, int Ho,
+                         int Wo, int K, void *stream);
+int ebfi_fac_backward_p16(const float *input_pad, const void *filters16, const void *f_slot, const float *grad_output,
+                          float *grad_input_pad, void *grad_kernel16, void *g_slot, float kernel_leaky_slope, int B, int C,
+                          int Ho, int Wo, int K, void *stream);
 int ebfi_scale_residual_cat_forward_c16(const float *a0, const float *s0, const float *a1, const float *s1, const float *x,
-                                        float *out, void *out16, void *slot, int B, int C, int64_t HW,
+                                        float *out, void *out16, void *slot, int B, int C, int H, int W,
                                         int64_t a_batch_stride, void *stream);
 int ebfi_scale_residual_cat_backward_slices(void);
 int ebfi_scale_residual_cat_backward_c16(const float *grad_out, const float *a0, const float *s0, const float *a1,
                                          const float *s1, void *grad_a16, void *slot, float *grad_x, float *grad_s0_part,
-                                         float *grad_s1_part, int B, int C, int64_t HW, int64_t a_batch_stride,
+                                         float *grad_s1_part, int B, int C, int H, int W, int64_t a_batch_stride,
                                          float mask_slope, void *stream);
 /* weight / bias gradient of such a (grouped) convolution from a pre-activation gradient: grad_weight
  * [Cout, Cin_per_group, k, k]; workspace as ebfi_conv2d_backward_weight_workspace(B, Cin_per_group, H, W, Cout, k, 1, pad) */

@@ -11,7 +11,7 @@ from ebfi_amd import _native as N  # noqa: E402
 
 def _ref_image(x, scale):
     B, C, H, W = x.shape
-    return (x * scale).half().reshape(B, C // 16, 16, H, W).permute(0, 1, 3, 4, 2).contiguous()
+    return (x * scale).half().reshape(B, C // 16, 2, 8, H, W).permute(0, 1, 4, 2, 5, 3).contiguous()
 
 
 def _banked(cin, cout, groups=1):
@@ -58,7 +58,7 @@ def test_forward_conv_writes_the_image_of_its_output(B, Cin, H, W, Cout, groups)
     args = (N.ptr(x), site.fwd_ptr(), site.fwd_bytes, N.ptr(site.bias()))
     geo = (B, Cin, H, W, Cout, 3, 1, groups, 1, 0.01, N.ptr(None), N.ptr(None), 0, 0.0)
     N.check(lib.ebfi_conv2d_packed_x3(*args, N.ptr(plain), *geo, st), "x3")
-    N.check(lib.ebfi_conv2d_packed_x3_c16(*args, N.ptr(out), *geo, N.ptr(img), book.ptr(i), st), "x3_c16")
+    N.check(lib.ebfi_conv2d_packed_x3_c16(*args, N.ptr(out), *geo, N.ptr(img), book.ptr(i), 0, st), "x3_c16")
     assert torch.equal(out, plain)                               # the fp32 output is unchanged by the side image
     assert torch.equal(img, _ref_image(out, 2.0))
     assert book.amax(i) == out.abs().max().item()
@@ -133,7 +133,7 @@ def test_weight_gradient_from_images(B, Cin, H, W, Cout, groups):
     N.check(rc, "f16g")
     x16, g16 = c16.to_c16(x, book.ptr(sx)), c16.to_c16(g, book.ptr(sg))
     gw_b, gb_b = torch.empty_like(gw_a), torch.empty_like(gb_a)
-    rc = lib.ebfi_conv2d_backward_weight_f16c(N.ptr(x16), N.ptr(g16), N.ptr(gw_b), N.ptr(gb_b), B, Cin, H, W, Cout, groups,
+    rc = lib.ebfi_conv2d_backward_weight_f16c(N.ptr(x16), N.ptr(g16), 0, N.ptr(gw_b), N.ptr(gb_b), B, Cin, H, W, Cout, groups,
                                               book.ptr(sx), book.ptr(sg), N.ptr(ws), need, st)
     N.check(rc, "f16c")
     assert torch.equal(gw_a, gw_b)
@@ -158,7 +158,7 @@ def test_fused_residual_control_stages_write_images():
     a1p = N._vp(a.data_ptr() + 4 * C * HW)
     out, out16 = torch.empty(B, 2 * C, H, W, device="cuda"), c16.empty(B, 2 * C, H, W, "cuda")
     N.check(lib.ebfi_scale_residual_cat_forward_c16(N.ptr(a), N.ptr(s0), a1p, N.ptr(s1), N.ptr(x), N.ptr(out), N.ptr(out16), book.ptr(so),
-                                                    B, C, HW, 2 * C * HW, st), "fwd_c16")
+                                                    B, C, H, W, 2 * C * HW, st), "fwd_c16")
     ref = torch.empty_like(out)
     N.check(lib.ebfi_scale_residual_cat_forward_ex(N.ptr(a), N.ptr(s0), a1p, N.ptr(s1), N.ptr(x), N.ptr(ref), B, C, HW, 2 * C * HW, st), "fwd")
     assert torch.equal(out, ref) and torch.equal(out16, _ref_image(ref, 4.0)) and book.amax(so) == ref.abs().max().item()
@@ -172,6 +172,104 @@ def test_fused_residual_control_stages_write_images():
     ga16 = c16.empty(B, 2 * C, H, W, "cuda")
     gx2, p0, p1 = torch.empty_like(gx), torch.empty(S, B, C, device="cuda"), torch.empty(S, B, C, device="cuda")
     N.check(lib.ebfi_scale_residual_cat_backward_c16(N.ptr(gc), N.ptr(a), N.ptr(s0), a1p, N.ptr(s1), N.ptr(ga16), book.ptr(sg), N.ptr(gx2),
-                                                     N.ptr(p0), N.ptr(p1), B, C, HW, 2 * C * HW, 0.01, st), "bwd_c16")
+                                                     N.ptr(p0), N.ptr(p1), B, C, H, W, 2 * C * HW, 0.01, st), "bwd_c16")
     assert torch.equal(gx2, gx) and torch.equal(ga16, _ref_image(ga, 512.0)) and book.amax(sg) == ga.abs().max().item()
     assert torch.allclose(p0.sum(0), gs0, rtol=1e-5, atol=1e-7) and torch.allclose(p1.sum(0), gs1, rtol=1e-5, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# planar fp16 storage of the KernelConv -> FAC pair's 1600-channel tensors (filters, grad_kernel)
+def _p16(x, scale):
+    return (x * scale).half()
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 8, 16, 64), (1, 64, 24, 132), (2, 3, 9, 36)])
+def test_fac_on_fp16_filter_planes(B, C, H, W):
+    """ebfi_fac_forward_p16 / _backward_p16 against the fp32 FAC kernels fed the de-quantised filters: same arithmetic, bit for
+    bit (output, grad_input); grad_kernel16 == fp16(grad_kernel32 * scale) exactly, its |max| recorded."""
+    from ebfi_amd import f16scale
+    from ebfi_amd.fac import fac_backward, fac_forward
+    torch.manual_seed(C + W)
+    K = 5
+    xp = torch.randn(B, C, H + 4, W + 4).cuda()
+    filt = torch.randn(B, C * K * K, H, W).cuda() * 0.2
+    go = torch.randn(B, C, H, W).cuda() * 1e-2
+    book = f16scale.ScaleBook("cuda")
+    sf, sg = book.slot("f"), book.slot("g")
+    book.calibrate(sf, filt)
+    book.slots[f16scale.SLOT_STRIDE * sg] = 256.0
+    f16 = _p16(filt, book.scale(sf))
+    fq = f16.float() / book.scale(sf)                      # what the kernels see
+    lib, st = N.lib(), N.stream_ptr(xp.device)
+    out = torch.empty(B, C, H, W, device="cuda")
+    N.check(lib.ebfi_fac_forward_p16(N.ptr(xp), N.ptr(f16), book.ptr(sf), N.ptr(out), B, C, H, W, K, st), "fac_forward_p16")
+    assert torch.equal(out, fac_forward(xp, fq, K))
+    gin = torch.empty_like(xp)
+    gk16 = torch.empty(B, C * K * K, H, W, dtype=torch.float16, device="cuda")
+    N.check(lib.ebfi_fac_backward_p16(N.ptr(xp), N.ptr(f16), book.ptr(sf), N.ptr(go), N.ptr(gin), N.ptr(gk16), book.ptr(sg), 0.01,
+                                      B, C, H, W, K, st), "fac_backward_p16")
+    rin, rk = fac_backward(xp, fq, K, go, kernel_leaky_slope=0.01)
+    assert torch.equal(gin, rin)
+    assert torch.equal(gk16, _p16(rk, 256.0)) and book.amax(sg) == rk.abs().max().item()
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout", [(2, 128, 16, 64, 200), (1, 64, 13, 36, 64)])
+def test_conv_writes_planar_fp16_filters_only(B, Cin, H, W, Cout):
+    from ebfi_amd import f16scale
+    torch.manual_seed(5)
+    w, b, bank, book, site = _banked(Cin, Cout)
+    i = book.slot("f")
+    book.slots[f16scale.SLOT_STRIDE * i] = 8.0
+    x = torch.randn(B, Cin, H, W).cuda()
+    ref = torch.empty(B, Cout, H, W, device="cuda")
+    lib, st = N.lib(), N.stream_ptr(x.device)
+    args = (N.ptr(x), site.fwd_ptr(), site.fwd_bytes, N.ptr(site.bias()))
+    geo = (B, Cin, H, W, Cout, 3, 1, 1, 1, 0.01, N.ptr(None), N.ptr(None), 0, 0.0)
+    N.check(lib.ebfi_conv2d_packed_x3(*args, N.ptr(ref), *geo, st), "x3")
+    f16 = torch.full((B, Cout, H, W), 7.0, dtype=torch.float16, device="cuda")
+    N.check(lib.ebfi_conv2d_packed_x3_c16(*args, N.ptr(None), *geo, N.ptr(f16), book.ptr(i), 1, st), "x3 planar16")
+    assert torch.equal(f16, _p16(ref, 8.0)) and book.amax(i) == ref.abs().max().item()
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout", [(2, 128, 16, 64, 200), (1, 64, 24, 68, 64)])
+def test_backward_convs_stage_planar_fp16_gradients(B, Cin, H, W, Cout):
+    """The data gradient reading a planar fp16 gradient == the fp32-input kernel fed the de-quantised tensor (bit for bit); the
+    weight gradient reading it == the image-reading kernel fed the image of the de-quantised tensor."""
+    from ebfi_amd import c16, f16scale
+    torch.manual_seed(6)
+    w, b, bank, book, site = _banked(Cin, Cout)          # layer Cin -> Cout; its gradients: Cout-channel g, Cin-channel x
+    x = torch.randn(B, Cin, H, W).cuda() * 0.5
+    g = torch.randn(B, Cout, H, W).cuda() * 1e-2
+    sx, sg = book.slot("x"), book.slot("g")
+    book.calibrate(sx, x)
+    book.calibrate(sg, g)
+    g16 = _p16(g, book.scale(sg))
+    gq = g16.float() / book.scale(sg)
+    lib, st = N.lib(), N.stream_ptr(x.device)
+
+    def dgrad(inp, mode, out):
+        N.check(lib.ebfi_conv2d_packed_f16_c16(N.ptr(inp), mode, site.tr16_ptr(), site.tr16_bytes, N.ptr(None), N.ptr(out), B, Cout, H, W, Cin,
+                                               3, 1, 1, 0, 0.0, N.ptr(None), N.ptr(None), 0, 0.0, book.ptr(sg), site.w_slot_ptr(),
+                                               N.ptr(None), N.ptr(None), st), "dgrad")
+    a, r = torch.empty(B, Cin, H, W, device="cuda"), torch.empty(B, Cin, H, W, device="cuda")
+    dgrad(gq, 0, r)
+    dgrad(g16, 2, a)
+    assert torch.equal(a, r)
+    need = int(lib.ebfi_conv2d_backward_weight_workspace(B, Cin, H, W, Cout, 3, 1, 1, N.EBFI_F32))
+    ws = torch.empty(max(need, 4), dtype=torch.uint8, device="cuda")
+    x16 = c16.to_c16(x, book.ptr(sx))
+    gw_a, gb_a = torch.empty(Cout, Cin, 3, 3, device="cuda"), torch.empty(Cout, device="cuda")
+    gw_b, gb_b = torch.empty_like(gw_a), torch.empty_like(gb_a)
+    N.check(lib.ebfi_conv2d_backward_weight_f16c(N.ptr(x16), N.ptr(g16), 1, N.ptr(gw_a), N.ptr(gb_a), B, Cin, H, W, Cout, 1, book.ptr(sx),
+                                                 book.ptr(sg), N.ptr(ws), need, st), "wgrad planar")
+    if Cout % 16 == 0:
+        gimg = c16.to_c16(gq, book.ptr(sg))
+        N.check(lib.ebfi_conv2d_backward_weight_f16c(N.ptr(x16), N.ptr(gimg), 0, N.ptr(gw_b), N.ptr(gb_b), B, Cin, H, W, Cout, 1, book.ptr(sx),
+                                                     book.ptr(sg), N.ptr(ws), need, st), "wgrad image")
+        assert torch.equal(gw_a, gw_b)
+        assert ((gb_a - gb_b).abs().max() / gb_b.abs().max()).item() < 1e-4
+    xq = c16.from_c16(x16, book.scale(sx))
+    ref_w = torch.nn.grad.conv2d_weight(xq.cpu().double(), (Cout, Cin, 3, 3), gq.cpu().double(), padding=1).float()
+    assert ((gw_a.cpu() - ref_w).abs().max() / ref_w.abs().max()).item() < 1e-4
+    ref_b = gq.sum((0, 2, 3))
+    assert ((gb_a - ref_b).abs().max() / ref_b.abs().max()).item() < 1e-4

@@ -375,8 +375,8 @@ def test_fp16_backward_kernels_vs_cpu(B, Cin, H, W, Cout, act, xs, gs):
         conv.set_compute_dtype("fp32")
     # both gradients took the fp16 kernels: the weight gradient in its pixel-major form (transposing LDS reads; with act != 0 it
     # folds act'(y) and writes grad * act' for the data gradient) or, switched, in the pair-word form
-    assert prof.get("conv_wgrad_f16_tr" if force_tr else "conv_wgrad_f16_ws") == 1, prof
-    assert prof.get("conv_fwd_f16_ws", 0) == (1 if Cin >= 48 and W % 4 == 0 else 0), prof   # (narrower data gradients, and rows
+    assert prof.get("conv_wgrad_f16_tr/f32" if force_tr else "conv_wgrad_f16_ws") == 1, prof
+    assert prof.get("conv_fwd_f16_ws/f32_f32", 0) == (1 if Cin >= 48 and W % 4 == 0 else 0), prof   # (narrower data gradients, and rows
     #                                                                       without quads, keep the split-precision form)
     assert "conv_wgrad_x3_ws" not in prof and ("conv_fwd_bf16x3_ws/dgrad" not in prof or W % 4 != 0)
     assert _rel(y.detach(), yr.detach()) < 1e-4             # (the split-precision forward: every tile written exactly once)
