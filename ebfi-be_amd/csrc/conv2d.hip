@@ -104,7 +104,9 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, unsigned byte_o
 // past the descriptor's extent, the bias is fetched as one batch (a missing bias reads zeros from an empty descriptor) and the
 // activation is selected outside the element loop.  The previous per-element `if` chain compiled to ~70 instructions and a
 // dependent bias load per element (4500 instructions per thread), several microseconds per workgroup.
-template <int MT, bool EXTRA = false>
+// XM: which epilogue extras are compiled in (so that a launch pays registers only for what it can use): bit 0 = addend / mask,
+// bit 1 = the fp16 side output (image or planes).  0 = the plain epilogue; `true` from older call sites means bit 0.
+template <int MT, int XM = 0>
 __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const float *__restrict__ bias, const f32x16 (&acc)[MT][2],
                                                const ConvGeom &g, int b, int co_base, int yo, int x0, int lane, int act,
                                                float slope, EpiExtra ex = EpiExtra{nullptr, nullptr, 0, 0.f}, float oscale = 1.f,
@@ -113,16 +115,25 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
     // amax16 (with ex.out16): running |max| of what this wave wrote into the fp16 image (recorded by the caller at the end)
     const int HWo = g.Ho * g.Wo;
     const unsigned plane = (unsigned)HWo * 4u;
+    constexpr bool EXTRA = XM != 0, XAM = (XM & 1) != 0, X16 = (XM & 2) != 0;
+    if constexpr (EXTRA) {
+        // Everything below is derived from `lane` and loop-invariant over the caller's tile walk: left alone, the compiler
+        // computes the per-lane offsets and descriptors once at kernel start, keeps them live across the MFMA main loop (where
+        // the 168-register forward kernel has none to spare) and spills 13-19 of them to scratch.  Laundering the lane id
+        // through an opaque asm pins the address arithmetic inside the epilogue: no scratch (and a kernel that needs scratch
+        // growing mid-stream is what broke the first image-writing builds on non-default streams and in graph replays).
+        asm volatile("" : "+v"(lane));
+    }
     const bool has32 = out != nullptr;
     const float *anyp = bias ? bias : (out ? out : reinterpret_cast<const float *>(ex.slot16));     // base of the empty descriptors
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(has32 ? out + (int64_t)b * g.Cout * HWo : anyp, has32 ? (unsigned)g.Cout * plane : 0u);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(bias ? bias : anyp, bias ? (unsigned)g.Cout * 4u : 0u);
     // the extras: descriptors over the same sample of tensors shaped like the output (absent: empty descriptor, reads 0)
-    const bool has_a = EXTRA && ex.addend != nullptr, has_m = EXTRA && ex.mask_y != nullptr, has16 = EXTRA && ex.out16 != nullptr;
+    const bool has_a = XAM && ex.addend != nullptr, has_m = XAM && ex.mask_y != nullptr, has16 = X16 && ex.out16 != nullptr;
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(has_a ? ex.addend + (int64_t)b * g.Cout * HWo : anyp, has_a ? (unsigned)g.Cout * plane : 0u);
     const __amdgpu_buffer_rsrc_t rm = make_rsrc(has_m ? ex.mask_y + (int64_t)b * g.Cout * HWo : anyp, has_m ? (unsigned)g.Cout * plane : 0u);
     const int cb16 = g.Cout >> 4;                                  // 16-channel blocks of the fp16 image
-    const bool planar = EXTRA && ex.planar16 != 0;
+    const bool planar = X16 && ex.planar16 != 0;
     const __amdgpu_buffer_rsrc_t r16 = __builtin_amdgcn_make_buffer_rsrc(
         has16 ? ex.out16 + (planar ? (int64_t)b * g.Cout * HWo : (int64_t)b * cb16 * HWo * 16)
               : const_cast<_Float16 *>(reinterpret_cast<const _Float16 *>(anyp)), 0,
@@ -133,73 +144,91 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
     auto emit = [&](auto actf) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            float bvm[16];                 // (per 32-row tile: both tiles' biases up front cost 16 more live registers -- spills)
+            [[maybe_unused]] float bvm[16];
+            if constexpr (!EXTRA) {        // (per 32-row tile: both tiles' biases up front cost 16 more live registers)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) bvm[r] = buf_ld(rb, (unsigned)(co_base + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 4u);
+                for (int r = 0; r < 16; ++r) bvm[r] = buf_ld(rb, (unsigned)(co_base + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 4u);
+            }
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const int xo = x0 + n * 32 + l31;
                 const bool px_ok = yo < g.Ho && xo < g.Wo;
                 const unsigned base = (px_ok && co_base + m * 32 + 4 * h < g.Cout)
                                           ? (unsigned)(co_base + m * 32 + 4 * h) * plane + (unsigned)(yo * g.Wo + xo) * 4u : SENT;
-                float v[16];
                 if constexpr (EXTRA) {
-                    float av[16], mv[16];
+                    // Eight values (one 16-channel block of the 32-row tile) at a time, each extra inside its own uniform branch
+                    // with an 8-value temporary: with everything live next to the accumulators the kernels spilled registers to
+                    // scratch (round 4).
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) av[r] = 0.f, mv[r] = 0.f;
-                    if (has_a) {
+                    for (int j = 0; j < 2; ++j) {
+                        float u[8];
+                        auto row_off = [&](int i) { return (unsigned)((i & 3) + 8 * (2 * j + (i >> 2))); };   // row of value i within the tile, minus 4h
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) av[r] = buf_ld(ra, base + (unsigned)((r & 3) + 8 * (r >> 2)) * plane);
-                    }
-                    if (has_m) {
+                        for (int i = 0; i < 8; ++i) u[i] = acc[m][n][8 * j + i] * oscale;
+                        if (bias != nullptr) {
+                            float t[8];
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) mv[r] = buf_ld(rm, base + (unsigned)((r & 3) + 8 * (r >> 2)) * plane);
-                    }
-                    // (LeakyReLU masks only -- the launchers refuse anything else with extras: one code path; mask absent: mv = 0
-                    // would select the slope, so the slope is 1 then)
-                    const float ms = has_m ? ex.mask_slope : 1.f;
+                            for (int i = 0; i < 8; ++i) t[i] = buf_ld(rb, (unsigned)(co_base + m * 32 + 4 * h) * 4u + row_off(i) * 4u);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float t = actf(acc[m][n][r] * oscale + bvm[r] + av[r]);
-                        v[r] = t * ((has_m && mv[r] > 0.f) ? 1.f : ms);
+                            for (int i = 0; i < 8; ++i) u[i] += t[i];
+                        }
+                        if constexpr (XAM) {
+                            if (has_a) {
+                                float t[8];
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) t[i] = buf_ld(ra, base + row_off(i) * plane);
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) u[i] += t[i];
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) u[i] = actf(u[i]);
+                        if constexpr (XAM) {
+                            if (has_m) {           // LeakyReLU masks only (the launchers refuse anything else with extras)
+                                float t[8];
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) t[i] = buf_ld(rm, base + row_off(i) * plane);
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) u[i] *= t[i] > 0.f ? 1.f : ex.mask_slope;
+                            }
+                        }
+                        if (has32) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(u[i]), ro, base + row_off(i) * plane, 0, 0);
+                        }
+                        if constexpr (X16) {
+                            if (has16) {
+                                am = fmaxf(am, fmaxf(fmaxf(fmaxf(fabsf(u[0]), fabsf(u[1])), fmaxf(fabsf(u[2]), fabsf(u[3]))),
+                                                     fmaxf(fmaxf(fabsf(u[4]), fabsf(u[5])), fmaxf(fabsf(u[6]), fabsf(u[7])))));
+                                if (planar) {
+                                    // planes: one 2-byte store per value, lanes = consecutive pixels (64-byte runs per channel)
+                                    const unsigned pb = (px_ok && co_base + m * 32 + 4 * h < g.Cout)
+                                                            ? (unsigned)(co_base + m * 32 + 4 * h) * (unsigned)HWo * 2u + (unsigned)(yo * g.Wo + xo) * 2u : SENT;
+#pragma unroll
+                                    for (int i = 0; i < 8; ++i) {
+                                        const _Float16 hv = (_Float16)(u[i] * s16);
+                                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), r16, pb + row_off(i) * (unsigned)HWo * 2u, 0, 0);
+                                    }
+                                } else {
+                                    const u32x4_c16 q = c16_gather_halves(pack_f16(u[0] * s16, u[1] * s16), pack_f16(u[2] * s16, u[3] * s16),
+                                                                          pack_f16(u[4] * s16, u[5] * s16), pack_f16(u[6] * s16, u[7] * s16));
+                                    const int cblk = ((co_base + m * 32) >> 4) + j;
+                                    // lower lanes: channels 0..7 of 32 consecutive pixels = one 512-byte run, upper lanes: channels 8..15
+                                    const unsigned o16 = (px_ok && cblk < cb16)
+                                                             ? ((unsigned)cblk * (unsigned)HWo * 2u + (unsigned)((yo * 2 + h) * g.Wo + xo)) * 16u : SENT;
+                                    __builtin_amdgcn_raw_buffer_store_b128(q, r16, o16, 0, 0);
+                                }
+                            }
+                        }
+                        // (keeps the scheduler from hoisting the next block's loads over this one: eight unrolled copies of the
+                        // body with their loads batched up front cost 13-19 spilled registers in the 168-register forward kernel)
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = actf(acc[m][n][r] * oscale + bvm[r]);
-                }
-                if (has32) {
-#pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ro, base + (unsigned)((r & 3) + 8 * (r >> 2)) * plane, 0, 0);
-                }
-                if constexpr (EXTRA) {
-                    if (has16 && planar) {
-                        // planes: one 2-byte store per value, lanes = consecutive pixels (64-byte runs per channel)
-                        const unsigned pb = (px_ok && co_base + m * 32 + 4 * h < g.Cout)
-                                                ? (unsigned)(co_base + m * 32 + 4 * h) * (unsigned)HWo * 2u + (unsigned)(yo * g.Wo + xo) * 2u : SENT;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            am = fmaxf(am, fabsf(v[r]));
-                            const _Float16 hv = (_Float16)(v[r] * s16);
-                            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), r16,
-                                                                  pb + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)HWo * 2u, 0, 0);
-                        }
-                    } else if (has16) {
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const float *u = v + 8 * j;             // rows 16 j + {4h..4h+3, 8+4h..8+4h+3} of the 32-row tile
-                            float mx = fmaxf(fmaxf(fmaxf(fabsf(u[0]), fabsf(u[1])), fmaxf(fabsf(u[2]), fabsf(u[3]))),
-                                             fmaxf(fmaxf(fabsf(u[4]), fabsf(u[5])), fmaxf(fabsf(u[6]), fabsf(u[7]))));
-                            am = fmaxf(am, mx);
-                            const u32x4_c16 q = c16_gather_halves(pack_f16(u[0] * s16, u[1] * s16), pack_f16(u[2] * s16, u[3] * s16),
-                                                                  pack_f16(u[4] * s16, u[5] * s16), pack_f16(u[6] * s16, u[7] * s16));
-                            const int cblk = ((co_base + m * 32) >> 4) + j;
-                            // lower lanes: channels 0..7 of 32 consecutive pixels = one 512-byte run, upper lanes: channels 8..15
-                            const unsigned o16 = (px_ok && cblk < cb16)
-                                                     ? ((unsigned)cblk * (unsigned)HWo * 2u + (unsigned)((yo * 2 + h) * g.Wo + xo)) * 16u : SENT;
-                            __builtin_amdgcn_raw_buffer_store_b128(q, r16, o16, 0, 0);
-                        }
-                    }
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(actf(acc[m][n][r] * oscale + bvm[r])), ro,
+                                                              base + (unsigned)((r & 3) + 8 * (r >> 2)) * plane, 0, 0);
                 }
             }
         }
@@ -2325,10 +2354,11 @@ int launch_wgrad_bf16(hipStream_t st, const float *x, const float *gout, const f
 // of the step -0.42 ms.  A first form with FOUR consumer waves (two rows each, single-buffered operands, 254 registers) ran
 // its consumers ALONE at 84-96 % of the real-clock matrix peak but lost it again beside the producers (1.10-1.12 ms).
 constexpr int NTWS = 768;              // conv_fwd_bf16x3_ws: 8 consumer waves + 4 producer waves
-template <bool EXTRA, bool FAC = false>
+template <int XM, bool FAC = false>
 __global__ __launch_bounds__(NTWS) void conv_fwd_bf16x3_ws(const float *__restrict__ x, const __bf16 *__restrict__ wp,
                                                            const float *__restrict__ bias, float *__restrict__ out, ConvGeom g, int K16,
                                                            int act, float slope, EpiExtra epi, int tiles_total, FacEpi fac) {
+    constexpr bool EXTRA = XM != 0;                            // XM: epilogue extras compiled in (store_out_tile)
     constexpr int KS = 3, KK = 9, MT = 2;
     constexpr int IH = TYB - 1 + KS, IW = TX - 1 + KS, PS = IH * IW, COS = 32 * MT;
     constexpr int NCW = 8, PT = 256;                           // consumer waves (one output row each); producer threads
@@ -2427,7 +2457,7 @@ __global__ __launch_bounds__(NTWS) void conv_fwd_bf16x3_ws(const float *__restri
             int cb_, cy0, cx0;
             tile_coords(tcur, cb_, cy0, cx0);
             if constexpr (FAC) fac_epilogue_tile<MT>(out, bias, acc, g, fac, cb_, co_base, cy0 + wave, cx0, lane, slope);
-            else store_out_tile<MT, EXTRA>(out, bias, acc, g, cb_, co_base, cy0 + wave, cx0, lane, act, slope, epi, 1.f, &amax16);
+            else store_out_tile<MT, XM>(out, bias, acc, g, cb_, co_base, cy0 + wave, cx0, lane, act, slope, epi, 1.f, &amax16);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -2632,15 +2662,18 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
         const dim3 pgrid((unsigned)gx, (unsigned)co_blocks);
         if constexpr (KS == 3) {
             if (use_ws) {
-                if (extra) {
-                    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_bf16x3_ws<true>), 160 * 1024)) return rc_;
-                    hipLaunchKernelGGL((conv_fwd_bf16x3_ws<true>), pgrid, dim3(NTWS), lds, st, x, wp, bias, out, g, K16, act, slope, epi,
-                                       (int)tiles, FacEpi{nullptr, 0});
-                } else {
-                    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_bf16x3_ws<false>), 160 * 1024)) return rc_;
-                    hipLaunchKernelGGL((conv_fwd_bf16x3_ws<false>), pgrid, dim3(NTWS), lds, st, x, wp, bias, out, g, K16, act, slope, epi,
-                                       (int)tiles, FacEpi{nullptr, 0});
-                }
+#define EBFI_LAUNCH_X3WS(XM_)                                                                                              \
+    do {                                                                                                                   \
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_bf16x3_ws<XM_>), 160 * 1024)) return rc_; \
+        hipLaunchKernelGGL((conv_fwd_bf16x3_ws<XM_>), pgrid, dim3(NTWS), lds, st, x, wp, bias, out, g, K16, act, slope, epi,  \
+                           (int)tiles, FacEpi{nullptr, 0});                                                               \
+    } while (0)
+                const bool xam = epi.addend != nullptr || epi.mask_y != nullptr, x16 = epi.out16 != nullptr;
+                if (xam && x16) EBFI_LAUNCH_X3WS(3);
+                else if (x16) EBFI_LAUNCH_X3WS(2);
+                else if (xam) EBFI_LAUNCH_X3WS(1);
+                else EBFI_LAUNCH_X3WS(0);
+#undef EBFI_LAUNCH_X3WS
                 return check_launch(name);
             }
         }
@@ -3348,8 +3381,8 @@ extern "C" int ebfi_kernelconv_fac_fused_x3(const void *input, const void *packe
     const double flops = 2.0 * B * g.Ho * g.Wo * (double)(C * 25) * Cin * 9 + 2.0 * B * g.Ho * g.Wo * (double)C * 25;
     const double bytes = 4.0 * B * (double)g.Ho * g.Wo * (Cin + 2.0 * C);      // conv input + feature map + output: no filter tensor
     ProfScope ps("conv_fwd_bf16x3_ws/kernelconv_fac", st, flops, bytes);
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_bf16x3_ws<false, true>), 160 * 1024)) return rc;
-    hipLaunchKernelGGL((conv_fwd_bf16x3_ws<false, true>), dim3((unsigned)gx, (unsigned)co_blocks), dim3(NTWS), lds, st,
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_bf16x3_ws<0, true>), 160 * 1024)) return rc;
+    hipLaunchKernelGGL((conv_fwd_bf16x3_ws<0, true>), dim3((unsigned)gx, (unsigned)co_blocks), dim3(NTWS), lds, st,
                        static_cast<const float *>(input), static_cast<const __bf16 *>(packed), static_cast<const float *>(bias32),
                        static_cast<float *>(output), g, K16, ACT_LEAKY, slope, EpiExtra{nullptr, nullptr, 0, 0.f}, (int)tiles,
                        FacEpi{static_cast<const float *>(feat), C});

@@ -146,8 +146,8 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
             // (written out per row: as a loop the EXTRA variant was not unrolled, `acc[r]` became a runtime index and the whole
             // accumulator array moved to scratch memory -- 410 instead of 45 us per launch)
             static_assert(RW == 2, "epilogue is written out for two rows");
-            store_out_tile<MT, EXTRA>(out, bias, acc[0], g, cb_, co_base, cy0 + RW * wave, cx0, lane, act, slope, epi, oscale, &amax16);
-            store_out_tile<MT, EXTRA>(out, bias, acc[1], g, cb_, co_base, cy0 + RW * wave + 1, cx0, lane, act, slope, epi, oscale, &amax16);
+            store_out_tile<MT, EXTRA ? 3 : 0>(out, bias, acc[0], g, cb_, co_base, cy0 + RW * wave, cx0, lane, act, slope, epi, oscale, &amax16);
+            store_out_tile<MT, EXTRA ? 3 : 0>(out, bias, acc[1], g, cb_, co_base, cy0 + RW * wave + 1, cx0, lane, act, slope, epi, oscale, &amax16);
 #pragma unroll
             for (int r = 0; r < RW; ++r)
 #pragma unroll

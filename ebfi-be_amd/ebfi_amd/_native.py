@@ -140,6 +140,15 @@ def build(verbose=False):
     return LIB_PATH
 
 
+def _counted(fn, name, n):
+    def call(*a):
+        if len(a) != n:
+            raise TypeError("%s takes %d arguments (include/ebfi_hip.h), %d given" % (name, n, len(a)))
+        return fn(*a)
+    call.__name__ = name
+    return call
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -162,6 +171,10 @@ def lib():
                 raise EbfiNativeError("%s does not export %s" % (LIB_PATH, name)) from e
             fn.restype = res
             fn.argtypes = args
+            # ctypes accepts EXTRA positional arguments silently (they are passed after the declared ones and ignored by the
+            # callee): a stray argument in front of the stream pointer put every image-reading data gradient on the NULL
+            # stream for two hours of round 4.  Every entry point is therefore called through a wrapper that checks the count.
+            setattr(h, name, _counted(fn, name, len(args)))
         if h.ebfi_abi_version() != ABI_VERSION:
             raise EbfiNativeError("ABI version mismatch: library %d, binding %d" % (h.ebfi_abi_version(), ABI_VERSION))
         _lib = h

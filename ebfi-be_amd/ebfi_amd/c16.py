@@ -16,6 +16,8 @@ def empty(B, C, H, W, device):
         raise ValueError("c16 images hold multiples of 16 channels (got %d)" % C)
     if W % 4 != 0:
         raise ValueError("c16 images need rows of whole pixel quads (W = %d)" % W)
+    if N.dev_env("EBFI_C16_POISON") == "1":            # (development: every element a writer misses shows up as NaN)
+        return torch.full((B, C // 16, H, 2, W, 8), float("nan"), dtype=torch.float16, device=device)
     return torch.empty((B, C // 16, H, 2, W, 8), dtype=torch.float16, device=device)
 
 

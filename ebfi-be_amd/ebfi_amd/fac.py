@@ -125,3 +125,89 @@ class KernelConv2D(nn.Module):
 
     def forward(self, input, kernel, kernel_leaky_slope=None):
         return KernelConv2DFunction.apply(self.pad(input), kernel, self.kernel_size, kernel_leaky_slope)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Training form of KernelConv -> FAC: the two [B, 1600, h, w] tensors of the pair -- the filters and
+# their gradient -- exist only as PLANAR fp16 tensors scaled by a power of two (csrc/fac.hip, include/ebfi_hip.h):
+#   forward   conv 128 -> 1600 + LeakyReLU writes the filters as fp16 planes (no fp32 output), the FAC forward reads them;
+#   backward  the FAC backward reads them again and writes grad_kernel (times the LeakyReLU derivative) as fp16 planes; the
+#             weight gradient and the data gradient of the convolution stage those planes.
+# 4.2 GB of fp32 traffic per step (B=8, 256x256) become 2.1 GB.  The forward sees filters rounded to 11 significant bits:
+# Sharp moves by 4e-5 and the packed gradient by 1.7e-3 of its norm (oracle experiment) -- inside the parity
+# bars (1e-3 / 5e-3), which tests/test_gpu_model.py::test_benchmarked_step_vs_oracle holds for the whole step.
+def kernelconv_fac_train_usable(site, book, cat, ev, ksize):
+    if site is None or book is None or N.dev_env("EBFI_NO_C16", "0") == "1" or N.dev_env("EBFI_NO_P16", "0") == "1":
+        return False
+    B, Cin, H, W = cat.shape
+    if not (cat.is_cuda and cat.dtype == torch.float32 and ksize == 5 and W % 4 == 0 and Cin % 16 == 0 and site.ks == 3 and
+            site.groups == 1 and site.has_bias and site.tr16_ptr() is not None and B * ev.shape[1] <= 65535 and
+            site.M == ev.shape[1] * ksize * ksize):
+        return False
+    return all(book.index.get((site.key, r)) in book.calibrated for r in ("x", "g", "f"))
+
+
+class KernelConvFacTrain(Function):
+    """apply(cat, ev, site, slope, ksize, weight, bias) -> FAC(ReplicationPad(ev), LeakyReLU(conv3x3(cat))).
+    weight / bias: the KernelConv parameters (inputs only so that autograd routes their gradients; values come from the bank)."""
+
+    @staticmethod
+    def forward(ctx, cat, ev, site, slope, ksize, weight, bias):
+        from . import c16, f16scale
+        book = f16scale.active_book()
+        cat, ev = cat.contiguous(), ev.contiguous()
+        B, Cin, H, W = (int(v) for v in cat.shape)
+        C = int(ev.shape[1])
+        lib = N.lib()
+        sp = lambda role: book.ptr(book.slot((site.key, role)))
+        filt16 = torch.empty((B, site.M, H, W), dtype=torch.float16, device=cat.device)
+        with torch.cuda.device_of(cat):
+            st = N.stream_ptr(cat.device)
+            rc = lib.ebfi_conv2d_packed_x3_c16(N.ptr(cat), site.fwd_ptr(), site.fwd_bytes, N.ptr(site.bias()), N.ptr(None), B, Cin, H, W,
+                                               site.M, 3, 1, 1, 1, float(slope), N.ptr(None), N.ptr(None), 0, 0.0, N.ptr(filt16), sp("f"),
+                                               1, st)
+            N.check(rc, "ebfi_conv2d_packed_x3_c16 (planar fp16 filters)")
+            r = ksize // 2
+            evp = torch.nn.functional.pad(ev, (r, r, r, r), mode="replicate")
+            out = torch.empty_like(ev)
+            N.check(lib.ebfi_fac_forward_p16(N.ptr(evp), N.ptr(filt16), sp("f"), N.ptr(out), B, C, H, W, int(ksize), st), "ebfi_fac_forward_p16")
+            cat16 = c16.to_c16(cat, sp("x"))          # the weight gradient's input operand (cat itself is not needed again)
+        ctx.site, ctx.cfg = site, (float(slope), int(ksize), B, Cin, C, H, W)
+        ctx.save_for_backward(cat16, evp, filt16)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        from . import f16scale
+        cat16, evp, filt16 = ctx.saved_tensors
+        site, (slope, ksize, B, Cin, C, H, W) = ctx.site, ctx.cfg
+        book = f16scale.active_book()
+        if book is None:
+            raise RuntimeError("KernelConv -> FAC ran its forward with fp16 filter storage: backward() must run inside the same "
+                               "scale-book context (Engine._fwd_bwd)")
+        gout = gout.contiguous()
+        lib = N.lib()
+        sp = lambda role: book.ptr(book.slot((site.key, role)))
+        dev = gout.device
+        with torch.cuda.device_of(gout):
+            st = N.stream_ptr(dev)
+            gevp = torch.empty_like(evp)
+            gk16 = torch.empty_like(filt16)
+            N.check(lib.ebfi_fac_backward_p16(N.ptr(evp), N.ptr(filt16), sp("f"), N.ptr(gout), N.ptr(gevp), N.ptr(gk16), sp("g"), slope,
+                                              B, C, H, W, ksize, st), "ebfi_fac_backward_p16")
+            r = ksize // 2
+            # (adjoint of the replicate padding; `gout` only lends its shape [B, C, H, W])
+            gev = torch.ops.aten.replication_pad2d_backward(gevp, gout, [r, r, r, r]) if ctx.needs_input_grad[1] else None
+            gw = torch.empty((site.M, Cin, 3, 3), dtype=torch.float32, device=dev)
+            gb = torch.empty(site.M, dtype=torch.float32, device=dev)
+            need = int(lib.ebfi_conv2d_backward_weight_workspace(B, Cin, H, W, site.M, 3, 1, 1, N.EBFI_F32))
+            ws = torch.empty(max(need, 4), dtype=torch.uint8, device=dev)
+            N.check(lib.ebfi_conv2d_backward_weight_f16c(N.ptr(cat16), N.ptr(gk16), 1, N.ptr(gw), N.ptr(gb), B, Cin, H, W, site.M, 1, sp("x"),
+                                                         sp("g"), N.ptr(ws), need, st), "ebfi_conv2d_backward_weight_f16c (planar)")
+            gcat = None
+            if ctx.needs_input_grad[0]:
+                gcat = torch.empty((B, Cin, H, W), dtype=torch.float32, device=dev)
+                N.check(lib.ebfi_conv2d_packed_f16_c16(N.ptr(gk16), 2, site.tr16_ptr(), site.tr16_bytes, N.ptr(None), N.ptr(gcat), B, site.M, H,
+                                                       W, Cin, 3, 1, 1, 0, 0.0, N.ptr(None), N.ptr(None), 0, 0.0, sp("g"), site.w_slot_ptr(),
+                                                       N.ptr(None), N.ptr(None), st), "ebfi_conv2d_packed_f16_c16 (planar)")
+        return gcat, gev, None, None, None, gw, gb

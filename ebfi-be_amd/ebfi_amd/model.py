@@ -232,11 +232,22 @@ class Modification(BaseModel):
             return FrameTensor * ev1 + self.Conv2(ev1)
         fuse = self.KernelConv.native(cat)
         import os
+        from . import f16scale, fac as facmod, weightbank
+        book = f16scale.active_book()
+        c = self.KernelConv.conv2d
+        site = weightbank.lookup(c.weight, "id") if (book is not None and conv.get_compute_dtype() == "bf16x3") else None
+        if fuse is not None and fuse[0] == conv.ACT_LEAKY and torch.is_grad_enabled() and \
+                facmod.kernelconv_fac_train_usable(site, book, cat, ev, self.KPN.kernel_size):
+            # training step with the fp16 backward: the filters and their gradient exist only as fp16 planes (ebfi_amd.fac)
+            ev1 = self.Conv3(facmod.KernelConvFacTrain.apply(cat, ev, site, fuse[1], self.KPN.kernel_size, c.weight, c.bias))
+            return FrameTensor * ev1 + self.Conv2(ev1)
         if fuse is not None and fuse[0] == conv.ACT_LEAKY and ev.is_cuda and N.dev_env("EBFI_NO_PREACT", "0") != "1":
             # the 1600-channel filter tensor has one consumer, the FAC op: its backward returns the gradient of the filters'
             # PRE-activation (kernel > 0 ? g : slope*g), so the 128 -> 1600 conv's weight / data gradient neither re-read the
             # 839 MB saved output for act' nor write / read a grad*act' side tensor of that size
             filters = self.KernelConv(cat, grad_is_preact=True)
+            if site is not None and torch.is_grad_enabled():
+                book.operand((site.key, "f"), filters)        # (calibration pass: the scale the fp16 filter planes will carry)
             ev1 = self.Conv3(self.KPN(ev, filters, kernel_leaky_slope=fuse[1]))
         else:
             ev1 = self.Conv3(self.KPN(ev, self.KernelConv(cat)))
