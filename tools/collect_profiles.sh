@@ -42,4 +42,7 @@ echo "[6c] train_ours.py steady-state rate (device-side synthetic batches, hipGr
 ( cd ebfi-be_amd && timeout -k 10 300 python train_ours.py --graph --iterations 120 ) > $OUT/train_ours_1gpu.log 2>&1; tail -2 $OUT/train_ours_1gpu.log
 echo "[7] two-rank rehearsal of the bench (both ranks on this GPU, gloo)"
 EBFI_BENCH_REHEARSAL=1 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs > $OUT/bench_2rank_rehearsal.out 2> $OUT/bench_2rank_rehearsal.err; grep '^{' $OUT/bench_2rank_rehearsal.out > $OUT/bench_2rank_rehearsal.json; cut -c1-160 $OUT/bench_2rank_rehearsal.json   # (gloo prints a connection banner on stdout)
+echo "[8] fp16 operand storage: readers / writers of the images in isolation; the detail branch by kernel"
+timeout -k 10 200 python tools/c16bench.py > $OUT/c16bench.log 2>&1 || true; tail -4 $OUT/c16bench.log
+timeout -k 10 200 python tools/detailprof.py > $OUT/detailprof.log 2>&1 || true; head -3 $OUT/detailprof.log
 du -sh $OUT

@@ -30,4 +30,6 @@ grep -v amdgpu.ids $S/train_ours_1gpu.log > $D/train_ours_1gpu.log
 grep -v amdgpu.ids $S/f16bench.log > $D/f16bench_final.log || true
 cp $S/bench_2rank_rehearsal.json $D/bench_final_2rank_rehearsal.json
 grep -v amdgpu.ids $S/smoke.log > $D/smoke_final.log
+grep -v amdgpu.ids $S/c16bench.log > $D/c16bench_final.log || true
+grep -v "amdgpu.ids\|Warning\|_warn_once" $S/detailprof.log > $D/detail_branch_by_kernel.txt || true
 echo "published $S -> $D"
