@@ -9,14 +9,14 @@ export TMPDIR=/tmp
 echo "[1] smoke"; timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 echo "[2] bench (default, with cpu baseline)"; timeout -k 10 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cut -c1-160 $OUT/bench.json
 echo "[3] rocprofv3 kernel stats of the bench command"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs > $OUT/bench_prof.json 2> $OUT/bench_prof.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs --no-inference --no-ops > $OUT/bench_prof.json 2> $OUT/bench_prof.err
 find $OUT/prof -name "*kernel_trace*" -delete; find $OUT/prof -name "*.csv" | head
 echo "[3b] timeline of graph-replayed steps"
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o g -- python3 tools/graphprof.py --steps 12 > $OUT/graphprof.log 2>&1
 f=$(find $OUT/trace -name "*kernel_trace.csv" | head -1); python3 tools/trace_summary.py $f auto > $OUT/graph_replay_timeline.txt; rm -rf $OUT/trace; head -5 $OUT/graph_replay_timeline.txt
 echo "[4] PMC passes (eager launches), FETCH_SIZE then WRITE_SIZE"
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs --no-graph > /dev/null 2> $OUT/pmc_$C.err
+  timeout -k 10 400 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs --no-inference --no-ops --no-graph > /dev/null 2> $OUT/pmc_$C.err
 done
 python3 tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE > $OUT/pmc_traffic_summary.json; cat $OUT/pmc_traffic_summary.json | head -30
 rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
