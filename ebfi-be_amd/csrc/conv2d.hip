@@ -3397,27 +3397,32 @@ extern "C" int ebfi_conv2d_packed_f16_c16(const void *input, int input_is_c16, c
                                           const void *bias, void *output, int B, int Cin_per_group, int H, int W, int Cout, int ksize,
                                           int pad, int groups, int act, float slope, const void *addend, const void *mask_y,
                                           int mask_act, float mask_slope, void *in_slot, const void *w_slot, void *out16,
-                                          void *slot16, void *stream);
+                                          void *slot16, int out16_planar, void *stream);
 extern "C" int ebfi_conv2d_packed_f16(const void *input, const void *packed16, size_t packed_bytes, const void *bias, void *output,
                                       int B, int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups, int act,
                                       float slope, const void *addend, const void *mask_y, int mask_act, float mask_slope,
                                       void *in_slot, const void *w_slot, void *stream) {
     if (!output) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: null argument");
     return ebfi_conv2d_packed_f16_c16(input, 0, packed16, packed_bytes, bias, output, B, Cin_per_group, H, W, Cout, ksize, pad, groups,
-                                      act, slope, addend, mask_y, mask_act, mask_slope, in_slot, w_slot, nullptr, nullptr, stream);
+                                      act, slope, addend, mask_y, mask_act, mask_slope, in_slot, w_slot, nullptr, nullptr, 0, stream);
 }
 
 // Same with fp16 operand STORAGE (round 4, c16.hpp): input_is_c16 != 0: `input` is the scaled fp16 image
 // [B][groups*Cin/16][H][W][16] of the tensor, written by its producer with in_slot's scale (Cin_per_group % 16 == 0);
-// out16 / slot16: the output as such an image for the next backward kernel -- in addition to `output`, or alone (output NULL).
+// out16 / slot16: the output as such an image for the next backward kernel -- in addition to `output`, or alone (output NULL);
+// out16_planar != 0: as PLANAR fp16 [B][Cout][H][W] instead (the FAC filters; `output` must then be NULL).
+// With a site's FORWARD fp16 weight image this is the fp16-operand forward convolution (bias + LeakyReLU in the epilogue).
 extern "C" int ebfi_conv2d_packed_f16_c16(const void *input, int input_is_c16, const void *packed16, size_t packed_bytes,
                                           const void *bias, void *output, int B, int Cin_per_group, int H, int W, int Cout, int ksize,
                                           int pad, int groups, int act, float slope, const void *addend, const void *mask_y,
                                           int mask_act, float mask_slope, void *in_slot, const void *w_slot, void *out16,
-                                          void *slot16, void *stream) {
+                                          void *slot16, int out16_planar, void *stream) {
     if (!input || !packed16 || (!output && !out16)) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: null argument");
     if ((out16 != nullptr) != (slot16 != nullptr)) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: out16 and slot16 come together");
-    if (out16 && (Cout % 16 != 0 || !aligned16(out16))) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_f16: fp16 output image needs Cout %% 16 == 0");
+    if (out16 && !out16_planar && (Cout % 16 != 0 || !aligned16(out16)))
+        return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_f16: fp16 output image needs Cout %% 16 == 0");
+    if (out16_planar && (!out16 || output || W % 4 != 0 || !aligned16(out16)))
+        return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_f16: planar fp16 output comes alone (output NULL), W %% 4 == 0");
     // input_is_c16: 0 = fp32 NCHW, 1 = c16 image, 2 = planar fp16 [B, groups*Cin, H, W] (scaled by in_slot like an image)
     if (input_is_c16 < 0 || input_is_c16 > 2) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: input storage %d", input_is_c16);
     if (input_is_c16 == 1 && (Cin_per_group % 16 != 0 || !in_slot))
@@ -3442,7 +3447,7 @@ extern "C" int ebfi_conv2d_packed_f16_c16(const void *input, int input_is_c16, c
     if ((addend || mask_y || out16) && (act == ACT_SIGMOID || mask_act == ACT_SIGMOID))
         return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_f16: the epilogue extras take LeakyReLU / no activation only");
     const EpiExtra epi{static_cast<const float *>(addend), mask_act == ACT_LEAKY ? static_cast<const float *>(mask_y) : nullptr, mask_act,
-                       mask_slope, static_cast<_Float16 *>(out16), static_cast<float *>(slot16)};
+                       mask_slope, static_cast<_Float16 *>(out16), static_cast<float *>(slot16), out16_planar ? 1 : 0};
     const int64_t tiles = (int64_t)B * ceil_div(g.Ho, TYB) * ceil_div(g.Wo, TX);
     if (tiles > 2147483647LL) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: too many tiles");
     constexpr int PSX = (TYB - 1 + 3) * (TX - 1 + 3);
@@ -3459,7 +3464,7 @@ extern "C" int ebfi_conv2d_packed_f16_c16(const void *input, int input_is_c16, c
     const double io_bytes = px * g.groups * g.Cin * (input_is_c16 ? 2.0 : 4.0) + px * g.Cout * ((output ? 4.0 : 0.0) + (out16 ? 2.0 : 0.0)) +
                             px * g.Cout * ((addend ? 4.0 : 0.0) + (mask_y ? 4.0 : 0.0)) + 2.0 * 9 * (double)g.Cout * g.Cin;
     // (label = kernel symbol / role: which operand storage the launch read and wrote)
-    ProfScope ps(input_is_c16 == 2 ? "conv_fwd_f16_ws/p16_f32" :
+    ProfScope ps(input_is_c16 == 2 ? "conv_fwd_f16_ws/p16_f32" : out16_planar ? (input_is_c16 ? "conv_fwd_f16_ws/img_p16" : "conv_fwd_f16_ws/f32_p16") :
                  input_is_c16 ? (out16 ? (output ? "conv_fwd_f16_ws/img_both" : "conv_fwd_f16_ws/img_img") : "conv_fwd_f16_ws/img_f32")
                               : (out16 ? "conv_fwd_f16_ws/f32_img" : "conv_fwd_f16_ws/f32_f32"), st, flops, io_bytes);
     const ScaleSlot isl{static_cast<float *>(in_slot)};

@@ -211,9 +211,11 @@ __global__ __launch_bounds__(256) void src_fwd_c16_kernel(const float *__restric
         f4 v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = pa[e * HW4] * ps[e] + px[e * HW4];
-        f4 *o = reinterpret_cast<f4 *>(out) + (b * 2 * C + co) * HW4 + q;
+        if (out) {                                                // (uniform: the fp32 copy is optional)
+            f4 *o = reinterpret_cast<f4 *>(out) + (b * 2 * C + co) * HW4 + q;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e * HW4] = v[e];
+            for (int e = 0; e < 8; ++e) o[e * HW4] = v[e];
+        }
         c16_store_quad(out16, c16_piece(b, 2 * C / 16, cg / 2, HW4, q, W4, (int)(cg & 1)), v, slot[0], amax);
     }
     ScaleSlot{slot}.record(amax);
@@ -389,7 +391,8 @@ extern "C" int ebfi_scale_residual_cat_forward_c16(const float *a0, const float 
                                                    float *out, void *out16, void *slot, int B, int C, int H, int W,
                                                    int64_t a_batch_stride, void *stream) {
     const int64_t HW = (int64_t)H * W;
-    if (!a0 || !s0 || !a1 || !s1 || !x || !out || !out16 || !slot) return fail(EBFI_ERR_ARG, "scale_residual_cat_forward_c16: null argument");
+    // `out` may be NULL: the image alone (the convolution that follows reads fp16 operand images in its forward pass too)
+    if (!a0 || !s0 || !a1 || !s1 || !x || !out16 || !slot) return fail(EBFI_ERR_ARG, "scale_residual_cat_forward_c16: null argument");
     if (W % 4 != 0) return fail(EBFI_ERR_UNSUPPORTED, "scale_residual_cat_forward_c16: W %% 4 != 0 (W = %d)", W);
     if (a_batch_stride % 4 != 0 || a_batch_stride < (int64_t)C * HW) return fail(EBFI_ERR_ARG, "scale_residual_cat_forward_c16: batch stride");
     if (C % 8 != 0) return fail(EBFI_ERR_UNSUPPORTED, "scale_residual_cat_forward_c16: %d channels (multiples of 8)", C);
@@ -398,7 +401,7 @@ extern "C" int ebfi_scale_residual_cat_forward_c16(const float *a0, const float 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t total = (int64_t)B * (2 * C / 8) * (HW / 4);
     {
-        ProfScope ps("scale_residual_cat_fwd", st, 0.0, 24.0 * B * C * (double)HW);
+        ProfScope ps("scale_residual_cat_fwd", st, 0.0, (out ? 24.0 : 16.0) * B * C * (double)HW);
         hipLaunchKernelGGL(src_fwd_c16_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, a0, s0, a1, s1, x, out,
                            static_cast<_Float16 *>(out16), static_cast<float *>(slot), C, HW / 4, W / 4, total, a_batch_stride / 4);
     }

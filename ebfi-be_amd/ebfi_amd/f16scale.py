@@ -48,6 +48,7 @@ class ScaleBook:
         self.guard = torch.zeros(2, dtype=torch.int32, device=self.device)   # [flag of the current step, skipped steps]
         self.index = {}
         self.calibrated = set()
+        self.forward_f16 = None         # Engine(forward_f16=...): None | "filters" | "all" -- which forward convolutions read fp16 operands
 
     def slot(self, key):
         """Index of the slot named `key` (created on first use; keys are any hashable: (site key, role))."""

@@ -163,15 +163,23 @@ class KernelConvFacTrain(Function):
         filt16 = torch.empty((B, site.M, H, W), dtype=torch.float16, device=cat.device)
         with torch.cuda.device_of(cat):
             st = N.stream_ptr(cat.device)
-            rc = lib.ebfi_conv2d_packed_x3_c16(N.ptr(cat), site.fwd_ptr(), site.fwd_bytes, N.ptr(site.bias()), N.ptr(None), B, Cin, H, W,
-                                               site.M, 3, 1, 1, 1, float(slope), N.ptr(None), N.ptr(None), 0, 0.0, N.ptr(filt16), sp("f"),
-                                               1, st)
-            N.check(rc, "ebfi_conv2d_packed_x3_c16 (planar fp16 filters)")
+            cat16 = c16.to_c16(cat, sp("x"))          # the weight gradient's input operand (cat itself is not needed again)
+            if book.forward_f16 in ("filters", "all") and site.fwd16_ptr() is not None:
+                # fp16-operand forward (Engine(forward_f16=...)): the convolution reads the image the weight gradient will read
+                # and the site's fp16 forward weight image -- one matrix-core product per tap instead of three
+                rc = lib.ebfi_conv2d_packed_f16_c16(N.ptr(cat16), 1, site.fwd16_ptr(), site.fwd16_bytes, N.ptr(site.bias()), N.ptr(None),
+                                                    B, Cin, H, W, site.M, 3, 1, 1, 1, float(slope), N.ptr(None), N.ptr(None), 0, 0.0,
+                                                    sp("x"), site.w_slot_ptr(), N.ptr(filt16), sp("f"), 1, st)
+                N.check(rc, "ebfi_conv2d_packed_f16_c16 (planar fp16 filters)")
+            else:
+                rc = lib.ebfi_conv2d_packed_x3_c16(N.ptr(cat), site.fwd_ptr(), site.fwd_bytes, N.ptr(site.bias()), N.ptr(None), B, Cin, H,
+                                                   W, site.M, 3, 1, 1, 1, float(slope), N.ptr(None), N.ptr(None), 0, 0.0, N.ptr(filt16),
+                                                   sp("f"), 1, st)
+                N.check(rc, "ebfi_conv2d_packed_x3_c16 (planar fp16 filters)")
             r = ksize // 2
             evp = torch.nn.functional.pad(ev, (r, r, r, r), mode="replicate")
             out = torch.empty_like(ev)
             N.check(lib.ebfi_fac_forward_p16(N.ptr(evp), N.ptr(filt16), sp("f"), N.ptr(out), B, C, H, W, int(ksize), st), "ebfi_fac_forward_p16")
-            cat16 = c16.to_c16(cat, sp("x"))          # the weight gradient's input operand (cat itself is not needed again)
         ctx.site, ctx.cfg = site, (float(slope), int(ksize), B, Cin, C, H, W)
         ctx.save_for_backward(cat16, evp, filt16)
         return out
@@ -209,5 +217,5 @@ class KernelConvFacTrain(Function):
                 gcat = torch.empty((B, Cin, H, W), dtype=torch.float32, device=dev)
                 N.check(lib.ebfi_conv2d_packed_f16_c16(N.ptr(gk16), 2, site.tr16_ptr(), site.tr16_bytes, N.ptr(None), N.ptr(gcat), B, site.M, H,
                                                        W, Cin, 3, 1, 1, 0, 0.0, N.ptr(None), N.ptr(None), 0, 0.0, sp("g"), site.w_slot_ptr(),
-                                                       N.ptr(None), N.ptr(None), st), "ebfi_conv2d_packed_f16_c16 (planar)")
+                                                       N.ptr(None), N.ptr(None), 0, st), "ebfi_conv2d_packed_f16_c16 (planar)")
         return gcat, gev, None, None, None, gw, gb

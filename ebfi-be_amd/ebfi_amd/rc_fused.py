@@ -151,7 +151,16 @@ def _conv16(lib, st, x, site, bias, out, B, cin_g, H, W, cout, groups, slope, ou
                                        groups, ACT, slope, N.ptr(None), N.ptr(None), 0, 0.0, N.ptr(out16),
                                        slot16 if out16 is not None else N.ptr(None), 0, st)
     N.check(rc, "ebfi_conv2d_packed_x3_c16")
-    _sync("fwd")
+
+
+def _fconv16(lib, st, x16, site, B, cin_g, H, W, cout, groups, slope, book, out=None, out16=None, slot16=None):
+    """fp16-operand FORWARD convolution + bias + LeakyReLU from the image of its input (scale slot (site, 'x')) on the site's
+    fp16 forward weight image; the result as fp32 (`out`) and / or as the next layer's input image (`out16`, `slot16`)."""
+    rc = lib.ebfi_conv2d_packed_f16_c16(N.ptr(x16), 1, site.fwd16_ptr(), site.fwd16_bytes, N.ptr(site.bias()), N.ptr(out), B, cin_g, H, W,
+                                        cout, 3, 1, groups, ACT, slope, N.ptr(None), N.ptr(None), 0, 0.0,
+                                        book.ptr(book.slot((site.key, "x"))), site.w_slot_ptr(), N.ptr(out16),
+                                        slot16 if out16 is not None else N.ptr(None), 0, st)
+    N.check(rc, "ebfi_conv2d_packed_f16_c16")
 
 
 def _wgrad16(lib, st, x16, g16, B, cin_g, H, W, cout, groups, ws_cache, book, site):
@@ -166,7 +175,6 @@ def _wgrad16(lib, st, x16, g16, B, cin_g, H, W, cout, groups, ws_cache, book, si
                                               book.ptr(book.slot((site.key, "x"))), book.ptr(book.slot((site.key, "g"))),
                                               N.ptr(ws), need, st)
     N.check(rc, "ebfi_conv2d_backward_weight_f16c")
-    _sync("wgrad")
     return gw, gb
 
 
@@ -176,33 +184,8 @@ def _dgrad16(lib, st, g16, site, B, cin_g, H, W, cout, groups, slope, book, out=
     rc = lib.ebfi_conv2d_packed_f16_c16(N.ptr(g16), 1, site.tr16_ptr(), site.tr16_bytes, N.ptr(None), N.ptr(out), B, cin_g, H, W, cout,
                                         3, 1, groups, 0, slope, N.ptr(addend), N.ptr(mask), ACT if mask is not None else 0,
                                         slope if mask is not None else 0.0, book.ptr(book.slot((site.key, "g"))), site.w_slot_ptr(),
-                                        N.ptr(out16), slot16 if out16 is not None else N.ptr(None), st)
+                                        N.ptr(out16), slot16 if out16 is not None else N.ptr(None), 0, st)
     N.check(rc, "ebfi_conv2d_packed_f16_c16")
-    _sync("dgrad")
-
-
-TRACE = []           # (development, EBFI_DEV=1 EBFI_C16_TRACE=1: (name, count of non-finite elements) per tensor of the image path)
-
-
-def _sync(kind="x"):
-    v = N.dev_env("EBFI_C16_SYNC")
-    if v == "1" or (v is not None and kind in v.split(",")):
-        torch.cuda.synchronize()
-    if v is not None and "cur" in v.split(",") and kind in ("wgrad", "dgrad", "srcb"):
-        torch.cuda.current_stream().synchronize()
-    if v is not None and "def" in v.split(",") and kind in ("wgrad", "dgrad", "srcb"):
-        torch.cuda.default_stream().synchronize()
-    if v is not None and "sleep" in v.split(",") and kind in ("wgrad", "dgrad", "srcb"):
-        import time
-        time.sleep(0.002)
-    if v is not None and "show" in v.split(",") and kind in ("wgrad", "fwd"):
-        import threading
-        print("   [%s] thread %s current stream %#x" % (kind, threading.current_thread().name, torch.cuda.current_stream().cuda_stream), flush=True)
-
-
-def _dbg(name, t):
-    if N.dev_env("EBFI_C16_TRACE") == "1" and t is not None:
-        TRACE.append((name, (~torch.isfinite(t.float())).sum(), t.float().abs().max(), t if name.endswith("b11.ga16") or name.endswith("b11.gb16") else None))
 
 
 class ResidualControlFn(Function):
@@ -231,19 +214,30 @@ class ResidualControlFn(Function):
                 img = lambda ch: c16.empty(B, ch, H, W, x.device)
                 sp = lambda site, role: book.ptr(book.slot((site.key, role)))
                 x16 = c16.to_c16(x, sp(sites[0][0], "x"))
+                f16fwd = book.forward_f16 == "all" and all(t.fwd16_ptr() is not None for r in sites for t in r)
                 for i, (sa, sb, sc) in enumerate(sites):
-                    ya, a, c, xn = new(2 * C), new(2 * C), new(2 * C), new(C)
-                    ya16, c16i = img(2 * C), img(2 * C)
                     nxt = sites[i + 1][0] if i + 1 < len(sites) else None
+                    ya, a, xn = new(2 * C), new(2 * C), new(C)
+                    ya16, c16i = img(2 * C), img(2 * C)
                     xn16 = img(C) if nxt is not None else None
-                    _conv16(lib, st, x, sa, sa.bias(), ya, B, C, H, W, 2 * C, 1, slope, ya16, sp(sb, "x"))
-                    _conv(lib, st, ya, sb.fwd_ptr(), sb.fwd_bytes, sb.bias(), a, B, C, H, W, 2 * C, 2, ACT, slope)
+                    if f16fwd:
+                        # fp16-operand forward: every convolution reads the image its producer wrote (the same images the
+                        # weight gradients read later) -- one matrix-core product per tap instead of three, half the input bytes
+                        _fconv16(lib, st, x16, sa, B, C, H, W, 2 * C, 1, slope, book, out=ya, out16=ya16, slot16=sp(sb, "x"))
+                        _fconv16(lib, st, ya16, sb, B, C, H, W, 2 * C, 2, slope, book, out=a)
+                        c = None
+                    else:
+                        c = new(2 * C)
+                        _conv16(lib, st, x, sa, sa.bias(), ya, B, C, H, W, 2 * C, 1, slope, ya16, sp(sb, "x"))
+                        _conv(lib, st, ya, sb.fwd_ptr(), sb.fwd_bytes, sb.bias(), a, B, C, H, W, 2 * C, 2, ACT, slope)
                     rc = lib.ebfi_scale_residual_cat_forward_c16(N.ptr(a), N.ptr(s_ex[i]), N._vp(a.data_ptr() + 4 * C * HW), N.ptr(s_t[i]),
                                                                  N.ptr(x), N.ptr(c), N.ptr(c16i), sp(sc, "x"), B, C, H, W, 2 * C * HW, st)
                     N.check(rc, "ebfi_scale_residual_cat_forward_c16")
-                    _sync("srcf")
-                    _conv16(lib, st, c, sc, sc.bias(), xn, B, 2 * C, H, W, C, 1, slope, xn16, sp(nxt, "x") if nxt is not None else None)
-                    _dbg("f%d.x16" % i, x16); _dbg("f%d.ya16" % i, ya16); _dbg("f%d.c16" % i, c16i); _dbg("f%d.xn" % i, xn)
+                    if f16fwd:
+                        _fconv16(lib, st, c16i, sc, B, 2 * C, H, W, C, 1, slope, book, out=xn, out16=xn16,
+                                 slot16=sp(nxt, "x") if nxt is not None else None)
+                    else:
+                        _conv16(lib, st, c, sc, sc.bias(), xn, B, 2 * C, H, W, C, 1, slope, xn16, sp(nxt, "x") if nxt is not None else None)
                     saved += [x, ya, a, x16, ya16, c16i]       # (c itself is not needed again: its image feeds the weight gradient)
                     x, x16 = xn, xn16
             ctx.sites, ctx.slope, ctx.dims = sites, slope, (B, C, H, W)
@@ -293,11 +287,7 @@ class ResidualControlFn(Function):
                 S = int(lib.ebfi_scale_residual_cat_backward_slices())
                 parts = torch.empty((2, nstep, S, B, C), dtype=torch.float32, device=dev)
                 # image of the last round's pre-activation gradient (later rounds get theirs from the data gradient's epilogue)
-                if N.dev_env("EBFI_C16_SYNC") is not None:
-                    print("   [bwd] st = %#x, current_stream = %#x, gout.device = %r" % (st.value or 0, torch.cuda.current_stream().cuda_stream, gout.device), flush=True)
-                _dbg("b.gout", gout); _dbg("b.xlast", xlast)
                 g5 = c16.to_c16(gout.contiguous(), sp(sites[-1][2], "g"), xlast, slope)
-                _dbg("b.g5", g5)
                 gdata = None
                 for i in range(nstep - 1, -1, -1):
                     sa, sb, sc = sites[i]
@@ -310,7 +300,6 @@ class ResidualControlFn(Function):
                         N.ptr(gc), N.ptr(a), N.ptr(s_ex[i]), N._vp(a.data_ptr() + 4 * C * HW), N.ptr(s_t[i]), N.ptr(gb16), sp(sb, "g"),
                         N.ptr(gxres), N.ptr(parts[0, i]), N.ptr(parts[1, i]), B, C, H, W, 2 * C * HW, slope, st)
                     N.check(rc, "ebfi_scale_residual_cat_backward_c16")
-                    _sync("srcb")
                     gwb, gbb = _wgrad16(lib, st, ya16, gb16, B, C, H, W, 2 * C, 2, ws_cache, book, sb)
                     ga16 = img(2 * C)
                     _dgrad16(lib, st, gb16, sb, B, C, H, W, 2 * C, 2, slope, book, out16=ga16, slot16=sp(sa, "g"), mask=ya)
@@ -322,9 +311,6 @@ class ResidualControlFn(Function):
                     else:
                         gdata = new(C)
                         _dgrad16(lib, st, ga16, sa, B, 2 * C, H, W, C, 1, slope, book, out=gdata, addend=gxres)
-                    _dbg("b%d.g5in" % i, None)
-                    _dbg("b%d.gc" % i, gc); _dbg("b%d.gb16" % i, gb16); _dbg("b%d.ga16" % i, ga16); _dbg("b%d.gwa" % i, gwa); _dbg("b%d.gba" % i, gba)
-                    _dbg("b%d.gw5" % i, gw5); _dbg("b%d.gwb" % i, gwb); _dbg("b%d.next_g5" % i, g5 if i > 0 else gdata)
                     pgrads[10 * i:10 * i + 10] = [gwa[:C], gba[:C], gwa[C:], gba[C:], gwb[:C], gbb[:C], gwb[C:], gbb[C:], gw5, gb5]
                 sums = parts.sum(2)                    # per-slice partials of the scale gradients, in slice order
                 gs_ex, gs_t = sums[0], sums[1]

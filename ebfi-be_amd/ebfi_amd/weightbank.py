@@ -41,7 +41,8 @@ def lookup(param, kind="id"):
 class Site:
     """Packed images of one (possibly folded / concatenated) conv weight [M = Cout, K = Cin, ks, ks]."""
     __slots__ = ("bank", "kind", "M", "K", "ks", "groups", "fwd_off", "tr_off", "fwd_bytes", "tr_bytes", "bias_off", "has_bias",
-                 "w_inv", "w_R", "b_inv", "b_R", "w_shapes", "b_shapes", "key", "tr16_off", "tr16_bytes", "w_slot", "weights")
+                 "w_inv", "w_R", "b_inv", "b_R", "w_shapes", "b_shapes", "key", "tr16_off", "tr16_bytes", "w_slot", "weights",
+                 "fwd16_off", "fwd16_bytes")
 
     def fwd_ptr(self):
         return N._vp(self.bank.packed.data_ptr() + self.fwd_off)
@@ -54,6 +55,12 @@ class Site:
         if self.bank.packed16 is None or self.tr16_bytes == 0:
             return None
         return N._vp(self.bank.packed16.data_ptr() + 2 * self.tr16_off)
+
+    def fwd16_ptr(self):
+        """fp16 forward image [tap][Cout][Cin16] scaled by the same weight slot (the fp16-operand FORWARD of a training step)."""
+        if self.bank.packed16 is None or self.fwd16_bytes == 0:
+            return None
+        return N._vp(self.bank.packed16.data_ptr() + 2 * self.fwd16_off)
 
     def w_slot_ptr(self):
         return self.bank.book.ptr(self.w_slot)
@@ -154,13 +161,15 @@ class WeightBank:
         s = Site()
         s.bank, s.kind, s.M, s.K, s.ks, s.groups = self, kind, int(M), int(K), int(ks), int(groups)
         s.key, s.weights = key, weights
-        s.tr_off, s.tr_bytes, s.tr16_off, s.tr16_bytes, s.w_slot = 0, 0, 0, 0, -1
-        if need_tr and ks == 3:           # one fp16 image (scaled by the site's weight slot); images start on 256-element bounds
-            s.tr16_off, s.tr16_bytes = self._n16, 2 * tr.numel()
-            padn = (-tr.numel()) % 256
-            self._tables16.append(torch.cat([tr.to(torch.int32), torch.full((padn,), -1, dtype=torch.int32)]))
-            self._segs.append((self._n16, s))
-            self._n16 += tr.numel() + padn
+        s.tr_off, s.tr_bytes, s.tr16_off, s.tr16_bytes, s.w_slot, s.fwd16_off, s.fwd16_bytes = 0, 0, 0, 0, -1, 0, 0
+        if need_tr and ks == 3:           # fp16 images (scaled by the site's weight slot); images start on 256-element bounds
+            for name, img in (("tr16", tr), ("fwd16", fwd)):
+                setattr(s, name + "_off", self._n16)
+                setattr(s, name + "_bytes", 2 * img.numel())
+                padn = (-img.numel()) % 256
+                self._tables16.append(torch.cat([img.to(torch.int32), torch.full((padn,), -1, dtype=torch.int32)]))
+                self._segs.append((self._n16, s))
+                self._n16 += img.numel() + padn
         for name, img in (("fwd", fwd), ("tr", tr)) if need_tr else (("fwd", fwd),):
             lo = torch.where(img >= 0, img | LO_FLAG, img)
             setattr(s, name + "_off", 2 * self._n_packed)
@@ -236,7 +245,7 @@ class WeightBank:
                 N.check(lib.ebfi_gather_sum(N.ptr(self.flat), N.ptr(self.bias_table), N.ptr(self.bias_buf), self._n_bias, 1, st),
                         "ebfi_gather_sum")
             if self.packed16 is not None:
-                for _, site in self._segs:      # first refresh: the weight scales from the weights themselves (later: delayed)
+                for _, site in self._segs:       # first refresh: the weight scales from the weights themselves (later: delayed)
                     self.book.calibrate(site.w_slot, *site.weights)
                 N.check(lib.ebfi_pack_table_f16(N.ptr(self.flat), N.ptr(self.table16), self.table16.numel(), N.ptr(self.packed16),
                                                 N.ptr(self.block_slot), N.ptr(self.book.slots), st), "ebfi_pack_table_f16")

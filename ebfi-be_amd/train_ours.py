@@ -161,6 +161,9 @@ def main():
     ap.add_argument("--no-f16-backward", action="store_true",
                     help="bf16x3 precision: keep the data / weight gradients on the split-precision kernels (3 MFMAs per product) "
                          "instead of the fp16 single-product ones with delayed operand scales (ebfi_amd.f16scale)")
+    ap.add_argument("--no-f16-forward", action="store_true",
+                    help="keep the 128 -> 1600 KernelConv of Modification on the split-precision kernel in the forward pass "
+                         "(default with the fp16 backward: fp16 operands, Engine(forward_f16='filters'))")
     ap.add_argument("--data", default=None,
                     help="recorded clips instead of synthetic batches: a directory of .npz clips (or .h5 in the reference's layout "
                          "when h5py is installed), a datalist .txt, or one clip file (ebfi_amd.clipdata); the dataset section of "
@@ -182,7 +185,7 @@ def main():
     eng = Engine(config["model"]["args"], device=device, precision=args.precision, lr=float(oargs.get("lr", 1e-4)),
                  betas=tuple(oargs.get("betas", (0.9, 0.999))), seed=args.seed,      # same init on every rank
                  graph=args.graph or bool(tr.get("graph", False)), accu_step=st["accu_step"],
-                 backward_f16=False if args.no_f16_backward else None)
+                 backward_f16=False if args.no_f16_backward else None, forward_f16=None if args.no_f16_forward else "filters")
     scheduler = build_lr_scheduler(config, eng.optimizer.inner)
     start = resume_checkpoint(args.resume, eng, scheduler, config, reset=args.reset, map_location=device) if args.resume else 0
     B, H, W = int(tr.get("batch_size", 8)), int(tr.get("height", 256)), int(tr.get("width", 256))

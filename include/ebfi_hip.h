@@ -50,7 +50,7 @@ extern "C" {
  * ebfi_conv2d_packed_x3, the fused KernelConv -> FAC forward, ...).  4: ebfi_se_gate_forward takes a workspace
  * (ebfi_se_gate_workspace).  5 (round 4): the never-implemented EBFI_BF16 storage value left ebfi_dtype; fp16 filter storage
  * and the fused-gradient entry points of the KernelConv -> FAC training path.  Bumped whenever an entry point is added or changed. */
-#define EBFI_ABI_VERSION 5
+#define EBFI_ABI_VERSION 6
 
 typedef enum {
     EBFI_OK = 0,
@@ -288,7 +288,7 @@ int ebfi_conv2d_packed_f16_c16(const void *input, int input_is_c16, const void *
                                const void *bias, void *output, int B, int Cin_per_group, int H, int W, int Cout, int ksize,
                                int pad, int groups, int act, float slope, const void *addend, const void *mask_y,
                                int mask_act, float mask_slope, void *in_slot, const void *w_slot, void *out16,
-                               void *slot16, void *stream);
+                               void *slot16, int out16_planar, void *stream);
 int ebfi_conv2d_backward_weight_f16c(const void *input16, const void *grad16, int grad_is_planar, void *grad_weight,
                                      void *grad_bias, int B, int Cin_per_group, int H, int W, int Cout, int groups,
                                      const void *x_slot, const void *g_slot, void *workspace, size_t workspace_bytes,

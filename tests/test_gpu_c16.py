@@ -88,7 +88,7 @@ def test_data_gradient_reads_and_writes_images(B, Cin, H, W, Cout, groups, extra
         rc = lib.ebfi_conv2d_packed_f16_c16(N.ptr(inp), is16, site.tr16_ptr(), site.tr16_bytes, N.ptr(None), N.ptr(out), B,
                                             gch // groups, H, W, och, 3, 1, groups, 0, 0.0, N.ptr(addend), N.ptr(mask),
                                             1 if extras else 0, 0.01 if extras else 0.0, book.ptr(si), site.w_slot_ptr(),
-                                            N.ptr(out16), book.ptr(so) if out16 is not None else N.ptr(None), st)
+                                            N.ptr(out16), book.ptr(so) if out16 is not None else N.ptr(None), 0, st)
         N.check(rc, "ebfi_conv2d_packed_f16_c16")
     ref32 = torch.empty(B, och, H, W, device="cuda")
     run(g, 0, ref32, None)
@@ -250,7 +250,7 @@ def test_backward_convs_stage_planar_fp16_gradients(B, Cin, H, W, Cout):
     def dgrad(inp, mode, out):
         N.check(lib.ebfi_conv2d_packed_f16_c16(N.ptr(inp), mode, site.tr16_ptr(), site.tr16_bytes, N.ptr(None), N.ptr(out), B, Cout, H, W, Cin,
                                                3, 1, 1, 0, 0.0, N.ptr(None), N.ptr(None), 0, 0.0, book.ptr(sg), site.w_slot_ptr(),
-                                               N.ptr(None), N.ptr(None), st), "dgrad")
+                                               N.ptr(None), N.ptr(None), 0, st), "dgrad")
     a, r = torch.empty(B, Cin, H, W, device="cuda"), torch.empty(B, Cin, H, W, device="cuda")
     dgrad(gq, 0, r)
     dgrad(g16, 2, a)

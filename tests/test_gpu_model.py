@@ -408,6 +408,47 @@ def _check_packed_gradient(flat, ref_flat, sizes, names):
     return err
 
 
+@pytest.mark.parametrize("seed", [31, 77, 5])
+def test_training_forward_within_tolerance(seed):
+    """The forward pass AS THE TRAINING STEP RUNS IT -- default Engine in split precision: fp16 operand images written inside
+    ResidualControl, the 128 -> 1600 KernelConv on fp16 operands writing fp16 filter planes (Engine(forward_f16='filters')) --
+    at the benchmark size (B=8, 256x256, default widths): Sharp and Final within 1e-3 of the exact fp32 mode on the same weights
+    and inputs, and sample 0 within 1e-3 of the CPU oracle.  (The losses and gradients of the same step are pinned by
+    test_benchmarked_step_vs_oracle; this test pins the OUTPUTS the reduced-precision operands could move.)"""
+    from ebfi_amd.engine import Engine, synthetic_batch
+    eng = Engine(DEFAULT_ARGS_FULL, device="cuda", precision="bf16x3", seed=4)
+    assert eng.book is not None and eng.book.forward_f16 == "filters"
+    gen = torch.Generator(device="cpu").manual_seed(11 + seed)
+    with torch.no_grad():                       # (the reference's x0.1 initialisation gives Sharp == 0.5 everywhere)
+        for p in eng.model.parameters():
+            if p.dim() > 1:
+                p.copy_((torch.randn(p.shape, generator=gen) * (1.2 / p[0].numel() ** 0.5)).cuda())
+            else:
+                p.add_((0.05 * torch.randn(p.shape, generator=gen)).cuda())
+    batch = synthetic_batch(8, 256, 256, device="cuda", seed=seed)
+    out = {}
+    for mode, passes in (("fp32", 1), ("bf16x3", 3)):     # (pass 1 calibrates the operand scales, 2-3 run on delayed ones)
+        eng.precision = mode
+        for _ in range(passes):
+            eng.bucket.zero()
+            eng.book.begin_step()
+            with eng._autocast(), eng._bank(), eng._book() as book:
+                s, f = eng.model(*batch[:4])
+                eng.loss(s.float(), f.float(), batch[4], 0, 1).backward()
+                if book is not None:
+                    book.finish()
+        out[mode] = (s.detach().clone(), f.detach().clone())
+    assert eng.book.guard.tolist() == [0, 0]
+    assert out["fp32"][0].std() > 0.01
+    es, ef = _rel(out["bf16x3"][0], out["fp32"][0]), _rel(out["bf16x3"][1], out["fp32"][1])
+    assert es < TOL and ef < TOL, (es, ef)
+    sd = {k: v.detach().cpu() for k, v in eng.model.state_dict().items()}
+    with torch.no_grad():
+        ref_s, ref_f = model_ref.evfi_forward(sd, DEFAULT_ARGS_FULL, *[v[:1].cpu() for v in batch[:3]])
+    es, ef = _rel(out["bf16x3"][0][:1], ref_s), _rel(out["bf16x3"][1][:1], ref_f)
+    assert es < TOL and ef < TOL, (es, ef)
+
+
 @pytest.mark.parametrize("B,seed", [(8, 31), (2, 77)])
 def test_benchmarked_step_vs_oracle(B, seed):
     """The exact step bench.py times -- default widths, B=8 (and a second seed at B=2), split-precision forward, fp16 backward,
