@@ -2063,10 +2063,8 @@ __global__ __launch_bounds__(256) void pack_table_bf16_kernel(const float *__res
 // 64 consecutive elements per workgroup, 4 thread rows each summing every 4th slab (4 loads in
 // flight), then a fixed-order combine through LDS: deterministic, and short dependent chains.
 // perm_cin > 0: the slabs hold the weight part as [co][tap][ci] (bf16 kernel); gw is always [co][ci][tap].
-__global__ __launch_bounds__(256) void conv_wgrad_reduce_f32(const float *__restrict__ slab, int nslabs,
-                                                             int64_t n_weight, int64_t n_total,
-                                                             float *__restrict__ gw, float *__restrict__ gb,
-                                                             int perm_cin, int perm_kk) {
+__device__ __forceinline__ void wgrad_reduce_body(const float *__restrict__ slab, int nslabs, int64_t n_weight, int64_t n_total,
+                                                  float *__restrict__ gw, float *__restrict__ gb, int perm_cin, int perm_kk) {
     __shared__ float part[4][64];
     const int jj = threadIdx.x & 63, kq = threadIdx.x >> 6;
     const int64_t j = (int64_t)blockIdx.x * 64 + jj;
@@ -2105,6 +2103,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_f32(const float *__rest
             gw[o] = s;
         } else if (gb) gb[j - n_weight] = s;
     }
+}
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_f32(const float *__restrict__ slab, int nslabs,
+                                                             int64_t n_weight, int64_t n_total,
+                                                             float *__restrict__ gw, float *__restrict__ gb,
+                                                             int perm_cin, int perm_kk) {
+    wgrad_reduce_body(slab, nslabs, n_weight, n_total, gw, gb, perm_cin, perm_kk);
+}
+// the reductions of a batched weight-gradient launch (conv_wgrad_f16_tr_batch): blockIdx.y = layer
+struct ReduceItem {
+    const float *slab;
+    float *gw, *gb;
+    int64_t n_weight, n_total;
+    int perm_cin;
+};
+struct ReduceBatch {
+    ReduceItem item[4];
+};
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_batch(ReduceBatch rb, int nslabs) {
+    ReduceItem it = rb.item[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if ((int)blockIdx.y == k) it = rb.item[k];
+    if ((int64_t)blockIdx.x * 64 >= it.n_total) return;      // (whole workgroup: layers of different sizes share the grid)
+    wgrad_reduce_body(it.slab, nslabs, it.n_weight, it.n_total, it.gw, it.gb, it.perm_cin, 9);
 }
 
 // algorithmic HBM bytes of one launch (every operand once, results once; workspaces and re-reads not counted)
@@ -3650,6 +3672,80 @@ extern "C" int ebfi_conv2d_backward_weight_f16c(const void *input16, const void 
                            n_total, static_cast<float *>(grad_weight), static_cast<float *>(grad_bias), Cin_per_group, 9);
     }
     return check_launch("conv_wgrad_reduce_f32");
+}
+
+// n (1..4) weight gradients over the SAME [B, H, W] pixels in one launch + one reduction launch (conv_wgrad_f16_tr_batch): the
+// layers of one ResidualControl round.  Every layer must consist of exactly two 64 x 64 blocks (Cout x Cin_per_group = 128 x 64,
+// 64 x 128, or 2 groups of 64 x 64); anything else: EBFI_ERR_UNSUPPORTED (callers then use ebfi_conv2d_backward_weight_f16c per
+// layer).  Arguments are arrays of n entries; workspace: ebfi_conv2d_backward_weight_f16c_batch_workspace bytes.
+static int wgrad_batch_per_xcd(int n) { return 32 / (2 * n); }
+extern "C" size_t ebfi_conv2d_backward_weight_f16c_batch_workspace(int n, const int *Cin_per_group, const int *Cout) {
+    if (n < 1 || n > WGRAD_BATCH_MAX || !Cin_per_group || !Cout) return 0;
+    size_t total = 0;
+    for (int k = 0; k < n; ++k) total += (size_t)8 * wgrad_batch_per_xcd(n) * ((size_t)Cout[k] * Cin_per_group[k] * 9 + Cout[k]) * sizeof(float);
+    return total;
+}
+extern "C" int ebfi_conv2d_backward_weight_f16c_batch(int n, const void *const *input16, const void *const *grad16,
+                                                      void *const *grad_weight, void *const *grad_bias, const int *Cin_per_group,
+                                                      const int *Cout, const int *groups, void *const *x_slot, void *const *g_slot,
+                                                      int B, int H, int W, void *workspace, size_t workspace_bytes, void *stream) {
+    if (n < 1 || n > WGRAD_BATCH_MAX) return fail(EBFI_ERR_ARG, "conv2d_backward_weight_f16c_batch: %d layers (1..%d)", n, WGRAD_BATCH_MAX);
+    if (!input16 || !grad16 || !grad_weight || !grad_bias || !Cin_per_group || !Cout || !groups || !x_slot || !g_slot)
+        return fail(EBFI_ERR_ARG, "conv2d_backward_weight_f16c_batch: null argument");
+    const int per_xcd = wgrad_batch_per_xcd(n);
+    ConvGeom g0;
+    if (int rc = make_geom(g0, B, 64, H, W, 64, 3, 1, 1)) return rc;
+    const int64_t tiles = (int64_t)B * ceil_div(g0.Ho, TRH) * ceil_div(g0.Wo, TRW);
+    if (tiles > 2147483647LL) return fail(EBFI_ERR_ARG, "conv2d_backward_weight_f16c_batch: too many tiles");
+    if (tiles < 8 * per_xcd) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_weight_f16c_batch: %lld tiles do not fill %d splits", (long long)tiles, 8 * per_xcd);
+    const size_t need = ebfi_conv2d_backward_weight_f16c_batch_workspace(n, Cin_per_group, Cout);
+    if (!workspace || workspace_bytes < need)
+        return fail(EBFI_ERR_WORKSPACE, "conv2d_backward_weight_f16c_batch: workspace %zu bytes < required %zu", workspace_bytes, need);
+    WgradBatch bt{};
+    ReduceBatch rb{};
+    float *slab = static_cast<float *>(workspace);
+    double flops = 0.0, bytes = 0.0;
+    int64_t n_total_max = 0;
+    const double px = (double)B * H * W;
+    for (int k = 0; k < n; ++k) {
+        const int ci = Cin_per_group[k], co = Cout[k], gr = groups[k];
+        if (!input16[k] || !grad16[k] || !grad_weight[k] || !x_slot[k] || !g_slot[k])
+            return fail(EBFI_ERR_ARG, "conv2d_backward_weight_f16c_batch: null argument (layer %d)", k);
+        if (gr < 1 || ci < 16 || ci % 16 != 0 || co % 16 != 0 || co % gr != 0 || (gr > 1 && ((co / gr) % 64 != 0 || ci % 64 != 0)) ||
+            ceil_div(co, 64) * ceil_div(ci, 64) != 2)
+            return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_weight_f16c_batch: layer %d (%d -> %d, %d groups) is not two 64 x 64 blocks", k, ci, co, gr);
+        if (!aligned16(input16[k]) || !aligned16(grad16[k])) return fail(EBFI_ERR_ARG, "conv2d_backward_weight_f16c_batch: images must be 16-byte aligned");
+        if ((int64_t)(gr * ci + 64) * H * W * 2 >= (1LL << 31) - (1LL << 26) || (int64_t)(co + 64) * H * W * 2 >= (1LL << 31) - (1LL << 26))
+            return fail(EBFI_ERR_ARG, "conv2d_backward_weight_f16c_batch: one sample exceeds the 2 GiB reach of 32-bit buffer offsets");
+        const int64_t n_weight = (int64_t)co * ci * 9, n_total = n_weight + co;
+        bt.item[k] = WgradItem{input16[k], grad16[k], slab, static_cast<float *>(x_slot[k]), static_cast<float *>(g_slot[k]), ci, co, gr,
+                               grad_bias[k] != nullptr ? 1 : 0};
+        rb.item[k] = ReduceItem{slab, static_cast<float *>(grad_weight[k]), static_cast<float *>(grad_bias[k]), n_weight, n_total, ci};
+        slab += (size_t)8 * per_xcd * n_total;
+        n_total_max = n_total > n_total_max ? n_total : n_total_max;
+        flops += 2.0 * px * (double)co * ci * 9;
+        bytes += 2.0 * px * (gr * ci + co) + 4.0 * (double)n_total;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (B == 0) {
+        for (int k = 0; k < n; ++k) {
+            (void)hipMemsetAsync(grad_weight[k], 0, (size_t)rb.item[k].n_weight * sizeof(float), st);
+            if (grad_bias[k]) (void)hipMemsetAsync(grad_bias[k], 0, (size_t)Cout[k] * sizeof(float), st);
+        }
+        return EBFI_OK;
+    }
+    {
+        ProfScope ps("conv_wgrad_f16_tr/img_batch", st, flops, bytes);
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_wgrad_f16_tr_batch), TR_LDS + KB_LDS_BYTES)) return rc_;
+        hipLaunchKernelGGL(conv_wgrad_f16_tr_batch, dim3((unsigned)(8 * 2 * n * per_xcd)), dim3(512), TR_LDS + KB_LDS_BYTES, st, bt, g0,
+                           (int)tiles, per_xcd, n);
+        if (int rc = check_launch("conv_wgrad_f16_tr_batch")) return rc;
+    }
+    {
+        ProfScope ps("conv_wgrad_reduce_f32", st);
+        hipLaunchKernelGGL(conv_wgrad_reduce_batch, dim3((unsigned)ceil_div(n_total_max, 64), (unsigned)n), dim3(256), 0, st, rb, 8 * per_xcd);
+    }
+    return check_launch("conv_wgrad_reduce_batch");
 }
 
 extern "C" int ebfi_f16_scales_finish(void *slots, int n, void *flag, void *stream) {

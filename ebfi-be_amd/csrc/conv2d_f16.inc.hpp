@@ -767,45 +767,26 @@ constexpr int TR_LDS = 2 * TR_BUFB + 4 * 64 * 4;                             // 
 // GP16 (with IN16): grad_out is a PLANAR fp16 tensor [B, Cout, H, W] scaled by g_slot's scale instead of a c16 image (the
 // grad_kernel the FAC backward writes plane by plane): staged like the fp32 form -- eight 8-byte loads of 4 pixels per thread,
 // byte permutes into four (pixel, 8 channels) pieces.
-template <int DACT, bool IN16 = false, bool GP16 = false>
-__global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict__ x, const float *__restrict__ gout,
-                                                         const float *__restrict__ yact, float *__restrict__ gpre_out,
-                                                         float *__restrict__ slab, ConvGeom g, float dslope, int total_tiles,
-                                                         int need_bias, ScaleSlot x_slot, ScaleSlot g_slot) {
+// The body is shared by the one-layer launch (conv_wgrad_f16_tr) and the batched one (conv_wgrad_f16_tr_batch): the caller
+// passes the workgroup's block (co_blk, ci_blk), its tile walk (first tile `split`, stride G, end total_tiles; xcd_map: the
+// tile ids go through xcd_tile) and the slab `my` that receives its partial sums.
+template <int DACT, bool IN16, bool GP16>
+__device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ x, const float *__restrict__ gout,
+                                              const float *__restrict__ yact, float *__restrict__ gpre_out, float *__restrict__ my,
+                                              const ConvGeom &g, float dslope, const int split, const int G, const int total_tiles,
+                                              const bool xcd_map, int need_bias, ScaleSlot x_slot, ScaleSlot g_slot, const int co_blk,
+                                              const int ci_blk) {
     saturate_fp16_conversions();
     constexpr int KK = 9, PT = 256, NQ = 4;
     constexpr int NXI = TRXR * TRXQ * 8, NXK = (NXI + PT - 1) / PT;          // input items (row, quad, 8-channel group): 480, 2 per thread
     static_assert(NXK == 2 && TRH * (TRW / 4) * 8 == PT, "one grad_out item and two input items per producer thread");
     extern __shared__ __attribute__((aligned(16))) char smt[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // Workgroup -> (split, co block, ci block).  The ci blocks of one (split, co block) read the SAME grad_out tiles (839 MB at
-    // 128 -> 1600): they are placed 8 workgroup ids apart, i.e. on the same XCD under the round-robin dispatch (speed only:
-    // MI355X_MICROARCH.md, workgroup dispatch), so that the second reader finds the tile in that XCD's L2.  PMC before:
-    // 2.2 GB fetched per launch for 0.91 GB of operands.
-    int split, co_blk, ci_blk;
-    {
-        const int nz = gridDim.z, ny = gridDim.y, nx = gridDim.x;
-        const int L = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z), total = nx * ny * nz;
-        const int T8 = total / (8 * nz) * (8 * nz);          // ids below T8: groups of 8 * nz; the remainder pairs up in id order
-        int rest;                                            // 0 .. nx * ny - 1: (split, co block)
-        if (L < T8) {
-            const int xcd = L & 7, i = L >> 3;
-            ci_blk = i % nz;
-            rest = (i / nz) * 8 + xcd;
-        } else {
-            ci_blk = (L - T8) % nz;
-            rest = T8 / nz + (L - T8) / nz;
-        }
-        split = rest % nx;
-        co_blk = rest / nx;
-    }
     const int co_base = co_blk * 64, ci_base = ci_blk * 64;
     const int grp = co_base / (g.Cout / g.groups);
     const int tiles_x = (g.Wo + TRW - 1) / TRW, tiles_y = (g.Ho + TRH - 1) / TRH;
     const int HW = g.H * g.W, HWo = g.Ho * g.Wo;
-    const int G = gridDim.x;
     const int64_t wsz = (int64_t)g.Cout * g.Cin * KK;
-    float *my = slab + (int64_t)split * (wsz + g.Cout);
     const float sx = x_slot.scale(), sg = g_slot.scale();
     [[maybe_unused]] char *smd = smt;
     [[maybe_unused]] constexpr int KB_LDS_OFF = TR_LDS;
@@ -951,7 +932,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict
         // planar grad_out item of this thread: 8-channel group chg, tile row pg_y, quad pg_q (as the fp32 form)
         const int chg = ptid & 7, pg_y = (ptid >> 3) >> 3, pg_q = (ptid >> 3) & 7;
         const unsigned gplane16 = (unsigned)HWo * 2u;
-        const bool xcd_map = (gridDim.x & 7) == 0;
         auto tile_coords = [&](int tile, int &b, int &y0, int &x0) {
             int t = (xcd_map && tile < total_tiles) ? xcd_tile(tile, total_tiles) : tile;
             const int tx = t % tiles_x; t /= tiles_x;
@@ -1120,7 +1100,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict
     float amax_g = 0.f, amax_x = 0.f;
     // (splits congruent mod 8 run on one XCD when gridDim.x is a multiple of 8 -- see the placement above -- so their tiles
     // split, split + G, .. are mapped onto one contiguous eighth of the tile sequence: shared halo lines hit that XCD's L2)
-    const bool xcd_map = (gridDim.x & 7) == 0;
     auto tile_coords = [&](int tile, int &b, int &y0, int &x0) {
         int t = (xcd_map && tile < total_tiles) ? xcd_tile(tile, total_tiles) : tile;
         const int tx = t % tiles_x; t /= tiles_x;
@@ -1283,4 +1262,75 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict
     __syncthreads();                       // (C)
     KB_STAMP(31);
     KB_FLUSH_SELF();
+}
+
+template <int DACT, bool IN16 = false, bool GP16 = false>
+__global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict__ x, const float *__restrict__ gout,
+                                                         const float *__restrict__ yact, float *__restrict__ gpre_out,
+                                                         float *__restrict__ slab, ConvGeom g, float dslope, int total_tiles,
+                                                         int need_bias, ScaleSlot x_slot, ScaleSlot g_slot) {
+    // Workgroup -> (split, co block, ci block).  The ci blocks of one (split, co block) read the SAME grad_out tiles (839 MB at
+    // 128 -> 1600): they are placed 8 workgroup ids apart, i.e. on the same XCD under the round-robin dispatch (speed only:
+    // MI355X_MICROARCH.md, workgroup dispatch), so that the second reader finds the tile in that XCD's L2.  PMC before:
+    // 2.2 GB fetched per launch for 0.91 GB of operands.
+    int split, co_blk, ci_blk;
+    {
+        const int nz = gridDim.z, ny = gridDim.y, nx = gridDim.x;
+        const int L = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z), total = nx * ny * nz;
+        const int T8 = total / (8 * nz) * (8 * nz);          // ids below T8: groups of 8 * nz; the remainder pairs up in id order
+        int rest;                                            // 0 .. nx * ny - 1: (split, co block)
+        if (L < T8) {
+            const int xcd = L & 7, i = L >> 3;
+            ci_blk = i % nz;
+            rest = (i / nz) * 8 + xcd;
+        } else {
+            ci_blk = (L - T8) % nz;
+            rest = T8 / nz + (L - T8) / nz;
+        }
+        split = rest % nx;
+        co_blk = rest / nx;
+    }
+    const int64_t wsz = (int64_t)g.Cout * g.Cin * 9;
+    // (splits congruent mod 8 run on one XCD when gridDim.x is a multiple of 8, so their tiles split, split + G, .. are mapped
+    // onto one contiguous eighth of the tile sequence -- xcd_tile: shared halo lines hit that XCD's L2)
+    wgrad_tr_body<DACT, IN16, GP16>(x, gout, yact, gpre_out, slab + (int64_t)split * (wsz + g.Cout), g, dslope, split, (int)gridDim.x,
+                                    total_tiles, (gridDim.x & 7) == 0, need_bias, x_slot, g_slot, co_blk, ci_blk);
+}
+
+// Several weight gradients over the SAME pixels in one launch (round 4): the three layers of a ResidualControl round, each
+// exactly two 64 x 64 blocks.  One launch of one layer splits the pixels 128 ways to fill the chip and every workgroup leaves a
+// 147 KB slab of partial sums: 37.7 MB written and read again by the reduction per layer -- as much HBM traffic as the operands,
+// and a quarter of the kernel's time (in-kernel stamps: 4.5 us until the first tile is staged, 5.5 us in the slab stores of a
+// 36 us launch).  Batched, the 256 CUs are shared by the 6 blocks: 40 splits per layer, a third of the slab traffic and of the
+// start-up per layer, 12 launches per step instead of 36.
+// Workgroup L: XCD L & 7 owns one contiguous eighth of the tiles; its 2 * nunits * per_xcd workgroups are (split within the XCD,
+// layer, block) -- the two blocks of a layer read a common operand (the input image for two co blocks, the gradient image for
+// two ci blocks) and find it in that XCD's L2, neighbouring tiles share their halo lines there.
+struct WgradItem {
+    const void *x16, *g16;
+    float *slab, *x_slot, *g_slot;
+    int Cin, Cout, groups, need_bias;
+};
+constexpr int WGRAD_BATCH_MAX = 4;
+struct WgradBatch {
+    WgradItem item[WGRAD_BATCH_MAX];
+};
+__global__ __launch_bounds__(512) void conv_wgrad_f16_tr_batch(WgradBatch bt, ConvGeom g0, int total_tiles, int per_xcd, int nunits) {
+    const int L = blockIdx.x, xcd = L & 7, i = L >> 3;
+    if (i >= 2 * nunits * per_xcd) return;                 // (whole workgroup, before any barrier)
+    const int which = i & 1, pu = i >> 1;
+    const int unit = pu % nunits, s_local = pu / nunits;
+    WgradItem it = bt.item[0];
+#pragma unroll
+    for (int k = 1; k < WGRAD_BATCH_MAX; ++k)
+        if (unit == k) it = bt.item[k];
+    ConvGeom g = g0;
+    g.Cin = it.Cin; g.Cout = it.Cout; g.groups = it.groups;
+    const int t0 = (int)((int64_t)total_tiles * xcd / 8), t1 = (int)((int64_t)total_tiles * (xcd + 1) / 8);
+    const bool two_co = g.Cout > 64;                       // (the launcher admits layers of exactly two blocks)
+    const int64_t wsz = (int64_t)g.Cout * g.Cin * 9;
+    wgrad_tr_body<ACT_NONE, true, false>(static_cast<const float *>(it.x16), static_cast<const float *>(it.g16), nullptr, nullptr,
+                                         it.slab + (int64_t)(xcd * per_xcd + s_local) * (wsz + g.Cout), g, 0.f, t0 + s_local, per_xcd, t1,
+                                         false, it.need_bias, ScaleSlot{it.x_slot}, ScaleSlot{it.g_slot}, two_co ? which : 0,
+                                         two_co ? 0 : which);
 }

@@ -76,6 +76,8 @@ SIGNATURES = {
     "ebfi_conv2d_packed_f16_c16": (_i, [_vp, _i, _vp, _sz, _vp, _vp] + [_i] * 8 + [_i, _c.c_float, _vp, _vp, _i, _c.c_float,
                                         _vp, _vp, _vp, _vp, _i, _vp]),
     "ebfi_conv2d_backward_weight_f16c": (_i, [_vp, _vp, _i, _vp, _vp] + [_i] * 6 + [_vp, _vp, _vp, _sz, _vp]),
+    "ebfi_conv2d_backward_weight_f16c_batch_workspace": (_sz, [_i, _vp, _vp]),
+    "ebfi_conv2d_backward_weight_f16c_batch": (_i, [_i] + [_vp] * 9 + [_i, _i, _i, _vp, _sz, _vp]),
     "ebfi_fac_forward_p16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ebfi_fac_backward_p16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_float, _i, _i, _i, _i, _i, _vp]),
     "ebfi_scale_residual_cat_forward_c16": (_i, [_vp] * 8 + [_i, _i, _i, _i, _i64, _vp]),

@@ -125,22 +125,23 @@ class Engine:
         # (ebfi_amd.weightbank); training reads the optimiser's flat parameter buffer, inference keeps its own copy
         self.bank = None
         from . import _native as N
-        if self.device.type == "cuda" and N.dev_env("EBFI_NO_BANK", "0") != "1":     # (switch for A/B measurements)
-            from . import weightbank
-            self.bank = weightbank.build_for(self.model, flat=self.optimizer.flat.data, params=self.optimizer.params) if train \
-                else weightbank.build_for(self.model, inference=True)
-        self.book = None
         if backward_f16 is None:
             backward_f16 = N.dev_env("EBFI_NO_F16_BWD", "0") != "1"
-        if train and self.bank is not None and precision == "bf16x3" and backward_f16:
+        use_book = train and precision == "bf16x3" and backward_f16
+        forward_f16 = N.dev_env("EBFI_F16_FWD", forward_f16) if use_book else None
+        if forward_f16 == "none":
+            forward_f16 = None
+        if forward_f16 not in (None, "filters", "all"):
+            raise ValueError("forward_f16 must be None, 'filters' or 'all'")
+        if self.device.type == "cuda" and N.dev_env("EBFI_NO_BANK", "0") != "1":     # (switch for A/B measurements)
+            from . import weightbank
+            self.bank = weightbank.build_for(self.model, flat=self.optimizer.flat.data, params=self.optimizer.params,
+                                             fwd16=forward_f16) if train else weightbank.build_for(self.model, inference=True)
+        self.book = None
+        if use_book and self.bank is not None:
             from . import f16scale
             self.book = f16scale.ScaleBook(self.device)
             self.bank.attach_scale_book(self.book)
-            forward_f16 = N.dev_env("EBFI_F16_FWD", forward_f16)
-            if forward_f16 == "none":
-                forward_f16 = None
-            if forward_f16 not in (None, "filters", "all"):
-                raise ValueError("forward_f16 must be None, 'filters' or 'all'")
             self.book.forward_f16 = forward_f16
 
     @property

@@ -178,6 +178,31 @@ def _wgrad16(lib, st, x16, g16, B, cin_g, H, W, cout, groups, ws_cache, book, si
     return gw, gb
 
 
+def _wgrad16_batch(lib, st, items, B, H, W, ws_cache, book):
+    """The weight / bias gradients of several layers over the same pixels as ONE launch (+ one reduction):
+    items = [(x16, g16, site, cin_g, cout, groups)], every layer two 64 x 64 blocks.  Returns [(gw, gb)]."""
+    import ctypes
+    n = len(items)
+    dev = items[0][0].device
+    gws = [torch.empty((cout, cin_g, 3, 3), dtype=torch.float32, device=dev) for _, _, _, cin_g, cout, _ in items]
+    gbs = [torch.empty(cout, dtype=torch.float32, device=dev) for _, _, _, _, cout, _ in items]
+    ints = lambda vals: (ctypes.c_int * n)(*vals)
+    ptrs = lambda vals: (ctypes.c_void_p * n)(*vals)
+    cin, cout, groups = ints([it[3] for it in items]), ints([it[4] for it in items]), ints([it[5] for it in items])
+    key = ("batch",) + tuple((it[3], it[4]) for it in items)
+    if key not in ws_cache:
+        need = int(lib.ebfi_conv2d_backward_weight_f16c_batch_workspace(n, cin, cout))
+        ws_cache[key] = (torch.empty(max(need, 4), dtype=torch.uint8, device=dev), need)
+    ws, need = ws_cache[key]
+    slot = lambda site, role: book.ptr(book.slot((site.key, role))).value
+    rc = lib.ebfi_conv2d_backward_weight_f16c_batch(
+        n, ptrs([it[0].data_ptr() for it in items]), ptrs([it[1].data_ptr() for it in items]), ptrs([t.data_ptr() for t in gws]),
+        ptrs([t.data_ptr() for t in gbs]), cin, cout, groups, ptrs([slot(it[2], "x") for it in items]),
+        ptrs([slot(it[2], "g") for it in items]), B, H, W, N.ptr(ws), need, st)
+    N.check(rc, "ebfi_conv2d_backward_weight_f16c_batch")
+    return list(zip(gws, gbs))
+
+
 def _dgrad16(lib, st, g16, site, B, cin_g, H, W, cout, groups, slope, book, out=None, out16=None, slot16=None, addend=None, mask=None):
     """Data gradient of `site`'s layer from the IMAGE of its pre-activation gradient; the result as fp32 (`out`) and / or as
     the image of the next pre-activation gradient (`out16`, scale slot `slot16`)."""
@@ -288,11 +313,15 @@ class ResidualControlFn(Function):
                 parts = torch.empty((2, nstep, S, B, C), dtype=torch.float32, device=dev)
                 # image of the last round's pre-activation gradient (later rounds get theirs from the data gradient's epilogue)
                 g5 = c16.to_c16(gout.contiguous(), sp(sites[-1][2], "g"), xlast, slope)
+                # (every layer of a round is two 64 x 64 blocks exactly when C == 64; enough 4 x 32 pixel tiles for the 40 splits)
+                batch = C == 64 and B * ((H + 3) // 4) * ((W + 31) // 32) >= 40 and N.dev_env("EBFI_NO_WGRAD_BATCH", "0") != "1"
                 gdata = None
                 for i in range(nstep - 1, -1, -1):
                     sa, sb, sc = sites[i]
                     x, ya, a, x16, ya16, c16i = saved[6 * i:6 * i + 6]
-                    gw5, gb5 = _wgrad16(lib, st, c16i, g5, B, 2 * C, H, W, C, 1, ws_cache, book, sc)
+                    g5_img = g5
+                    if not batch:
+                        gw5, gb5 = _wgrad16(lib, st, c16i, g5, B, 2 * C, H, W, C, 1, ws_cache, book, sc)
                     gc = new(2 * C)
                     _dgrad16(lib, st, g5, sc, B, C, H, W, 2 * C, 1, 0.0, book, out=gc)
                     gb16, gxres = img(2 * C), new(C)
@@ -300,10 +329,16 @@ class ResidualControlFn(Function):
                         N.ptr(gc), N.ptr(a), N.ptr(s_ex[i]), N._vp(a.data_ptr() + 4 * C * HW), N.ptr(s_t[i]), N.ptr(gb16), sp(sb, "g"),
                         N.ptr(gxres), N.ptr(parts[0, i]), N.ptr(parts[1, i]), B, C, H, W, 2 * C * HW, slope, st)
                     N.check(rc, "ebfi_scale_residual_cat_backward_c16")
-                    gwb, gbb = _wgrad16(lib, st, ya16, gb16, B, C, H, W, 2 * C, 2, ws_cache, book, sb)
+                    if not batch:
+                        gwb, gbb = _wgrad16(lib, st, ya16, gb16, B, C, H, W, 2 * C, 2, ws_cache, book, sb)
                     ga16 = img(2 * C)
                     _dgrad16(lib, st, gb16, sb, B, C, H, W, 2 * C, 2, slope, book, out16=ga16, slot16=sp(sa, "g"), mask=ya)
-                    gwa, gba = _wgrad16(lib, st, x16, ga16, B, C, H, W, 2 * C, 1, ws_cache, book, sa)
+                    if batch:       # the round's three weight gradients as one launch, once the last of their operands exists
+                        (gwa, gba), (gwb, gbb), (gw5, gb5) = _wgrad16_batch(
+                            lib, st, [(x16, ga16, sa, C, 2 * C, 1), (ya16, gb16, sb, C, 2 * C, 2), (c16i, g5_img, sc, 2 * C, C, 1)],
+                            B, H, W, ws_cache, book)
+                    else:
+                        gwa, gba = _wgrad16(lib, st, x16, ga16, B, C, H, W, 2 * C, 1, ws_cache, book, sa)
                     if i > 0:       # leaves as the image of the previous round's Conv5 pre-activation gradient
                         g5 = img(C)
                         _dgrad16(lib, st, ga16, sa, B, 2 * C, H, W, C, 1, slope, book, out16=g5, slot16=sp(sites[i - 1][2], "g"),

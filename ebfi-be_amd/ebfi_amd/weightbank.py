@@ -93,12 +93,15 @@ def _adjoint_table(src_ids, n_src, first):
 
 
 class WeightBank:
-    def __init__(self, params, flat=None, inference=False):
+    def __init__(self, params, flat=None, inference=False, fwd16=None):
         """`params`: the tensors the sites may draw from.  `flat`: one fp32 buffer the params are views of, in this order
         (FlatAdam.flat); None = the bank keeps its own concatenation and re-copies it when a parameter's version changes.
         `inference`: modules may register forward-only sites that a training step would not use (the fused KernelConv -> FAC
         layout of Modification) -- they would only lengthen the per-step pack launch of a training bank."""
         self.inference = bool(inference)
+        # which sites also get an fp16 FORWARD image (Engine(forward_f16=...)): None, "filters" (convolutions whose module
+        # carries `_ebfi_fwd16`: Modification.KernelConv) or "all" (every 3x3 site)
+        self.fwd16 = fwd16
         self.params = list(params)
         self.owns_flat = flat is None
         self._offsets, off = {}, 0
@@ -129,12 +132,12 @@ class WeightBank:
             raise KeyError("parameter is not part of this bank")
         return ent[0]
 
-    def register(self, weights, biases=None, kind="id", fold_w=None, fold_b=None, groups=1, need_tr=True):
+    def register(self, weights, biases=None, kind="id", fold_w=None, fold_b=None, groups=1, need_tr=True, fwd16=False):
         """`weights`: one parameter, or a list concatenated along the (folded) output-channel axis.  `fold_w` / `fold_b`:
         0/1 linear maps from the parameter's shape to [M, K, ks, ks] / [M] (None = identity).  Keyed by the FIRST weight.
         `groups` > 1: the M rows form that many groups, each convolving its own K input channels (a grouped convolution:
         the data-gradient image is then [tap][(group, ci)][co within the group]).  `need_tr` = False: forward images only
-        (a site no data gradient will ever be taken through)."""
+        (a site no data gradient will ever be taken through).  `fwd16`: also keep an fp16 forward image (with the scale book)."""
         weights = list(weights) if isinstance(weights, (list, tuple)) else [weights]
         biases = list(biases) if isinstance(biases, (list, tuple)) else ([biases] if biases is not None else [])
         if any(b is None for b in biases):
@@ -163,7 +166,7 @@ class WeightBank:
         s.key, s.weights = key, weights
         s.tr_off, s.tr_bytes, s.tr16_off, s.tr16_bytes, s.w_slot, s.fwd16_off, s.fwd16_bytes = 0, 0, 0, 0, -1, 0, 0
         if need_tr and ks == 3:           # fp16 images (scaled by the site's weight slot); images start on 256-element bounds
-            for name, img in (("tr16", tr), ("fwd16", fwd)):
+            for name, img in (("tr16", tr), ("fwd16", fwd)) if (fwd16 or self.fwd16 == "all") else (("tr16", tr),):
                 setattr(s, name + "_off", self._n16)
                 setattr(s, name + "_bytes", 2 * img.numel())
                 padn = (-img.numel()) % 256
@@ -265,21 +268,21 @@ class WeightBank:
             _ACTIVE = prev
 
 
-def build_for(model, flat=None, params=None, inference=False):
+def build_for(model, flat=None, params=None, inference=False, fwd16=None):
     """A bank over every eligible convolution of `model` (nn.Conv2d 1x1 / 3x3 stride 1; the depth-2 Conv3d /
     ConvTranspose3d of the detail branch), plus the concatenations modules declare through `_ebfi_bank_register(bank)`."""
     import torch.nn as nn
 
     from . import fold3d
     params = list(params) if params is not None else [p for p in model.parameters()]
-    bank = WeightBank(params, flat, inference=inference)
+    bank = WeightBank(params, flat, inference=inference, fwd16=fwd16)
     known = set(p.data_ptr() for p in params)
     ok = lambda *ts: all(t is None or t.data_ptr() in known for t in ts)
     for m in model.modules():
         if isinstance(m, nn.Conv2d) and ok(m.weight, m.bias):
             k = m.kernel_size
             if k[0] == k[1] and k[0] in (1, 3) and m.stride == (1, 1) and m.dilation == (1, 1) and m.groups == 1:
-                bank.register(m.weight, m.bias, "id")
+                bank.register(m.weight, m.bias, "id", fwd16=fwd16 is not None and getattr(m, "_ebfi_fwd16", False))
         elif isinstance(m, nn.Conv3d) and ok(m.weight, m.bias):
             kd, kh, kw = m.kernel_size
             if kd in (1, 3) and kh == kw and kh in (1, 3) and (kh == 1 or m.stride[1] == 1) and m.stride[0] == 1 and \

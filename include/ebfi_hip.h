@@ -293,6 +293,15 @@ int ebfi_conv2d_backward_weight_f16c(const void *input16, const void *grad16, in
                                      void *grad_bias, int B, int Cin_per_group, int H, int W, int Cout, int groups,
                                      const void *x_slot, const void *g_slot, void *workspace, size_t workspace_bytes,
                                      void *stream);
+/* n (1..4) weight gradients over the SAME [B, H, W] pixels as ONE launch + one reduction (the three layers of a ResidualControl
+ * round, models/Ours/model_singleframe.py:127-133): arguments are arrays of n entries; every layer must be exactly two 64 x 64
+ * blocks (128 x 64, 64 x 128, or 2 groups of 64 x 64) -- otherwise EBFI_ERR_UNSUPPORTED and the caller uses the per-layer entry.
+ * A third of the partial-sum slab traffic and of the start-up per layer. */
+size_t ebfi_conv2d_backward_weight_f16c_batch_workspace(int n, const int *Cin_per_group, const int *Cout);
+int ebfi_conv2d_backward_weight_f16c_batch(int n, const void *const *input16, const void *const *grad16, void *const *grad_weight,
+                                           void *const *grad_bias, const int *Cin_per_group, const int *Cout, const int *groups,
+                                           void *const *x_slot, void *const *g_slot, int B, int H, int W, void *workspace,
+                                           size_t workspace_bytes, void *stream);
 /* The 1600-channel tensors of the KernelConv -> FAC pair in the TRAINING step (reference
  * models/Ours/model_singleframe.py:161-162, KernelConv2D_kernel.cu:25-150): the filters and grad_kernel as PLANAR fp16
  * [B, C*K*K, Ho, Wo] scaled by a slot's power of two -- the layout the FAC kernels stream plane by plane.  The 128 -> 1600

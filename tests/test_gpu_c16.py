@@ -142,6 +142,63 @@ def test_weight_gradient_from_images(B, Cin, H, W, Cout, groups):
     assert ((gb_b - ref_b).abs().max() / ref_b.abs().max()).item() < 1e-3
 
 
+@pytest.mark.parametrize("B,H,W,n", [(8, 128, 128, 3), (2, 52, 72, 3), (2, 37, 100, 2), (4, 64, 64, 1)])
+def test_batched_weight_gradients_equal_the_single_launches(B, H, W, n):
+    """ebfi_conv2d_backward_weight_f16c_batch (the three layers of a ResidualControl round in one launch: 64 -> 128, 2 x (64 -> 64)
+    grouped, 128 -> 64; pixel splits laid out per XCD, ragged tile counts) against ebfi_conv2d_backward_weight_f16c per layer: the
+    same fp16 products, summed over a different number of pixel splits -> equal to fp32 summation order (2e-6 of the tensor's
+    scale), and against the exact fp32 weight gradient of the de-quantised operands."""
+    import ctypes
+    from ebfi_amd import c16, f16scale
+    torch.manual_seed(5)
+    layers = [(64, 128, 1), (64, 128, 2), (128, 64, 1)][:n]
+    book = f16scale.ScaleBook("cuda")
+    lib, st = N.lib(), N.stream_ptr(torch.device("cuda"))
+    xs, gs, imgs, slots, single = [], [], [], [], []
+    for k, (cin, cout, groups) in enumerate(layers):
+        x = torch.randn(B, groups * cin, H, W).cuda() * 0.4
+        g = torch.randn(B, cout, H, W).cuda() * 3e-2
+        sx, sg = book.slot(("x", k)), book.slot(("g", k))
+        book.calibrate(sx, x)
+        book.calibrate(sg, g)
+        x16, g16 = c16.to_c16(x, book.ptr(sx)), c16.to_c16(g, book.ptr(sg))
+        need = int(lib.ebfi_conv2d_backward_weight_workspace(B, cin, H, W, cout, 3, 1, 1, N.EBFI_F32))
+        ws = torch.empty(max(need, 4), dtype=torch.uint8, device="cuda")
+        gw, gb = torch.empty(cout, cin, 3, 3, device="cuda"), torch.empty(cout, device="cuda")
+        N.check(lib.ebfi_conv2d_backward_weight_f16c(N.ptr(x16), N.ptr(g16), 0, N.ptr(gw), N.ptr(gb), B, cin, H, W, cout, groups,
+                                                     book.ptr(sx), book.ptr(sg), N.ptr(ws), need, st), "f16c")
+        xs.append(x); gs.append(g); imgs.append((x16, g16)); slots.append((sx, sg)); single.append((gw, gb))
+    ints = lambda v: (ctypes.c_int * n)(*v)
+    ptrs = lambda v: (ctypes.c_void_p * n)(*v)
+    cin_a, cout_a, gr_a = ints([l[0] for l in layers]), ints([l[1] for l in layers]), ints([l[2] for l in layers])
+    need = int(lib.ebfi_conv2d_backward_weight_f16c_batch_workspace(n, cin_a, cout_a))
+    assert need == sum(8 * (32 // (2 * n)) * (l[0] * l[1] * 9 + l[1]) * 4 for l in layers)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    out = [(torch.full((l[1], l[0], 3, 3), float("nan"), device="cuda"), torch.full((l[1],), float("nan"), device="cuda")) for l in layers]
+    rc = lib.ebfi_conv2d_backward_weight_f16c_batch(
+        n, ptrs([a.data_ptr() for a, _ in imgs]), ptrs([b.data_ptr() for _, b in imgs]), ptrs([w.data_ptr() for w, _ in out]),
+        ptrs([b.data_ptr() for _, b in out]), cin_a, cout_a, gr_a, ptrs([book.ptr(a).value for a, _ in slots]),
+        ptrs([book.ptr(b).value for _, b in slots]), B, H, W, N.ptr(ws), need, st)
+    N.check(rc, "f16c_batch")
+    for k, (cin, cout, groups) in enumerate(layers):
+        (gw, gb), (rw, rb) = out[k], single[k]
+        assert torch.isfinite(gw).all() and torch.isfinite(gb).all()
+        assert ((gw - rw).abs().max() / rw.abs().max()).item() < 2e-6, k
+        assert ((gb - rb).abs().max() / rb.abs().max()).item() < 2e-6, k
+        # exact fp32 reference on the operands the kernels saw (fp16-rounded at the slot scales)
+        xq = c16.from_c16(imgs[k][0], book.scale(slots[k][0]))
+        gq = c16.from_c16(imgs[k][1], book.scale(slots[k][1]))
+        ref = torch.nn.grad.conv2d_weight(xq.double(), (cout, cin, 3, 3), gq.double(), padding=1, groups=groups).float()
+        assert ((gw - ref).abs().max() / ref.abs().max()).item() < 1e-5, k
+    # a layer that is not two 64 x 64 blocks is refused (callers fall back to the per-layer entry)
+    bad = ints([64] * n)
+    rc = lib.ebfi_conv2d_backward_weight_f16c_batch(
+        n, ptrs([a.data_ptr() for a, _ in imgs]), ptrs([b.data_ptr() for _, b in imgs]), ptrs([w.data_ptr() for w, _ in out]),
+        ptrs([b.data_ptr() for _, b in out]), bad, bad, ints([1] * n), ptrs([book.ptr(a).value for a, _ in slots]),
+        ptrs([book.ptr(b).value for _, b in slots]), B, H, W, N.ptr(ws), need, st)
+    assert rc != 0 and b"two 64 x 64 blocks" in lib.ebfi_last_error()
+
+
 def test_fused_residual_control_stages_write_images():
     from ebfi_amd import c16, f16scale
     torch.manual_seed(4)

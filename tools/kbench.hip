@@ -247,8 +247,43 @@ int main(int argc, char **argv) {
         CK(hipMemcpyToSymbol(HIP_SYMBOL(g_kb_stamps), &null_stamps, sizeof(null_stamps)));
         report_stamps(d_stamps, std::min((size_t)256, nwg_max), "conv_wgrad_f16_tr (wave 0 = consumer | wave 4 = producer)");
 #endif
+    } else if (mode == "f16img") {
+        // the weight gradient on fp16 operand IMAGES (c16 layout; random halves: the timing does not depend on the values), with
+        // the in-kernel stamps; KBENCH_COLD=n rotates over n operand sets
+        const int ncold = getenv("KBENCH_COLD") ? std::max(1, atoi(getenv("KBENCH_COLD"))) : 1;
+        auto dev_halves = [&](size_t n, unsigned seed) {
+            std::vector<_Float16> h(n);
+            unsigned s = seed * 2654435761u + 99u;
+            for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; h[i] = (_Float16)(((float)((s >> 9) & 0xfff) / 2048.f - 1.f) * 2.f); }
+            void *d;
+            CK(hipMalloc(&d, n * 2));
+            CK(hipMemcpy(d, h.data(), n * 2, hipMemcpyHostToDevice));
+            return d;
+        };
+        std::vector<void *> xs, gs;
+        for (int i = 0; i < ncold; ++i) { xs.push_back(dev_halves(nx, 10 + i)); gs.push_back(dev_halves(ny, 40 + i)); }
+        std::vector<float> hslot(128, 0.f);
+        hslot[0] = 1.f; hslot[64] = 1.f;
+        float *slots;
+        CK(hipMalloc(&slots, 128 * 4));
+        CK(hipMemcpy(slots, hslot.data(), 128 * 4, hipMemcpyHostToDevice));
+        int rot = 0;
+        auto wg = [&] { const int i = rot++ % ncold; return ebfi_conv2d_backward_weight_f16c(xs[i], gs[i], 0, gw, gb, B, Cin, H, W, Cout, 1, slots, slots + 64, wgs, wgb, nullptr); };
+        printf("  operand sets in rotation: %d\n", ncold);
+        if (wg()) { fprintf(stderr, "%s\n", ebfi_last_error()); return 3; }
+        std::vector<Variant> vs;
+        vs.push_back({"wgrad f16 images + reduce", wg, {}});
+        time_variants(vs, 7, 20);
+#ifdef EBFI_KBENCH
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_kb_stamps), &d_stamps, sizeof(d_stamps)));
+        CK(hipMemset(d_stamps, 0, nwg_max * 2 * KB_NSTAMP * 8));
+        wg();
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_kb_stamps), &null_stamps, sizeof(null_stamps)));
+        report_stamps(d_stamps, std::min((size_t)256, nwg_max), "conv_wgrad_f16_tr<IN16> (wave 0 = consumer | wave 4 = producer)");
+#endif
     } else {
-        fprintf(stderr, "usage: kbench fwd|wgrad|f16 [Cin Cout H W B]\n");
+        fprintf(stderr, "usage: kbench fwd|wgrad|f16|f16img [Cin Cout H W B]\n");
         return 1;
     }
     return 0;
