@@ -57,6 +57,11 @@ struct EpiExtra {
     // planar16 != 0: out16 is a PLANAR fp16 tensor [B][Cout][Ho][Wo] instead (the filters of the FAC op, whose kernels read
     // planes: csrc/fac.hip); any Cout
     int planar16 = 0;
+    // mask16 (instead of mask_y): the mask tensor as a c16 IMAGE (only the signs are read) -- inside the backward chain of
+    // ResidualControl the activations whose derivative a data gradient applies already exist as images (the operands of the
+    // weight gradients): half the bytes of the fp32 tensor.  (A positive value below the fp16 denormal range of its scale
+    // reads as 0 and takes the slope: 1e-8 of the tensor's |max|.)
+    const _Float16 *mask16 = nullptr;
 };
 
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
@@ -130,10 +135,14 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(bias ? bias : anyp, bias ? (unsigned)g.Cout * 4u : 0u);
     // the extras: descriptors over the same sample of tensors shaped like the output (absent: empty descriptor, reads 0)
     const bool has_a = XAM && ex.addend != nullptr, has_m = XAM && ex.mask_y != nullptr, has16 = X16 && ex.out16 != nullptr;
+    const bool has_m16 = XAM && ex.mask16 != nullptr;
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(has_a ? ex.addend + (int64_t)b * g.Cout * HWo : anyp, has_a ? (unsigned)g.Cout * plane : 0u);
     const __amdgpu_buffer_rsrc_t rm = make_rsrc(has_m ? ex.mask_y + (int64_t)b * g.Cout * HWo : anyp, has_m ? (unsigned)g.Cout * plane : 0u);
     const int cb16 = g.Cout >> 4;                                  // 16-channel blocks of the fp16 image
     const bool planar = X16 && ex.planar16 != 0;
+    const __amdgpu_buffer_rsrc_t rm16 = __builtin_amdgcn_make_buffer_rsrc(
+        has_m16 ? const_cast<_Float16 *>(ex.mask16) + (int64_t)b * cb16 * HWo * 16 : const_cast<_Float16 *>(reinterpret_cast<const _Float16 *>(anyp)), 0,
+        has_m16 ? (unsigned)cb16 * (unsigned)HWo * 32u : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t r16 = __builtin_amdgcn_make_buffer_rsrc(
         has16 ? ex.out16 + (planar ? (int64_t)b * g.Cout * HWo : (int64_t)b * cb16 * HWo * 16)
               : const_cast<_Float16 *>(reinterpret_cast<const _Float16 *>(anyp)), 0,
@@ -190,6 +199,20 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
                                 for (int i = 0; i < 8; ++i) t[i] = buf_ld(rm, base + row_off(i) * plane);
 #pragma unroll
                                 for (int i = 0; i < 8; ++i) u[i] *= t[i] > 0.f ? 1.f : ex.mask_slope;
+                            }
+                            if (has_m16) {         // the same signs from the image: this lane's 4 channels of either half-piece
+                                typedef unsigned u32x2_m __attribute__((ext_vector_type(2)));
+                                const int cblk = ((co_base + m * 32) >> 4) + j;
+                                const unsigned om = (px_ok && cblk < cb16) ? ((unsigned)cblk * (unsigned)HWo * 2u + (unsigned)(yo * 2 * g.Wo + xo)) * 16u + 8u * (unsigned)h : SENT;
+                                const u32x2_m lo = __builtin_amdgcn_raw_buffer_load_b64(rm16, om, 0, 0);
+                                const u32x2_m hi = __builtin_amdgcn_raw_buffer_load_b64(rm16, om + (unsigned)g.Wo * 16u, 0, 0);
+                                const unsigned wds[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) {
+                                    // positive = sign bit clear and not zero (fp16 bits; NaN cannot occur in a saturated image)
+                                    const unsigned hbits = (wds[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+                                    u[i] *= (hbits != 0u && hbits < 0x8000u) ? 1.f : ex.mask_slope;
+                                }
                             }
                         }
                         if (has32) {
@@ -3419,14 +3442,14 @@ extern "C" int ebfi_conv2d_packed_f16_c16(const void *input, int input_is_c16, c
                                           const void *bias, void *output, int B, int Cin_per_group, int H, int W, int Cout, int ksize,
                                           int pad, int groups, int act, float slope, const void *addend, const void *mask_y,
                                           int mask_act, float mask_slope, void *in_slot, const void *w_slot, void *out16,
-                                          void *slot16, int out16_planar, void *stream);
+                                          void *slot16, int out16_planar, int mask_is_c16, void *stream);
 extern "C" int ebfi_conv2d_packed_f16(const void *input, const void *packed16, size_t packed_bytes, const void *bias, void *output,
                                       int B, int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups, int act,
                                       float slope, const void *addend, const void *mask_y, int mask_act, float mask_slope,
                                       void *in_slot, const void *w_slot, void *stream) {
     if (!output) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: null argument");
     return ebfi_conv2d_packed_f16_c16(input, 0, packed16, packed_bytes, bias, output, B, Cin_per_group, H, W, Cout, ksize, pad, groups,
-                                      act, slope, addend, mask_y, mask_act, mask_slope, in_slot, w_slot, nullptr, nullptr, 0, stream);
+                                      act, slope, addend, mask_y, mask_act, mask_slope, in_slot, w_slot, nullptr, nullptr, 0, 0, stream);
 }
 
 // Same with fp16 operand STORAGE (round 4, c16.hpp): input_is_c16 != 0: `input` is the scaled fp16 image
@@ -3434,15 +3457,18 @@ extern "C" int ebfi_conv2d_packed_f16(const void *input, const void *packed16, s
 // out16 / slot16: the output as such an image for the next backward kernel -- in addition to `output`, or alone (output NULL);
 // out16_planar != 0: as PLANAR fp16 [B][Cout][H][W] instead (the FAC filters; `output` must then be NULL).
 // With a site's FORWARD fp16 weight image this is the fp16-operand forward convolution (bias + LeakyReLU in the epilogue).
+// mask_is_c16 != 0: mask_y is the c16 IMAGE of the mask tensor (Cout % 16 == 0; only its signs are read).
 extern "C" int ebfi_conv2d_packed_f16_c16(const void *input, int input_is_c16, const void *packed16, size_t packed_bytes,
                                           const void *bias, void *output, int B, int Cin_per_group, int H, int W, int Cout, int ksize,
                                           int pad, int groups, int act, float slope, const void *addend, const void *mask_y,
                                           int mask_act, float mask_slope, void *in_slot, const void *w_slot, void *out16,
-                                          void *slot16, int out16_planar, void *stream) {
+                                          void *slot16, int out16_planar, int mask_is_c16, void *stream) {
     if (!input || !packed16 || (!output && !out16)) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: null argument");
     if ((out16 != nullptr) != (slot16 != nullptr)) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: out16 and slot16 come together");
     if (out16 && !out16_planar && (Cout % 16 != 0 || !aligned16(out16)))
         return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_f16: fp16 output image needs Cout %% 16 == 0");
+    if (mask_is_c16 && mask_y && (Cout % 16 != 0 || !aligned16(mask_y)))
+        return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_f16: an fp16 mask image needs Cout %% 16 == 0");
     if (out16_planar && (!out16 || output || W % 4 != 0 || !aligned16(out16)))
         return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_f16: planar fp16 output comes alone (output NULL), W %% 4 == 0");
     // input_is_c16: 0 = fp32 NCHW, 1 = c16 image, 2 = planar fp16 [B, groups*Cin, H, W] (scaled by in_slot like an image)
@@ -3468,8 +3494,10 @@ extern "C" int ebfi_conv2d_packed_f16_c16(const void *input, int input_is_c16, c
     hipStream_t st = static_cast<hipStream_t>(stream);
     if ((addend || mask_y || out16) && (act == ACT_SIGMOID || mask_act == ACT_SIGMOID))
         return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_f16: the epilogue extras take LeakyReLU / no activation only");
-    const EpiExtra epi{static_cast<const float *>(addend), mask_act == ACT_LEAKY ? static_cast<const float *>(mask_y) : nullptr, mask_act,
-                       mask_slope, static_cast<_Float16 *>(out16), static_cast<float *>(slot16), out16_planar ? 1 : 0};
+    const bool m16 = mask_is_c16 != 0 && mask_y != nullptr && mask_act == ACT_LEAKY;
+    const EpiExtra epi{static_cast<const float *>(addend), (mask_act == ACT_LEAKY && !m16) ? static_cast<const float *>(mask_y) : nullptr,
+                       mask_act, mask_slope, static_cast<_Float16 *>(out16), static_cast<float *>(slot16), out16_planar ? 1 : 0,
+                       m16 ? static_cast<const _Float16 *>(mask_y) : nullptr};
     const int64_t tiles = (int64_t)B * ceil_div(g.Ho, TYB) * ceil_div(g.Wo, TX);
     if (tiles > 2147483647LL) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: too many tiles");
     constexpr int PSX = (TYB - 1 + 3) * (TX - 1 + 3);
@@ -3479,12 +3507,12 @@ extern "C" int ebfi_conv2d_packed_f16_c16(const void *input, int input_is_c16, c
     if (gx < 1) gx = 1;
     if (gx > tiles) gx = tiles;
     const dim3 grid((unsigned)gx, (unsigned)co_blocks);
-    const bool extra = epi.addend != nullptr || epi.mask_y != nullptr || epi.out16 != nullptr;
+    const bool extra = epi.addend != nullptr || epi.mask_y != nullptr || epi.mask16 != nullptr || epi.out16 != nullptr;
     const double flops = 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * 9;
     // algorithmic bytes: input + output in the element size they are stored in (fp16 images: 2 bytes) + the packed weights
     const double px = (double)g.B * g.Ho * g.Wo;
     const double io_bytes = px * g.groups * g.Cin * (input_is_c16 ? 2.0 : 4.0) + px * g.Cout * ((output ? 4.0 : 0.0) + (out16 ? 2.0 : 0.0)) +
-                            px * g.Cout * ((addend ? 4.0 : 0.0) + (mask_y ? 4.0 : 0.0)) + 2.0 * 9 * (double)g.Cout * g.Cin;
+                            px * g.Cout * ((addend ? 4.0 : 0.0) + (mask_y ? (m16 ? 2.0 : 4.0) : 0.0)) + 2.0 * 9 * (double)g.Cout * g.Cin;
     // (label = kernel symbol / role: which operand storage the launch read and wrote)
     ProfScope ps(input_is_c16 == 2 ? "conv_fwd_f16_ws/p16_f32" : out16_planar ? (input_is_c16 ? "conv_fwd_f16_ws/img_p16" : "conv_fwd_f16_ws/f32_p16") :
                  input_is_c16 ? (out16 ? (output ? "conv_fwd_f16_ws/img_both" : "conv_fwd_f16_ws/img_img") : "conv_fwd_f16_ws/img_f32")

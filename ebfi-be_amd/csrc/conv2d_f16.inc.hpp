@@ -834,22 +834,49 @@ __device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ x, const
         for (int tile = split; tile < total_tiles; tile += G) {
             const char *base = smt + cur * TR_BUFB;
             if (kb_i < 12) KB_STAMP(2 + 2 * kb_i);
-#pragma unroll
-            for (int ks = 0; ks < TRH * 2; ++ks) {
+            // Software pipeline over the 8 k-steps of a tile: the 14 transposing reads of step ks + 1 are issued BEFORE the 9 MFMAs
+            // of step ks and land in a second set of fragment registers.  Left to itself the compiler reuses one B fragment
+            // for consecutive column tiles and waits for each read right before the MFMA pair that needs it: the in-kernel stamps
+            // showed 490 cycles per k-step for 288 cycles of MFMA issue (LDS latency exposed six times per step).
+            struct Frags {
+                f16x8 a0, a1, b0, b1, b2, b3, b4;
+            };
+            auto load_frags = [&](int ks) {
                 const int y = ks >> 1, px0 = (ks & 1) * 16;
                 const char *ga = base + (y * TRW + px0) * 128;              // + 4 * 128 for the second half of a fragment
                 const char *xa = base + (y * TRXW + px0) * 128;
-                f16x8 a[2], b[5];
+                Frags f;
+                f.a0 = tr_frag(ga + aoff[0], ga + aoff[0] + 512);
+                f.a1 = tr_frag(ga + aoff[1], ga + aoff[1] + 512);
+                f.b0 = tr_frag(xa + boff[0], xa + boff[0] + 512);
+                f.b1 = tr_frag(xa + boff[1], xa + boff[1] + 512);
+                f.b2 = tr_frag(xa + boff[2], xa + boff[2] + 512);
+                f.b3 = tr_frag(xa + boff[3], xa + boff[3] + 512);
+                f.b4 = tr_frag(xa + boff[4], xa + boff[4] + 512);
+                return f;
+            };
+            auto multiply = [&](const Frags &f) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a0, f.b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a1, f.b0, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a0, f.b1, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a1, f.b1, acc[1][1], 0, 0, 0);
+                acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a0, f.b2, acc[2][0], 0, 0, 0);
+                acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a1, f.b2, acc[2][1], 0, 0, 0);
+                acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a0, f.b3, acc[3][0], 0, 0, 0);
+                acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a1, f.b3, acc[3][1], 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(xm ? f.a1 : f.a0, f.b4, accx, 0, 0, 0);
+            };
+            Frags f0 = load_frags(0), f1;
 #pragma unroll
-                for (int m = 0; m < 2; ++m) a[m] = tr_frag(ga + aoff[m], ga + aoff[m] + 512);
-#pragma unroll
-                for (int j = 0; j < 5; ++j) b[j] = tr_frag(xa + boff[j], xa + boff[j] + 512);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-                        acc[j][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b[j], acc[j][m], 0, 0, 0);
-                accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(xm ? a[1] : a[0], b[4], accx, 0, 0, 0);
+            for (int k2 = 0; k2 < TRH; ++k2) {
+                f1 = load_frags(2 * k2 + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                multiply(f0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (k2 + 1 < TRH) f0 = load_frags(2 * k2 + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                multiply(f1);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (kb_i < 12) KB_STAMP(3 + 2 * kb_i);
             ++kb_i;

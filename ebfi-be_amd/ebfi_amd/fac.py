@@ -169,7 +169,7 @@ class KernelConvFacTrain(Function):
                 # and the site's fp16 forward weight image -- one matrix-core product per tap instead of three
                 rc = lib.ebfi_conv2d_packed_f16_c16(N.ptr(cat16), 1, site.fwd16_ptr(), site.fwd16_bytes, N.ptr(site.bias()), N.ptr(None),
                                                     B, Cin, H, W, site.M, 3, 1, 1, 1, float(slope), N.ptr(None), N.ptr(None), 0, 0.0,
-                                                    sp("x"), site.w_slot_ptr(), N.ptr(filt16), sp("f"), 1, st)
+                                                    sp("x"), site.w_slot_ptr(), N.ptr(filt16), sp("f"), 1, 0, st)
                 N.check(rc, "ebfi_conv2d_packed_f16_c16 (planar fp16 filters)")
             else:
                 rc = lib.ebfi_conv2d_packed_x3_c16(N.ptr(cat), site.fwd_ptr(), site.fwd_bytes, N.ptr(site.bias()), N.ptr(None), B, Cin, H,
@@ -217,5 +217,5 @@ class KernelConvFacTrain(Function):
                 gcat = torch.empty((B, Cin, H, W), dtype=torch.float32, device=dev)
                 N.check(lib.ebfi_conv2d_packed_f16_c16(N.ptr(gk16), 2, site.tr16_ptr(), site.tr16_bytes, N.ptr(None), N.ptr(gcat), B, site.M, H,
                                                        W, Cin, 3, 1, 1, 0, 0.0, N.ptr(None), N.ptr(None), 0, 0.0, sp("g"), site.w_slot_ptr(),
-                                                       N.ptr(None), N.ptr(None), 0, st), "ebfi_conv2d_packed_f16_c16 (planar)")
+                                                       N.ptr(None), N.ptr(None), 0, 0, st), "ebfi_conv2d_packed_f16_c16 (planar)")
         return gcat, gev, None, None, None, gw, gb

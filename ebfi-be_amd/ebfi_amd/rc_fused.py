@@ -159,7 +159,7 @@ def _fconv16(lib, st, x16, site, B, cin_g, H, W, cout, groups, slope, book, out=
     rc = lib.ebfi_conv2d_packed_f16_c16(N.ptr(x16), 1, site.fwd16_ptr(), site.fwd16_bytes, N.ptr(site.bias()), N.ptr(out), B, cin_g, H, W,
                                         cout, 3, 1, groups, ACT, slope, N.ptr(None), N.ptr(None), 0, 0.0,
                                         book.ptr(book.slot((site.key, "x"))), site.w_slot_ptr(), N.ptr(out16),
-                                        slot16 if out16 is not None else N.ptr(None), 0, st)
+                                        slot16 if out16 is not None else N.ptr(None), 0, 0, st)
     N.check(rc, "ebfi_conv2d_packed_f16_c16")
 
 
@@ -203,13 +203,15 @@ def _wgrad16_batch(lib, st, items, B, H, W, ws_cache, book):
     return list(zip(gws, gbs))
 
 
-def _dgrad16(lib, st, g16, site, B, cin_g, H, W, cout, groups, slope, book, out=None, out16=None, slot16=None, addend=None, mask=None):
+def _dgrad16(lib, st, g16, site, B, cin_g, H, W, cout, groups, slope, book, out=None, out16=None, slot16=None, addend=None, mask=None,
+             mask16=None):
     """Data gradient of `site`'s layer from the IMAGE of its pre-activation gradient; the result as fp32 (`out`) and / or as
     the image of the next pre-activation gradient (`out16`, scale slot `slot16`)."""
+    m = mask16 if mask16 is not None else mask            # (mask16: the c16 image of the mask tensor -- only its signs are read)
     rc = lib.ebfi_conv2d_packed_f16_c16(N.ptr(g16), 1, site.tr16_ptr(), site.tr16_bytes, N.ptr(None), N.ptr(out), B, cin_g, H, W, cout,
-                                        3, 1, groups, 0, slope, N.ptr(addend), N.ptr(mask), ACT if mask is not None else 0,
-                                        slope if mask is not None else 0.0, book.ptr(book.slot((site.key, "g"))), site.w_slot_ptr(),
-                                        N.ptr(out16), slot16 if out16 is not None else N.ptr(None), 0, st)
+                                        3, 1, groups, 0, slope, N.ptr(addend), N.ptr(m), ACT if m is not None else 0,
+                                        slope if m is not None else 0.0, book.ptr(book.slot((site.key, "g"))), site.w_slot_ptr(),
+                                        N.ptr(out16), slot16 if out16 is not None else N.ptr(None), 0, 1 if mask16 is not None else 0, st)
     N.check(rc, "ebfi_conv2d_packed_f16_c16")
 
 
@@ -263,7 +265,9 @@ class ResidualControlFn(Function):
                                  slot16=sp(nxt, "x") if nxt is not None else None)
                     else:
                         _conv16(lib, st, c, sc, sc.bias(), xn, B, 2 * C, H, W, C, 1, slope, xn16, sp(nxt, "x") if nxt is not None else None)
-                    saved += [x, ya, a, x16, ya16, c16i]       # (c itself is not needed again: its image feeds the weight gradient)
+                    # (neither x, ya nor c is needed again in fp32: their images feed the weight gradients and give the
+                    # data gradients the signs of the LeakyReLU derivatives)
+                    saved += [a, x16, ya16, c16i]
                     x, x16 = xn, xn16
             ctx.sites, ctx.slope, ctx.dims = sites, slope, (B, C, H, W)
             ctx.save_for_backward(s_ex, s_t, x, *saved)
@@ -318,7 +322,7 @@ class ResidualControlFn(Function):
                 gdata = None
                 for i in range(nstep - 1, -1, -1):
                     sa, sb, sc = sites[i]
-                    x, ya, a, x16, ya16, c16i = saved[6 * i:6 * i + 6]
+                    a, x16, ya16, c16i = saved[4 * i:4 * i + 4]
                     g5_img = g5
                     if not batch:
                         gw5, gb5 = _wgrad16(lib, st, c16i, g5, B, 2 * C, H, W, C, 1, ws_cache, book, sc)
@@ -332,7 +336,7 @@ class ResidualControlFn(Function):
                     if not batch:
                         gwb, gbb = _wgrad16(lib, st, ya16, gb16, B, C, H, W, 2 * C, 2, ws_cache, book, sb)
                     ga16 = img(2 * C)
-                    _dgrad16(lib, st, gb16, sb, B, C, H, W, 2 * C, 2, slope, book, out16=ga16, slot16=sp(sa, "g"), mask=ya)
+                    _dgrad16(lib, st, gb16, sb, B, C, H, W, 2 * C, 2, slope, book, out16=ga16, slot16=sp(sa, "g"), mask16=ya16)
                     if batch:       # the round's three weight gradients as one launch, once the last of their operands exists
                         (gwa, gba), (gwb, gbb), (gw5, gb5) = _wgrad16_batch(
                             lib, st, [(x16, ga16, sa, C, 2 * C, 1), (ya16, gb16, sb, C, 2 * C, 2), (c16i, g5_img, sc, 2 * C, C, 1)],
@@ -342,7 +346,7 @@ class ResidualControlFn(Function):
                     if i > 0:       # leaves as the image of the previous round's Conv5 pre-activation gradient
                         g5 = img(C)
                         _dgrad16(lib, st, ga16, sa, B, 2 * C, H, W, C, 1, slope, book, out16=g5, slot16=sp(sites[i - 1][2], "g"),
-                                 addend=gxres, mask=x)
+                                 addend=gxres, mask16=x16)
                     else:
                         gdata = new(C)
                         _dgrad16(lib, st, ga16, sa, B, 2 * C, H, W, C, 1, slope, book, out=gdata, addend=gxres)

@@ -50,7 +50,7 @@ extern "C" {
  * ebfi_conv2d_packed_x3, the fused KernelConv -> FAC forward, ...).  4: ebfi_se_gate_forward takes a workspace
  * (ebfi_se_gate_workspace).  5 (round 4): the never-implemented EBFI_BF16 storage value left ebfi_dtype; fp16 filter storage
  * and the fused-gradient entry points of the KernelConv -> FAC training path.  Bumped whenever an entry point is added or changed. */
-#define EBFI_ABI_VERSION 6
+#define EBFI_ABI_VERSION 7
 
 typedef enum {
     EBFI_OK = 0,
@@ -273,7 +273,8 @@ int ebfi_conv2d_backward_weight_f16g(const void *input, const void *grad_output,
  *   ebfi_to_c16                        fp32 [B,C,HW] -> image (optionally times LeakyReLU'(mask_y): a pre-activation gradient)
  *   ebfi_conv2d_packed_x3_c16          ebfi_conv2d_packed_x3 writing its output also as an image (out16, slot16)
  *   ebfi_conv2d_packed_f16_c16         ebfi_conv2d_packed_f16 reading an image (input_is_c16 = 1; 2 = planar fp16; scale in in_slot) and / or
- *                                      writing its output as one (out16 / slot16; `output` may then be NULL)
+ *                                      writing its output as one (out16 / slot16; `output` may then be NULL); mask_is_c16: mask_y is
+ *                                      the c16 image of the mask tensor (its signs are read) instead of the fp32 tensor
  *   ebfi_conv2d_backward_weight_f16c   weight / bias gradient from the images of the input and of the pre-activation gradient
  *   ebfi_scale_residual_cat_forward_c16 / _backward_c16   the fused ResidualControl stages writing images: forward out + out16;
  *                                      backward [grad_a0 | grad_a1] * LeakyReLU'(a) as ONE image of 2C channels, grad_x fp32,
@@ -288,7 +289,7 @@ int ebfi_conv2d_packed_f16_c16(const void *input, int input_is_c16, const void *
                                const void *bias, void *output, int B, int Cin_per_group, int H, int W, int Cout, int ksize,
                                int pad, int groups, int act, float slope, const void *addend, const void *mask_y,
                                int mask_act, float mask_slope, void *in_slot, const void *w_slot, void *out16,
-                               void *slot16, int out16_planar, void *stream);
+                               void *slot16, int out16_planar, int mask_is_c16, void *stream);
 int ebfi_conv2d_backward_weight_f16c(const void *input16, const void *grad16, int grad_is_planar, void *grad_weight,
                                      void *grad_bias, int B, int Cin_per_group, int H, int W, int Cout, int groups,
                                      const void *x_slot, const void *g_slot, void *workspace, size_t workspace_bytes,

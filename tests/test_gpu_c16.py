@@ -88,7 +88,7 @@ def test_data_gradient_reads_and_writes_images(B, Cin, H, W, Cout, groups, extra
         rc = lib.ebfi_conv2d_packed_f16_c16(N.ptr(inp), is16, site.tr16_ptr(), site.tr16_bytes, N.ptr(None), N.ptr(out), B,
                                             gch // groups, H, W, och, 3, 1, groups, 0, 0.0, N.ptr(addend), N.ptr(mask),
                                             1 if extras else 0, 0.01 if extras else 0.0, book.ptr(si), site.w_slot_ptr(),
-                                            N.ptr(out16), book.ptr(so) if out16 is not None else N.ptr(None), 0, st)
+                                            N.ptr(out16), book.ptr(so) if out16 is not None else N.ptr(None), 0, 0, st)
         N.check(rc, "ebfi_conv2d_packed_f16_c16")
     ref32 = torch.empty(B, och, H, W, device="cuda")
     run(g, 0, ref32, None)
@@ -102,6 +102,17 @@ def test_data_gradient_reads_and_writes_images(B, Cin, H, W, Cout, groups, extra
     run(g16, 1, None, only16)
     assert torch.equal(only16, b16)
     assert book.amax(so) == ref32.abs().max().item()
+    if extras:
+        # the mask as the c16 IMAGE of the mask tensor (only its signs are read): the same result bit for bit
+        sm = book.slot("m")
+        book.calibrate(sm, mask)
+        mask16 = c16.to_c16(mask, book.ptr(sm))
+        m32, m16 = torch.empty_like(ref32), c16.empty(B, och, H, W, "cuda")
+        rc = lib.ebfi_conv2d_packed_f16_c16(N.ptr(g16), 1, site.tr16_ptr(), site.tr16_bytes, N.ptr(None), N.ptr(m32), B, gch // groups, H, W,
+                                            och, 3, 1, groups, 0, 0.0, N.ptr(addend), N.ptr(mask16), 1, 0.01, book.ptr(si),
+                                            site.w_slot_ptr(), N.ptr(m16), book.ptr(so), 0, 1, st)
+        N.check(rc, "ebfi_conv2d_packed_f16_c16 (image mask)")
+        assert torch.equal(m32, ref32) and torch.equal(m16, b16)
     # against fp32 math (loose: fp16 operands)
     wt = w.detach()
     ref = torch.nn.functional.conv_transpose2d(g.cpu(), wt.cpu(), None, 1, 1, groups=groups) if True else None
@@ -307,7 +318,7 @@ def test_backward_convs_stage_planar_fp16_gradients(B, Cin, H, W, Cout):
     def dgrad(inp, mode, out):
         N.check(lib.ebfi_conv2d_packed_f16_c16(N.ptr(inp), mode, site.tr16_ptr(), site.tr16_bytes, N.ptr(None), N.ptr(out), B, Cout, H, W, Cin,
                                                3, 1, 1, 0, 0.0, N.ptr(None), N.ptr(None), 0, 0.0, book.ptr(sg), site.w_slot_ptr(),
-                                               N.ptr(None), N.ptr(None), 0, st), "dgrad")
+                                               N.ptr(None), N.ptr(None), 0, 0, st), "dgrad")
     a, r = torch.empty(B, Cin, H, W, device="cuda"), torch.empty(B, Cin, H, W, device="cuda")
     dgrad(gq, 0, r)
     dgrad(g16, 2, a)

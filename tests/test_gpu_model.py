@@ -404,6 +404,8 @@ def _check_packed_gradient(flat, ref_flat, sizes, names):
         off += k
         if r.norm() > 1e-6 * ref_flat.norm():          # (gradients that vanish against the rest: pure rounding)
             worst = max(worst, (((g - r).norm() / r.norm()).item(), n))
+        if os.environ.get("EBFI_TEST_VERBOSE") == "1":
+            print("   grad %-52s share %.3e  rel %.3e" % (n, (r.norm() / ref_flat.norm()).item(), ((g - r).norm() / r.norm().clamp_min(1e-30)).item()), flush=True)
     assert worst[0] < 5e-2, worst
     return err
 

@@ -65,7 +65,7 @@ for name, cin_g, cout, groups in (("A 64->128", 64, 128, 1), ("B 2x(64->64)", 64
     def dg(inp, is16, out, out16, m=None):
         return lib.ebfi_conv2d_packed_f16_c16(N.ptr(inp), is16, site.tr16_ptr(), site.tr16_bytes, None, N.ptr(out), B, cout // groups, H, W,
                                               cin, 3, 1, groups, 0, 0.0, None, N.ptr(m), 1 if m is not None else 0, 0.01,
-                                              book.ptr(sg), site.w_slot_ptr(), N.ptr(out16), book.ptr(so) if out16 is not None else None, 0, st)
+                                              book.ptr(sg), site.w_slot_ptr(), N.ptr(out16), book.ptr(so) if out16 is not None else None, 0, 0, st)
     r = []
     for label, args in (("fp32->fp32", (g, 0, gin, None)), ("img->fp32", (g16, 1, gin, None)), ("img->img", (g16, 1, None, gin16)),
                         ("img->img+mask", (g16, 1, None, gin16, mask)), ("fp32->fp32+mask", (g, 0, gin, None, mask))):
