@@ -231,7 +231,17 @@ def ops_block(device, iters=20):
     out["fac_backward"] = hbm(fac_bwd_bytes, fac_bwd_ms)
     out["dcn_forward"] = dict(hbm(dcn_fwd_bytes, dcn_fwd_ms), TFLOPs=round(dcn_flops / dcn_fwd_ms / 1e9, 2),
                               frac_f32_mfma=round(dcn_flops / dcn_fwd_ms / 1e9 / F32_MFMA_PEAK_TFS, 4))
-    out["dcn_backward"] = {"ms": round(sum(tb.values()), 4), "kernels_ms": {k: round(v, 4) for k, v in sorted(tb.items())}}
+    # backward, algorithmic: reads x, offset, mask, grad_out and the weight; writes grad_input, grad_offset, grad_mask, grad_weight,
+    # grad_bias (no column tensor, no slabs); matrix work = colgrad (W^T . grad_out) + the weight gradient, 2 * P * C * 9 * C each,
+    # plus the sampling walk's 4 FMAs per sample forward and 4 per coordinate gradient
+    dcn_bwd_ms = sum(tb.values())
+    dcn_bwd_bytes = 4.0 * (P * (C + 3 * dg * 9 + C) + P * (C + 3 * dg * 9) + 2 * C * C * 9 + C)
+    dcn_bwd_flops = 2.0 * P * C * 9 * (2 * C + 8)
+    out["dcn_backward"] = dict(hbm(dcn_bwd_bytes, dcn_bwd_ms), TFLOPs=round(dcn_bwd_flops / dcn_bwd_ms / 1e9, 2),
+                               frac_f32_mfma=round(dcn_bwd_flops / dcn_bwd_ms / 1e9 / F32_MFMA_PEAK_TFS, 4),
+                               bound="mfma (exact fp32 matrix cores: the floor of the two products is %.0f us, of the bytes %.0f us)"
+                                     % (1e6 * dcn_bwd_flops / (F32_MFMA_PEAK_TFS * 1e12), 1e6 * dcn_bwd_bytes / (HBM_PEAK_GBS * 1e9)),
+                               kernels_ms={k: round(v, 4) for k, v in sorted(tb.items())})
     out["dcn_fac_forward"] = dict(hbm(fac_fwd_bytes + dcn_fwd_bytes, fac_fwd_ms + dcn_fwd_ms),
                                   target_frac_hbm=0.30, note="BASELINE.json north_star target: DCNv2+FAC forward at "
                                   "B=8 256x256 (128x128 features), exact fp32 kernels, sum of the two launches")
