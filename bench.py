@@ -468,8 +468,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16x3": ("bf16x3 fwd%s / f16 bwd" % (" (f16 KernelConv)" if eng.book.forward_f16 == "filters" else
-                                                                    " (f16 RC + KernelConv)" if eng.book.forward_f16 == "all" else ""))
+            "dtype": {"fp32": "f32", "bf16x3": ("bf16x3 fwd%s / f16 bwd" % {None: "", "filters": " (f16 KernelConv)",
+                                                                   "all": " (f16 KernelConv, ResidualControl)"}[eng.book.forward_f16])
                                 if eng.book is not None else "bf16x3", "bf16": "bf16"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "EVFIAutoEx (config/train_ours.yml defaults, 5.69 M params) train step: fwd + "

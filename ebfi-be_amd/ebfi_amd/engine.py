@@ -131,8 +131,9 @@ class Engine:
         forward_f16 = N.dev_env("EBFI_F16_FWD", forward_f16) if use_book else None
         if forward_f16 == "none":
             forward_f16 = None
-        if forward_f16 not in (None, "filters", "all"):
-            raise ValueError("forward_f16 must be None, 'filters' or 'all'")
+        from .f16scale import FORWARD_LEVELS
+        if forward_f16 not in FORWARD_LEVELS:
+            raise ValueError("forward_f16 must be one of %r" % (FORWARD_LEVELS,))
         if self.device.type == "cuda" and N.dev_env("EBFI_NO_BANK", "0") != "1":     # (switch for A/B measurements)
             from . import weightbank
             self.bank = weightbank.build_for(self.model, flat=self.optimizer.flat.data, params=self.optimizer.params,

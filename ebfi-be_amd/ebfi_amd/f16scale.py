@@ -38,6 +38,16 @@ def active_book():
     return _ACTIVE
 
 
+# Engine(forward_f16=...): which FORWARD convolutions of a training step read fp16 operands, in increasing reach
+FORWARD_LEVELS = (None, "filters", "all")
+
+
+def forward_level(book):
+    """0 = none, 1 = the KernelConv ("filters"), 2 = + every convolution of ResidualControl ("all": outside the parity bar, an
+    experiment)."""
+    return FORWARD_LEVELS.index(book.forward_f16) if book is not None else 0
+
+
 class ScaleBook:
     def __init__(self, device, capacity=4096):
         self.device = torch.device(device)
@@ -48,7 +58,7 @@ class ScaleBook:
         self.guard = torch.zeros(2, dtype=torch.int32, device=self.device)   # [flag of the current step, skipped steps]
         self.index = {}
         self.calibrated = set()
-        self.forward_f16 = None         # Engine(forward_f16=...): None | "filters" | "all" -- which forward convolutions read fp16 operands
+        self.forward_f16 = None         # Engine(forward_f16=...): one of FORWARD_LEVELS
 
     def slot(self, key):
         """Index of the slot named `key` (created on first use; keys are any hashable: (site key, role))."""

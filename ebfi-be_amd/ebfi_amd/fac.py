@@ -164,7 +164,7 @@ class KernelConvFacTrain(Function):
         with torch.cuda.device_of(cat):
             st = N.stream_ptr(cat.device)
             cat16 = c16.to_c16(cat, sp("x"))          # the weight gradient's input operand (cat itself is not needed again)
-            if book.forward_f16 in ("filters", "all") and site.fwd16_ptr() is not None:
+            if f16scale.forward_level(book) >= 1 and site.fwd16_ptr() is not None:
                 # fp16-operand forward (Engine(forward_f16=...)): the convolution reads the image the weight gradient will read
                 # and the site's fp16 forward weight image -- one matrix-core product per tap instead of three
                 rc = lib.ebfi_conv2d_packed_f16_c16(N.ptr(cat16), 1, site.fwd16_ptr(), site.fwd16_bytes, N.ptr(site.bias()), N.ptr(None),

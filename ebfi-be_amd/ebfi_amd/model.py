@@ -197,7 +197,7 @@ class Modification(BaseModel):
         self.KPN = KernelConv2D(kernel_size=KernelSize)
         self.Conv3 = _conv(FrameBasech, FrameBasech, 3, 1, 1, norm, activation)
         initialize_weights([self.Conv1, self.Conv2, self.Conv3, self.KernelConv], 0.1)
-        self.KernelConv.conv2d._ebfi_fwd16 = True      # (weight bank: the layer Engine(forward_f16="filters") runs on fp16 operands)
+        self.KernelConv.conv2d._ebfi_fwd16 = "filters"     # (weight bank: the layer Engine(forward_f16="filters") runs on fp16 operands)
 
     def _ebfi_bank_register(self, bank):
         """Inference banks also hold the KernelConv weight re-tiled to one FAC channel per 32-row matrix tile: the layout of

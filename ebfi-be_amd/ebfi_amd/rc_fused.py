@@ -241,7 +241,7 @@ class ResidualControlFn(Function):
                 img = lambda ch: c16.empty(B, ch, H, W, x.device)
                 sp = lambda site, role: book.ptr(book.slot((site.key, role)))
                 x16 = c16.to_c16(x, sp(sites[0][0], "x"))
-                f16fwd = book.forward_f16 == "all" and all(t.fwd16_ptr() is not None for r in sites for t in r)
+                f16fwd = f16scale.forward_level(book) >= 2 and all(t.fwd16_ptr() is not None for r in sites for t in r)
                 for i, (sa, sb, sc) in enumerate(sites):
                     nxt = sites[i + 1][0] if i + 1 < len(sites) else None
                     ya, a, xn = new(2 * C), new(2 * C), new(C)

@@ -42,7 +42,7 @@ class Site:
     """Packed images of one (possibly folded / concatenated) conv weight [M = Cout, K = Cin, ks, ks]."""
     __slots__ = ("bank", "kind", "M", "K", "ks", "groups", "fwd_off", "tr_off", "fwd_bytes", "tr_bytes", "bias_off", "has_bias",
                  "w_inv", "w_R", "b_inv", "b_R", "w_shapes", "b_shapes", "key", "tr16_off", "tr16_bytes", "w_slot", "weights",
-                 "fwd16_off", "fwd16_bytes")
+                 "fwd16_off", "fwd16_bytes", "fwd16_tag")
 
     def fwd_ptr(self):
         return N._vp(self.bank.packed.data_ptr() + self.fwd_off)
@@ -99,8 +99,8 @@ class WeightBank:
         `inference`: modules may register forward-only sites that a training step would not use (the fused KernelConv -> FAC
         layout of Modification) -- they would only lengthen the per-step pack launch of a training bank."""
         self.inference = bool(inference)
-        # which sites also get an fp16 FORWARD image (Engine(forward_f16=...)): None, "filters" (convolutions whose module
-        # carries `_ebfi_fwd16`: Modification.KernelConv) or "all" (every 3x3 site)
+        # which sites also get an fp16 FORWARD image (Engine(forward_f16=...), f16scale.FORWARD_LEVELS): the convolutions whose
+        # module carries a tag `_ebfi_fwd16` ("filters": Modification.KernelConv) up to this level; "all": every 3x3 site
         self.fwd16 = fwd16
         self.params = list(params)
         self.owns_flat = flat is None
@@ -164,6 +164,7 @@ class WeightBank:
         s = Site()
         s.bank, s.kind, s.M, s.K, s.ks, s.groups = self, kind, int(M), int(K), int(ks), int(groups)
         s.key, s.weights = key, weights
+        s.fwd16_tag = fwd16 if isinstance(fwd16, str) else None
         s.tr_off, s.tr_bytes, s.tr16_off, s.tr16_bytes, s.w_slot, s.fwd16_off, s.fwd16_bytes = 0, 0, 0, 0, -1, 0, 0
         if need_tr and ks == 3:           # fp16 images (scaled by the site's weight slot); images start on 256-element bounds
             for name, img in (("tr16", tr), ("fwd16", fwd)) if (fwd16 or self.fwd16 == "all") else (("tr16", tr),):
@@ -282,7 +283,10 @@ def build_for(model, flat=None, params=None, inference=False, fwd16=None):
         if isinstance(m, nn.Conv2d) and ok(m.weight, m.bias):
             k = m.kernel_size
             if k[0] == k[1] and k[0] in (1, 3) and m.stride == (1, 1) and m.dilation == (1, 1) and m.groups == 1:
-                bank.register(m.weight, m.bias, "id", fwd16=fwd16 is not None and getattr(m, "_ebfi_fwd16", False))
+                tag = getattr(m, "_ebfi_fwd16", None)
+                from .f16scale import FORWARD_LEVELS
+                want = tag is not None and fwd16 is not None and FORWARD_LEVELS.index(tag) <= FORWARD_LEVELS.index(fwd16)
+                bank.register(m.weight, m.bias, "id", fwd16=tag if want else False)
         elif isinstance(m, nn.Conv3d) and ok(m.weight, m.bias):
             kd, kh, kw = m.kernel_size
             if kd in (1, 3) and kh == kw and kh in (1, 3) and (kh == 1 or m.stride[1] == 1) and m.stride[0] == 1 and \
