@@ -454,6 +454,288 @@ __global__ __launch_bounds__(256, X3 ? 3 : 4) void dcn_fwd_f32(const float *__re
     }
 }
 
+// (development builds with -DDCN_STAMPS -DEBFI_ABLATE: per-phase s_memtime sums of one workgroup, read by tools/dcnprof.py)
+#ifdef DCN_STAMPS
+__device__ unsigned long long g_dcn_stamps[16];
+#define DSTAMP(k)                                                       \
+    do {                                                                \
+        const unsigned long long _t = __builtin_amdgcn_s_memtime();     \
+        _acc[k] += _t - _t0;                                            \
+        _t0 = _t;                                                       \
+    } while (0)
+#else
+#define DSTAMP(k)
+#endif
+
+// ------------------------------------------------------------------------------------------------ forward, LDS-staged window
+// dcn_fwd_win (round 4): the forward for the model-shaped configuration -- 3x3 taps, stride 1, dilation 1, padding 1, EIGHT
+// channels per deformable group -- with the sampling window of a pixel tile staged in LDS.
+//
+// dcn_fwd_f32 above gathers every corner pair from global memory: 2.4 M divergent 8-byte gather instructions per launch at the
+// benchmark size (16-32 cache lines each through the L1 / texture addresser) and ~180 instructions of per-tap set-up for every
+// eight samples; the matrix product is not its limit.  Here a workgroup owns a 16 x 8 pixel tile and walks the deformable groups:
+//   stage   the group's 8 input channels over the window [y0 - 1 - R, y0 + 9 + R] x [x0 - 1 - R, x0 + 17 + R] (R = 6: 23 x 31
+//           positions) into LDS as [position][8 channels] (32 bytes per position; positions outside the image are zeros, so a
+//           corner needs no validity test of its own), coalesced row reads, two 16-byte LDS stores per position;
+//   sample  one item = (pixel, tap): the tap is wave-uniform; offset / mask loads, ONE set of bilinear coefficients (x mask),
+//           four corners x 8 channels = eight 16-byte LDS reads, 32 FMAs, eight column stores.  A sample whose low corner falls
+//           outside the window (|offset| > R) takes the global-gather path of dcn_fwd_f32 for that lane (same arithmetic);
+//   product as in dcn_fwd_f32: [k][pixel] column image x weight slice, exact fp32 MFMA (or split precision), 64 output channels
+//           x 128 pixels per workgroup = two 32 x 32 tiles per wave.
+// Sample arithmetic: c1 * v1 + c2 * v2 + c3 * v3 + c4 * v4 with c = bilinear weight * mask (fmaf chain in this order); results
+// agree with dcn_fwd_f32 to fp32 rounding, not bit for bit.
+constexpr int WPX = 16, WPY = 8, WNP = WPX * WPY;
+constexpr int WR = 6;
+constexpr int WWD = WPX + 3 + 2 * WR, WHT = WPY + 3 + 2 * WR, WPOS = WWD * WHT;      // 31 x 23 = 713 positions
+template <bool X3>
+constexpr int dcn_win_lds_bytes() {
+    return (KC * (WSTR + WNP) + WPOS * 8) * 4;       // 78.4 KB: two workgroups per CU
+}
+template <bool X3>
+__global__ __launch_bounds__(256, 2) void dcn_fwd_win(const float *__restrict__ x, const float *__restrict__ wgt,
+                                                      const float *__restrict__ bias, const float *__restrict__ off,
+                                                      const float *__restrict__ msk, float *__restrict__ out, Geom g, int tiles_x,
+                                                      int tiles_y) {
+    constexpr int ROWS = KC;                  // 72 rows exactly (the split-precision product's last 16-row step: see below)
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    float *sW = dsm;                          // [kl][co], kl = tap * 8 + channel
+    float *sCol = sW + ROWS * WSTR;           // [kl][pixel]
+    // the window as TWO planes [position][4 channels]: neighbouring pixels read neighbouring positions, and 16 lanes x 16 bytes at a
+    // 16-byte stride cover all banks exactly twice (the minimum for 256 bytes); with 32 bytes per position lanes i and i + 4
+    // met in the same banks -- a 4-way conflict on every corner read
+    float *sWin = sCol + ROWS * WNP;          // channels 0..3
+    float *sWin1 = sWin + WPOS * 4;           // channels 4..7
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile = blockIdx.x;                    // (one contiguous eighth of the tiles per XCD: see dcn_fwd_f32)
+    if ((gridDim.x & 7) == 0) {
+        const int T = gridDim.x, q = T >> 3;
+        tile = (tile & 7) * q + (tile >> 3);
+    }
+    const int tpi = tiles_x * tiles_y;
+    const int b = tile / tpi, tt = tile - b * tpi;
+    const int y0 = (tt / tiles_x) * WPY, x0 = (tt % tiles_x) * WPX;
+    const int oy = y0 - 1 - WR, ox = x0 - 1 - WR;
+    const int co_base = blockIdx.y * 64;
+    const int mt = wave >> 1, nt = wave & 1;                 // 32-row co tile, 64-pixel half (two 32-pixel tiles each)
+    const bool tile_live = co_base + mt * 32 < g.Co;
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+
+    constexpr int KL = 72;                                   // rows of a chunk (9 taps x 8 channels)
+    constexpr int NWT = (64 * KL + 255) / 256;               // 18 weight elements per thread
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wgt), 0, (unsigned)g.Co * (unsigned)g.Kd * 4u, 0x00020000);
+    unsigned w_off[NWT];
+    int w_dst[NWT];
+#pragma unroll
+    for (int it = 0; it < NWT; ++it) {
+        const int i = tid + it * 256;                        // (co, r) with r = channel * 9 + tap: contiguous in memory
+        const int co = i / KL, r = i - co * KL;
+        w_off[it] = (unsigned)((co_base + co) * g.Kd + r) * 4u;
+        w_dst[it] = ((r % 9) * 8 + r / 9) * WSTR + co;       // LDS row = tap * 8 + channel
+    }
+    const unsigned plane_bytes = (unsigned)(g.H * g.W) * 4u;
+    const __amdgpu_buffer_rsrc_t rxs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(x + (int64_t)b * g.C * g.H * g.W), 0, (unsigned)g.C * plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t roff = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(off + (int64_t)b * g.dg * 18 * g.HWo), 0, (unsigned)(g.dg * 18) * (unsigned)g.HWo * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rmsk = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(msk + (int64_t)b * g.dg * 9 * g.HWo), 0, (unsigned)(g.dg * 9) * (unsigned)g.HWo * 4u, 0x00020000);
+    // window positions of this thread (fixed over the chunks): 713 = 2 x 256 + 201
+    constexpr int NWP = (WPOS + 255) / 256;
+    unsigned win_off[NWP];
+#pragma unroll
+    for (int k = 0; k < NWP; ++k) {
+        const int pos = tid + k * 256;
+        const int wy = pos / WWD, wx = pos - wy * WWD;
+        const int yy = oy + wy, xx = ox + wx;
+        win_off[k] = (pos < WPOS && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) ? (unsigned)(yy * g.W + xx) * 4u : 0x80000000u;
+    }
+
+    // Per chunk the wave handles the wave-items it = wave, wave + 4, .. < 18 (tap = it >> 1, pixel half = it & 1): at most 5.
+    // Everything a chunk needs from global memory -- weight slice, window, and the offsets / masks of the wave's items -- is
+    // requested one chunk ahead (before the previous chunk's matrix product) and only consumed after the next barrier: the first
+    // version loaded offsets inside the item loop and spent 10 us per chunk waiting for them (8 waves per CU hide nothing).
+    constexpr int NIT = 5;
+    const int py_l = lane >> 4, px_l = lane & 15;
+    float rwv[NWT], wv[NWP][8], ody[NIT], odx[NIT], omk[NIT];
+    auto prefetch = [&](int grp) {
+        const unsigned cbyte = (unsigned)(grp * 8) * plane_bytes;
+        const unsigned wb = (unsigned)(grp * 8 * 9) * 4u;
+#pragma unroll
+        for (int it = 0; it < NWT; ++it) rwv[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, w_off[it] + wb, 0, 0));
+#pragma unroll
+        for (int k = 0; k < NWP; ++k)
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                wv[k][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rxs, win_off[k], (unsigned)__builtin_amdgcn_readfirstlane((int)(cbyte + (unsigned)c * plane_bytes)), 0));
+        const unsigned plane = (unsigned)g.HWo * 4u;
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int it = wave + 4 * j;
+            const int tap = it >> 1, px = (it & 1) * 64 + lane;
+            const int yo = y0 + (px >> 4), xo = x0 + (px & 15);
+            const bool ok = it < 18 && yo < g.Ho && xo < g.Wo;
+            const unsigned p4 = ok ? (unsigned)(yo * g.Wo + xo) * 4u : 0x80000000u;
+            const unsigned ob = ok ? (unsigned)(grp * 18 + 2 * tap) * plane + p4 : 0x80000000u;
+            ody[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(roff, ob, 0, 0));
+            odx[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(roff, ok ? ob + plane : ob, 0, 0));
+            omk[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rmsk, ok ? (unsigned)(grp * 9 + tap) * plane + p4 : ob, 0, 0));
+        }
+    };
+    (void)py_l; (void)px_l;
+#ifdef DCN_STAMPS
+    unsigned long long _acc[16] = {0};
+    unsigned long long _t0 = __builtin_amdgcn_s_memtime();
+#endif
+    prefetch(0);
+    DSTAMP(0);
+    for (int grp = 0; grp < g.dg; ++grp) {
+        const unsigned cbyte = (unsigned)(grp * 8) * plane_bytes;
+        __syncthreads();                                     // the previous chunk's MFMA reads are done
+        DSTAMP(1);
+#pragma unroll
+        for (int it = 0; it < NWT; ++it) sW[w_dst[it]] = col_word<X3>(rwv[it]);
+#pragma unroll
+        for (int k = 0; k < NWP; ++k) {
+            const int pos = tid + k * 256;
+            if (pos < WPOS) {
+                *reinterpret_cast<f32x4 *>(sWin + pos * 4) = f32x4{wv[k][0], wv[k][1], wv[k][2], wv[k][3]};
+                *reinterpret_cast<f32x4 *>(sWin1 + pos * 4) = f32x4{wv[k][4], wv[k][5], wv[k][6], wv[k][7]};
+            }
+        }
+        float cdy[NIT], cdx[NIT], cmk[NIT];                  // this chunk's offsets leave the prefetch registers
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) cdy[j] = ody[j], cdx[j] = odx[j], cmk[j] = omk[j];
+        DSTAMP(2);
+        __syncthreads();                                     // window and weight slice are in LDS
+        DSTAMP(3);
+        if (grp + 1 < g.dg) prefetch(grp + 1);               // (in flight during the sampling and the matrix product below)
+        DSTAMP(5);
+        // ---- sampling
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int it = wave + 4 * j;
+            if (it >= 18) break;                             // (wave-uniform)
+            const int tap = it >> 1, px = (it & 1) * 64 + lane;
+            const int ti = tap / 3, tj = tap - ti * 3;
+            const int py = px >> 4, pxx = px & 15;
+            const int yo = y0 + py, xo = x0 + pxx;
+            const bool p_ok = yo < g.Ho && xo < g.Wo;
+            float *col = sCol + (tap * 8) * WNP + px;
+            float sv[8];
+            // straight-line common path (the compiler overlaps the LDS reads of one item with the arithmetic of its neighbours):
+            // a pixel outside the output, an excluded sample and a sample outside the window all get zero coefficients and
+            // read position 0; only the last case -- rare -- then takes the divergent global-gather branch
+            const float dy = cdy[j], dx = cdx[j], mk = cmk[j];
+            float h = (float)(yo - 1 + ti) + dy, w = (float)(xo - 1 + tj) + dx;
+            const bool valid = p_ok && (h > -1.f) && (w > -1.f) && (h < (float)g.H) && (w < (float)g.W);   // dcn_v2_im2col_cuda.cu:180
+            h = valid ? h : 0.f;
+            w = valid ? w : 0.f;
+            const float fh = floorf(h), fw = floorf(w);
+            const int h0 = (int)fh, w0 = (int)fw;
+            const float lh = h - fh, lw = w - fw, hh = 1.f - lh, hw = 1.f - lw;
+            const int rh = h0 - oy, rw_ = w0 - ox;
+            const bool inwin = valid && rh >= 0 && rh < WHT - 1 && rw_ >= 0 && rw_ < WWD - 1;
+            const float m = inwin ? mk : 0.f;
+            const float c1 = hh * hw * m, c2 = hh * lw * m, c3 = lh * hw * m, c4 = lh * lw * m;
+            {
+                const int idx = inwin ? rh * WWD + rw_ : 0;
+                const f32x4 *q = reinterpret_cast<const f32x4 *>(sWin) + idx;
+                const f32x4 *q1 = reinterpret_cast<const f32x4 *>(sWin1) + idx;
+                const f32x4 a0 = q[0], b0 = q[1], c0 = q[WWD], d0 = q[WWD + 1];               // (h0, w0), (h0, w0 + 1), row h0 + 1
+                const f32x4 a1 = q1[0], b1 = q1[1], c1v = q1[WWD], d1 = q1[WWD + 1];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    sv[c] = fmaf(c4, d0[c], fmaf(c3, c0[c], fmaf(c2, b0[c], c1 * a0[c])));
+                    sv[4 + c] = fmaf(c4, d1[c], fmaf(c3, c1v[c], fmaf(c2, b1[c], c1 * a1[c])));
+                }
+            }
+            if (valid && !inwin) {
+                // outside the staged window: the corners from global memory (rows / columns outside the image read as 0)
+                const float e1 = hh * hw * mk, e2 = hh * lw * mk, e3 = lh * hw * mk, e4 = lh * lw * mk;
+                const bool r0 = h0 >= 0, r1 = h0 + 1 <= g.H - 1, k0 = w0 >= 0, k1 = w0 + 1 <= g.W - 1;
+                const unsigned o00 = (r0 && k0) ? (unsigned)(h0 * g.W + w0) * 4u : 0x80000000u;
+                const unsigned o01 = (r0 && k1) ? (unsigned)(h0 * g.W + w0 + 1) * 4u : 0x80000000u;
+                const unsigned o10 = (r1 && k0) ? (unsigned)((h0 + 1) * g.W + w0) * 4u : 0x80000000u;
+                const unsigned o11 = (r1 && k1) ? (unsigned)((h0 + 1) * g.W + w0 + 1) * 4u : 0x80000000u;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const unsigned cb_ = cbyte + (unsigned)c * plane_bytes;
+                    const float v1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rxs, o00 == 0x80000000u ? o00 : o00 + cb_, 0, 0));
+                    const float v2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rxs, o01 == 0x80000000u ? o01 : o01 + cb_, 0, 0));
+                    const float v3 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rxs, o10 == 0x80000000u ? o10 : o10 + cb_, 0, 0));
+                    const float v4 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rxs, o11 == 0x80000000u ? o11 : o11 + cb_, 0, 0));
+                    sv[c] = fmaf(e4, v4, fmaf(e3, v3, fmaf(e2, v2, e1 * v1)));
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) col[c * WNP] = col_word<X3>(sv[c]);
+        }
+        DSTAMP(4);
+        __syncthreads();
+        DSTAMP(6);
+        if (tile_live) {
+            if constexpr (X3) {
+                const float *ap = sW + 8 * (lane >> 5) * WSTR + mt * 32 + (lane & 31);
+#pragma unroll
+                for (int ks = 0; ks < KCP; ks += 16) {
+                    // (the last step covers rows 64..79: its upper lane half would read rows 72..79, which do not exist -- zero
+                    // pairs instead of 8 more LDS rows per image, which is what lets two workgroups share a CU)
+                    const bool live = ks + 8 * (lane >> 5) < KL;
+                    unsigned aw[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) aw[j] = live ? __float_as_uint(ap[(ks + j) * WSTR]) : 0u;
+                    bf16x8 ah, al;
+                    peel(aw, ah, al);
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2) {
+                        const float *bp = sCol + 8 * (lane >> 5) * WNP + nt * 64 + t2 * 32 + (lane & 31);
+                        unsigned bw[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) bw[j] = live ? __float_as_uint(bp[(ks + j) * WNP]) : 0u;
+                        bf16x8 bh, bl;
+                        peel(bw, bh, bl);
+                        acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t2], 0, 0, 0);
+                        acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t2], 0, 0, 0);
+                        acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t2], 0, 0, 0);
+                    }
+                }
+            } else {
+                const float *ap = sW + (lane >> 5) * WSTR + mt * 32 + (lane & 31);
+                const float *bp = sCol + (lane >> 5) * WNP + nt * 64 + (lane & 31);
+#pragma unroll 4
+                for (int ks = 0; ks < KL; ks += 2) {
+                    const float a = ap[ks * WSTR];
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[ks * WNP], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[ks * WNP + 32], acc[1], 0, 0, 0);
+                }
+            }
+        }
+#ifdef DCN_STAMPS
+        asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][0]));
+#endif
+        DSTAMP(7);
+    }
+#ifdef DCN_STAMPS
+    if (blockIdx.x == 37 && blockIdx.y == 0 && threadIdx.x == 0)
+        for (int k = 0; k < 16; ++k) g_dcn_stamps[k] = _acc[k];
+#endif
+    if (tile_live) {
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const int px = nt * 64 + t2 * 32 + (lane & 31);
+            const int yo = y0 + (px >> 4), xo = x0 + (px & 15);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < g.Co && yo < g.Ho && xo < g.Wo) out[(int64_t)(b * g.Co + co) * g.HWo + yo * g.Wo + xo] = acc[t2][r] + bias[co];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ backward: data
 // grad_offset, grad_mask (plain stores, one owner per element) and grad_input.
 //
@@ -517,17 +799,6 @@ __device__ __forceinline__ float wg_max256(float v, float *red) {
     return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
-#ifdef DCN_STAMPS
-__device__ unsigned long long g_dcn_stamps[16];
-#define DSTAMP(k)                                                       \
-    do {                                                                \
-        const unsigned long long _t = __builtin_amdgcn_s_memtime();     \
-        _acc[k] += _t - _t0;                                            \
-        _t0 = _t;                                                       \
-    } while (0)
-#else
-#define DSTAMP(k)
-#endif
 
 __global__ __launch_bounds__(256, 2) void dcn_bwd_data_f32(const float *__restrict__ x, const float *__restrict__ wgt,
                                                         const float *__restrict__ off, const float *__restrict__ msk,
@@ -1029,6 +1300,31 @@ extern "C" int ebfi_dcn_forward(const void *input, const void *weight, const voi
     if (int rc = make_geom(g, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, deformable_group)) return rc;
     if (B == 0) return EBFI_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // the model-shaped configuration (3x3, stride 1, dilation 1, padding 1, 8 channels per deformable group): sampling window in LDS
+    if (kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 && dw == 1 && g.cpg == 8 &&
+        !dev_getenv("EBFI_DCN_NO_WINDOW")) {
+        const int tiles_x = (g.Wo + WPX - 1) / WPX, tiles_y = (g.Ho + WPY - 1) / WPY;
+        const int64_t tiles = (int64_t)B * tiles_x * tiles_y;
+        if (tiles <= 2147483647LL) {
+            const dim3 wgrid((unsigned)tiles, (unsigned)((Co + 63) / 64));
+            const double P = (double)B * g.HWo;
+            const bool x3 = dtype == EBFI_F32_BF16X3MMA;
+            ProfScope ps(x3 ? "dcn_fwd_bf16x3" : "dcn_fwd_f32", st, 2.0 * P * C * g.kk * (4 + Co),
+                         4.0 * (P * (C + 3.0 * deformable_group * g.kk + Co) + (double)Co * C * g.kk));
+            if (x3) {
+                if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&dcn_fwd_win<true>), dcn_win_lds_bytes<true>())) return rc;
+                hipLaunchKernelGGL(dcn_fwd_win<true>, wgrid, dim3(256), dcn_win_lds_bytes<true>(), st, static_cast<const float *>(input),
+                                   static_cast<const float *>(weight), static_cast<const float *>(bias), static_cast<const float *>(offset),
+                                   static_cast<const float *>(mask), static_cast<float *>(output), g, tiles_x, tiles_y);
+            } else {
+                if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&dcn_fwd_win<false>), dcn_win_lds_bytes<false>())) return rc;
+                hipLaunchKernelGGL(dcn_fwd_win<false>, wgrid, dim3(256), dcn_win_lds_bytes<false>(), st, static_cast<const float *>(input),
+                                   static_cast<const float *>(weight), static_cast<const float *>(bias), static_cast<const float *>(offset),
+                                   static_cast<const float *>(mask), static_cast<float *>(output), g, tiles_x, tiles_y);
+            }
+            return check_launch("dcn_fwd_win");
+        }
+    }
     dim3 grid((unsigned)(B * g.tiles_per_img), (unsigned)((Co + 63) / 64));
     if (dtype == EBFI_F32_BF16X3MMA) {
         const double P = (double)B * g.HWo;

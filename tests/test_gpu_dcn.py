@@ -36,6 +36,10 @@ CASES = [
     dict(B=1, C=20, H=10, W=12, Co=6, k=3, s=1, p=1, d=1, dg=1),     # cpg=20 > 8 per chunk: sub-blocks
     dict(B=1, C=4, H=12, W=10, Co=3, k=(3, 5), s=1, p=(1, 2), d=1, dg=2),  # kh != kw, ph != pw (pad quirk)
     dict(B=1, C=2, H=9, W=9, Co=2, k=7, s=1, p=3, d=1, dg=1),        # 49 taps: one channel per chunk
+    # the LDS-window forward (3x3, stride 1, pad 1, 8 channels per group): ragged 16 x 8 pixel tiles in both directions, offsets
+    # wide enough (sigma 4 against a window reach of 6) that many samples take the global-gather path next to the window path
+    dict(B=2, C=16, H=19, W=37, Co=40, k=3, s=1, p=1, d=1, dg=2, off_scale=4.0),
+    dict(B=1, C=8, H=7, W=5, Co=3, k=3, s=1, p=1, d=1, dg=1, off_scale=0.5),   # an image smaller than one tile and its window
 ]
 
 
