@@ -1228,6 +1228,221 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restric
     }
 }
 
+// dcn_bwd_weight_win (round 4): the weight gradient for the model-shaped configuration with the sampling of dcn_fwd_win --
+// 16 x 8 pixel tiles, the deformable group's window staged in LDS, items = (pixel, tap) with all 8 channels.  One 512-thread
+// workgroup per CU (93 KB of LDS: grad_out tile [co][px], column image [kl][px] with kl = tap * 8 + channel, window planes), so
+// nothing but its own prefetch hides a load: the grad_out tile, the window and the wave's offsets / masks of the NEXT
+// (group, tile) step are requested before the matrix product of the current one.  Product: acc[co][kl] += sum_px
+// gout[co][px] * col[kl][px] with 16x16x4 fp32 MFMA; wave w owns co rows 16 (w & 3) .. +15 and the kl tiles {0,1,2} (w < 4) or
+// {3,4} (w >= 4).  Slab layout and reduction as dcn_bwd_weight_f32; 256 workgroups = half its slab traffic.
+constexpr int GSTR = WNP + 1;          // row stride of both [row][pixel] images: odd, so 16 lanes reading a column hit 16 banks
+constexpr int dcn_wwin_lds_bytes() { return ((64 + KC) * GSTR + WPOS * 8) * 4; }
+__global__ __launch_bounds__(512) void dcn_bwd_weight_win(const float *__restrict__ x, const float *__restrict__ off,
+                                                          const float *__restrict__ msk, const float *__restrict__ gout,
+                                                          float *__restrict__ slab, Geom g, int tiles_x, int tiles_y, int total_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    float *sG = dsm;                       // [co][pixel]
+    float *sCol = sG + 64 * GSTR;          // [kl][pixel]
+    float *sWin = sCol + KC * GSTR;        // channels 0..3 per position
+    float *sWin1 = sWin + WPOS * 4;        // channels 4..7
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co_base = blockIdx.y * 64;
+    const int64_t slab_stride = (int64_t)g.Co * g.Kd + g.Co;
+    float *my = slab + (int64_t)blockIdx.x * slab_stride;
+    const int tpi = tiles_x * tiles_y;
+    const unsigned plane_bytes = (unsigned)(g.H * g.W) * 4u;
+    const int mrow = wave & 3, nlo = wave < 4 ? 0 : 3, ncnt = wave < 4 ? 3 : 2;
+    float bpart[16];                       // bias partials: channel tid / 128 + 4 k, pixel tid & 127
+#pragma unroll
+    for (int k = 0; k < 16; ++k) bpart[k] = 0.f;
+    constexpr int NIT = 3, NWP = 2;        // wave-items per wave (18 over 8 waves), window positions per thread (713 over 512)
+    float pg[16], wv[NWP][8], ody[NIT], odx[NIT], omk[NIT];
+    auto prefetch = [&](int grp, int tile) {
+        const int b = tile / tpi, tt = tile - b * tpi;
+        const int y0 = (tt / tiles_x) * WPY, x0 = (tt % tiles_x) * WPX;
+        const int oy = y0 - 1 - WR, ox = x0 - 1 - WR;
+        const __amdgpu_buffer_rsrc_t rxs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(x + (int64_t)b * g.C * g.H * g.W), 0, (unsigned)g.C * plane_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rgo = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(gout + (int64_t)b * g.Co * g.HWo), 0, (unsigned)g.Co * (unsigned)g.HWo * 4u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t roff = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(off + (int64_t)b * g.dg * 18 * g.HWo), 0, (unsigned)(g.dg * 18) * (unsigned)g.HWo * 4u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rmsk = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(msk + (int64_t)b * g.dg * 9 * g.HWo), 0, (unsigned)(g.dg * 9) * (unsigned)g.HWo * 4u, 0x00020000);
+        const unsigned plane = (unsigned)g.HWo * 4u;
+        {
+            const int px = tid & (WNP - 1);
+            const int yo = y0 + (px >> 4), xo = x0 + (px & 15);
+            const bool ok = yo < g.Ho && xo < g.Wo;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int co = co_base + (tid >> 7) + 4 * k;
+                const unsigned o = (ok && co < g.Co) ? (unsigned)co * plane + (unsigned)(yo * g.Wo + xo) * 4u : 0x80000000u;
+                pg[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rgo, o, 0, 0));
+            }
+        }
+        const unsigned cbyte = (unsigned)(grp * 8) * plane_bytes;
+#pragma unroll
+        for (int k = 0; k < NWP; ++k) {
+            const int pos = tid + k * 512;
+            const int wy = pos / WWD, wx = pos - wy * WWD;
+            const int yy = oy + wy, xx = ox + wx;
+            const unsigned wo = (pos < WPOS && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) ? (unsigned)(yy * g.W + xx) * 4u : 0x80000000u;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                wv[k][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rxs, wo, (unsigned)__builtin_amdgcn_readfirstlane((int)(cbyte + (unsigned)c * plane_bytes)), 0));
+        }
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int it = wave + 8 * j;
+            const int tap = it >> 1, px = (it & 1) * 64 + lane;
+            const int yo = y0 + (px >> 4), xo = x0 + (px & 15);
+            const bool ok = it < 18 && yo < g.Ho && xo < g.Wo;
+            const unsigned p4 = ok ? (unsigned)(yo * g.Wo + xo) * 4u : 0x80000000u;
+            const unsigned ob = ok ? (unsigned)(grp * 18 + 2 * tap) * plane + p4 : 0x80000000u;
+            ody[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(roff, ob, 0, 0));
+            odx[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(roff, ok ? ob + plane : ob, 0, 0));
+            omk[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rmsk, ok ? (unsigned)(grp * 9 + tap) * plane + p4 : ob, 0, 0));
+        }
+    };
+    const bool any_tile = (int)blockIdx.x < total_tiles;
+    if (any_tile) prefetch(0, blockIdx.x);
+    for (int grp = 0; grp < g.dg; ++grp) {
+        f32x4 acc[3];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+            const int b = tile / tpi, tt = tile - b * tpi;
+            const int y0 = (tt / tiles_x) * WPY, x0 = (tt % tiles_x) * WPX;
+            const int oy = y0 - 1 - WR, ox = x0 - 1 - WR;
+            __syncthreads();                                 // the previous step's MFMA reads are done
+            {
+                const int px = tid & (WNP - 1);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    sG[((tid >> 7) + 4 * k) * GSTR + px] = pg[k];
+                    if (grp == 0) bpart[k] += pg[k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NWP; ++k) {
+                const int pos = tid + k * 512;
+                if (pos < WPOS) {
+                    *reinterpret_cast<f32x4 *>(sWin + pos * 4) = f32x4{wv[k][0], wv[k][1], wv[k][2], wv[k][3]};
+                    *reinterpret_cast<f32x4 *>(sWin1 + pos * 4) = f32x4{wv[k][4], wv[k][5], wv[k][6], wv[k][7]};
+                }
+            }
+            float cdy[NIT], cdx[NIT], cmk[NIT];
+#pragma unroll
+            for (int j = 0; j < NIT; ++j) cdy[j] = ody[j], cdx[j] = odx[j], cmk[j] = omk[j];
+            __syncthreads();                                 // grad_out tile and window are in LDS
+            {   // the next step's data: next tile of this group, else the first tile of the next group
+                int ntile = tile + (int)gridDim.x, ngrp = grp;
+                if (ntile >= total_tiles) { ntile = blockIdx.x; ++ngrp; }
+                if (ngrp < g.dg) prefetch(ngrp, ntile);
+            }
+            const unsigned cbyte = (unsigned)(grp * 8) * plane_bytes;
+            const __amdgpu_buffer_rsrc_t rxs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float *>(x + (int64_t)b * g.C * g.H * g.W), 0, (unsigned)g.C * plane_bytes, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < NIT; ++j) {
+                const int it = wave + 8 * j;
+                if (it >= 18) break;                         // (wave-uniform)
+                const int tap = it >> 1, px = (it & 1) * 64 + lane;
+                const int ti = tap / 3, tj = tap - ti * 3;
+                const int yo = y0 + (px >> 4), xo = x0 + (px & 15);
+                const bool p_ok = yo < g.Ho && xo < g.Wo;
+                float *col = sCol + (tap * 8) * GSTR + px;
+                float sv[8];
+                const float dy = cdy[j], dx = cdx[j], mk = cmk[j];
+                float h = (float)(yo - 1 + ti) + dy, w = (float)(xo - 1 + tj) + dx;
+                const bool valid = p_ok && (h > -1.f) && (w > -1.f) && (h < (float)g.H) && (w < (float)g.W);
+                h = valid ? h : 0.f;
+                w = valid ? w : 0.f;
+                const float fh = floorf(h), fw = floorf(w);
+                const int h0 = (int)fh, w0 = (int)fw;
+                const float lh = h - fh, lw = w - fw, hh = 1.f - lh, hw = 1.f - lw;
+                const int rh = h0 - oy, rw_ = w0 - ox;
+                const bool inwin = valid && rh >= 0 && rh < WHT - 1 && rw_ >= 0 && rw_ < WWD - 1;
+                const float m = inwin ? mk : 0.f;
+                const float c1 = hh * hw * m, c2 = hh * lw * m, c3 = lh * hw * m, c4 = lh * lw * m;
+                {
+                    const int idx = inwin ? rh * WWD + rw_ : 0;
+                    const f32x4 *q = reinterpret_cast<const f32x4 *>(sWin) + idx;
+                    const f32x4 *q1 = reinterpret_cast<const f32x4 *>(sWin1) + idx;
+                    const f32x4 a0 = q[0], b0 = q[1], c0 = q[WWD], d0 = q[WWD + 1];
+                    const f32x4 a1 = q1[0], b1 = q1[1], c1v = q1[WWD], d1 = q1[WWD + 1];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        sv[c] = fmaf(c4, d0[c], fmaf(c3, c0[c], fmaf(c2, b0[c], c1 * a0[c])));
+                        sv[4 + c] = fmaf(c4, d1[c], fmaf(c3, c1v[c], fmaf(c2, b1[c], c1 * a1[c])));
+                    }
+                }
+                if (valid && !inwin) {
+                    const float e1 = hh * hw * mk, e2 = hh * lw * mk, e3 = lh * hw * mk, e4 = lh * lw * mk;
+                    const bool r0 = h0 >= 0, r1 = h0 + 1 <= g.H - 1, k0 = w0 >= 0, k1 = w0 + 1 <= g.W - 1;
+                    const unsigned o00 = (r0 && k0) ? (unsigned)(h0 * g.W + w0) * 4u : 0x80000000u;
+                    const unsigned o01 = (r0 && k1) ? (unsigned)(h0 * g.W + w0 + 1) * 4u : 0x80000000u;
+                    const unsigned o10 = (r1 && k0) ? (unsigned)((h0 + 1) * g.W + w0) * 4u : 0x80000000u;
+                    const unsigned o11 = (r1 && k1) ? (unsigned)((h0 + 1) * g.W + w0 + 1) * 4u : 0x80000000u;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const unsigned cb_ = cbyte + (unsigned)c * plane_bytes;
+                        const float v1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rxs, o00 == 0x80000000u ? o00 : o00 + cb_, 0, 0));
+                        const float v2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rxs, o01 == 0x80000000u ? o01 : o01 + cb_, 0, 0));
+                        const float v3 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rxs, o10 == 0x80000000u ? o10 : o10 + cb_, 0, 0));
+                        const float v4 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rxs, o11 == 0x80000000u ? o11 : o11 + cb_, 0, 0));
+                        sv[c] = fmaf(e4, v4, fmaf(e3, v3, fmaf(e2, v2, e1 * v1)));
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) col[c * GSTR] = sv[c];
+            }
+            __syncthreads();
+            // acc[co][kl] += sum_px gout[co][px] * col[kl][px]
+            const float *ap = sG + (mrow * 16 + (lane & 15)) * GSTR + (lane >> 4);
+#pragma unroll 4
+            for (int ks = 0; ks < WNP; ks += 4) {
+                const float av = ap[ks];
+#pragma unroll
+                for (int n = 0; n < 3; ++n) {
+                    const int kl = (nlo + n) * 16 + (lane & 15);
+                    const float bv = (n < ncnt && kl < KC) ? sCol[kl * GSTR + (lane >> 4) + ks] : 0.f;
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[n], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+            if (n < ncnt) {
+                const int kl = (nlo + n) * 16 + (lane & 15);          // LDS row = tap * 8 + channel
+                const int tap = kl >> 3, c = kl & 7;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co_base + mrow * 16 + (lane >> 4) * 4 + r;
+                    if (kl < KC && co < g.Co) my[(int64_t)co * g.Kd + (int64_t)(grp * 8 + c) * 9 + tap] = acc[n][r];
+                }
+            }
+    }
+    // bias partials: channel (tid >> 7) + 4 k summed over the 128 threads (two waves) that hold its pixels
+    __syncthreads();
+    float *red = sG;                                          // [16][8 waves]
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        float v = bpart[k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (lane == 0) red[k * 8 + wave] = v;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int k = tid >> 2, q = tid & 3;                  // channel q + 4 k: waves 2 q, 2 q + 1
+        const int co = co_base + q + 4 * k;
+        if (co < g.Co) my[(int64_t)g.Co * g.Kd + co] = red[k * 8 + 2 * q] + red[k * 8 + 2 * q + 1];
+    }
+}
+
 // 64 consecutive elements per workgroup, 4 thread rows each summing every 4th slab, fixed-order combine
 __global__ __launch_bounds__(256) void dcn_bwd_reduce_f32(const float *__restrict__ slab, int nslabs, int64_t n_weight,
                                                           int64_t n_total, float *__restrict__ gw,
@@ -1408,8 +1623,21 @@ extern "C" int ebfi_dcn_backward(const void *input, const void *weight, const vo
                            static_cast<float *>(grad_mask), wn2, g, bx);
     }
     if (int rc = check_launch("dcn_bwd_data_f32")) return rc;
-    const int nwg = weight_grid(g);
-    {
+    int nwg = weight_grid(g);
+    const bool win = kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 && dw == 1 && g.cpg == 8 &&
+                     !dev_getenv("EBFI_DCN_NO_WINDOW");
+    if (win) {
+        // the model-shaped configuration: sampling window in LDS (dcn_bwd_weight_win), one workgroup per CU
+        const int tiles_x = (g.Wo + WPX - 1) / WPX, tiles_y = (g.Ho + WPY - 1) / WPY;
+        const int64_t tiles = (int64_t)B * tiles_x * tiles_y;
+        if (tiles > 2147483647LL) return fail(EBFI_ERR_ARG, "dcn_backward: too many tiles");
+        const int cap = nwg < 256 ? nwg : 256;                // (never more slabs than the workspace of weight_grid(g) holds)
+        nwg = (int)(tiles < cap ? tiles : cap);
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&dcn_bwd_weight_win), dcn_wwin_lds_bytes())) return rc;
+        ProfScope ps("dcn_bwd_weight_f32", st);
+        hipLaunchKernelGGL(dcn_bwd_weight_win, dim3((unsigned)nwg, (unsigned)((Co + 63) / 64)), dim3(512), dcn_wwin_lds_bytes(), st, x, off,
+                           msk, go, static_cast<float *>(workspace), g, tiles_x, tiles_y, (int)tiles);
+    } else {
         ProfScope ps("dcn_bwd_weight_f32", st);
         hipLaunchKernelGGL(dcn_bwd_weight_f32, dim3((unsigned)nwg, (unsigned)((Co + 63) / 64)), dim3(256), 0, st, x, off,
                            msk, go, static_cast<float *>(workspace), g, B * g.tiles_per_img);
