@@ -1235,7 +1235,8 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restric
 // (group, tile) step are requested before the matrix product of the current one.  Product: acc[co][kl] += sum_px
 // gout[co][px] * col[kl][px] with 16x16x4 fp32 MFMA; wave w owns co rows 16 (w & 3) .. +15 and the kl tiles {0,1,2} (w < 4) or
 // {3,4} (w >= 4).  Slab layout and reduction as dcn_bwd_weight_f32; 256 workgroups = half its slab traffic.
-constexpr int GSTR = WNP + 1;          // row stride of both [row][pixel] images: odd, so 16 lanes reading a column hit 16 banks
+constexpr int GSTR = WNP + 4;          // row stride of both [row][pixel] images: a 16x16x4 operand read (lane = (row l & 15, pixel l >> 4))
+                                       // lands on bank 4 * row + pixel: each bank exactly twice, the minimum for 64 lanes
 constexpr int dcn_wwin_lds_bytes() { return ((64 + KC) * GSTR + WPOS * 8) * 4; }
 __global__ __launch_bounds__(512) void dcn_bwd_weight_win(const float *__restrict__ x, const float *__restrict__ off,
                                                           const float *__restrict__ msk, const float *__restrict__ gout,
@@ -1307,7 +1308,12 @@ __global__ __launch_bounds__(512) void dcn_bwd_weight_win(const float *__restric
         }
     };
     const bool any_tile = (int)blockIdx.x < total_tiles;
+#ifdef DCN_STAMPS
+    unsigned long long _acc[16] = {0};
+    unsigned long long _t0 = __builtin_amdgcn_s_memtime();
+#endif
     if (any_tile) prefetch(0, blockIdx.x);
+    DSTAMP(0);
     for (int grp = 0; grp < g.dg; ++grp) {
         f32x4 acc[3];
 #pragma unroll
@@ -1317,6 +1323,7 @@ __global__ __launch_bounds__(512) void dcn_bwd_weight_win(const float *__restric
             const int y0 = (tt / tiles_x) * WPY, x0 = (tt % tiles_x) * WPX;
             const int oy = y0 - 1 - WR, ox = x0 - 1 - WR;
             __syncthreads();                                 // the previous step's MFMA reads are done
+            DSTAMP(1);
             {
                 const int px = tid & (WNP - 1);
 #pragma unroll
@@ -1336,12 +1343,15 @@ __global__ __launch_bounds__(512) void dcn_bwd_weight_win(const float *__restric
             float cdy[NIT], cdx[NIT], cmk[NIT];
 #pragma unroll
             for (int j = 0; j < NIT; ++j) cdy[j] = ody[j], cdx[j] = odx[j], cmk[j] = omk[j];
+            DSTAMP(2);
             __syncthreads();                                 // grad_out tile and window are in LDS
+            DSTAMP(3);
             {   // the next step's data: next tile of this group, else the first tile of the next group
                 int ntile = tile + (int)gridDim.x, ngrp = grp;
                 if (ntile >= total_tiles) { ntile = blockIdx.x; ++ngrp; }
                 if (ngrp < g.dg) prefetch(ngrp, ntile);
             }
+            DSTAMP(4);
             const unsigned cbyte = (unsigned)(grp * 8) * plane_bytes;
             const __amdgpu_buffer_rsrc_t rxs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float *>(x + (int64_t)b * g.C * g.H * g.W), 0, (unsigned)g.C * plane_bytes, 0x00020000);
@@ -1399,20 +1409,65 @@ __global__ __launch_bounds__(512) void dcn_bwd_weight_win(const float *__restric
 #pragma unroll
                 for (int c = 0; c < 8; ++c) col[c * GSTR] = sv[c];
             }
+            DSTAMP(5);
             __syncthreads();
+            DSTAMP(6);
             // acc[co][kl] += sum_px gout[co][px] * col[kl][px]
+            // operands of 8 k-steps (32 pixels) per batch, the next batch's LDS reads issued before this batch's 24 MFMAs: the
+            // plain loop waited for its reads in front of every MFMA group (stamps: 10 000 cycles per step for 3 000 of MFMA issue)
             const float *ap = sG + (mrow * 16 + (lane & 15)) * GSTR + (lane >> 4);
-#pragma unroll 4
-            for (int ks = 0; ks < WNP; ks += 4) {
-                const float av = ap[ks];
+            const float *bp0 = sCol + ((nlo + 0) * 16 + (lane & 15)) * GSTR + (lane >> 4);
+            const float *bp1 = sCol + ((nlo + 1) * 16 + (lane & 15)) * GSTR + (lane >> 4);
+            const int kl2 = (nlo + 2) * 16 + (lane & 15);
+            const bool live2 = ncnt > 2 && kl2 < KC;
+            const float *bp2 = sCol + (live2 ? kl2 : 0) * GSTR + (lane >> 4);
+            const bool live1 = (nlo + 1) * 16 + (lane & 15) < KC;            // (tile 4 = rows 64..79: rows >= 72 do not exist)
+            struct Ops {
+                float a[8], b0[8], b1[8], b2[8];
+            };
+            auto load_ops = [&](int k0) {
+                Ops o;
 #pragma unroll
-                for (int n = 0; n < 3; ++n) {
-                    const int kl = (nlo + n) * 16 + (lane & 15);
-                    const float bv = (n < ncnt && kl < KC) ? sCol[kl * GSTR + (lane >> 4) + ks] : 0.f;
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[n], 0, 0, 0);
+                for (int j = 0; j < 8; ++j) {
+                    o.a[j] = ap[k0 + 4 * j];
+                    o.b0[j] = bp0[k0 + 4 * j];
+                    o.b1[j] = live1 ? bp1[k0 + 4 * j] : 0.f;
+                    o.b2[j] = live2 ? bp2[k0 + 4 * j] : 0.f;
                 }
-            }
+                return o;
+            };
+            auto multiply = [&](const Ops &o) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[j], o.b0[j], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[j], o.b1[j], acc[1], 0, 0, 0);
+                    if (ncnt > 2) acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[j], o.b2[j], acc[2], 0, 0, 0);   // (wave-uniform)
+                }
+            };
+            static_assert(WNP == 128, "four batches of 32 pixels");
+            Ops o0 = load_ops(0), o1;
+            o1 = load_ops(32);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(o0);
+            __builtin_amdgcn_sched_barrier(0);
+            o0 = load_ops(64);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(o1);
+            __builtin_amdgcn_sched_barrier(0);
+            o1 = load_ops(96);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(o0);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(o1);
+#ifdef DCN_STAMPS
+            asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]));
+#endif
+            DSTAMP(7);
         }
+#ifdef DCN_STAMPS
+        if (grp == g.dg - 1 && blockIdx.x == 37 && blockIdx.y == 0 && threadIdx.x == 0)
+            for (int k = 0; k < 16; ++k) g_dcn_stamps[8 + (k & 7)] = _acc[k & 7];
+#endif
 #pragma unroll
         for (int n = 0; n < 3; ++n)
             if (n < ncnt) {
