@@ -212,7 +212,6 @@ class Modification(BaseModel):
     def _fused_filters_apply(self, ev, cat):
         """FAC(ev, LeakyReLU(KernelConv(cat))) as one kernel, or None when the fused form does not apply (training, other
         precision modes, no inference bank, rows that do not split into 16-byte quads)."""
-        import os
         from . import fac, weightbank
         if torch.is_grad_enabled() and (cat.requires_grad or any(p.requires_grad for p in self.KernelConv.parameters())):
             return None
@@ -232,7 +231,6 @@ class Modification(BaseModel):
             ev1 = self.Conv3(fused)
             return FrameTensor * ev1 + self.Conv2(ev1)
         fuse = self.KernelConv.native(cat)
-        import os
         from . import f16scale, fac as facmod, weightbank
         book = f16scale.active_book()
         c = self.KernelConv.conv2d

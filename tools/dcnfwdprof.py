@@ -1,11 +1,16 @@
 #!/usr/bin/env python3
 """Phase times of dcn_fwd_win for one workgroup (development aid; needs a library built with -DDCN_STAMPS -DEBFI_ABLATE into a
 separate file and selected with EBFI_DEV=1 EBFI_LIB_PATH=...)."""
-import ctypes, os, sys, torch
-ROOT = "/root/repo" if os.path.isdir("/root/repo/ebfi-be_amd") else os.environ.get("GRAFT_REPO_ROOT", ".")
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ebfi-be_amd"))
-from ebfi_amd import _native as N
-from ebfi_amd.dcn import dcn_v2_forward
+from ebfi_amd import _native as N  # noqa: E402
+from ebfi_amd.dcn import dcn_v2_forward  # noqa: E402
+
 B, C, h, w, dg = 8, 64, 128, 128, 8
 torch.manual_seed(0)
 x = torch.randn(B, C, h, w, device="cuda")
@@ -14,8 +19,8 @@ msk = torch.sigmoid(torch.randn(B, dg * 9, h, w, device="cuda"))
 wt = torch.randn(C, C, 3, 3, device="cuda") / 24
 bias = torch.randn(C, device="cuda")
 cfg = ((1, 1), (1, 1), (1, 1), dg)
-lib = N.lib()
-import ctypes as C_
+N.lib()
+import ctypes as C_  # noqa: E402
 raw = C_.CDLL(N.LIB_PATH)
 f = raw.ebfi_dcn_debug_stamps
 f.argtypes = [C_.c_void_p, C_.c_int]
