@@ -3542,12 +3542,34 @@ extern "C" int ebfi_conv2d_packed_f16_c16(const void *input, int input_is_c16, c
 
 // weight / bias gradient of a (grouped) 3x3 convolution with fp16 operands: grad_output optionally times act'(saved_output)
 // (side output grad_preact_out as in ebfi_conv2d_backward_weight_ex); Cin_per_group a multiple of 64.
+extern "C" int ebfi_conv2d_backward_weight_f16g_ex(const void *input, const void *grad_output, const void *saved_output,
+                                                   void *grad_weight, void *grad_bias, void *grad_preact_out, int grad_preact_is_c16,
+                                                   int B, int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups,
+                                                   int act, float slope, void *x_slot, void *g_slot, void *workspace,
+                                                   size_t workspace_bytes, void *stream);
 extern "C" int ebfi_conv2d_backward_weight_f16g(const void *input, const void *grad_output, const void *saved_output,
                                                 void *grad_weight, void *grad_bias, void *grad_preact_out, int B,
                                                 int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups, int act,
                                                 float slope, void *x_slot, void *g_slot, void *workspace,
                                                 size_t workspace_bytes, void *stream) {
+    return ebfi_conv2d_backward_weight_f16g_ex(input, grad_output, saved_output, grad_weight, grad_bias, grad_preact_out, 0, B,
+                                               Cin_per_group, H, W, Cout, ksize, pad, groups, act, slope, x_slot, g_slot, workspace,
+                                               workspace_bytes, stream);
+}
+
+// grad_preact_is_c16 != 0: grad_preact_out (grad_output * act'(saved_output), the data gradient's input) leaves as a c16 IMAGE
+// scaled by g_slot's scale instead of an fp32 tensor (Cout % 16 == 0; only with the pixel-major kernel: 3x3, pad 1, W % 4 == 0,
+// 16-byte aligned tensors -- otherwise EBFI_ERR_UNSUPPORTED); ebfi_conv2d_packed_f16_c16(input_is_c16 = 1, in_slot = g_slot)
+// reads it.
+extern "C" int ebfi_conv2d_backward_weight_f16g_ex(const void *input, const void *grad_output, const void *saved_output,
+                                                   void *grad_weight, void *grad_bias, void *grad_preact_out, int grad_preact_is_c16,
+                                                   int B, int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups,
+                                                   int act, float slope, void *x_slot, void *g_slot, void *workspace,
+                                                   size_t workspace_bytes, void *stream) {
     if (!input || !grad_output || !grad_weight) return fail(EBFI_ERR_ARG, "conv2d_backward_weight_f16g: null argument");
+    const bool gp16 = grad_preact_is_c16 != 0 && grad_preact_out != nullptr;
+    if (gp16 && (act == ACT_NONE || Cout % 16 != 0 || !g_slot))
+        return fail(EBFI_ERR_ARG, "conv2d_backward_weight_f16g: an fp16 image of grad * act' needs an activation, Cout %% 16 == 0 and g_slot");
     if (ksize != 3) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_weight_f16g: k=%d", ksize);
     // input channels: multiples of 64 for the pair-word kernel; the pixel-major kernel zero-fills a partial 64-channel block
     // (loads past the sample's last channel read 0, columns past Cin are not stored), which serves the 32 / 48-channel layers
@@ -3590,14 +3612,15 @@ extern "C" int ebfi_conv2d_backward_weight_f16g(const void *input, const void *g
         dim3 grid((unsigned)nsplit, (unsigned)ceil_div(g.Cout, 64), (unsigned)ceil_div(g.Cin, 64));
         const ScaleSlot xs{static_cast<float *>(x_slot)}, gs{static_cast<float *>(g_slot)};
         ProfScope ps("conv_wgrad_f16_tr/f32", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * 9,
-                     conv_bytes_wgrad(g, 9, act != ACT_NONE, grad_preact_out != nullptr));
+                     conv_bytes_wgrad(g, 9, act != ACT_NONE, grad_preact_out != nullptr) -
+                         (gp16 ? 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout : 0.0));
 #define EBFI_LAUNCH_WTR(DA_)                                                                                               \
     do {                                                                                                                   \
         if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_wgrad_f16_tr<DA_>), TR_LDS + KB_LDS_BYTES)) return rc_;       \
         hipLaunchKernelGGL((conv_wgrad_f16_tr<DA_>), grid, dim3(512), TR_LDS + KB_LDS_BYTES, st, static_cast<const float *>(input),           \
                            static_cast<const float *>(grad_output), static_cast<const float *>(saved_output),              \
                            static_cast<float *>(grad_preact_out), slab, g, slope, (int)tiles, grad_bias != nullptr ? 1 : 0,  \
-                           xs, gs);                                                                                        \
+                           xs, gs, gp16 ? 1 : 0);                                                                          \
     } while (0)
         if (act == ACT_LEAKY) EBFI_LAUNCH_WTR(ACT_LEAKY);
         else if (act == ACT_SIGMOID) EBFI_LAUNCH_WTR(ACT_SIGMOID);
@@ -3605,6 +3628,8 @@ extern "C" int ebfi_conv2d_backward_weight_f16g(const void *input, const void *g
 #undef EBFI_LAUNCH_WTR
         if (int rc = check_launch("conv_wgrad_f16_tr")) return rc;
     } else {
+        if (gp16) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_weight_f16g: the fp16 image of grad * act' needs the pixel-major kernel "
+                                                    "(3x3, pad 1, W %% 4 == 0, 16-byte aligned tensors)");
         if (ragged_ci)
             return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_weight_f16g: %d input channels need the pixel-major kernel (3x3, pad 1, W %% 4 == 0, "
                                               "16-byte aligned tensors)", Cin_per_group);

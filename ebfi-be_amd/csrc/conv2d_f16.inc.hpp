@@ -775,7 +775,7 @@ __device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ x, const
                                               const float *__restrict__ yact, float *__restrict__ gpre_out, float *__restrict__ my,
                                               const ConvGeom &g, float dslope, const int split, const int G, const int total_tiles,
                                               const bool xcd_map, int need_bias, ScaleSlot x_slot, ScaleSlot g_slot, const int co_blk,
-                                              const int ci_blk) {
+                                              const int ci_blk, const int gpre_c16 = 0) {
     saturate_fp16_conversions();
     constexpr int KK = 9, PT = 256, NQ = 4;
     constexpr int NXI = TRXR * TRXQ * 8, NXK = (NXI + PT - 1) / PT;          // input items (row, quad, 8-channel group): 480, 2 per thread
@@ -1170,7 +1170,7 @@ __device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ x, const
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     rg[e][j] = __float_as_uint(__uint_as_float(rg[e][j]) * act_grad_c<DACT>(__uint_as_float(ry[e][j]), dslope));
-            if (gpre_out != nullptr && ci_blk == 0) {        // grad * act' for the data gradient: one writer per output-channel block
+            if (gpre_out != nullptr && ci_blk == 0 && !gpre_c16) {   // grad * act' for the data gradient: one writer per output-channel block
                 int b, y0, x0;
                 tile_coords(tile, b, y0, x0);
                 const bool live = tile < total_tiles;
@@ -1194,6 +1194,24 @@ __device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ x, const
             }
             const int pix = g_y * TRW + 4 * g_q + j;
             *reinterpret_cast<u32x4 *>(gi + pix * 128 + ((chg ^ (((pix >> 1) & 1) << 2)) << 4)) = hv;
+            if constexpr (DACT != 0) {
+                // gpre_c16: grad * act' leaves as the c16 IMAGE the data gradient stages (c16.hpp) -- `hv` IS its piece (this
+                // pixel, channels 8 chg .. 8 chg + 7, times the slot's scale): one 16-byte store per pixel instead of eight
+                // fp32 quads per 4 pixels, and the data gradient copies pieces instead of converting planes
+                if (gpre_c16 && gpre_out != nullptr && ci_blk == 0) {
+                    int b, y0, x0;
+                    tile_coords(tile, b, y0, x0);
+                    const bool live = tile < total_tiles;
+                    const int cb16 = g.Cout >> 4, cblk = (co_base >> 4) + (chg >> 1);
+                    const __amdgpu_buffer_rsrc_t rgi = __builtin_amdgcn_make_buffer_rsrc(
+                        reinterpret_cast<_Float16 *>(gpre_out) + (int64_t)(live ? b : 0) * cb16 * HWo * 16, 0,
+                        live ? (unsigned)cb16 * (unsigned)HWo * 32u : 0u, 0x00020000);
+                    const int gy = y0 + g_y, gx = x0 + 4 * g_q + j;
+                    const unsigned o = (gy < g.Ho && gx < g.Wo && cblk < cb16)
+                                           ? ((unsigned)cblk * (unsigned)HWo * 2u + (unsigned)((gy * 2 + (chg & 1)) * g.Wo + gx)) * 16u : SENT;
+                    __builtin_amdgcn_raw_buffer_store_b128(hv, rgi, o, 0, 0);
+                }
+            }
         }
     };
     auto commit_x = [&](int buf, XStage &s) {
@@ -1295,7 +1313,7 @@ template <int DACT, bool IN16 = false, bool GP16 = false>
 __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict__ x, const float *__restrict__ gout,
                                                          const float *__restrict__ yact, float *__restrict__ gpre_out,
                                                          float *__restrict__ slab, ConvGeom g, float dslope, int total_tiles,
-                                                         int need_bias, ScaleSlot x_slot, ScaleSlot g_slot) {
+                                                         int need_bias, ScaleSlot x_slot, ScaleSlot g_slot, int gpre_c16 = 0) {
     // Workgroup -> (split, co block, ci block).  The ci blocks of one (split, co block) read the SAME grad_out tiles (839 MB at
     // 128 -> 1600): they are placed 8 workgroup ids apart, i.e. on the same XCD under the round-robin dispatch (speed only:
     // MI355X_MICROARCH.md, workgroup dispatch), so that the second reader finds the tile in that XCD's L2.  PMC before:
@@ -1321,7 +1339,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_tr(const float *__restrict
     // (splits congruent mod 8 run on one XCD when gridDim.x is a multiple of 8, so their tiles split, split + G, .. are mapped
     // onto one contiguous eighth of the tile sequence -- xcd_tile: shared halo lines hit that XCD's L2)
     wgrad_tr_body<DACT, IN16, GP16>(x, gout, yact, gpre_out, slab + (int64_t)split * (wsz + g.Cout), g, dslope, split, (int)gridDim.x,
-                                    total_tiles, (gridDim.x & 7) == 0, need_bias, x_slot, g_slot, co_blk, ci_blk);
+                                    total_tiles, (gridDim.x & 7) == 0, need_bias, x_slot, g_slot, co_blk, ci_blk, gpre_c16);
 }
 
 // Several weight gradients over the SAME pixels in one launch (round 4): the three layers of a ResidualControl round, each

@@ -30,7 +30,7 @@ HEADER = os.path.join(REPO_ROOT, "include", "ebfi_hip.h")
 BUILD_SCRIPT = os.path.join(PKG_ROOT, "csrc", "build.sh")
 
 EBFI_F32, EBFI_F32_BF16MMA, EBFI_F32_BF16X3MMA = 0, 2, 3
-ABI_VERSION = 7          # include/ebfi_hip.h EBFI_ABI_VERSION
+ABI_VERSION = 8          # include/ebfi_hip.h EBFI_ABI_VERSION
 
 
 class EbfiNativeError(RuntimeError):
@@ -71,6 +71,7 @@ SIGNATURES = {
     "ebfi_pack_table_f16": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "ebfi_conv2d_packed_f16": (_i, [_vp, _vp, _sz, _vp, _vp] + [_i] * 8 + [_i, _c.c_float, _vp, _vp, _i, _c.c_float, _vp, _vp, _vp]),
     "ebfi_conv2d_backward_weight_f16g": (_i, [_vp] * 6 + [_i] * 8 + [_i, _c.c_float, _vp, _vp, _vp, _sz, _vp]),
+    "ebfi_conv2d_backward_weight_f16g_ex": (_i, [_vp] * 6 + [_i] * 9 + [_i, _c.c_float, _vp, _vp, _vp, _sz, _vp]),
     "ebfi_to_c16": (_i, [_vp, _vp, _c.c_float, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ebfi_conv2d_packed_x3_c16": (_i, [_vp, _vp, _sz, _vp, _vp] + [_i] * 8 + [_i, _c.c_float, _vp, _vp, _i, _c.c_float, _vp, _vp, _i, _vp]),
     "ebfi_conv2d_packed_f16_c16": (_i, [_vp, _i, _vp, _sz, _vp, _vp] + [_i] * 8 + [_i, _c.c_float, _vp, _vp, _i, _c.c_float,

@@ -245,13 +245,21 @@ class SiteConvBiasAct(Function):
                 gb2 = torch.empty(site.M, dtype=x.dtype, device=x.device) if site.has_bias else None
                 need = int(lib.ebfi_conv2d_backward_weight_workspace(*geo, N.EBFI_F32))
                 ws = torch.empty(max(need, 4), dtype=torch.uint8, device=x.device)
+                # grad * act' for the data gradient: as the fp16 image that kernel stages (ebfi_amd.c16) when both gradients run on fp16
+                # operands and the pixel-major weight-gradient kernel applies -- half the bytes written and read again
+                gpre16 = need_x and act != ACT_NONE and f16_w and f16_x and al16 and W % 4 == 0 and M % 16 == 0 and site.groups == 1 and \
+                    N.dev_env("EBFI_NO_GPRE16", "0") != "1" and N.dev_env("EBFI_WGRAD_TR", "1") != "0"
                 if need_x and act != ACT_NONE:
-                    gpre = torch.empty_like(gout)
+                    if gpre16:
+                        from . import c16
+                        gpre = c16.empty(B, M, H, W, x.device)
+                    else:
+                        gpre = torch.empty_like(gout)
                 if f16_w:
-                    rc = lib.ebfi_conv2d_backward_weight_f16g(N.ptr(x), N.ptr(gout), N.ptr(y), N.ptr(gw2), N.ptr(gb2), N.ptr(gpre),
-                                                              B, Cin, H, W, M, ks, pad, 1, act, slope,
-                                                              book.operand((site.key, "x"), x), book.operand((site.key, "g"), gout),
-                                                              N.ptr(ws), need, st)
+                    rc = lib.ebfi_conv2d_backward_weight_f16g_ex(N.ptr(x), N.ptr(gout), N.ptr(y), N.ptr(gw2), N.ptr(gb2), N.ptr(gpre),
+                                                                 1 if gpre16 else 0, B, Cin, H, W, M, ks, pad, 1, act, slope,
+                                                                 book.operand((site.key, "x"), x), book.operand((site.key, "g"), gout),
+                                                                 N.ptr(ws), need, st)
                 else:
                     rc = lib.ebfi_conv2d_backward_weight_ex(N.ptr(x), N.ptr(gout), N.ptr(y), N.ptr(gw2), N.ptr(gb2), N.ptr(gpre), *geo,
                                                             act, slope, N.ptr(ws), need, N.EBFI_F32_BF16X3MMA, st)
@@ -260,7 +268,14 @@ class SiteConvBiasAct(Function):
             if need_x:
                 gx = torch.empty_like(x)
                 src, sy, a = (gpre, None, ACT_NONE) if gpre is not None else (gout, y, act)
-                if f16_x and a == ACT_NONE:
+                if gpre is not None and gpre.dtype == torch.float16:
+                    # the image the weight gradient just wrote (scale: the slot it recorded into)
+                    rc = lib.ebfi_conv2d_packed_f16_c16(N.ptr(gpre), 1, site.tr16_ptr(), site.tr16_bytes, N.ptr(None), N.ptr(gx), B,
+                                                        M // site.groups, H, W, Cin * site.groups, ks, pad, site.groups, ACT_NONE, 0.0,
+                                                        N.ptr(None), N.ptr(None), 0, 0.0, book.ptr(book.slot((site.key, "g"))),
+                                                        site.w_slot_ptr(), N.ptr(None), N.ptr(None), 0, 0, st)
+                    N.check(rc, "ebfi_conv2d_packed_f16_c16 (data gradient from the image of grad * act')")
+                elif f16_x and a == ACT_NONE:
                     # the data gradient as a convolution of the pre-activation gradient with the transposed fp16 image
                     rc = lib.ebfi_conv2d_packed_f16(N.ptr(src), site.tr16_ptr(), site.tr16_bytes, N.ptr(None), N.ptr(gx), B,
                                                     M // site.groups, H, W, Cin * site.groups, ks, pad, site.groups, ACT_NONE, 0.0,

@@ -50,7 +50,7 @@ extern "C" {
  * ebfi_conv2d_packed_x3, the fused KernelConv -> FAC forward, ...).  4: ebfi_se_gate_forward takes a workspace
  * (ebfi_se_gate_workspace).  5 (round 4): the never-implemented EBFI_BF16 storage value left ebfi_dtype; fp16 filter storage
  * and the fused-gradient entry points of the KernelConv -> FAC training path.  Bumped whenever an entry point is added or changed. */
-#define EBFI_ABI_VERSION 7
+#define EBFI_ABI_VERSION 8
 
 typedef enum {
     EBFI_OK = 0,
@@ -262,6 +262,14 @@ int ebfi_conv2d_backward_weight_f16g(const void *input, const void *grad_output,
                                      int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups, int act,
                                      float slope, void *x_slot, void *g_slot, void *workspace,
                                      size_t workspace_bytes, void *stream);
+/* _ex: grad_preact_is_c16 != 0 writes grad_preact_out (grad_output * act'(saved_output)) as a c16 image scaled by g_slot's scale
+ * (see "fp16 operand STORAGE" below) for ebfi_conv2d_packed_f16_c16 to stage; needs an activation, Cout % 16 == 0, 3x3 / pad 1,
+ * W % 4 == 0 and 16-byte aligned tensors (EBFI_ERR_UNSUPPORTED otherwise) */
+int ebfi_conv2d_backward_weight_f16g_ex(const void *input, const void *grad_output, const void *saved_output,
+                                        void *grad_weight, void *grad_bias, void *grad_preact_out, int grad_preact_is_c16, int B,
+                                        int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups, int act,
+                                        float slope, void *x_slot, void *g_slot, void *workspace,
+                                        size_t workspace_bytes, void *stream);
 /* ------------------------------------------------------------------ fp16 operand STORAGE of the backward pass (round 4)
  * Layout "c16": a tensor [B, C, H, W] (C % 16 == 0, W % 4 == 0) as fp16 [B][C/16][H][2][W][8] -- 16-channel blocks; an image
  * row holds the channels 0..7 of its W pixels, then the channels 8..15 -- multiplied by the power-of-two scale in slot[0] of

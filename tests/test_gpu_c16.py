@@ -210,6 +210,47 @@ def test_batched_weight_gradients_equal_the_single_launches(B, H, W, n):
     assert rc != 0 and b"two 64 x 64 blocks" in lib.ebfi_last_error()
 
 
+@pytest.mark.parametrize("B,Cin,H,W,Cout", [(2, 64, 16, 64, 64), (1, 48, 13, 36, 32), (2, 128, 24, 68, 80), (1, 64, 260, 256, 64)])
+def test_weight_gradient_writes_the_image_of_the_preactivation_gradient(B, Cin, H, W, Cout):
+    """ebfi_conv2d_backward_weight_f16g_ex with grad_preact_is_c16: grad_out * LeakyReLU'(saved_output) leaves as the c16 image the
+    data gradient stages -- exactly fp16(value * scale) of the fp32 tensor the plain form writes; grad_weight / grad_bias unchanged;
+    the data gradient from the image equals the data gradient from the fp32 tensor bit for bit."""
+    from ebfi_amd import c16
+    torch.manual_seed(7)
+    w, b, bank, book, site = _banked(Cin, Cout)
+    x = torch.randn(B, Cin, H, W).cuda() * 0.5
+    y = torch.randn(B, Cout, H, W).cuda()
+    g = torch.randn(B, Cout, H, W).cuda() * 1e-2
+    sx, sg = book.slot("x"), book.slot("g")
+    book.calibrate(sx, x)
+    book.calibrate(sg, g)
+    lib, st = N.lib(), N.stream_ptr(x.device)
+    need = int(lib.ebfi_conv2d_backward_weight_workspace(B, Cin, H, W, Cout, 3, 1, 1, N.EBFI_F32))
+    ws = torch.empty(max(need, 4), dtype=torch.uint8, device="cuda")
+
+    def wgrad(gpre, is16):
+        gw, gb = torch.empty(Cout, Cin, 3, 3, device="cuda"), torch.empty(Cout, device="cuda")
+        rc = lib.ebfi_conv2d_backward_weight_f16g_ex(N.ptr(x), N.ptr(g), N.ptr(y), N.ptr(gw), N.ptr(gb), N.ptr(gpre), is16, B, Cin, H, W,
+                                                     Cout, 3, 1, 1, 1, 0.01, book.ptr(sx), book.ptr(sg), N.ptr(ws), need, st)
+        N.check(rc, "ebfi_conv2d_backward_weight_f16g_ex")
+        return gw, gb
+    gpre32 = torch.empty_like(g)
+    gw0, gb0 = wgrad(gpre32, 0)
+    gpre16 = torch.full_like(c16.empty(B, Cout, H, W, "cuda"), float("nan"))
+    gw1, gb1 = wgrad(gpre16, 1)
+    assert torch.equal(gw0, gw1) and torch.equal(gb0, gb1)
+    ref = g * torch.where(y > 0, 1.0, 0.01)
+    assert torch.equal(gpre32, ref)
+    assert torch.equal(gpre16, _ref_image(ref, book.scale(sg)))
+    if Cin >= 48:                       # the data gradient reads either form of the same values
+        a, r = torch.empty(B, Cin, H, W, device="cuda"), torch.empty(B, Cin, H, W, device="cuda")
+        for inp, mode, out in ((gpre32, 0, r), (gpre16, 1, a)):
+            N.check(lib.ebfi_conv2d_packed_f16_c16(N.ptr(inp), mode, site.tr16_ptr(), site.tr16_bytes, N.ptr(None), N.ptr(out), B, Cout, H, W,
+                                                   Cin, 3, 1, 1, 0, 0.0, N.ptr(None), N.ptr(None), 0, 0.0, book.ptr(sg), site.w_slot_ptr(),
+                                                   N.ptr(None), N.ptr(None), 0, 0, st), "dgrad")
+        assert torch.equal(a, r)
+
+
 def test_fused_residual_control_stages_write_images():
     from ebfi_amd import c16, f16scale
     torch.manual_seed(4)

@@ -376,8 +376,12 @@ def test_fp16_backward_kernels_vs_cpu(B, Cin, H, W, Cout, act, xs, gs):
     # both gradients took the fp16 kernels: the weight gradient in its pixel-major form (transposing LDS reads; with act != 0 it
     # folds act'(y) and writes grad * act' for the data gradient) or, switched, in the pair-word form
     assert prof.get("conv_wgrad_f16_tr/f32" if force_tr else "conv_wgrad_f16_ws") == 1, prof
-    assert prof.get("conv_fwd_f16_ws/f32_f32", 0) == (1 if Cin >= 48 and W % 4 == 0 else 0), prof   # (narrower data gradients, and rows
-    #                                                                       without quads, keep the split-precision form)
+    # the data gradient on fp16 operands (narrower ones, and rows without quads, keep the split-precision form); behind an
+    # activation it reads grad * act' as the fp16 IMAGE the weight gradient wrote (Cout % 16 == 0), else the fp32 gradient
+    f16_x = Cin >= 48 and W % 4 == 0
+    img = f16_x and act != 0 and Cout % 16 == 0
+    assert prof.get("conv_fwd_f16_ws/img_f32", 0) == (1 if img else 0) and \
+        prof.get("conv_fwd_f16_ws/f32_f32", 0) == (1 if f16_x and not img else 0), prof
     assert "conv_wgrad_x3_ws" not in prof and ("conv_fwd_bf16x3_ws/dgrad" not in prof or W % 4 != 0)
     assert _rel(y.detach(), yr.detach()) < 1e-4             # (the split-precision forward: every tile written exactly once)
     assert _rel(xd.grad, xr.grad) < 1e-3 and _rel(w.grad, wr.grad) < 1e-3 and _rel(b.grad, br.grad) < 1e-5
