@@ -455,6 +455,51 @@ def test_training_forward_within_tolerance(seed):
     torch.cuda.empty_cache()
 
 
+def test_forward_f16_levels():
+    """Engine(forward_f16=...): None and "filters" run the same kernels except for the KernelConv (conv_fwd_f16_ws/img_p16 instead of
+    conv_fwd_bf16x3_ws/fwd_img with planar output); "all" -- the experiment switch that also runs ResidualControl's forward on fp16
+    operand images -- stays a working path (its outputs within 5e-3 of the fp32 mode: OUTSIDE the 1e-3 parity bar, which is why it
+    is never a default); anything else is refused."""
+    from ebfi_amd import _native as N
+    from ebfi_amd.engine import Engine, synthetic_batch
+    with pytest.raises(ValueError):
+        Engine(DEFAULT_ARGS_FULL, device="cuda", precision="bf16x3", forward_f16="everything")
+    batch = synthetic_batch(2, 128, 128, device="cuda", seed=3)
+    outs, profs = {}, {}
+    for level in (None, "filters", "all"):
+        eng = Engine(DEFAULT_ARGS_FULL, device="cuda", precision="bf16x3", seed=4, forward_f16=level)
+        assert eng.book.forward_f16 == level
+        gen = torch.Generator(device="cpu").manual_seed(21)
+        with torch.no_grad():
+            for p in eng.model.parameters():
+                if p.dim() > 1:
+                    p.copy_((torch.randn(p.shape, generator=gen) * (1.2 / p[0].numel() ** 0.5)).cuda())
+        for k in range(3):                    # (pass 1 calibrates the operand scales, 2-3 run the image paths)
+            eng.bucket.zero()
+            eng.book.begin_step()
+            if k == 2:
+                N.prof_reset()
+                N.prof_enable(True)
+            with eng._autocast(), eng._bank(), eng._book() as book:
+                s, f = eng.model(*batch[:4])
+                eng.loss(s.float(), f.float(), batch[4], 0, 1).backward()
+                book.finish()
+        torch.cuda.synchronize()
+        N.prof_enable(False)
+        profs[level] = {k: v[0] for k, v in N.prof_collect().items() if v[0] > 0}
+        outs[level] = (s.detach().clone(), f.detach().clone())
+        assert eng.book.guard.tolist() == [0, 0]
+        del eng
+    assert profs[None].get("conv_fwd_f16_ws/img_p16", 0) == 0 and profs["filters"]["conv_fwd_f16_ws/img_p16"] == 1
+    assert profs["all"]["conv_fwd_f16_ws/img_p16"] == 1
+    # ResidualControl's 36 forward convolutions move from the split-precision kernel to the fp16 one only under "all"
+    assert profs["filters"].get("conv_fwd_f16_ws/img_both", 0) == 0 and profs["all"].get("conv_fwd_f16_ws/img_both", 0) >= 12
+    base = outs[None]
+    assert base[0].std() > 0.01
+    assert _rel(outs["filters"][0], base[0]) < TOL and _rel(outs["filters"][1], base[1]) < TOL
+    assert _rel(outs["all"][0], base[0]) < 5e-3 and _rel(outs["all"][1], base[1]) < 5e-3
+
+
 @pytest.mark.parametrize("B,seed", [(8, 31), (2, 77)])
 def test_benchmarked_step_vs_oracle(B, seed):
     """The exact step bench.py times -- default widths, B=8 (and a second seed at B=2), split-precision forward, fp16 backward,
