@@ -45,4 +45,5 @@ EBFI_BENCH_REHEARSAL=1 timeout -k 10 400 python -m torch.distributed.run --nnode
 echo "[8] fp16 operand storage: readers / writers of the images in isolation; the detail branch by kernel"
 timeout -k 10 200 python tools/c16bench.py > $OUT/c16bench.log 2>&1 || true; tail -4 $OUT/c16bench.log
 timeout -k 10 200 python tools/detailprof.py > $OUT/detailprof.log 2>&1 || true; head -3 $OUT/detailprof.log
+timeout -k 10 200 python tools/detail_layers.py > $OUT/detail_layers.txt 2> $OUT/detail_layers.err || true
 du -sh $OUT

@@ -32,4 +32,5 @@ cp $S/bench_2rank_rehearsal.json $D/bench_final_2rank_rehearsal.json
 grep -v amdgpu.ids $S/smoke.log > $D/smoke_final.log
 grep -v amdgpu.ids $S/c16bench.log > $D/c16bench_final.log || true
 grep -v "amdgpu.ids\|Warning\|_warn_once" $S/detailprof.log > $D/detail_branch_by_kernel.txt || true
+[ -s $S/detail_layers.txt ] && cp $S/detail_layers.txt $D/detail_branch_by_stage_latest.txt || true
 echo "published $S -> $D"
