@@ -2,11 +2,13 @@
 """Headline benchmark: interpolated frames/s of the EVFIAutoEx training step (forward + Lap/census
 loss + backward + flat RCCL gradient all-reduce + Adam) at B=8 per GPU, 256x256, synthetic data.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its N ranks itself, as a child process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One process per GPU; weak scaling (B=8 per rank).  Rank 0 prints ONE JSON line.  Default precision: bf16x3
+One process per GPU; weak scaling (B=8 per rank); ONE collective per step (the flat gradient buffer with the fp16 overflow
+flag as its last element).  Rank 0 prints ONE JSON line.  For N > 1 a failed hipGraph capture is an error (--strict-graph is
+the default there).  Default precision: bf16x3
 (split-precision conv operands, fp32-grade accuracy, parity-tested at 1e-3 like the exact fp32 mode); forward + loss +
 backward + gradient packing are replayed from one captured hipGraph (--no-graph launches eagerly).  Besides the contract
 fields the line carries
@@ -319,6 +321,26 @@ def inference_block(device):
     return out
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher's environment: run
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same flags>`
+    as a child process and return its exit code.  Nothing here touches the GPU (a process that has initialised HIP must not
+    be replaced or forked into ranks); stdout / stderr are inherited, so rank 0's JSON line is this command's JSON line."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as s:                 # a free port on the loopback interface
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.pop("MASTER_PORT", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    note("--gpus %d without WORLD_SIZE: launching the ranks as a child process: %s" % (n, " ".join(cmd[1:])))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -332,18 +354,29 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ops", action="store_true", help="skip the FAC / DCNv2 op block (north_star target figure)")
     ap.add_argument("--no-inference", action="store_true", help="skip the inference block (BASELINE configs 2 and 5)")
-    ap.add_argument("--strict-graph", action="store_true",
+    ap.add_argument("--strict-graph", dest="strict_graph", action="store_true", default=None,
                     help="exit non-zero when the hipGraph capture of the step failed and the engine fell back to eager launches "
-                         "(default: report it as config.graph_capture_failed and in config.launch)")
+                         "(default for --gpus > 1: one rank silently 20 %% slower would drag every rank; with one GPU the default "
+                         "is to report it as config.graph_capture_failed and in config.launch)")
+    ap.add_argument("--no-strict-graph", dest="strict_graph", action="store_false")
     ap.add_argument("--no-bf16-leg", "--no-extra-legs", dest="no_extra_legs", action="store_true",
                     help="skip the secondary measurement of the same step in the exact-fp32 mode")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, as a CHILD process (never an exec), before anything
+        # in this process has touched the GPU; relay the child's output (rank 0 prints the one JSON line) and its exit code
+        raise SystemExit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU: python bench.py --gpus N, or "
+                         "python -m torch.distributed.run --nproc-per-node N bench.py --gpus N)" % (args.gpus, world))
+    # the torch.distributed path at world size 1 (EBFI_BENCH_FORCE_DIST=1): RCCL communicator, its watchdog thread next to the
+    # hipGraph capture, the collective on the packed bucket -- everything a one-GPU box can exercise of the N > 1 path
+    force_dist = os.environ.get("EBFI_BENCH_FORCE_DIST", "0") == "1"
+    strict_graph = args.strict_graph if args.strict_graph is not None else (world > 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)")
     # Rehearsal hook for a one-GPU box: EBFI_BENCH_REHEARSAL=1 puts every rank on device 0 and uses gloo, so the
@@ -352,8 +385,11 @@ def main():
     dev_index = 0 if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29655")
+        if force_dist:
+            os.environ["EBFI_FORCE_COLLECTIVES"] = "1"          # (ebfi_amd.dp: collectives also at world size 1)
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -362,11 +398,13 @@ def main():
     from ebfi_amd import _native as N
     from ebfi_amd.engine import DEFAULT_MODEL_ARGS, Engine, synthetic_batch
 
-    eng = Engine(DEFAULT_MODEL_ARGS, device=device, precision=args.precision, lr=1e-4, seed=123, graph=not args.no_graph)
+    # (strictness is handled HERE: a failed capture still yields the JSON line, flagged, and then a non-zero exit code)
+    eng = Engine(DEFAULT_MODEL_ARGS, device=device, precision=args.precision, lr=1e-4, seed=123, graph=not args.no_graph,
+                 strict_graph=False)
     batch = synthetic_batch(B_PER_GPU, H, W, TB, device=device, seed=123, rank=rank)   # resident in HBM
 
     def sync():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -397,7 +435,7 @@ def main():
         sync()
         elapsed = time.perf_counter() - t0
         t_max = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
-        if world > 1:
+        if dist.is_initialized():
             dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         note("%s timed region: %d steps in %.3f s (max over ranks %.3f s)" % (tag, args.steps, elapsed, t_max.item()))
         loss_value = float(loss.item())
@@ -476,7 +514,8 @@ def main():
                                    "Lap/census loss + bwd + flat grad all-reduce + Adam; B=%d per GPU, %dx%d frames, "
                                    "TB=%d event bins, Poisson(0.35) event counts" % (B_PER_GPU, H, W, TB),
                        "global_batch": world * B_PER_GPU, "parallelism": "dp%d" % world, "loss": loss,
-                       "world_size": world, "collective_backend": (dist.get_backend() if world > 1 else None),
+                       "world_size": world, "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
+                       "collectives_per_step": 1 if dist.is_initialized() else 0,
                        "replica_param_checksum": {"sum": checks[0][0], "sum_sq": checks[0][1], "ranks_identical": True},
                        "precision": {"fp32": "fp32 tensors, exact fp32 matrix cores",
                                      "bf16x3": "fp32 tensors and accumulation; forward conv operands split into bf16 hi+lo pairs, 3 MFMAs "
@@ -512,10 +551,10 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
-    if args.strict_graph and capture_failed:
+    if strict_graph and capture_failed:
         raise SystemExit(3)
 
 

@@ -43,14 +43,23 @@ __device__ __forceinline__ void saturate_fp16_conversions() { __builtin_amdgcn_s
 // maximum is within 1/8 of the previous one) and lets the floor decay.
 constexpr int SLOT_STRIDE = 64, SLOT_AMAX = 32, SLOT_FLOOR = 1;
 constexpr int F16_TARGET_EXP = 2;          // next scale: |max| * scale in [2^(F16_TARGET_EXP-1), 2^F16_TARGET_EXP) (f16scale.TARGET_EXP)
+// Running |max| of staged values, taken on the float BITS: non-negative floats order like unsigned integers and every NaN
+// pattern orders above +inf, so ONE NaN element survives into the slot and raises the guard -- fmaxf returns its non-NaN
+// operand and would drop it (round-4 advisory: with saturating conversions the recorded maximum is the only overflow signal).
+__device__ __forceinline__ float amax_acc(float m, float v) {
+    return __uint_as_float(max(__float_as_uint(m), __float_as_uint(v) & 0x7fffffffu));
+}
+__device__ __forceinline__ float amax_acc(float m, float a, float b) { return amax_acc(amax_acc(m, a), b); }
+
 struct ScaleSlot {
     float *p;
     __device__ __forceinline__ float scale() const { return p ? p[0] : 1.f; }
     __device__ __forceinline__ void record(float wave_max_candidate) const {
-        // one atomic per wave: butterfly over the 64 lanes, lane 0 publishes (NaN / Inf propagate as large unsigned values)
+        // one atomic per wave: butterfly over the 64 lanes on the float bits (amax_acc: NaN / Inf stay the largest), lane 0
+        // publishes
         float m = wave_max_candidate;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+        for (int d = 32; d >= 1; d >>= 1) m = amax_acc(m, __shfl_xor(m, d, 64));
         // (many workgroups report into one word: only a value above the one already there needs the atomic -- NaN compares
         // false and goes through)
         if (p && (threadIdx.x & 63) == 0 && !(m <= fmaxf(__builtin_nontemporal_load(p + SLOT_AMAX), p[SLOT_FLOOR])))

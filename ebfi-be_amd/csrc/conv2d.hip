@@ -221,8 +221,8 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
                         }
                         if constexpr (X16) {
                             if (has16) {
-                                am = fmaxf(am, fmaxf(fmaxf(fmaxf(fabsf(u[0]), fabsf(u[1])), fmaxf(fabsf(u[2]), fabsf(u[3]))),
-                                                     fmaxf(fmaxf(fabsf(u[4]), fabsf(u[5])), fmaxf(fabsf(u[6]), fabsf(u[7])))));
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) am = amax_acc(am, u[i]);
                                 if (planar) {
                                     // planes: one 2-byte store per value, lanes = consecutive pixels (64-byte runs per channel)
                                     const unsigned pb = (px_ok && co_base + m * 32 + 4 * h < g.Cout)
@@ -267,7 +267,7 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
         else if (act == ACT_SIGMOID) emit([](float v) { return 1.f / (1.f + __expf(-v)); });
         else emit([](float v) { return v; });
     }
-    if (amax16) *amax16 = fmaxf(*amax16, am);
+    if (amax16) *amax16 = amax_acc(*amax16, am);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
                             hv[e >> 1] = __builtin_amdgcn_perm(s.rq[k][e + 1][j >> 1], s.rq[k][e][j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
                         } else {
                             const float v0 = __uint_as_float(s.rq[k][e][j]), v1 = __uint_as_float(s.rq[k][e + 1][j]);
-                            amax = fmaxf(amax, fmaxf(fabsf(v0), fabsf(v1)));
+                            amax = amax_acc(amax, v0, v1);
                             hv[e >> 1] = pack_f16(v0 * sx, v1 * sx);
                         }
                     }
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_ws(const float *__restrict
         for (int it = 0; it < NG; ++it) {
             if constexpr (DACT != 0) s.rg[it] *= act_grad_c<DACT>(s.ry[it], dslope);
             bacc[it] += s.rg[it];
-            amax_g = fmaxf(amax_g, fabsf(s.rg[it]));
+            amax_g = amax_acc(amax_g, s.rg[it]);
         }
         // thread row gco holds channels gco + 4 it: `it` and `it + 8` are channels c and c + 32 of pair row gco + 4 it
 #pragma unroll
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_ws(const float *__restrict
             for (int it = 0; it < NG; ++it) buf_st(rgp, o0 + (unsigned)(NW64 * it) * (unsigned)HWo * 4u, s.rg[it]);
         }
 #pragma unroll
-        for (int i = 0; i < NI; ++i) amax_x = fmaxf(amax_x, fabsf(s.ri[i]));
+        for (int i = 0; i < NI; ++i) amax_x = amax_acc(amax_x, s.ri[i]);
         if (icol < IW) {
             // thread row irow holds channels irow + 8 k: k and k + 4 are channels c and c + 32 of pair plane irow + 8 k
 #pragma unroll
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_ws(const float *__restrict
             // element e: channel e & 63; its pair partner (channel ^ 32) sits 32 lanes away in the same wave
             const int e = ptid + i * PT, rc = e / CIB, ch = e & (CIB - 1);
             const float v = s.rex[i];
-            amax_x = fmaxf(amax_x, fabsf(v));
+            amax_x = amax_acc(amax_x, v);
             const float o = __shfl_xor(v, 32, 64);
             if (e < EXC * IH * CIB && ch < CP) sIn[ch * PS + (rc / EXC) * IWS + IWP + rc % EXC] = pack_f16(v * sx, o * sx);
         }
@@ -1189,7 +1189,7 @@ __device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ x, const
                 const float v0 = __uint_as_float(rg[e][j]), v1 = __uint_as_float(rg[e + 1][j]);
                 bacc[e] += v0;
                 bacc[e + 1] += v1;
-                amax_g = fmaxf(amax_g, fmaxf(fabsf(v0), fabsf(v1)));
+                amax_g = amax_acc(amax_g, v0, v1);
                 hv[e >> 1] = pack_f16(v0 * sg, v1 * sg);
             }
             const int pix = g_y * TRW + 4 * g_q + j;
@@ -1226,7 +1226,7 @@ __device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ x, const
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
                         const float v0 = __uint_as_float(s.rx[k][e][j]), v1 = __uint_as_float(s.rx[k][e + 1][j]);
-                        amax_x = fmaxf(amax_x, fmaxf(fabsf(v0), fabsf(v1)));
+                        amax_x = amax_acc(amax_x, v0, v1);
                         hv[e >> 1] = pack_f16(v0 * sx, v1 * sx);
                     }
                     if (c < 0 || c >= TRXW) continue;

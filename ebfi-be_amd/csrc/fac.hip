@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void fac_bwd_rows_f32(const float *__restrict_
                                          inr[kx + 2] * g.z * (w.z > 0.f ? 1.f : kslope), inr[kx + 3] * g.w * (w.w > 0.f ? 1.f : kslope)};
                         const int64_t go_ = gkbase + (int64_t)t * gks.s1 + (int64_t)y * gks.s2 + x;
                         if constexpr (H16) {
-                            gk_amax = fmaxf(gk_amax, fmaxf(fmaxf(fabsf(p[0]), fabsf(p[1])), fmaxf(fabsf(p[2]), fabsf(p[3]))));
+                            gk_amax = amax_acc(amax_acc(gk_amax, p[0], p[1]), p[2], p[3]);
                             st_stream4h(static_cast<_Float16 *>(gkern) + go_, p, gsc);
                         } else {
                             st_stream4(static_cast<float *>(gkern) + go_, p);

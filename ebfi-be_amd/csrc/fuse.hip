@@ -149,7 +149,7 @@ __device__ __forceinline__ void c16_store_quad(_Float16 *__restrict__ dst, int64
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
             const float a = v[e][j], b = v[e + 1][j];
-            amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));
+            amax = amax_acc(amax, a, b);
             q[e >> 1] = pack_f16(a * s, b * s);
         }
         *reinterpret_cast<u4 *>(dst + (piece0 + j) * 8) = q;

@@ -13,15 +13,23 @@ namespace {
 __global__ __launch_bounds__(256) void adam_flat_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                                                         float *__restrict__ v, float *__restrict__ step, int64_t n4,
                                                         int64_t n, double lr, double beta1, double beta2, double eps,
-                                                        int *__restrict__ guard) {
+                                                        int *__restrict__ guard, const float *__restrict__ flag) {
     // guard (optional): guard[0] != 0 marks this step's gradient as unusable (an fp16 operand of the backward pass left its
-    // range, conv2d_f16.inc.hpp): nothing is updated, the step count is taken back, guard[1] counts the skipped steps
-    if (guard != nullptr && guard[0] != 0) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            step[0] -= 1.f;
-            guard[1] += 1;
+    // range, conv2d_f16.inc.hpp): nothing is updated, the step count is taken back, guard[1] counts the skipped steps.
+    // flag (optional, with guard): the ranks' guard flags summed by the gradient all-reduce (ebfi_grad_gather put this rank's
+    // into the wire buffer); anything but an exact zero skips the step on every rank and is written back to guard[0].
+    // (Every thread reads the same two words; thread 0 of block 0 is the only writer and writes only values that keep the
+    // other threads' decision: guard[0] becomes non-zero only when the flag already said "skip".)
+    if (guard != nullptr) {
+        const bool by_flag = flag != nullptr && !(flag[0] == 0.f);
+        if (guard[0] != 0 || by_flag) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                step[0] -= 1.f;
+                guard[1] += 1;
+                if (by_flag) guard[0] = 1;
+            }
+            return;
         }
-        return;
     }
     const double t = (double)step[0];
     const double c1 = 1.0 - pow(beta1, t), c2 = 1.0 - pow(beta2, t);
@@ -49,18 +57,69 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float *__restrict__ p, c
         for (int64_t k = n4 * 4; k < n; ++k) upd(p[k], g[k], m[k], v[k]);
 }
 
+// Gradient packing of the training step (ebfi_amd.dp.FlatGradBucket.gather): the per-parameter gradient tensors autograd
+// produced are copied into the one flat buffer the all-reduce and the Adam launch work on.  One workgroup per table segment
+// {source address (0 = no gradient: zeros), destination element offset, element count <= 16384}; the last `pad` floats of
+// the buffer carry this rank's overflow flag (guard[0] != 0) and zeros, so the flag travels inside the gradient message.
+struct GatherSeg {
+    const float *src;
+    int64_t dst;
+    int64_t n;
+};
+
+__global__ __launch_bounds__(256) void grad_gather_kernel(const GatherSeg *__restrict__ table, int nseg, float *__restrict__ flat,
+                                                          int64_t numel, int pad, const int *__restrict__ guard) {
+    if ((int)blockIdx.x == nseg) {                  // the extra workgroup writes the trailer
+        if ((int)threadIdx.x < pad) flat[numel + threadIdx.x] = (threadIdx.x == 0 && guard != nullptr && guard[0] != 0) ? 1.f : 0.f;
+        return;
+    }
+    const GatherSeg s = table[blockIdx.x];
+    float *__restrict__ d = flat + s.dst;
+    const int n = (int)s.n;
+    if (s.src == nullptr) {
+        for (int i = threadIdx.x; i < n; i += 256) d[i] = 0.f;
+        return;
+    }
+    const float *__restrict__ a = s.src;
+    // 16-byte accesses where source and destination are aligned alike (parameter offsets are arbitrary element counts)
+    const int head = (int)((16u - ((unsigned)reinterpret_cast<uintptr_t>(d) & 15u)) & 15u) >> 2;
+    if (((reinterpret_cast<uintptr_t>(a) ^ reinterpret_cast<uintptr_t>(d)) & 15u) == 0 && n >= head + 4) {
+        if ((int)threadIdx.x < head) d[threadIdx.x] = a[threadIdx.x];
+        const int n4 = (n - head) >> 2;
+        const float4 *a4 = reinterpret_cast<const float4 *>(a + head);
+        float4 *d4 = reinterpret_cast<float4 *>(d + head);
+        for (int i = threadIdx.x; i < n4; i += 256) d4[i] = a4[i];
+        for (int i = head + 4 * n4 + threadIdx.x; i < n; i += 256) d[i] = a[i];
+    } else {
+        for (int i = threadIdx.x; i < n; i += 256) d[i] = a[i];
+    }
+}
+
 }  // namespace
 
-extern "C" int ebfi_adam_step_guarded(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *step, int64_t n,
-                                      double lr, double beta1, double beta2, double eps, int *guard, void *stream);
-
-extern "C" int ebfi_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *step, int64_t n,
-                              double lr, double beta1, double beta2, double eps, void *stream) {
-    return ebfi_adam_step_guarded(param, grad, exp_avg, exp_avg_sq, const_cast<float *>(step), n, lr, beta1, beta2, eps, nullptr, stream);
+extern "C" int ebfi_grad_gather(const void *table, int nseg, float *flat, int64_t numel, int pad, const int *guard, void *stream) {
+    if (!table || !flat || nseg <= 0 || numel <= 0 || pad < 1 || pad > 256) return fail(EBFI_ERR_ARG, "grad_gather: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    {
+        ProfScope ps("grad_gather", st, 0.0, 8.0 * (double)numel);
+        hipLaunchKernelGGL(grad_gather_kernel, dim3((unsigned)nseg + 1u), dim3(256), 0, st, static_cast<const GatherSeg *>(table), nseg,
+                           flat, numel, pad, guard);
+    }
+    return check_launch("grad_gather");
 }
 
 extern "C" int ebfi_adam_step_guarded(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *step, int64_t n,
-                                      double lr, double beta1, double beta2, double eps, int *guard, void *stream) {
+                                      double lr, double beta1, double beta2, double eps, int *guard, const float *flag, void *stream);
+
+extern "C" int ebfi_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *step, int64_t n,
+                              double lr, double beta1, double beta2, double eps, void *stream) {
+    return ebfi_adam_step_guarded(param, grad, exp_avg, exp_avg_sq, const_cast<float *>(step), n, lr, beta1, beta2, eps, nullptr, nullptr,
+                                  stream);
+}
+
+extern "C" int ebfi_adam_step_guarded(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *step, int64_t n,
+                                      double lr, double beta1, double beta2, double eps, int *guard, const float *flag, void *stream) {
+    if (flag && !guard) return fail(EBFI_ERR_ARG, "adam_step: an overflow flag needs the guard words");
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step || n < 0) return fail(EBFI_ERR_ARG, "adam_step: null argument");
     if (!aligned16(param) || !aligned16(grad) || !aligned16(exp_avg) || !aligned16(exp_avg_sq))
         return fail(EBFI_ERR_ARG, "adam_step: buffers must be 16-byte aligned");
@@ -70,7 +129,7 @@ extern "C" int ebfi_adam_step_guarded(float *param, const float *grad, float *ex
     {
         ProfScope ps("adam_flat", st, 0.0, 28.0 * (double)n);
         hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)ceil_div(std::max<int64_t>(n4, 1), 256)), dim3(256), 0, st, param, grad,
-                           exp_avg, exp_avg_sq, step, n4, n, lr, beta1, beta2, eps, guard);
+                           exp_avg, exp_avg_sq, step, n4, n, lr, beta1, beta2, eps, guard, flag);
     }
     return check_launch("adam_flat");
 }

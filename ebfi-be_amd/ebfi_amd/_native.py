@@ -30,7 +30,7 @@ HEADER = os.path.join(REPO_ROOT, "include", "ebfi_hip.h")
 BUILD_SCRIPT = os.path.join(PKG_ROOT, "csrc", "build.sh")
 
 EBFI_F32, EBFI_F32_BF16MMA, EBFI_F32_BF16X3MMA = 0, 2, 3
-ABI_VERSION = 8          # include/ebfi_hip.h EBFI_ABI_VERSION
+ABI_VERSION = 9          # include/ebfi_hip.h EBFI_ABI_VERSION
 
 
 class EbfiNativeError(RuntimeError):
@@ -114,7 +114,8 @@ SIGNATURES = {
     "ebfi_ed_head_backward": (_i, [_vp] * 11 + [_i, _i, _i64, _i, _vp, _sz, _vp]),
     "ebfi_conv2d_backward_data_s2_bf16x3": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ebfi_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64] + [_c.c_double] * 4 + [_vp]),
-    "ebfi_adam_step_guarded": (_i, [_vp, _vp, _vp, _vp, _vp, _i64] + [_c.c_double] * 4 + [_vp, _vp]),
+    "ebfi_adam_step_guarded": (_i, [_vp, _vp, _vp, _vp, _vp, _i64] + [_c.c_double] * 4 + [_vp, _vp, _vp]),
+    "ebfi_grad_gather": (_i, [_vp, _i, _vp, _i64, _i, _vp, _vp]),
     "ebfi_laploss_workspace_floats": (_i64, [_i64, _i, _i, _i]),
     "ebfi_laploss_partials": (_i64, [_i64, _i, _i, _i]),
     "ebfi_laploss_forward": (_i, [_vp, _vp, _vp, _c.c_float, _c.c_float, _vp, _vp, _i64, _i, _i, _i, _vp]),

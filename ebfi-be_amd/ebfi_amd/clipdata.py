@@ -151,12 +151,17 @@ class ClipDataset:
     Frames are produced on the host and moved to `device`; the event stack is binned on the device."""
 
     def __init__(self, paths, time_bins=16, frames_per_period=16, frames_per_blurry=16, exposure_method="Fixed",
-                 exposure_time=None, crop=None, crop_mode="random", flips=False, device="cuda", seed=0):
+                 exposure_time=None, crop=None, crop_mode="random", flips=False, device="cuda", seed=0,
+                 flip_probs=(0.5, 0.5), center_crop=None):
+        """crop / crop_mode: the first crop of AugmentData's list (RandomCrop when enabled, else CenterCrop); center_crop: a
+        CenterCrop applied AFTER a random crop when the config enables both (the reference walks its `augment` list in order,
+        h5dataset.py:410-433); flip_probs: (horizontal_prob, vertical_prob) of data_augment.flip."""
         self.clips = [open_clip(p) for p in (list_clips(paths) if isinstance(paths, str) else list(paths))]
         if not self.clips:
             raise ValueError("no clips under %r" % (paths,))
         self.time_bins, self.P = int(time_bins), int(frames_per_period)
         self.crop, self.crop_mode, self.flips = crop, crop_mode, bool(flips)
+        self.flip_probs, self.center_crop = (float(flip_probs[0]), float(flip_probs[1])), center_crop
         self.device = torch.device(device)
         self.items = []
         for ci, clip in enumerate(self.clips):
@@ -188,10 +193,16 @@ class ClipDataset:
             if win is not None:
                 i, j, th, tw = win
                 tensors = [v[..., i:i + th, j:j + tw] for v in tensors]
+                H, W = th, tw
+        if self.center_crop is not None:
+            win = crop_window(H, W, self.center_crop, "center", 1, seed + 2)
+            if win is not None:
+                i, j, th, tw = win
+                tensors = [v[..., i:i + th, j:j + tw] for v in tensors]
         if self.flips:
-            if random.Random(seed).random() < 0.5:
+            if random.Random(seed).random() < self.flip_probs[0]:
                 tensors = [v.flip(-1) for v in tensors]
-            if random.Random(seed + 1).random() < 0.5:
+            if random.Random(seed + 1).random() < self.flip_probs[1]:
                 tensors = [v.flip(-2) for v in tensors]
         return tensors
 
@@ -215,6 +226,51 @@ class ClipDataset:
                                 self.time_bins, sensor_size=res).transpose(0, 1)                # [TB,2,H,W]
         sharp, blur, stack = self.augment([sharp.to(dev), blur.to(dev), stack], res, seed)
         return self.assemble(sharp, blur, stack, duty)
+
+
+SUPPORTED_AUGMENT_ORDER = ["RandomCrop", "CenterCrop", "HorizontalFlip", "VertivcalFlip", "Noise", "HotPixel"]
+
+
+def dataset_args_from_config(ds_cfg):
+    """The reference's `train_dataloader.dataset` keys (config/train_ours.yml:115-150) -> ClipDataset keyword arguments.
+    Everything the keys can ask for that this reader does NOT do is refused here instead of being ignored silently
+    (round-4 advisory): noise on the event stacks (h5dataset.py:455-463; its values come from torch's global CPU generator
+    on a strided view and are not reproduced), another `augment` order than the shipped one (crops, then flips), and
+    scale / ori_scale pairs whose ground truth is not the 'ori' groups of a clip.  hot_pixel needs no code: the
+    reference's own test `type == [...]` (h5dataset.py:436) is never true, so it never adds hot pixels."""
+    aug = ds_cfg.get("data_augment") or {}
+    out = dict(crop=None, crop_mode="random", center_crop=None, flips=False, flip_probs=(0.5, 0.5))
+    # the tensors the model sees come from the reference's `gt_prex` groups (h5dataset.py:36-100): 'ori' exactly when `scale`
+    # equals the factor `ori_scale` names -- the shipped pair (2, 'down2') and (1, 'ori') among them; any other pair reads
+    # down-scaled groups this reader does not open
+    scale, ori = int(ds_cfg.get("scale", 2)), str(ds_cfg.get("ori_scale", "down2"))
+    factor = {"ori": 1, "down2": 2, "down4": 4, "down8": 8, "down16": 16}.get(ori)
+    if factor is None or scale != factor:
+        raise NotImplementedError("dataset.scale %r with ori_scale %r selects the reference's %s ground-truth groups; this reader "
+                                  "opens the 'ori' groups only (scale == the factor ori_scale names)" % (scale, ori, "down-scaled"))
+    if not aug.get("enabled", False):
+        return out
+    order = list(aug.get("augment") or SUPPORTED_AUGMENT_ORDER)
+    known = [m for m in order if m in SUPPORTED_AUGMENT_ORDER]
+    if known != [m for m in SUPPORTED_AUGMENT_ORDER if m in known] or len(known) != len(order):
+        raise NotImplementedError("data_augment.augment %r: supported is the shipped order %r (crops before flips) or a "
+                                  "sub-list of it" % (order, SUPPORTED_AUGMENT_ORDER))
+    if (aug.get("noise") or {}).get("enabled") and "Noise" in order:
+        raise NotImplementedError("data_augment.noise.enabled: event-stack noise is not implemented by this reader "
+                                  "(the shipped config has NoiseEnabled: False)")
+    rc, cc = aug.get("random_crop") or {}, aug.get("center_crop") or {}
+    if rc.get("enabled") and "RandomCrop" in order:
+        out["crop"], out["crop_mode"] = rc["size"], "random"
+        if cc.get("enabled") and "CenterCrop" in order:
+            out["center_crop"] = cc["size"]
+    elif cc.get("enabled") and "CenterCrop" in order:
+        out["crop"], out["crop_mode"] = cc["size"], "center"
+    fl = aug.get("flip") or {}
+    if fl.get("enabled"):
+        ph = float(fl.get("horizontal_prob", 0.5)) if "HorizontalFlip" in order else 0.0
+        pv = float(fl.get("vertical_prob", 0.5)) if "VertivcalFlip" in order else 0.0
+        out["flips"], out["flip_probs"] = True, (ph, pv)
+    return out
 
 
 def collate(samples):

@@ -8,22 +8,31 @@ code evidently intends: identical replicas, per-rank batches, gradients averaged
 MI355X-first choices: the whole model is 5.69 M parameters = 22.8 MB of fp32
 gradients.  xGMI is point-to-point (7 links per GPU), a ring all-reduce is bound by one link, so
 many small buckets would only multiply latency.  We therefore pack ALL gradients into ONE flat
-buffer (one batched concatenation after backward) and issue exactly one all-reduce per optimiser
-step on it (average = SUM then one fused scale); afterwards ``param.grad`` are views of that buffer.
+buffer (one gather launch after backward: csrc/optim.hip grad_gather) and issue exactly ONE collective
+per optimiser step on it (average = SUM then one fused scale); afterwards ``param.grad`` are views of
+that buffer.  The overflow flag of the fp16 backward rides in the same message (one extra element:
+SUM > 0 <=> some rank raised it), so a step has one all-reduce, not two.
 With gloo (CPU tests) the same code path runs unchanged.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
 def is_distributed():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """More than one rank -- or EBFI_FORCE_COLLECTIVES=1 with an initialised group of one: the collectives then run at
+    world size 1 (bench.py EBFI_BENCH_FORCE_DIST: what a one-GPU box can exercise of the RCCL path)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("EBFI_FORCE_COLLECTIVES") == "1"
 
 
 @torch.no_grad()
 def sync_guard(guard):
-    """Overflow guard of the fp16 backward (ebfi_amd.f16scale: int32[2] = [flag of this step, skipped steps]): every rank must
-    take -- or skip -- the same update, so the flag is MAX-reduced over ranks before the guarded optimiser launch reads it."""
+    """Overflow guard of the fp16 backward (ebfi_amd.f16scale: int32[2] = [flag of this step, skipped steps]) MAX-reduced over
+    ranks with a collective of its own.  The engine does NOT use this any more: FlatGradBucket.gather(guard=...) carries the
+    flag inside the gradient message (one collective per step); kept for callers that hold a guard without a bucket."""
     if guard is not None and is_distributed():
         if guard.is_cuda and dist.get_backend() == "gloo":     # (rehearsal fabric: reduce through the host)
             host = guard[0:1].cpu()
@@ -68,15 +77,25 @@ def broadcast_parameters(module, src=0):
             off += t.numel()
 
 
+SEG_ELEMS = 16384          # elements per segment of the gather launch (one workgroup each)
+WIRE_PAD = 4               # floats behind the gradients in the wire buffer: [overflow flag, 0, 0, 0] (keeps 16-byte multiples)
+
+
 class FlatGradBucket:
     """All trainable gradients of `module` in one contiguous buffer, built AFTER backward.
 
     Autograd hands every parameter a freshly written gradient tensor (the conv kernels already write
-    their own outputs), so the cheapest way to a flat buffer is one batched concatenation per step
-    (22.8 MB, a single kernel) instead of 255 in-place accumulations into pre-assigned views plus a
-    memset.  ``gather()`` packs, ``all_reduce_mean()`` averages over ranks with one collective, and
-    afterwards every ``param.grad`` is a view of the flat buffer, so optimisers see ordinary ``.grad``
-    tensors.  ``zero()`` drops the gradients (set-to-None) for the next step."""
+    their own outputs), so the cheapest way to a flat buffer is ONE gather launch per step
+    (libebfi_hip.so `ebfi_grad_gather`: a table of (source pointer, destination offset, count) segments,
+    one workgroup per segment; 22.8 MB read + written once) instead of 255 in-place accumulations into
+    pre-assigned views plus a memset -- or a 255-piece torch.cat, whose batched copy kernel took three
+    launches and 90 us.  ``gather()`` packs, ``all_reduce_mean()`` averages over ranks with one
+    collective, and afterwards every ``param.grad`` is a view of the flat buffer, so optimisers see
+    ordinary ``.grad`` tensors.  ``zero()`` drops the gradients (set-to-None) for the next step.
+
+    Wire format: ``wire`` = [numel gradients | flag | 3 zeros]; ``flat`` = wire[:numel].  ``flag`` is the
+    overflow guard of the fp16 backward as a float (gather(guard=book.guard) writes guard[0] != 0 there),
+    summed over ranks by the SAME all-reduce: a positive value on any rank skips the update on all."""
 
     def __init__(self, module, dtype=None):
         self.params = [p for p in module.parameters() if p.requires_grad]
@@ -84,42 +103,137 @@ class FlatGradBucket:
             raise ValueError("module has no trainable parameters")
         self.dtype = dtype or self.params[0].dtype
         self.numel = sum(p.numel() for p in self.params)
+        self.wire = None
         self.flat = None
         self._offsets = []
         off = 0
         for p in self.params:
             self._offsets.append(off)
             off += p.numel()
+        # segment table of the native gather: parameter index, element offset inside the parameter, destination, count
+        import numpy as np
+        seg_p, seg_o, seg_d, seg_n = [], [], [], []
+        for i, (p, off) in enumerate(zip(self.params, self._offsets)):
+            for o in range(0, p.numel(), SEG_ELEMS):
+                seg_p.append(i)
+                seg_o.append(o)
+                seg_d.append(off + o)
+                seg_n.append(min(SEG_ELEMS, p.numel() - o))
+        self._seg_param = np.asarray(seg_p, dtype=np.int64)
+        self._seg_byte = np.asarray(seg_o, dtype=np.int64) * 4
+        self._seg_dst = np.asarray(seg_d, dtype=np.int64)
+        self._seg_n = np.asarray(seg_n, dtype=np.int64)
+        self._ring, self._ring_pos = [], 0         # pinned host tables + the event of their last upload (eager launches)
+        self._dev_table = None
+        self._pending = []                         # (device table, host table) of gathers recorded inside a graph capture
+
+    @property
+    def flag(self):
+        """The overflow flag element of the wire buffer (a 1-element view), None before the first gather."""
+        return None if self.wire is None else self.wire[self.numel:self.numel + 1]
 
     def zero(self):
         for p in self.params:
             p.grad = None
 
-    def gather(self):
-        """Concatenate the per-parameter gradients (missing ones count as zero) and re-point .grad at it."""
-        pieces = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(self.dtype) for p in self.params]
-        self.flat = torch.cat(pieces)
+    def adopt(self, wire):
+        """Make `wire` (a full wire buffer, e.g. a graph's static output or an accumulation buffer) the current one."""
+        self.wire = wire
+        self.flat = wire[:self.numel]
+
+    def _host_table(self, grads):
+        import numpy as np
+        ptrs = np.fromiter((0 if g is None else g.data_ptr() for g in grads), dtype=np.int64, count=len(grads))
+        base = ptrs[self._seg_param]
+        tab = np.empty((len(self._seg_n), 3), dtype=np.int64)
+        tab[:, 0] = np.where(base != 0, base + self._seg_byte, 0)          # NULL source: the segment is zero-filled
+        tab[:, 1] = self._seg_dst
+        tab[:, 2] = self._seg_n
+        return tab
+
+    def gather(self, guard=None):
+        """Pack the per-parameter gradients (missing ones count as zero) into a fresh wire buffer and re-point .grad at it.
+        `guard`: int32[2] device tensor of f16scale.ScaleBook (or a CPU tensor in the gloo tests): its flag rides along."""
+        first = self.params[0]
+        dev = first.device
+        grads = []
+        for p in self.params:
+            g = p.grad
+            if g is not None and (g.dtype != self.dtype or not g.is_contiguous()):
+                g = g.to(self.dtype).contiguous()
+            grads.append(g)
+        if dev.type != "cuda":
+            flag = torch.zeros(WIRE_PAD, dtype=self.dtype)
+            if guard is not None:
+                flag[0] = 1.0 if int(guard[0]) != 0 else 0.0
+            pieces = [(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(grads, self.params)]
+            self.adopt(torch.cat(pieces + [flag]))
+        else:
+            if self.dtype != torch.float32:
+                raise NotImplementedError("the native gradient gather packs float32 gradients")
+            from . import _native as N
+            wire = torch.empty(self.numel + WIRE_PAD, dtype=self.dtype, device=dev)
+            host = torch.from_numpy(self._host_table(grads))
+            if torch.cuda.is_current_stream_capturing():
+                # the table's CONTENT is static for the life of the graph (its allocations keep their addresses): it is
+                # uploaded once after the capture (flush_pending) instead of by a copy node inside every replay
+                table = torch.empty(host.numel(), dtype=torch.int64, device=dev)
+                self._pending.append((table, host))
+            else:
+                table = self._upload(host, dev)
+            with torch.cuda.device(dev):
+                rc = N.lib().ebfi_grad_gather(N.ptr(table), host.shape[0], N.ptr(wire), self.numel, WIRE_PAD,
+                                              N.ptr(guard), N.stream_ptr(dev))
+            N.check(rc, "ebfi_grad_gather")
+            # (the sources may be freed right away: the caching allocator reuses memory in stream order only)
+            self.adopt(wire)
         for p, off in zip(self.params, self._offsets):
             p.grad = self.flat[off:off + p.numel()].view_as(p)
         return self.flat
 
+    def _upload(self, host, dev):
+        """Eager launches: the table goes through one of four pinned host buffers (a buffer is rewritten only after the
+        copy that last read it has run) into one device table."""
+        if self._dev_table is None:
+            self._dev_table = torch.empty(host.numel(), dtype=torch.int64, device=dev)
+            self._ring = [[torch.empty(host.numel(), dtype=torch.int64).pin_memory(), None] for _ in range(4)]
+        slot = self._ring[self._ring_pos]
+        self._ring_pos = (self._ring_pos + 1) % len(self._ring)
+        if slot[1] is not None:
+            slot[1].synchronize()
+        slot[0].copy_(host.reshape(-1))
+        self._dev_table.copy_(slot[0], non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record(torch.cuda.current_stream(dev))
+        return self._dev_table
+
+    def flush_pending(self):
+        """After a graph capture: upload the segment tables of the gathers recorded inside it (before the first replay)."""
+        for table, host in self._pending:
+            table.copy_(host.reshape(-1))
+        if self._pending:
+            torch.cuda.synchronize(self._pending[0][0].device)
+        kept, self._pending = [t for t, _ in self._pending], []
+        return kept                                 # (the caller keeps them alive with the graph)
+
     def reduce_mean_packed(self):
-        """Average the already packed buffer over ranks in place (one collective; no-op on one rank)."""
+        """Average the already packed wire buffer over ranks in place -- gradients AND the overflow flag in ONE collective
+        (no-op on one rank).  The flag ends up as (ranks that raised it) / world: > 0 iff any did."""
         if is_distributed():
-            if self.flat.is_cuda and dist.get_backend() == "gloo":
+            if self.wire.is_cuda and dist.get_backend() == "gloo":
                 # rehearsal / CPU-only fabrics: gloo reduces device tensors through tiny staged chunks (seconds for
                 # 22.8 MB); one explicit round trip through host memory is two copies and a host all-reduce
-                host = self.flat.cpu()
+                host = self.wire.cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM)
-                self.flat.copy_(host)
+                self.wire.copy_(host)
             else:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.mul_(1.0 / dist.get_world_size())
+                dist.all_reduce(self.wire, op=dist.ReduceOp.SUM)
+            self.wire.mul_(1.0 / dist.get_world_size())
         return self.flat
 
-    def all_reduce_mean(self):
+    def all_reduce_mean(self, guard=None):
         """gather() + average over ranks in place.  Returns the flat buffer."""
-        self.gather()
+        self.gather(guard)
         return self.reduce_mean_packed()
 
     def views_intact(self):
@@ -158,21 +272,28 @@ class FlatAdam:
     def param_groups(self):
         return self.inner.param_groups
 
-    def step(self, flat_grad, guard=None):
-        """`flat_grad`: the packed gradient in the order of `params` (FlatGradBucket.flat).  `guard`: int32[2] device tensor
-        of ebfi_amd.f16scale.ScaleBook -- a non-zero guard[0] makes the native launch skip this update (guard[1] counts)."""
+    def step(self, flat_grad, guard=None, flag=None):
+        """`flat_grad`: the packed gradient in the order of `params` (FlatGradBucket.flat).  `guard`: int32[2] tensor of
+        ebfi_amd.f16scale.ScaleBook -- a non-zero guard[0] skips this update (guard[1] counts the skipped steps).  `flag`:
+        FlatGradBucket.flag after the all-reduce -- the ranks' overflow flags summed by the gradient collective; a non-zero
+        (or non-finite) value skips the update as well and is written back to guard[0], so every rank takes the same branch."""
         if flat_grad.numel() != self.flat.numel():
             raise ValueError("packed gradient has %d elements, parameters %d" % (flat_grad.numel(), self.flat.numel()))
-        if self._native_step(flat_grad, guard):
+        if flag is not None and guard is None:
+            raise ValueError("an overflow flag needs the guard tensor that counts the skipped steps")
+        if self._native_step(flat_grad, guard, flag):
             return
-        if guard is not None and int(guard[0].item()) != 0:       # torch's own step (CPU / unusual options): host-side check
-            guard[1] += 1
-            return
+        if guard is not None:                                     # torch's own step (CPU / unusual options): host-side check
+            if flag is not None and not float(flag[0]) == 0.0:
+                guard[0] = 1
+            if int(guard[0].item()) != 0:
+                guard[1] += 1
+                return
         self.flat.grad = flat_grad
         self.inner.step()
         self.flat.grad = None
 
-    def _native_step(self, flat_grad, guard=None):
+    def _native_step(self, flat_grad, guard=None, flag=None):
         """The update as ONE bandwidth-bound launch of libebfi_hip.so (csrc/optim.hip) on the state tensors of the inner
         torch.optim.Adam (which keeps owning hyper-parameters, state and checkpoint layout).  CPU tensors, weight decay,
         amsgrad or maximize take torch's own step."""
@@ -200,7 +321,7 @@ class FlatAdam:
         with torch.cuda.device_of(self.flat):
             rc = N.lib().ebfi_adam_step_guarded(N.ptr(self.flat.data), N.ptr(flat_grad), N.ptr(st["exp_avg"]), N.ptr(st["exp_avg_sq"]),
                                                 N.ptr(st["step"]), self.flat.numel(), float(grp["lr"]), float(b1), float(b2),
-                                                float(grp["eps"]), N.ptr(guard), N.stream_ptr(self.flat.device))
+                                                float(grp["eps"]), N.ptr(guard), N.ptr(flag), N.stream_ptr(self.flat.device))
         N.check(rc, "ebfi_adam_step_guarded")
         opt._opt_called = True
         if hasattr(opt, "_step_count"):

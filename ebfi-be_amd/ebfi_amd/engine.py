@@ -70,8 +70,10 @@ def synthetic_batch_from_raw_events(B, H, W, TB=16, device="cuda", seed=123, ran
 
 class Engine:
     def __init__(self, model_args=None, device="cuda", precision="fp32", lr=1e-4, seed=None, train=True, graph=False,
-                 accu_step=1, betas=(0.9, 0.999), backward_f16=None, forward_f16="filters"):
-        """forward_f16 (only with the fp16 backward; ignored otherwise): which FORWARD convolutions read fp16 operand images (one matrix-core product per
+                 accu_step=1, betas=(0.9, 0.999), backward_f16=None, forward_f16="filters", strict_graph=None):
+        """strict_graph: a hipGraph capture that fails raises instead of continuing with eager launches.  Default: on when
+        the process is one rank of several (a rank that silently runs ~20 % slower drags every rank of the job), off alone.
+        forward_f16 (only with the fp16 backward; ignored otherwise): which FORWARD convolutions read fp16 operand images (one matrix-core product per
         tap, fp32 accumulation) instead of running in split precision:
           "filters"  the 128 -> 1600 KernelConv of Modification, whose output exists only as fp16 planes anyway (ebfi_amd.fac):
                      Sharp / Final move from 1.6-2.9e-4 to 2.8-4.1e-4 of the fp32 result (tools/f16fwd_check.py, three seeds),
@@ -111,6 +113,10 @@ class Engine:
         self.use_graph = bool(graph) and self.device.type == "cuda"
         self._graphs = {}
         self.graph_capture_failed, self.graph_capture_error = False, None    # set when a capture fell back to eager launches
+        if strict_graph is None:
+            from .dp import is_distributed
+            strict_graph = is_distributed()
+        self.strict_graph = bool(strict_graph)
         if train:
             self.model.train()
             self.loss = TrainLoss(self.model_args.get("DetailEnabled", True)).to(self.device)
@@ -198,25 +204,27 @@ class Engine:
         if self.book is not None and self.precision == "bf16x3" and self._micro == 0:
             self.book.begin_step()
 
-    def _finish_micro_step(self, flat):
-        """`flat`: this call's packed gradient (of loss / accu_step).  Sums the calls of one accumulation window in place
-        and, on the window's last call, averages over ranks and takes the optimiser step.  True when a step was taken."""
+    def _guard(self):
+        return self.book.guard if (self.book is not None and self.precision == "bf16x3") else None
+
+    def _finish_micro_step(self, wire):
+        """`wire`: this call's packed gradient (of loss / accu_step) with the overflow flag behind it (FlatGradBucket.wire).
+        Sums the calls of one accumulation window in place and, on the window's last call, averages over ranks -- ONE
+        collective: the flag travels with the gradients -- and takes the optimiser step.  True when a step was taken."""
         if self.accu_step > 1:
             if self._micro == 0:
-                self._accum = flat.clone() if self._accum is None else self._accum.copy_(flat)
+                self._accum = wire.clone() if self._accum is None else self._accum.copy_(wire)
             else:
-                self._accum.add_(flat)
+                self._accum.add_(wire)           # (the flags add up too: > 0 if any micro-step raised the guard)
             self._micro += 1
             if self._micro < self.accu_step:
                 return False
             self._micro = 0
-            self.bucket.flat = self._accum
+            wire = self._accum
+        self.bucket.adopt(wire)
         self.bucket.reduce_mean_packed()
-        guard = None
-        if self.book is not None and self.precision == "bf16x3":
-            from .dp import sync_guard
-            guard = sync_guard(self.book.guard)     # every rank must take (or skip) the same update
-        self.optimizer.step(self.bucket.flat, guard=guard)
+        guard = self._guard()
+        self.optimizer.step(self.bucket.flat, guard=guard, flag=self.bucket.flag if guard is not None else None)
         self.iteration += 1
         self._steps_run += 1
         return True
@@ -230,7 +238,8 @@ class Engine:
         self._begin_micro_step()
         self.bucket.zero()
         loss = self._fwd_bwd(frame, event, t, gtex, target)
-        self._finish_micro_step(self.bucket.gather())
+        self.bucket.gather(self._guard())
+        self._finish_micro_step(self.bucket.wire)
         return loss
 
     def train_step_graph(self, frame, event, t, gtex, target):
@@ -245,6 +254,13 @@ class Engine:
             static_in = [torch.empty_like(v) for v in inputs]
             for s, v in zip(static_in, inputs):
                 s.copy_(v)
+            # The warm-up passes and the capture run _fwd_bwd -> book.finish() outside any accumulation window: a flag they
+            # raise (or their three advances of the delayed scales on one batch) must not leak into the window this call
+            # belongs to -- with accu_step > 1 the capture can happen mid-window, where nothing clears the guard afterwards
+            # (round-4 advisory).  The guard words are restored after the capture; the scales keep what the warm-up passes
+            # measured on this batch (restoring them could undo the just-in-time calibration of a slot first met here).
+            guard = self._guard()
+            saved = None if guard is None else guard.clone()
             side = torch.cuda.Stream(self.device)          # warm-up off the default stream (allocator, lazy inits)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):
@@ -259,8 +275,16 @@ class Engine:
                 # invalidate the capture
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     loss = self._fwd_bwd(*static_in)
-                    flat = self.bucket.gather()
+                    self.bucket.gather(guard)
+                    wire = self.bucket.wire
             except RuntimeError as err:
+                self.bucket._pending.clear()
+                if saved is not None:
+                    torch.cuda.synchronize(self.device)
+                    guard.copy_(saved)
+                if self.strict_graph:
+                    raise RuntimeError("ebfi_amd.engine: hipGraph capture failed and strict_graph is set (the default for one "
+                                       "rank of several): %s" % str(err).splitlines()[0]) from err
                 # a capture that cannot be taken must not cost the run: say so and continue with eager launches
                 import sys
                 print("ebfi_amd.engine: hipGraph capture failed (%s); continuing with eager launches" % str(err).splitlines()[0],
@@ -269,18 +293,21 @@ class Engine:
                 self.graph_capture_failed, self.graph_capture_error = True, str(err).splitlines()[0]
                 torch.cuda.synchronize(self.device)
                 return self.train_step(frame, event, t, gtex, target)
-            entry = (graph, static_in, loss, flat, [p.grad for p in self.bucket.params])
+            tables = self.bucket.flush_pending()           # segment tables of the captured gather launch (static content)
+            if saved is not None:
+                guard.copy_(saved)
+            entry = (graph, static_in, loss, wire, [p.grad for p in self.bucket.params], tables)
             self._graphs[key] = entry
-        graph, static_in, loss, flat, grads = entry
+        graph, static_in, loss, wire, grads, _tables = entry
         self._begin_micro_step()
         for s, v in zip(static_in, inputs):
             if s.data_ptr() != v.data_ptr():
                 s.copy_(v)
         graph.replay()
-        self.bucket.flat = flat
+        self.bucket.adopt(wire)
         for p, g in zip(self.bucket.params, grads):        # (another shape's graph may have re-pointed them)
             p.grad = g
-        self._finish_micro_step(flat)
+        self._finish_micro_step(wire)
         return loss.clone()
 
     @torch.no_grad()
@@ -298,8 +325,10 @@ class ClipInterpolator:
     (inference weight bank, incl. the fused KernelConv -> FAC layout)."""
 
     def __init__(self, model, precision="bf16x3", graph=True, hoist=True):
-        self.model = model.eval()
+        # (inference needs eval mode; the caller's model is NOT switched for good: its mode is restored after every call)
+        self.model = model
         self.precision, self.graph, self.hoist = precision, bool(graph), bool(hoist)
+        self.graph_capture_failed, self.graph_capture_error = False, None    # as Engine: a failed capture continues eagerly
         self.bank = None
         if precision == "bf16x3" and next(model.parameters()).is_cuda:
             from . import weightbank
@@ -312,11 +341,18 @@ class ClipInterpolator:
         from . import conv
         prev = conv.get_compute_dtype()
         conv.set_compute_dtype(self.precision)
+        was_training = self.model.training
+        self.model.eval()
         try:
+            if self.bank is not None:
+                # the images are packed once; a load_state_dict / optimiser step since then bumps the parameters' version
+                # counters (WeightBank._current_stamp) and the bank is re-packed here instead of serving stale weights
+                self.bank.ensure_fresh()
             with (self.bank.active() if self.bank is not None else contextlib.nullcontext()):
                 yield
         finally:
             conv.set_compute_dtype(prev)
+            self.model.train(was_training)
 
     def refresh_weights(self):
         if self.bank is not None:
@@ -352,8 +388,20 @@ class ClipInterpolator:
                     call()                                  # warm-up off the capturing stream (allocator, lazy inits)
                 torch.cuda.current_stream(dev).wait_stream(side)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    out_static = call()
+                try:
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        out_static = call()
+                except RuntimeError as err:
+                    # as Engine.train_step_graph: say so and continue with eager launches (the flag is there for callers)
+                    import sys
+                    print("ebfi_amd.engine: hipGraph capture of the inference step failed (%s); continuing with eager launches"
+                          % str(err).splitlines()[0], file=sys.stderr, flush=True)
+                    self.graph, self.graph_capture_failed, self.graph_capture_error = False, True, str(err).splitlines()[0]
+                    torch.cuda.synchronize(dev)
+                    for ts in timestamps:
+                        t = ts if torch.is_tensor(ts) else torch.full((B, 1), float(ts), device=dev)
+                        outs.append(self._step(state, frame, event, gtex, t))
+                    return torch.stack(outs, 1)
                 ent = self._captured[key] = (g, st_in, t_static, out_static)
             g, st_in, t_static, out_static = ent
             src = state if self.hoist else (frame, event, gtex)

@@ -99,7 +99,8 @@ class ScaleBook:
         return self.ptr(i)
 
     def begin_step(self):
-        """Clear the guard flag of the step (first node of the step's graph)."""
+        """Clear the guard flag at the start of an accumulation window -- an EAGER launch, never part of the captured graph
+        (Engine._begin_micro_step: a clear baked into the graph would wipe a flag an earlier micro-step raised)."""
         self.guard[0:1].zero_()
 
     def finish(self):

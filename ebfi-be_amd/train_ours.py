@@ -123,20 +123,12 @@ def real_data_passes(path, config, B, TB, device, rank, world, seed):
     are the reference's (config train_dataloader.dataset, train_ours.yml:115-150); defaults = its shipped values."""
     from ebfi_amd import clipdata
     ds_cfg = ((config.get("train_dataloader") or {}).get("dataset") or {})
-    aug = ds_cfg.get("data_augment") or {}
-    crop, mode = None, "random"
-    if aug.get("enabled", False):
-        if (aug.get("random_crop") or {}).get("enabled"):
-            crop, mode = aug["random_crop"]["size"], "random"
-        elif (aug.get("center_crop") or {}).get("enabled"):
-            crop, mode = aug["center_crop"]["size"], "center"
     ds = clipdata.ClipDataset(path, time_bins=int(ds_cfg.get("time_bins", TB)),
                               frames_per_period=int(ds_cfg.get("NumFramePerPeriod", 16)),
                               frames_per_blurry=int(ds_cfg.get("NumFramePerBlurry", 16)),
                               exposure_method=ds_cfg.get("ExposureMethod", "Custom"),
                               exposure_time=ds_cfg.get("ExposureTime", [9, 10, 11, 12, 13, 14, 15]),
-                              crop=crop, crop_mode=mode, flips=bool((aug.get("flip") or {}).get("enabled", False)) and
-                              aug.get("enabled", False), device=device, seed=seed)
+                              device=device, seed=seed, **clipdata.dataset_args_from_config(ds_cfg))
     if len(ds) < B * world:
         raise SystemExit("--data: %d periods in %s, need at least batch_size x world = %d" % (len(ds), path, B * world))
     for batch in clipdata.batches(ds, B, rank=rank, world=world, seed=seed):

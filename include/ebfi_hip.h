@@ -32,6 +32,7 @@
  *   ebfi_gauss5_*               GaussianConv of the Laplacian-pyramid loss (loss/restore.py:149-163)
  *   ebfi_laploss_*              whole Laplacian-pyramid L1 term of a step as one difference pyramid (loss/restore.py:166-213)
  *   ebfi_adam_step              optimizer.step() of train_ours.py:276-277 over the flat parameter buffer
+ *   ebfi_grad_gather            gradient bucket packing of DistributedDataParallel (train_ours.py:754) as one launch
  *   ebfi_gather_sum             weight re-layouts of the depth-2 Conv3d / ConvTranspose3d (models/model_misc/resnet_3D.py)
  *   ebfi_events_to_stack        dataloader/encodings.py:307-350 (events_to_stack)
  *   ebfi_frame2lap / _frame2dcp myutils/utils.py:34-49 / :15-31
@@ -46,11 +47,21 @@
 extern "C" {
 #endif
 
-/* 3: round 2/3 additions (ebfi_ed_head_*, ebfi_laploss_*, ebfi_se_gate_*, ebfi_adam_step, ebfi_pack_table_bf16,
- * ebfi_conv2d_packed_x3, the fused KernelConv -> FAC forward, ...).  4: ebfi_se_gate_forward takes a workspace
- * (ebfi_se_gate_workspace).  5 (round 4): the never-implemented EBFI_BF16 storage value left ebfi_dtype; fp16 filter storage
- * and the fused-gradient entry points of the KernelConv -> FAC training path.  Bumped whenever an entry point is added or changed. */
-#define EBFI_ABI_VERSION 8
+/* ABI history (bumped whenever an entry point is added or changed; the Python binding refuses any other value):
+ *   3  round 2/3 additions (ebfi_ed_head_*, ebfi_laploss_*, ebfi_se_gate_*, ebfi_adam_step, ebfi_pack_table_bf16,
+ *      ebfi_conv2d_packed_x3, the fused KernelConv -> FAC forward, ...)
+ *   4  ebfi_se_gate_forward takes a workspace (ebfi_se_gate_workspace)
+ *   5  (round 4) the never-implemented EBFI_BF16 storage value left ebfi_dtype; fp16 filter storage and the fused-gradient
+ *      entry points of the KernelConv -> FAC training path (ebfi_fac_forward_p16 / _backward_p16, ebfi_conv2d_packed_*_c16,
+ *      ebfi_conv2d_backward_weight_f16c*, ebfi_to_c16, ebfi_scale_residual_cat_*_c16)
+ *   6  fp16-operand FORWARD: ebfi_pack_table_f16 writes forward weight images too; ebfi_conv2d_packed_f16_c16 takes the
+ *      planar-fp16 output form (the 128 -> 1600 KernelConv of the training step)
+ *   7  EpiExtra masks from fp16 images: ebfi_conv2d_packed_f16_c16 takes mask_is_c16 (the LeakyReLU derivative read from the
+ *      sign of the c16 image instead of an fp32 tensor)
+ *   8  ebfi_conv2d_backward_weight_f16g_ex: the weight gradient writes grad * act'(y) as a c16 image for the data gradient
+ *   9  (round 5) ebfi_grad_gather (gradient packing + overflow flag in the wire buffer); ebfi_adam_step_guarded takes the
+ *      all-reduced flag */
+#define EBFI_ABI_VERSION 9
 
 typedef enum {
     EBFI_OK = 0,
@@ -474,9 +485,18 @@ int ebfi_laploss_backward(const float *grad_loss, float *workspace, float *grad_
 int ebfi_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *step, int64_t n,
                    double lr, double beta1, double beta2, double eps, void *stream);
 /* Same update, guarded: when guard[0] != 0 (set by ebfi_f16_scales_finish: an fp16 operand of this step's backward pass
- * left its range) nothing is updated, step[0] is decremented again and guard[1] counts the skipped step.  guard may be NULL. */
+ * left its range) nothing is updated, step[0] is decremented again and guard[1] counts the skipped step.  guard may be NULL.
+ * flag (optional, needs guard): one device float, the ranks' guard flags summed by the gradient all-reduce (ebfi_grad_gather
+ * wrote this rank's into the wire buffer): anything but an exact 0 skips the step too and sets guard[0] = 1, so every rank
+ * of a data-parallel job takes the same branch without a collective of its own for the flag. */
 int ebfi_adam_step_guarded(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *step, int64_t n,
-                           double lr, double beta1, double beta2, double eps, int *guard, void *stream);
+                           double lr, double beta1, double beta2, double eps, int *guard, const float *flag, void *stream);
+
+/* Gradient packing of a training step (replaces the bucket copy of DistributedDataParallel, train_ours.py:754, and the
+ * 255-piece concatenation of earlier rounds): `table` = nseg device records {const float *src; int64 dst; int64 n} -- copy n
+ * (<= 16384) floats from src (NULL: write zeros) to flat[dst ...]; then flat[numel] = (guard && guard[0] != 0) ? 1 : 0 and
+ * flat[numel + 1 .. numel + pad - 1] = 0 (1 <= pad <= 256: the wire buffer's trailer).  One workgroup per record. */
+int ebfi_grad_gather(const void *table, int nseg, float *flat, int64_t numel, int pad, const int *guard, void *stream);
 
 
 /* ------------------------------------------------------------------ per-kernel device timing

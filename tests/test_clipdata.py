@@ -143,3 +143,47 @@ def test_train_ours_runs_on_recorded_clips(tmp_path):
                           "--iterations", "3"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "Iteration: 2/3" in out.stdout and "saved" in out.stdout
+
+
+def test_dataset_config_keys_are_honoured_or_refused():
+    """clipdata.dataset_args_from_config: the reference's dataset keys (config/train_ours.yml:115-150) either change what the
+    reader does (flip probabilities, crop order) or are refused -- never ignored (round-4 advisory)."""
+    import copy
+    from ebfi_amd import clipdata
+    # the `train_dataloader.dataset` section with the reference's key names and shipped values
+    cfg = {"scale": 2, "ori_scale": "down2", "time_bins": 16, "NumFramePerPeriod": 16, "NumFramePerBlurry": 16,
+           "ExposureMethod": "Custom", "ExposureTime": [9, 10, 11, 12, 13, 14, 15],
+           "data_augment": {"enabled": True,
+                            "augment": ["RandomCrop", "CenterCrop", "HorizontalFlip", "VertivcalFlip", "Noise", "HotPixel"],
+                            "random_crop": {"enabled": True, "size": [128, 128]},
+                            "center_crop": {"enabled": False, "size": [128, 128]},
+                            "flip": {"enabled": True, "horizontal_prob": 0.5, "vertical_prob": 0.5},
+                            "noise": {"enabled": False, "noise_std": 1.0, "noise_fraction": 0.05},
+                            "hot_pixel": {"enabled": False, "hot_pixel_std": 2.0, "hot_pixel_fraction": 0.001}}}
+    a = clipdata.dataset_args_from_config(cfg)
+    assert a["crop"] == [128, 128] and a["crop_mode"] == "random" and a["center_crop"] is None
+    assert a["flips"] is True and a["flip_probs"] == (0.5, 0.5)
+    c = copy.deepcopy(cfg)
+    c["data_augment"]["flip"].update(horizontal_prob=1.0, vertical_prob=0.0)
+    c["data_augment"]["center_crop"].update(enabled=True, size=[64, 64])
+    b = clipdata.dataset_args_from_config(c)
+    assert b["flip_probs"] == (1.0, 0.0) and b["center_crop"] == [64, 64]
+    for breaker in (lambda d: d["data_augment"]["noise"].update(enabled=True),
+                    lambda d: d["data_augment"].update(augment=["HorizontalFlip", "RandomCrop"]),
+                    lambda d: d.update(scale=2, ori_scale="down4"),
+                    lambda d: d.update(scale=1, ori_scale="down2")):
+        c = copy.deepcopy(cfg)
+        breaker(c)
+        with pytest.raises(NotImplementedError):
+            clipdata.dataset_args_from_config(c)
+    c = copy.deepcopy(cfg)
+    c.update(scale=1, ori_scale="ori")
+    clipdata.dataset_args_from_config(c)
+    c["data_augment"]["hot_pixel"]["enabled"] = True            # the reference never applies it either (h5dataset.py:436)
+    clipdata.dataset_args_from_config(c)
+    # flips with probability 1 / 0 are deterministic: horizontal always, vertical never
+    t = torch.arange(24.0).reshape(1, 4, 6)
+    ds = clipdata.ClipDataset.__new__(clipdata.ClipDataset)
+    ds.crop, ds.crop_mode, ds.center_crop, ds.flips, ds.flip_probs = None, "random", None, True, (1.0, 0.0)
+    for seed in range(5):
+        assert torch.equal(ds.augment([t], (4, 6), seed)[0], t.flip(-1))

@@ -382,3 +382,115 @@ def test_backward_convs_stage_planar_fp16_gradients(B, Cin, H, W, Cout):
     assert ((gw_a.cpu() - ref_w).abs().max() / ref_w.abs().max()).item() < 1e-4
     ref_b = gq.sum((0, 2, 3))
     assert ((gb_a - ref_b).abs().max() / ref_b.abs().max()).item() < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The storage forms against INDEPENDENT fp32 math (CPU torch conv2d + autograd on the un-rounded tensors), not against the HIP
+# fp32-operand forms of the same kernels: a bug shared by both forms of a kernel would pass every test above.
+@pytest.mark.parametrize("B,Cin,H,W,Cout", [(2, 128, 16, 64, 208), (1, 64, 24, 68, 64)])
+def test_storage_kernels_against_cpu_fp32_autograd(B, Cin, H, W, Cout):
+    """conv_fwd_f16_ws/img_p16 (fp16 image in, fp16 weight image, planar fp16 out: the training step's KernelConv forward),
+    conv_fwd_f16_ws/p16_f32 (its data gradient from planar fp16 gradients) and conv_wgrad_f16_tr<0, IN16, GP16> (its weight
+    gradient from the image and the planes) against torch's CPU conv2d forward / autograd in fp32 on the SAME tensors before any
+    rounding.  Tolerance = what rounding both operands of a product to fp16 (2^-11 each) and, for the forward, the output to fp16
+    allows on sums of Cin * 9 terms: 2e-3 of the result's maximum (measured 3-6e-4)."""
+    from ebfi_amd import c16, f16scale, weightbank
+    torch.manual_seed(Cin + Cout)
+    w = torch.nn.Parameter((torch.randn(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5).cuda())
+    b = torch.nn.Parameter((torch.randn(Cout) * 0.1).cuda())
+    bank = weightbank.WeightBank([w, b])
+    site = bank.register(w, b, "id", fwd16="filters")
+    book = f16scale.ScaleBook("cuda")
+    bank.attach_scale_book(book)
+    bank.refresh()
+    assert site.fwd16_ptr() is not None and site.tr16_ptr() is not None
+    x = torch.randn(B, Cin, H, W) * 0.7
+    g = torch.randn(B, Cout, H, W) * 2e-2
+    # ---- the oracle side: plain fp32 on the CPU
+    xc = x.clone().requires_grad_()
+    wc, bc = w.detach().cpu().clone().requires_grad_(), b.detach().cpu().clone().requires_grad_()
+    pre = torch.nn.functional.conv2d(xc, wc, bc, padding=1)
+    yc = torch.nn.functional.leaky_relu(pre, 0.01)
+    gpre = g * torch.where(pre.detach() > 0, 1.0, 0.01)          # what the FAC backward hands over: grad * act'
+    pre.backward(gpre)
+    rel = lambda a, r: ((a.float().cpu() - r).abs().max() / r.abs().max()).item()
+    # ---- device side
+    xd, gd = x.cuda(), gpre.cuda()
+    sx, sg, sf = book.slot("x"), book.slot("g"), book.slot("f")
+    book.calibrate(sx, xd)
+    book.calibrate(sg, gd)
+    book.calibrate(sf, yc.cuda())
+    lib, st = N.lib(), N.stream_ptr(xd.device)
+    x16 = c16.to_c16(xd, book.ptr(sx))
+    # forward: image -> planar fp16 filters (conv_fwd_f16_ws/img_p16)
+    f16 = torch.empty(B, Cout, H, W, dtype=torch.float16, device="cuda")
+    N.check(lib.ebfi_conv2d_packed_f16_c16(N.ptr(x16), 1, site.fwd16_ptr(), site.fwd16_bytes, N.ptr(site.bias()), N.ptr(None), B, Cin, H, W,
+                                           Cout, 3, 1, 1, 1, 0.01, N.ptr(None), N.ptr(None), 0, 0.0, book.ptr(sx), site.w_slot_ptr(),
+                                           N.ptr(f16), book.ptr(sf), 1, 0, st), "img_p16")
+    assert rel(f16.float() / book.scale(sf), yc.detach()) < 2e-3
+    # data gradient: planar fp16 gradient -> fp32 (conv_fwd_f16_ws/p16_f32)
+    g16 = (gd * book.scale(sg)).half()
+    gx = torch.empty(B, Cin, H, W, device="cuda")
+    N.check(lib.ebfi_conv2d_packed_f16_c16(N.ptr(g16), 2, site.tr16_ptr(), site.tr16_bytes, N.ptr(None), N.ptr(gx), B, Cout, H, W, Cin,
+                                           3, 1, 1, 0, 0.0, N.ptr(None), N.ptr(None), 0, 0.0, book.ptr(sg), site.w_slot_ptr(),
+                                           N.ptr(None), N.ptr(None), 0, 0, st), "p16_f32")
+    assert rel(gx, xc.grad) < 2e-3
+    # weight gradient: image x planes (conv_wgrad_f16_tr<0, IN16, GP16>)
+    need = int(lib.ebfi_conv2d_backward_weight_workspace(B, Cin, H, W, Cout, 3, 1, 1, N.EBFI_F32))
+    ws = torch.empty(max(need, 4), dtype=torch.uint8, device="cuda")
+    gw, gb = torch.empty(Cout, Cin, 3, 3, device="cuda"), torch.empty(Cout, device="cuda")
+    N.check(lib.ebfi_conv2d_backward_weight_f16c(N.ptr(x16), N.ptr(g16), 1, N.ptr(gw), N.ptr(gb), B, Cin, H, W, Cout, 1, book.ptr(sx),
+                                                 book.ptr(sg), N.ptr(ws), need, st), "wgrad IN16 GP16")
+    assert rel(gw, wc.grad) < 2e-3 and rel(gb, bc.grad) < 2e-3
+
+
+def test_one_nan_element_reaches_the_slot_and_raises_the_guard():
+    """The running |max| of every fp16 writer is taken on the float bits (c16.hpp amax_acc), so a tensor that is only PARTLY NaN
+    still leaves a NaN pattern in its slot and ebfi_f16_scales_finish raises guard[0] -- fmaxf would have dropped the NaN and
+    the saturating conversions would have hidden it (round-4 advisory).  Writers covered: to_c16, the fused ResidualControl
+    backward stage (src_bwd_c16) and the forward epilogue's side image."""
+    from ebfi_amd import c16, f16scale
+    torch.manual_seed(8)
+    lib, st = N.lib(), N.stream_ptr(torch.device("cuda"))
+
+    def guard_after(fill):
+        book = f16scale.ScaleBook("cuda")
+        i = book.slot("t")
+        fill(book, i)
+        book.finish()
+        torch.cuda.synchronize()
+        return int(book.guard[0].item())
+    x = torch.randn(2, 64, 16, 64).cuda()
+    bad = x.clone()
+    bad[1, 37, 5, 11] = float("nan")
+    assert guard_after(lambda bk, i: c16.to_c16(x, bk.ptr(i))) == 0
+    assert guard_after(lambda bk, i: c16.to_c16(bad, bk.ptr(i))) == 1
+    # src_bwd_c16: one NaN in the incoming gradient
+    B, C, H, W = 2, 64, 16, 32
+    HW = H * W
+    a = torch.randn(B, 2 * C, H, W).cuda()
+    s0, s1 = torch.randn(B, C).cuda(), torch.randn(B, C).cuda()
+    a1p = N._vp(a.data_ptr() + 4 * C * HW)
+    S = int(lib.ebfi_scale_residual_cat_backward_slices())
+
+    def src_bwd(gc):
+        def fill(bk, i):
+            ga16 = c16.empty(B, 2 * C, H, W, "cuda")
+            gx, p0, p1 = torch.empty(B, C, H, W, device="cuda"), torch.empty(S, B, C, device="cuda"), torch.empty(S, B, C, device="cuda")
+            N.check(lib.ebfi_scale_residual_cat_backward_c16(N.ptr(gc), N.ptr(a), N.ptr(s0), a1p, N.ptr(s1), N.ptr(ga16), bk.ptr(i), N.ptr(gx),
+                                                             N.ptr(p0), N.ptr(p1), B, C, H, W, 2 * C * HW, 0.01, st), "bwd_c16")
+        return fill
+    gc = torch.randn(B, 2 * C, H, W).cuda() * 1e-2
+    gbad = gc.clone()
+    gbad[0, 100, 3, 7] = float("nan")
+    assert guard_after(src_bwd(gc)) == 0 and guard_after(src_bwd(gbad)) == 1
+    # the forward epilogue's side image (store_out_tile): a NaN in the conv's input reaches some outputs only
+    w, b, bank, book0, site = _banked(64, 64)
+
+    def fwd_img(inp):
+        def fill(bk, i):
+            out, img = torch.empty(2, 64, 16, 64, device="cuda"), c16.empty(2, 64, 16, 64, "cuda")
+            N.check(lib.ebfi_conv2d_packed_x3_c16(N.ptr(inp), site.fwd_ptr(), site.fwd_bytes, N.ptr(site.bias()), N.ptr(out), 2, 64, 16, 64, 64,
+                                                  3, 1, 1, 1, 0.01, N.ptr(None), N.ptr(None), 0, 0.0, N.ptr(img), bk.ptr(i), 0, st), "x3_c16")
+        return fill
+    assert guard_after(fwd_img(x)) == 0 and guard_after(fwd_img(bad)) == 1

@@ -93,6 +93,47 @@ def test_graph_replay_step_equals_eager_step():
         assert torch.allclose(a, b, rtol=1e-3, atol=1e-5), n
 
 
+def test_bench_plain_form_launches_its_own_ranks():
+    """`python bench.py --gpus 2` -- the form the driver uses, no launcher, no WORLD_SIZE -- starts its two ranks as a child
+    process (torch.distributed.run), relays rank 0's one JSON line and the exit code.  Two ranks share the one GPU of this
+    box over gloo (EBFI_BENCH_REHEARSAL=1); strict graph capture is the default for N > 1 and must hold."""
+    import json
+    env = dict(os.environ, EBFI_BENCH_REHEARSAL="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-extra-legs"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["config"]["global_batch"] == 16
+    assert d["config"]["collectives_per_step"] == 1 and d["config"]["graph_capture_failed"] is False
+    assert "hipGraph replay" in d["config"]["launch"] and d["config"]["replica_param_checksum"]["ranks_identical"] is True
+    # a mismatch between --gpus and the launcher's world size is an error, not a silent 1-rank run
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr + r.stdout
+
+
+def test_bench_single_rank_over_rccl():
+    """What a one-GPU box can exercise of the RCCL path: bench.py as ONE rank with the process group initialised on backend
+    'nccl' (= RCCL), its watchdog thread alive during the hipGraph capture (strict), and the step's collective -- the
+    all-reduce of the wire buffer, gradients + overflow flag -- going through RCCL at world size 1 (EBFI_BENCH_FORCE_DIST=1)."""
+    import json
+    env = dict(os.environ, EBFI_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29667", WORLD_SIZE="1", RANK="0",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("EBFI_BENCH_REHEARSAL", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--no-extra-legs", "--no-ops", "--no-inference", "--no-cpu-baseline", "--strict-graph"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["config"]["collective_backend"] == "nccl" and d["config"]["collectives_per_step"] == 1
+    assert "hipGraph replay" in d["config"]["launch"] and d["config"]["graph_capture_failed"] is False
+    assert d["config"]["fp16_overflow_guard"]["optimiser_steps_skipped"] == 0
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs on the node (the round's GPU box has one)")
 def test_bench_two_gpus_rccl():
     """bench.py with 2 ranks on 2 GPUs over RCCL (backend 'nccl'): the hipGraph capture of forward + loss + backward happens

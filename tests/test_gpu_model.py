@@ -284,6 +284,49 @@ def test_native_flat_adam_matches_torch_adam():
         assert _rel(sb[i]["exp_avg"], sa[i]["exp_avg"]) < 1e-5 and _rel(sb[i]["exp_avg_sq"], sa[i]["exp_avg_sq"]) < 1e-5
 
 
+def test_native_gradient_gather_packs_like_cat_and_carries_the_guard_flag():
+    """csrc/optim.hip grad_gather (FlatGradBucket.gather on the GPU): bit-identical to the concatenation of the per-parameter
+    gradients for parameters of every alignment class (odd element counts shift the destination offsets, a sliced gradient
+    shifts the source), zeros for a parameter without gradient, segments > 16384 elements, and the trailer
+    [guard flag, 0, 0, 0]; the guarded Adam launch skips on the all-reduced flag alone and writes it back to guard[0]."""
+    from ebfi_amd.dp import WIRE_PAD, FlatAdam, FlatGradBucket
+    torch.manual_seed(11)
+    shapes = [(3,), (7, 5), (1,), (40000,), (33, 3, 3), (2,), (16385,), (64, 64, 3, 3), (5,)]
+    params = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(*sh, device="cuda")) for sh in shapes])
+    bucket = FlatGradBucket(params)
+    big = torch.randn(2 * 40000 + 3, device="cuda")
+    grads = [torch.randn(*sh, device="cuda") for sh in shapes]
+    grads[3] = big[3:40003]                                        # a source that is 12 bytes off a 16-byte boundary
+    grads[5] = None                                                # no gradient: counts as zero
+    for p, g in zip(params, grads):
+        p.grad = g
+    guard = torch.zeros(2, dtype=torch.int32, device="cuda")
+    want = torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1) for p, g in zip(params, grads)])
+    for flagged in (0, 1):
+        for p, g in zip(params, grads):
+            p.grad = g
+        guard[0] = flagged
+        flat = bucket.gather(guard)
+        assert torch.equal(flat, want) and bucket.views_intact()
+        assert bucket.wire.numel() == bucket.numel + WIRE_PAD
+        assert bucket.wire[bucket.numel:].tolist() == [float(flagged), 0.0, 0.0, 0.0]
+    # the optimiser launch takes the decision from the FLAG (the local guard word is clear: another rank raised it)
+    opt = FlatAdam(list(params), lr=1e-2)
+    bucket2 = FlatGradBucket(params)
+    for p, g in zip(params, grads):
+        p.grad = g
+    guard.zero_()
+    bucket2.gather(guard)
+    before = opt.flat.detach().clone()
+    bucket2.flag.fill_(0.5)                                        # = one of two ranks raised the guard, after the averaging
+    opt.step(bucket2.flat, guard=guard, flag=bucket2.flag)
+    assert torch.equal(before, opt.flat.detach()) and guard.tolist() == [1, 1]
+    guard[0] = 0
+    bucket2.flag.zero_()
+    opt.step(bucket2.flat, guard=guard, flag=bucket2.flag)
+    assert not torch.equal(before, opt.flat.detach()) and guard.tolist() == [0, 1]
+
+
 def test_census_kernel_pair_vs_slice_formulation():
     from ebfi_amd.loss import Ternary
     torch.manual_seed(9)

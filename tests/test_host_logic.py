@@ -126,33 +126,39 @@ def test_flat_bucket_allreduce_equals_large_batch_math(tmp_path):
 def _guard_worker(rank, world, port, outdir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from ebfi_amd.dp import FlatAdam, FlatGradBucket, broadcast_parameters, sync_guard
+    from ebfi_amd.dp import FlatAdam, FlatGradBucket, broadcast_parameters
     torch.manual_seed(100 + rank)
     net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(4, 2, 1))
     broadcast_parameters(net, 0)
     bucket, opt = FlatGradBucket(net), FlatAdam(list(net.parameters()), lr=1e-2)
     guard = torch.zeros(2, dtype=torch.int32)           # f16scale.ScaleBook.guard: [flag of this step, skipped steps]
     snaps = []
+    calls = []
+    real_all_reduce = dist.all_reduce
+    dist.all_reduce = lambda *a, **k: (calls.append(a[0].numel()), real_all_reduce(*a, **k))[1]
     for step, raise_on in enumerate((None, 1, None)):   # step 1: ONLY rank 1 sees an overflow
         torch.manual_seed(7 + step)
         data = torch.randn(4, 3, 8, 8)
         bucket.zero()
         net(data[rank * 2:(rank + 1) * 2]).pow(2).sum().backward()
-        bucket.gather()
         guard[0] = 1 if raise_on == rank else 0         # (what f16_scales_finish does on the rank whose operand overflowed)
-        bucket.reduce_mean_packed()
-        opt.step(bucket.flat, guard=sync_guard(guard))  # Engine._finish_micro_step's order
+        bucket.gather(guard)                            # Engine.train_step's order: the flag rides in the wire buffer
+        bucket.reduce_mean_packed()                     # the step's ONE collective
+        opt.step(bucket.flat, guard=guard, flag=bucket.flag)
         st = opt.inner.state.get(opt.flat, {})
         snaps.append((opt.flat.detach().clone(), int(guard[0]), int(guard[1]),
                       st["exp_avg"].clone() if st else None, float(st["step"]) if st else 0.0))
+    dist.all_reduce = real_all_reduce
+    assert calls == [bucket.numel + 4] * 3, calls       # exactly one all-reduce per step, gradients + flag in one message
     torch.save(snaps, os.path.join(outdir, "g%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_overflow_guard_raised_on_one_rank_skips_the_update_on_every_rank(tmp_path):
-    """Data parallelism with the fp16 backward: the guard flag is MAX-reduced (dp.sync_guard) before the guarded optimiser
-    step, so a flag raised on ONE rank skips the update on BOTH (parameters, moments and step count untouched, the skip
+    """Data parallelism with the fp16 backward: the guard flag travels INSIDE the gradient all-reduce (one element of the
+    wire buffer, SUM > 0 <=> raised somewhere; one collective per step) and the guarded optimiser step reads it, so a flag
+    raised on ONE rank skips the update on BOTH (parameters, moments and step count untouched, the skip
     counted) and the replicas stay bit-identical; the next clean step updates both."""
     ctx = mp.get_context("spawn")
     port = 29500 + ((os.getpid() + 137) % 500)

@@ -18,8 +18,12 @@ for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
             continue
         m = re.search(r"probe<(\d+), (\d+)>", r["Kernel_Name"])
         if m:
-            rows[(int(m.group(2)), int(m.group(1)), int(r.get("Workgroup_Size", 0)))].append(float(r["Counter_Value"]))
-for (planes, nl, wg), v in sorted(rows.items()):
+            rows[("planes 16 B/lane" if int(m.group(2)) else "linear 16 B/lane", int(m.group(1)),
+                  int(r.get("Workgroup_Size", 0)))].append(float(r["Counter_Value"]))
+        m = re.search(r"probe_narrow<(\d+), (\d+)>", r["Kernel_Name"])
+        if m:
+            rows[("linear %2d B/lane" % int(m.group(2)), int(m.group(1)), int(r.get("Workgroup_Size", 0)))].append(float(r["Counter_Value"]))
+for (kind, nl, wg), v in sorted(rows.items()):
     kb = sum(v) / len(v)          # FETCH_SIZE is reported in kilobytes
     print("%s  loads in flight %2d  workgroup %4d : counted %8.1f MB of %6.0f MB actual  -> factor %.3f  (%d dispatches)"
-          % ("planes" if planes else "linear", nl, wg, kb / 1024.0, mb, mb / (kb / 1024.0), len(v)))
+          % (kind, nl, wg, kb / 1024.0, mb, mb / (kb / 1024.0), len(v)))
