@@ -63,7 +63,9 @@ static inline Str4 str4(const int64_t *p) { return Str4{p[0], p[1], p[2], p[3]};
 // ------------------------------------------------------------------------------------------------
 // forward, vectorised tile kernel.  Requirements (checked by the launcher): innermost stride 1 for
 // all three tensors, Wo % 4 == 0, filter/output rows 16-byte aligned.
-template <int K, int TH, int TW, bool H16 = false>
+// CLAMP (round 5): `in` is the UNPADDED [B, C, Ho, Wo] tensor and the replicate padding of KernelConv2D.py:82-86 happens here,
+// as clamped reads while the halo tile is staged -- no padded copy of the input exists (the F.pad launch and its 35 MB).
+template <int K, int TH, int TW, bool H16 = false, bool CLAMP = false>
 __global__ __launch_bounds__(256) void fac_fwd_tile_f32(const float *__restrict__ in, Str4 is,
                                                         const void *__restrict__ kern, Str4 ks,
                                                         float *__restrict__ out, Str4 os, int C, int Ho,
@@ -86,7 +88,10 @@ __global__ __launch_bounds__(256) void fac_fwd_tile_f32(const float *__restrict_
         const int r = i / IWP, col = i - r * IWP;
         const int yy = y0 + r, xx = x0 + col;
         float v = 0.f;
-        if (col < IW && yy < Hi && xx < Wi) v = inp[(int64_t)yy * is.s2 + xx];
+        if (col < IW && yy < Hi && xx < Wi) {
+            if constexpr (CLAMP) v = inp[(int64_t)min(max(yy - K / 2, 0), Ho - 1) * is.s2 + min(max(xx - K / 2, 0), Wo - 1)];
+            else v = inp[(int64_t)yy * is.s2 + xx];
+        }
         tile[i] = v;
     }
     __syncthreads();
@@ -148,7 +153,14 @@ __global__ void fac_fwd_generic_f32(const float *__restrict__ in, Str4 is, const
 // ------------------------------------------------------------------------------------------------
 // backward, fused row kernel (see file header).  K in {1,3,5}; innermost strides 1; Wo % 4 == 0;
 // filter / grad_kernel / grad_output rows 16-byte aligned.  TPR = lanes per row (power of two <= 64).
-template <int K, int TPR, bool H16 = false>
+// CLAMP (round 5): `in` / `gin` are the UNPADDED [B, C, Ho, Wo] tensors.  The padded grid still exists -- as coordinates: the
+// input is read with clamped indices, and grad_input is the ADJOINT of the replicate padding applied on the fly: padded
+// position (Y, X) adds into (clamp(Y - K/2), clamp(X - K/2)).  A thread owns 4 padded columns of an OUTPUT row R: interior rows
+// have one padded row (R + K/2), the first / last row own the K/2 + 1 padded rows that clamp onto them and walk them in order
+// (plain store for the first, read-modify-write of their own elements for the rest); the 3 padded columns of either border
+// lie inside one thread's 4 and are summed in registers.  Fixed summation order, no atomics -- unlike torch's
+// replication_pad2d_backward, whose atomic adds were one of the step's two sources of run-to-run noise.
+template <int K, int TPR, bool H16 = false, bool CLAMP = false>
 __global__ __launch_bounds__(256) void fac_bwd_rows_f32(const float *__restrict__ in, Str4 is,
                                                         const void *__restrict__ kern, Str4 ks,
                                                         const float *__restrict__ gout, Str4 gs,
@@ -163,86 +175,126 @@ __global__ __launch_bounds__(256) void fac_bwd_rows_f32(const float *__restrict_
     // kslope: grad_kernel leaves multiplied by (kernel > 0 ? 1 : kslope) -- the derivative of the LeakyReLU that produced the
     // filters, so that the layer below receives the gradient of its PRE-activation (1.0 = plain grad_kernel, bit for bit)
     static_assert(K == 1 || K == 3 || K == 5, "carry scheme needs K-1 <= 4");
+    static_assert(!CLAMP || K == 5, "the in-kernel replicate padding is written for K = 5");
     constexpr int RPW = 64 / TPR;          // rows per wave
     constexpr int ROWS = 4 * RPW;          // rows per 256-thread workgroup
     constexpr int NS = 4 + K - 1;          // private partial sums / input values per thread
     constexpr int NU = K - 1;              // partials owned by the next lane
+    constexpr int R2 = K / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane / TPR, tx = lane % TPR;
-    const int Y = blockIdx.x * ROWS + wave * RPW + r;   // row of the padded grid
+    const int row = blockIdx.x * ROWS + wave * RPW + r;   // row of the padded grid (CLAMP: output row)
     const int b = blockIdx.y / C, c = blockIdx.y % C;
     const int Hi = Ho + K - 1, Wi = Wo + K - 1;
     const int nx4 = Wo >> 2;
-    const bool rowok = Y < Hi;
+    const bool rowok = CLAMP ? row < Ho : row < Hi;
     const int nchunks = nx4 / TPR + 1;     // the lane right after the last loading lane writes the tail
+    // padded rows this thread walks: [Ylo, Yhi]
+    const int Ylo = CLAMP ? (row == 0 ? 0 : row + R2) : row;
+    const int Yhi = CLAMP ? (row == Ho - 1 ? Ho - 1 + 2 * R2 : row + R2) : row;
 
-    const float *inrow = in + (int64_t)b * is.s0 + (int64_t)c * is.s1 + (int64_t)Y * is.s2;
+    const float *inpl = in + (int64_t)b * is.s0 + (int64_t)c * is.s1;
     const int64_t kbase = (int64_t)b * ks.s0 + (int64_t)c * K * K * ks.s1;
     const float *gbase = gout + (int64_t)b * gs.s0 + (int64_t)c * gs.s1;
     const bool has_gk = gkern != nullptr;
     const int64_t gkbase = (int64_t)b * gks.s0 + (int64_t)c * K * K * gks.s1;
-    float *ginrow = gin ? gin + (int64_t)b * gis.s0 + (int64_t)c * gis.s1 + (int64_t)Y * gis.s2 : nullptr;
+    float *ginpl = gin ? gin + (int64_t)b * gis.s0 + (int64_t)c * gis.s1 : nullptr;
 
-    float carry[NU > 0 ? NU : 1];
+    for (int yi = 0; yi < (CLAMP ? K : 1); ++yi) {
+        const int Y = Ylo + yi;
+        const bool yok = rowok && Y <= Yhi;
+        if constexpr (CLAMP) {
+            if (__builtin_amdgcn_ballot_w64(yok) == 0) break;      // (wave-uniform: the shuffles below need every lane)
+        }
+        const float *inrow = inpl + (int64_t)(CLAMP ? min(max(Y - R2, 0), Ho - 1) : Y) * is.s2;
+        float *ginrow = ginpl ? ginpl + (int64_t)(CLAMP ? row : Y) * gis.s2 : nullptr;
+        float carry[NU > 0 ? NU : 1];
 #pragma unroll
-    for (int m = 0; m < NU; ++m) carry[m] = 0.f;
+        for (int m = 0; m < NU; ++m) carry[m] = 0.f;
 
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const int x4 = chunk * TPR + tx;
-        const int x = x4 << 2;
-        const bool active = rowok && x4 < nx4;
-        float s[NS];
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const int x4 = chunk * TPR + tx;
+            const int x = x4 << 2;
+            const bool active = yok && x4 < nx4;
+            float s[NS];
 #pragma unroll
-        for (int j = 0; j < NS; ++j) s[j] = 0.f;
-        if (active) {
-            float inr[NS];
-            if (has_gk) {
+            for (int j = 0; j < NS; ++j) s[j] = 0.f;
+            if (active) {
+                float inr[NS];
+                if (has_gk) {
 #pragma unroll
-                for (int j = 0; j < NS; ++j) inr[j] = inrow[x + j];   // x + j <= Wo - 4 + 3 + K - 1 < Wi
-            }
-#pragma unroll
-            for (int ky = 0; ky < K; ++ky) {
-                const int y = Y - ky;
-                if (y < 0 || y >= Ho) continue;
-                const float4 g = *reinterpret_cast<const float4 *>(gbase + (int64_t)y * gs.s2 + x);
-#pragma unroll
-                for (int kx = 0; kx < K; ++kx) {
-                    const int t = ky * K + kx;
-                    const f32x4 w = ld_filter4<H16>(kern, kbase + (int64_t)t * ks.s1 + (int64_t)y * ks.s2 + x, finv);
-                    if (has_gk) {
-                        const f32x4 p = {inr[kx + 0] * g.x * (w.x > 0.f ? 1.f : kslope), inr[kx + 1] * g.y * (w.y > 0.f ? 1.f : kslope),
-                                         inr[kx + 2] * g.z * (w.z > 0.f ? 1.f : kslope), inr[kx + 3] * g.w * (w.w > 0.f ? 1.f : kslope)};
-                        const int64_t go_ = gkbase + (int64_t)t * gks.s1 + (int64_t)y * gks.s2 + x;
-                        if constexpr (H16) {
-                            gk_amax = amax_acc(amax_acc(gk_amax, p[0], p[1]), p[2], p[3]);
-                            st_stream4h(static_cast<_Float16 *>(gkern) + go_, p, gsc);
-                        } else {
-                            st_stream4(static_cast<float *>(gkern) + go_, p);
-                        }
+                    for (int j = 0; j < NS; ++j) {
+                        if constexpr (CLAMP) inr[j] = inrow[min(max(x + j - R2, 0), Wo - 1)];
+                        else inr[j] = inrow[x + j];   // x + j <= Wo - 4 + 3 + K - 1 < Wi
                     }
-                    s[kx + 0] = fmaf(w.x, g.x, s[kx + 0]);
-                    s[kx + 1] = fmaf(w.y, g.y, s[kx + 1]);
-                    s[kx + 2] = fmaf(w.z, g.z, s[kx + 2]);
-                    s[kx + 3] = fmaf(w.w, g.w, s[kx + 3]);
+                }
+#pragma unroll
+                for (int ky = 0; ky < K; ++ky) {
+                    const int y = Y - ky;
+                    if (y < 0 || y >= Ho) continue;
+                    const float4 g = *reinterpret_cast<const float4 *>(gbase + (int64_t)y * gs.s2 + x);
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) {
+                        const int t = ky * K + kx;
+                        const f32x4 w = ld_filter4<H16>(kern, kbase + (int64_t)t * ks.s1 + (int64_t)y * ks.s2 + x, finv);
+                        if (has_gk) {
+                            const f32x4 p = {inr[kx + 0] * g.x * (w.x > 0.f ? 1.f : kslope), inr[kx + 1] * g.y * (w.y > 0.f ? 1.f : kslope),
+                                             inr[kx + 2] * g.z * (w.z > 0.f ? 1.f : kslope), inr[kx + 3] * g.w * (w.w > 0.f ? 1.f : kslope)};
+                            const int64_t go_ = gkbase + (int64_t)t * gks.s1 + (int64_t)y * gks.s2 + x;
+                            if constexpr (H16) {
+                                gk_amax = amax_acc(amax_acc(gk_amax, p[0], p[1]), p[2], p[3]);
+                                st_stream4h(static_cast<_Float16 *>(gkern) + go_, p, gsc);
+                            } else {
+                                st_stream4(static_cast<float *>(gkern) + go_, p);
+                            }
+                        }
+                        s[kx + 0] = fmaf(w.x, g.x, s[kx + 0]);
+                        s[kx + 1] = fmaf(w.y, g.y, s[kx + 1]);
+                        s[kx + 2] = fmaf(w.z, g.z, s[kx + 2]);
+                        s[kx + 3] = fmaf(w.w, g.w, s[kx + 3]);
+                    }
                 }
             }
-        }
-        // hand the K-1 upper partials to the lane that owns those columns (all lanes take part)
-        float o[4] = {s[0], s[1], s[2], s[3]};
-        if constexpr (NU > 0) {
+            // hand the K-1 upper partials to the lane that owns those columns (all lanes take part)
+            float o[4] = {s[0], s[1], s[2], s[3]};
+            if constexpr (NU > 0) {
 #pragma unroll
-            for (int m = 0; m < NU; ++m) {
-                float left = __shfl_up(s[4 + m], 1, TPR);
-                if (tx == 0) left = carry[m];
-                const float last = __shfl(s[4 + m], TPR - 1, TPR);
-                o[m] += left;
-                carry[m] = last;
+                for (int m = 0; m < NU; ++m) {
+                    float left = __shfl_up(s[4 + m], 1, TPR);
+                    if (tx == 0) left = carry[m];
+                    const float last = __shfl(s[4 + m], TPR - 1, TPR);
+                    o[m] += left;
+                    carry[m] = last;
+                }
             }
-        }
-        if (ginrow != nullptr && rowok) {
+            if constexpr (CLAMP) {
+                if (ginrow != nullptr && yok && x < Wi) {
+                    // padded columns x .. x + 3 -> output columns clamp(X - 2): the left border's three (X = 0, 1, 2 -> 0) sit in the
+                    // thread with x == 0, the right border's three (X = Wo + 1 .. Wo + 3 -> Wo - 1) in the tail thread x == Wo
+                    float v[4];
+                    int xo[4], n;
+                    if (x == 0) { v[0] = (o[0] + o[1]) + o[2]; xo[0] = 0; v[1] = o[3]; xo[1] = 1; n = 2; }
+                    else if (x == Wo) { v[0] = o[0]; xo[0] = Wo - 2; v[1] = (o[1] + o[2]) + o[3]; xo[1] = Wo - 1; n = 2; }
+                    else {
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
-                if (x + m < Wi) ginrow[x + m] = o[m];
+                        for (int m = 0; m < 4; ++m) { v[m] = o[m]; xo[m] = x - R2 + m; }
+                        n = 4;
+                    }
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        if (m < n) {
+                            // (yi > 0 only in the first / last output row: this thread wrote the element in an earlier pass)
+                            if (yi == 0) ginrow[xo[m]] = v[m];
+                            else ginrow[xo[m]] += v[m];
+                        }
+                }
+            } else {
+                if (ginrow != nullptr && rowok) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        if (x + m < Wi) ginrow[x + m] = o[m];
+                }
+            }
         }
     }
     if constexpr (H16) {
@@ -310,7 +362,7 @@ int check_shapes(const int64_t *ish, const int64_t *ksh, int K, int64_t *B, int6
     return EBFI_OK;
 }
 
-template <int K, bool H16 = false>
+template <int K, bool H16 = false, bool CLAMP = false>
 void launch_fwd_tile(hipStream_t st, const float *in, Str4 is, const void *kern, Str4 ks, float *out, Str4 os,
                      int B, int C, int Ho, int Wo, const float *f_slot = nullptr) {
     const double bytes = B * C * (double)Ho * Wo * (4.0 + (H16 ? 2.0 : 4.0) * K * K + 4.0);   // in + K*K filter planes + out
@@ -318,37 +370,37 @@ void launch_fwd_tile(hipStream_t st, const float *in, Str4 is, const void *kern,
     if (Wo <= 64) {
         dim3 grid((unsigned)ceil_div(Wo, 64), (unsigned)ceil_div(Ho, 16), (unsigned)(B * C));
         ProfScope ps(name, st, 2.0 * B * C * (double)Ho * Wo * K * K, bytes);
-        hipLaunchKernelGGL((fac_fwd_tile_f32<K, 16, 64, H16>), grid, dim3(256), 0, st, in, is, kern, ks, out, os, C, Ho, Wo, f_slot);
+        hipLaunchKernelGGL((fac_fwd_tile_f32<K, 16, 64, H16, CLAMP>), grid, dim3(256), 0, st, in, is, kern, ks, out, os, C, Ho, Wo, f_slot);
     } else {
         dim3 grid((unsigned)ceil_div(Wo, 128), (unsigned)ceil_div(Ho, 8), (unsigned)(B * C));
         ProfScope ps(name, st, 2.0 * B * C * (double)Ho * Wo * K * K, bytes);
-        hipLaunchKernelGGL((fac_fwd_tile_f32<K, 8, 128, H16>), grid, dim3(256), 0, st, in, is, kern, ks, out, os, C, Ho, Wo, f_slot);
+        hipLaunchKernelGGL((fac_fwd_tile_f32<K, 8, 128, H16, CLAMP>), grid, dim3(256), 0, st, in, is, kern, ks, out, os, C, Ho, Wo, f_slot);
     }
 }
 
-template <int K, int TPR, bool H16 = false>
+template <int K, int TPR, bool H16 = false, bool CLAMP = false>
 void launch_bwd_rows_t(hipStream_t st, const float *in, Str4 is, const void *kern, Str4 ks, const float *go,
                        Str4 gs, float *gin, Str4 gis, void *gk, Str4 gks, int B, int C, int Ho, int Wo, float kslope,
                        const float *f_slot = nullptr, float *g_slot = nullptr) {
     constexpr int ROWS = 4 * (64 / TPR);
-    dim3 grid((unsigned)ceil_div(Ho + K - 1, ROWS), (unsigned)(B * C));
+    dim3 grid((unsigned)ceil_div(CLAMP ? Ho : Ho + K - 1, ROWS), (unsigned)(B * C));
     const double px = (double)B * C * Ho * Wo;     // filters + gout + in read, grad_in + grad_kernel written
     const double e = H16 ? 2.0 : 4.0;
     ProfScope ps(H16 ? "fac_bwd_rows_f32/p16" : "fac_bwd_rows_f32", st, 4.0 * px * K * K,
                  px * (e * K * K + 4.0 + 4.0 + (gin ? 4.0 : 0.0) + (gk ? e * K * K : 0.0)));
-    hipLaunchKernelGGL((fac_bwd_rows_f32<K, TPR, H16>), grid, dim3(256), 0, st, in, is, kern, ks, go, gs, gin, gis, gk, gks,
+    hipLaunchKernelGGL((fac_bwd_rows_f32<K, TPR, H16, CLAMP>), grid, dim3(256), 0, st, in, is, kern, ks, go, gs, gin, gis, gk, gks,
                        C, Ho, Wo, kslope, f_slot, g_slot);
 }
 
-template <int K, bool H16 = false>
+template <int K, bool H16 = false, bool CLAMP = false>
 void launch_bwd_rows(hipStream_t st, const float *in, Str4 is, const void *kern, Str4 ks, const float *go, Str4 gs,
                      float *gin, Str4 gis, void *gk, Str4 gks, int B, int C, int Ho, int Wo, float kslope,
                      const float *f_slot = nullptr, float *g_slot = nullptr) {
     const int nx4 = Wo / 4;
-    if (nx4 <= 8) launch_bwd_rows_t<K, 8, H16>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo, kslope, f_slot, g_slot);
-    else if (nx4 <= 16) launch_bwd_rows_t<K, 16, H16>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo, kslope, f_slot, g_slot);
-    else if (nx4 <= 32) launch_bwd_rows_t<K, 32, H16>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo, kslope, f_slot, g_slot);
-    else launch_bwd_rows_t<K, 64, H16>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo, kslope, f_slot, g_slot);
+    if (nx4 <= 8) launch_bwd_rows_t<K, 8, H16, CLAMP>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo, kslope, f_slot, g_slot);
+    else if (nx4 <= 16) launch_bwd_rows_t<K, 16, H16, CLAMP>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo, kslope, f_slot, g_slot);
+    else if (nx4 <= 32) launch_bwd_rows_t<K, 32, H16, CLAMP>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo, kslope, f_slot, g_slot);
+    else launch_bwd_rows_t<K, 64, H16, CLAMP>(st, in, is, kern, ks, go, gs, gin, gis, gk, gks, B, C, Ho, Wo, kslope, f_slot, g_slot);
 }
 
 }  // namespace
@@ -467,35 +519,46 @@ extern "C" int ebfi_fac_backward_ex(const void *input, const int64_t input_shape
 // [B, C, Ho+K-1, Wo+K-1], output / grad_output [B, C, Ho, Wo], grad_input_pad like input_pad (fp32).  K = 5 (the model's),
 // Wo % 4 == 0.  grad_kernel16 leaves multiplied by the LeakyReLU(kernel_leaky_slope) derivative of the filters, times
 // g_slot[0], its |max| recorded into g_slot (the WRITER of an fp16 tensor records, c16.hpp).
-extern "C" int ebfi_fac_forward_p16(const float *input_pad, const void *filters16, const void *f_slot, float *output, int B, int C, int Ho,
-                                    int Wo, int K, void *stream) {
-    if (!input_pad || !filters16 || !f_slot || !output) return fail(EBFI_ERR_ARG, "fac_forward_p16: null argument");
+extern "C" int ebfi_fac_forward_p16(const float *input, int input_is_unpadded, const void *filters16, const void *f_slot, float *output,
+                                    int B, int C, int Ho, int Wo, int K, void *stream) {
+    if (!input || !filters16 || !f_slot || !output) return fail(EBFI_ERR_ARG, "fac_forward_p16: null argument");
     if (K != 5 || Wo % 4 != 0 || B < 0 || C < 1 || Ho < 1 || Wo < 4 || (int64_t)B * C > 65535)
         return fail(EBFI_ERR_UNSUPPORTED, "fac_forward_p16: K = 5, Wo %% 4 == 0, B*C <= 65535 (K=%d Wo=%d)", K, Wo);
     if (!aligned16(filters16) || !aligned16(output)) return fail(EBFI_ERR_ARG, "fac_forward_p16: 16-byte aligned tensors");
     if (B == 0) return EBFI_OK;
     const int64_t Hi = Ho + K - 1, Wi = Wo + K - 1, HW = (int64_t)Ho * Wo;
-    const Str4 is{C * Hi * Wi, Hi * Wi, Wi, 1}, ks{(int64_t)C * K * K * HW, HW, Wo, 1}, os{C * HW, HW, Wo, 1};
-    launch_fwd_tile<5, true>(static_cast<hipStream_t>(stream), input_pad, is, filters16, ks, output, os, B, C, Ho, Wo,
-                             static_cast<const float *>(f_slot));
+    const Str4 ks{(int64_t)C * K * K * HW, HW, Wo, 1}, os{C * HW, HW, Wo, 1};
+    if (input_is_unpadded)
+        launch_fwd_tile<5, true, true>(static_cast<hipStream_t>(stream), input, os, filters16, ks, output, os, B, C, Ho, Wo,
+                                       static_cast<const float *>(f_slot));
+    else
+        launch_fwd_tile<5, true>(static_cast<hipStream_t>(stream), input, Str4{C * Hi * Wi, Hi * Wi, Wi, 1}, filters16, ks, output, os,
+                                 B, C, Ho, Wo, static_cast<const float *>(f_slot));
     return check_launch("fac_fwd_tile_f32/p16");
 }
 
-extern "C" int ebfi_fac_backward_p16(const float *input_pad, const void *filters16, const void *f_slot, const float *grad_output,
-                                     float *grad_input_pad, void *grad_kernel16, void *g_slot, float kernel_leaky_slope, int B, int C,
-                                     int Ho, int Wo, int K, void *stream) {
-    if (!input_pad || !filters16 || !f_slot || !grad_output) return fail(EBFI_ERR_ARG, "fac_backward_p16: null argument");
+extern "C" int ebfi_fac_backward_p16(const float *input, int input_is_unpadded, const void *filters16, const void *f_slot,
+                                     const float *grad_output, float *grad_input, void *grad_kernel16, void *g_slot,
+                                     float kernel_leaky_slope, int B, int C, int Ho, int Wo, int K, void *stream) {
+    if (!input || !filters16 || !f_slot || !grad_output) return fail(EBFI_ERR_ARG, "fac_backward_p16: null argument");
     if (grad_kernel16 && !g_slot) return fail(EBFI_ERR_ARG, "fac_backward_p16: grad_kernel16 needs its scale slot");
     if (K != 5 || Wo % 4 != 0 || B < 0 || C < 1 || Ho < 1 || Wo < 4 || (int64_t)B * C > 65535)
         return fail(EBFI_ERR_UNSUPPORTED, "fac_backward_p16: K = 5, Wo %% 4 == 0, B*C <= 65535 (K=%d Wo=%d)", K, Wo);
     if (!aligned16(filters16) || !aligned16(grad_output) || (grad_kernel16 && !aligned16(grad_kernel16)))
         return fail(EBFI_ERR_ARG, "fac_backward_p16: 16-byte aligned tensors");
-    if (!grad_input_pad && !grad_kernel16) return EBFI_OK;
+    if (!grad_input && !grad_kernel16) return EBFI_OK;
     if (B == 0) return EBFI_OK;
     const int64_t Hi = Ho + K - 1, Wi = Wo + K - 1, HW = (int64_t)Ho * Wo;
-    const Str4 is{C * Hi * Wi, Hi * Wi, Wi, 1}, ks{(int64_t)C * K * K * HW, HW, Wo, 1}, gs{C * HW, HW, Wo, 1};
-    launch_bwd_rows<5, true>(static_cast<hipStream_t>(stream), input_pad, is, filters16, ks, grad_output, gs, grad_input_pad, is,
-                             grad_kernel16, ks, B, C, Ho, Wo, kernel_leaky_slope, static_cast<const float *>(f_slot),
-                             static_cast<float *>(g_slot));
+    const Str4 ks{(int64_t)C * K * K * HW, HW, Wo, 1}, gs{C * HW, HW, Wo, 1};
+    if (input_is_unpadded) {
+        launch_bwd_rows<5, true, true>(static_cast<hipStream_t>(stream), input, gs, filters16, ks, grad_output, gs, grad_input, gs,
+                                       grad_kernel16, ks, B, C, Ho, Wo, kernel_leaky_slope, static_cast<const float *>(f_slot),
+                                       static_cast<float *>(g_slot));
+    } else {
+        const Str4 is{C * Hi * Wi, Hi * Wi, Wi, 1};
+        launch_bwd_rows<5, true>(static_cast<hipStream_t>(stream), input, is, filters16, ks, grad_output, gs, grad_input, is,
+                                 grad_kernel16, ks, B, C, Ho, Wo, kernel_leaky_slope, static_cast<const float *>(f_slot),
+                                 static_cast<float *>(g_slot));
+    }
     return check_launch("fac_bwd_rows_f32/p16");
 }

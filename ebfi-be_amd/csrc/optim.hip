@@ -58,29 +58,43 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float *__restrict__ p, c
 }
 
 // Gradient packing of the training step (ebfi_amd.dp.FlatGradBucket.gather): the per-parameter gradient tensors autograd
-// produced are copied into the one flat buffer the all-reduce and the Adam launch work on.  One workgroup per table segment
-// {source address (0 = no gradient: zeros), destination element offset, element count <= 16384}; the last `pad` floats of
-// the buffer carry this rank's overflow flag (guard[0] != 0) and zeros, so the flag travels inside the gradient message.
-struct GatherSeg {
-    const float *src;
-    int64_t dst;
-    int64_t n;
+// produced are copied into the one flat buffer the all-reduce and the Adam launch work on.  The source pointers travel BY VALUE
+// in the kernel arguments, 128 tensors per launch (3 launches for the model's 255 parameters) -- nothing to upload, and a
+// captured launch replays with the addresses its capture saw.  A tensor is cut into chunks of 16384 elements, one workgroup
+// each (torch.cat's batched copy gives every input the same number of workgroups: the 1.8 M-element KernelConv weight next to
+// 64-element biases took 90 us for the 22.8 MB); the workgroup finds its tensor by bisection over the chunk prefix sums.
+// The last `pad` floats of the buffer carry this rank's overflow flag (guard[0] != 0) and zeros, so the flag travels inside the
+// gradient message.
+constexpr int GG_BATCH = 128, GG_CHUNK = 16384;
+struct GatherBatch {
+    const float *src[GG_BATCH];        // NULL: the parameter has no gradient, its range is zero-filled
+    long long dst[GG_BATCH];           // element offset in the flat buffer
+    int n[GG_BATCH];                   // elements
+    unsigned chunk0[GG_BATCH + 1];     // prefix sums of ceil(n / GG_CHUNK); chunk0[count] = workgroups of this launch
+    int count;
+    int trailer;                       // 1: one extra workgroup writes the trailer
 };
 
-__global__ __launch_bounds__(256) void grad_gather_kernel(const GatherSeg *__restrict__ table, int nseg, float *__restrict__ flat,
-                                                          int64_t numel, int pad, const int *__restrict__ guard) {
-    if ((int)blockIdx.x == nseg) {                  // the extra workgroup writes the trailer
+__global__ __launch_bounds__(256) void grad_gather_kernel(GatherBatch bt, float *__restrict__ flat, int64_t numel, int pad,
+                                                          const int *__restrict__ guard) {
+    const unsigned wg = blockIdx.x;
+    if (wg == bt.chunk0[bt.count]) {                // (only when bt.trailer: the grid has one workgroup more)
         if ((int)threadIdx.x < pad) flat[numel + threadIdx.x] = (threadIdx.x == 0 && guard != nullptr && guard[0] != 0) ? 1.f : 0.f;
         return;
     }
-    const GatherSeg s = table[blockIdx.x];
-    float *__restrict__ d = flat + s.dst;
-    const int n = (int)s.n;
-    if (s.src == nullptr) {
+    int lo = 0, hi = bt.count;                      // chunk0[lo] <= wg < chunk0[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (bt.chunk0[mid] <= wg) lo = mid; else hi = mid;
+    }
+    const int o = (int)(wg - bt.chunk0[lo]) * GG_CHUNK;
+    const int n = min(GG_CHUNK, bt.n[lo] - o);
+    float *__restrict__ d = flat + bt.dst[lo] + o;
+    if (bt.src[lo] == nullptr) {
         for (int i = threadIdx.x; i < n; i += 256) d[i] = 0.f;
         return;
     }
-    const float *__restrict__ a = s.src;
+    const float *__restrict__ a = bt.src[lo] + o;
     // 16-byte accesses where source and destination are aligned alike (parameter offsets are arbitrary element counts)
     const int head = (int)((16u - ((unsigned)reinterpret_cast<uintptr_t>(d) & 15u)) & 15u) >> 2;
     if (((reinterpret_cast<uintptr_t>(a) ^ reinterpret_cast<uintptr_t>(d)) & 15u) == 0 && n >= head + 4) {
@@ -97,13 +111,38 @@ __global__ __launch_bounds__(256) void grad_gather_kernel(const GatherSeg *__res
 
 }  // namespace
 
-extern "C" int ebfi_grad_gather(const void *table, int nseg, float *flat, int64_t numel, int pad, const int *guard, void *stream) {
-    if (!table || !flat || nseg <= 0 || numel <= 0 || pad < 1 || pad > 256) return fail(EBFI_ERR_ARG, "grad_gather: bad argument");
+extern "C" int ebfi_grad_gather(const void *const *grads, const int64_t *numels, int count, float *flat, int64_t total, int pad,
+                                const int *guard, void *stream) {
+    if (!grads || !numels || !flat || count <= 0 || total <= 0 || pad < 1 || pad > 256) return fail(EBFI_ERR_ARG, "grad_gather: bad argument");
+    int64_t sum = 0;
+    for (int k = 0; k < count; ++k) {
+        if (numels[k] < 0 || numels[k] > 0x7fffffff) return fail(EBFI_ERR_ARG, "grad_gather: tensor %d has %lld elements", k, (long long)numels[k]);
+        if (grads[k] && (reinterpret_cast<uintptr_t>(grads[k]) & 3u)) return fail(EBFI_ERR_ARG, "grad_gather: tensor %d is not 4-byte aligned", k);
+        sum += numels[k];
+    }
+    if (sum != total) return fail(EBFI_ERR_ARG, "grad_gather: the tensors hold %lld elements, the buffer %lld", (long long)sum, (long long)total);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    {
-        ProfScope ps("grad_gather", st, 0.0, 8.0 * (double)numel);
-        hipLaunchKernelGGL(grad_gather_kernel, dim3((unsigned)nseg + 1u), dim3(256), 0, st, static_cast<const GatherSeg *>(table), nseg,
-                           flat, numel, pad, guard);
+    int64_t off = 0;
+    for (int k0 = 0; k0 < count; k0 += GG_BATCH) {
+        GatherBatch bt;
+        bt.count = std::min(GG_BATCH, count - k0);
+        bt.trailer = k0 + GG_BATCH >= count ? 1 : 0;
+        unsigned chunks = 0;
+        double bytes = 0.0;
+        for (int j = 0; j < bt.count; ++j) {
+            bt.src[j] = static_cast<const float *>(grads[k0 + j]);
+            bt.dst[j] = off;
+            bt.n[j] = (int)numels[k0 + j];
+            bt.chunk0[j] = chunks;
+            chunks += (unsigned)ceil_div(numels[k0 + j], (int64_t)GG_CHUNK);
+            off += numels[k0 + j];
+            bytes += 8.0 * (double)numels[k0 + j];
+        }
+        bt.chunk0[bt.count] = chunks;
+        for (int j = bt.count; j < GG_BATCH; ++j) bt.src[j] = nullptr, bt.dst[j] = 0, bt.n[j] = 0, bt.chunk0[j + 1] = chunks;
+        if (chunks + (unsigned)bt.trailer == 0) continue;
+        ProfScope ps("grad_gather", st, 0.0, bytes);
+        hipLaunchKernelGGL(grad_gather_kernel, dim3(chunks + (unsigned)bt.trailer), dim3(256), 0, st, bt, flat, total, pad, guard);
     }
     return check_launch("grad_gather");
 }

@@ -79,8 +79,8 @@ SIGNATURES = {
     "ebfi_conv2d_backward_weight_f16c": (_i, [_vp, _vp, _i, _vp, _vp] + [_i] * 6 + [_vp, _vp, _vp, _sz, _vp]),
     "ebfi_conv2d_backward_weight_f16c_batch_workspace": (_sz, [_i, _vp, _vp]),
     "ebfi_conv2d_backward_weight_f16c_batch": (_i, [_i] + [_vp] * 9 + [_i, _i, _i, _vp, _sz, _vp]),
-    "ebfi_fac_forward_p16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "ebfi_fac_backward_p16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_float, _i, _i, _i, _i, _i, _vp]),
+    "ebfi_fac_forward_p16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ebfi_fac_backward_p16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_float, _i, _i, _i, _i, _i, _vp]),
     "ebfi_scale_residual_cat_forward_c16": (_i, [_vp] * 8 + [_i, _i, _i, _i, _i64, _vp]),
     "ebfi_scale_residual_cat_backward_slices": (_i, []),
     "ebfi_scale_residual_cat_backward_c16": (_i, [_vp] * 10 + [_i, _i, _i, _i, _i64, _c.c_float, _vp]),
@@ -115,7 +115,8 @@ SIGNATURES = {
     "ebfi_conv2d_backward_data_s2_bf16x3": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ebfi_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64] + [_c.c_double] * 4 + [_vp]),
     "ebfi_adam_step_guarded": (_i, [_vp, _vp, _vp, _vp, _vp, _i64] + [_c.c_double] * 4 + [_vp, _vp, _vp]),
-    "ebfi_grad_gather": (_i, [_vp, _i, _vp, _i64, _i, _vp, _vp]),
+    "ebfi_reflect_pad2d_backward": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp]),
+    "ebfi_grad_gather": (_i, [_vp, _vp, _i, _vp, _i64, _i, _vp, _vp]),
     "ebfi_laploss_workspace_floats": (_i64, [_i64, _i, _i, _i]),
     "ebfi_laploss_partials": (_i64, [_i64, _i, _i, _i]),
     "ebfi_laploss_forward": (_i, [_vp, _vp, _vp, _c.c_float, _c.c_float, _vp, _vp, _i64, _i, _i, _i, _vp]),

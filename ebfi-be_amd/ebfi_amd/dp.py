@@ -77,7 +77,6 @@ def broadcast_parameters(module, src=0):
             off += t.numel()
 
 
-SEG_ELEMS = 16384          # elements per segment of the gather launch (one workgroup each)
 WIRE_PAD = 4               # floats behind the gradients in the wire buffer: [overflow flag, 0, 0, 0] (keeps 16-byte multiples)
 
 
@@ -85,13 +84,14 @@ class FlatGradBucket:
     """All trainable gradients of `module` in one contiguous buffer, built AFTER backward.
 
     Autograd hands every parameter a freshly written gradient tensor (the conv kernels already write
-    their own outputs), so the cheapest way to a flat buffer is ONE gather launch per step
-    (libebfi_hip.so `ebfi_grad_gather`: a table of (source pointer, destination offset, count) segments,
-    one workgroup per segment; 22.8 MB read + written once) instead of 255 in-place accumulations into
-    pre-assigned views plus a memset -- or a 255-piece torch.cat, whose batched copy kernel took three
-    launches and 90 us.  ``gather()`` packs, ``all_reduce_mean()`` averages over ranks with one
-    collective, and afterwards every ``param.grad`` is a view of the flat buffer, so optimisers see
-    ordinary ``.grad`` tensors.  ``zero()`` drops the gradients (set-to-None) for the next step.
+    their own outputs), so the cheapest way to a flat buffer is one gather per step (libebfi_hip.so
+    `ebfi_grad_gather`: the source pointers travel by value in the kernel arguments, 128 tensors per
+    launch, one workgroup per 16384-element chunk; 22.8 MB read + written once) instead of 255 in-place
+    accumulations into pre-assigned views plus a memset -- or a 255-piece torch.cat, whose batched copy
+    gives every input the same number of workgroups and took 90 us.  ``gather()`` packs,
+    ``all_reduce_mean()`` averages over ranks with one collective, and afterwards every ``param.grad``
+    is a view of the flat buffer, so optimisers see ordinary ``.grad`` tensors.  ``zero()`` drops the
+    gradients (set-to-None) for the next step.
 
     Wire format: ``wire`` = [numel gradients | flag | 3 zeros]; ``flat`` = wire[:numel].  ``flag`` is the
     overflow guard of the fp16 backward as a float (gather(guard=book.guard) writes guard[0] != 0 there),
@@ -110,22 +110,7 @@ class FlatGradBucket:
         for p in self.params:
             self._offsets.append(off)
             off += p.numel()
-        # segment table of the native gather: parameter index, element offset inside the parameter, destination, count
-        import numpy as np
-        seg_p, seg_o, seg_d, seg_n = [], [], [], []
-        for i, (p, off) in enumerate(zip(self.params, self._offsets)):
-            for o in range(0, p.numel(), SEG_ELEMS):
-                seg_p.append(i)
-                seg_o.append(o)
-                seg_d.append(off + o)
-                seg_n.append(min(SEG_ELEMS, p.numel() - o))
-        self._seg_param = np.asarray(seg_p, dtype=np.int64)
-        self._seg_byte = np.asarray(seg_o, dtype=np.int64) * 4
-        self._seg_dst = np.asarray(seg_d, dtype=np.int64)
-        self._seg_n = np.asarray(seg_n, dtype=np.int64)
-        self._ring, self._ring_pos = [], 0         # pinned host tables + the event of their last upload (eager launches)
-        self._dev_table = None
-        self._pending = []                         # (device table, host table) of gathers recorded inside a graph capture
+        self._numels = None                         # ctypes int64 array of the parameters' element counts (native gather)
 
     @property
     def flag(self):
@@ -141,21 +126,10 @@ class FlatGradBucket:
         self.wire = wire
         self.flat = wire[:self.numel]
 
-    def _host_table(self, grads):
-        import numpy as np
-        ptrs = np.fromiter((0 if g is None else g.data_ptr() for g in grads), dtype=np.int64, count=len(grads))
-        base = ptrs[self._seg_param]
-        tab = np.empty((len(self._seg_n), 3), dtype=np.int64)
-        tab[:, 0] = np.where(base != 0, base + self._seg_byte, 0)          # NULL source: the segment is zero-filled
-        tab[:, 1] = self._seg_dst
-        tab[:, 2] = self._seg_n
-        return tab
-
     def gather(self, guard=None):
         """Pack the per-parameter gradients (missing ones count as zero) into a fresh wire buffer and re-point .grad at it.
         `guard`: int32[2] device tensor of f16scale.ScaleBook (or a CPU tensor in the gloo tests): its flag rides along."""
-        first = self.params[0]
-        dev = first.device
+        dev = self.params[0].device
         grads = []
         for p in self.params:
             g = p.grad
@@ -171,50 +145,22 @@ class FlatGradBucket:
         else:
             if self.dtype != torch.float32:
                 raise NotImplementedError("the native gradient gather packs float32 gradients")
+            import ctypes
             from . import _native as N
+            n = len(self.params)
+            if self._numels is None:
+                self._numels = (ctypes.c_int64 * n)(*[p.numel() for p in self.params])
+            ptrs = (ctypes.c_void_p * n)(*[None if g is None else g.data_ptr() for g in grads])
             wire = torch.empty(self.numel + WIRE_PAD, dtype=self.dtype, device=dev)
-            host = torch.from_numpy(self._host_table(grads))
-            if torch.cuda.is_current_stream_capturing():
-                # the table's CONTENT is static for the life of the graph (its allocations keep their addresses): it is
-                # uploaded once after the capture (flush_pending) instead of by a copy node inside every replay
-                table = torch.empty(host.numel(), dtype=torch.int64, device=dev)
-                self._pending.append((table, host))
-            else:
-                table = self._upload(host, dev)
             with torch.cuda.device(dev):
-                rc = N.lib().ebfi_grad_gather(N.ptr(table), host.shape[0], N.ptr(wire), self.numel, WIRE_PAD,
-                                              N.ptr(guard), N.stream_ptr(dev))
+                rc = N.lib().ebfi_grad_gather(ptrs, self._numels, n, N.ptr(wire), self.numel, WIRE_PAD, N.ptr(guard), N.stream_ptr(dev))
             N.check(rc, "ebfi_grad_gather")
-            # (the sources may be freed right away: the caching allocator reuses memory in stream order only)
+            # (the sources may be freed right away: the caching allocator reuses memory in stream order only; inside a graph
+            # capture they are pool allocations whose addresses the captured launches keep)
             self.adopt(wire)
         for p, off in zip(self.params, self._offsets):
             p.grad = self.flat[off:off + p.numel()].view_as(p)
         return self.flat
-
-    def _upload(self, host, dev):
-        """Eager launches: the table goes through one of four pinned host buffers (a buffer is rewritten only after the
-        copy that last read it has run) into one device table."""
-        if self._dev_table is None:
-            self._dev_table = torch.empty(host.numel(), dtype=torch.int64, device=dev)
-            self._ring = [[torch.empty(host.numel(), dtype=torch.int64).pin_memory(), None] for _ in range(4)]
-        slot = self._ring[self._ring_pos]
-        self._ring_pos = (self._ring_pos + 1) % len(self._ring)
-        if slot[1] is not None:
-            slot[1].synchronize()
-        slot[0].copy_(host.reshape(-1))
-        self._dev_table.copy_(slot[0], non_blocking=True)
-        slot[1] = torch.cuda.Event()
-        slot[1].record(torch.cuda.current_stream(dev))
-        return self._dev_table
-
-    def flush_pending(self):
-        """After a graph capture: upload the segment tables of the gathers recorded inside it (before the first replay)."""
-        for table, host in self._pending:
-            table.copy_(host.reshape(-1))
-        if self._pending:
-            torch.cuda.synchronize(self._pending[0][0].device)
-        kept, self._pending = [t for t, _ in self._pending], []
-        return kept                                 # (the caller keeps them alive with the graph)
 
     def reduce_mean_packed(self):
         """Average the already packed wire buffer over ranks in place -- gradients AND the overflow flag in ONE collective

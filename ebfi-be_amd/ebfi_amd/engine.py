@@ -278,7 +278,6 @@ class Engine:
                     self.bucket.gather(guard)
                     wire = self.bucket.wire
             except RuntimeError as err:
-                self.bucket._pending.clear()
                 if saved is not None:
                     torch.cuda.synchronize(self.device)
                     guard.copy_(saved)
@@ -293,12 +292,11 @@ class Engine:
                 self.graph_capture_failed, self.graph_capture_error = True, str(err).splitlines()[0]
                 torch.cuda.synchronize(self.device)
                 return self.train_step(frame, event, t, gtex, target)
-            tables = self.bucket.flush_pending()           # segment tables of the captured gather launch (static content)
             if saved is not None:
                 guard.copy_(saved)
-            entry = (graph, static_in, loss, wire, [p.grad for p in self.bucket.params], tables)
+            entry = (graph, static_in, loss, wire, [p.grad for p in self.bucket.params])
             self._graphs[key] = entry
-        graph, static_in, loss, wire, grads, _tables = entry
+        graph, static_in, loss, wire, grads = entry
         self._begin_micro_step()
         for s, v in zip(static_in, inputs):
             if s.data_ptr() != v.data_ptr():

@@ -176,18 +176,17 @@ class KernelConvFacTrain(Function):
                                                    W, site.M, 3, 1, 1, 1, float(slope), N.ptr(None), N.ptr(None), 0, 0.0, N.ptr(filt16),
                                                    sp("f"), 1, st)
                 N.check(rc, "ebfi_conv2d_packed_x3_c16 (planar fp16 filters)")
-            r = ksize // 2
-            evp = torch.nn.functional.pad(ev, (r, r, r, r), mode="replicate")
+            # (the replicate padding of KernelConv2D.py:82-86 happens inside the kernels: clamped reads of `ev`, no padded copy)
             out = torch.empty_like(ev)
-            N.check(lib.ebfi_fac_forward_p16(N.ptr(evp), N.ptr(filt16), sp("f"), N.ptr(out), B, C, H, W, int(ksize), st), "ebfi_fac_forward_p16")
+            N.check(lib.ebfi_fac_forward_p16(N.ptr(ev), 1, N.ptr(filt16), sp("f"), N.ptr(out), B, C, H, W, int(ksize), st), "ebfi_fac_forward_p16")
         ctx.site, ctx.cfg = site, (float(slope), int(ksize), B, Cin, C, H, W)
-        ctx.save_for_backward(cat16, evp, filt16)
+        ctx.save_for_backward(cat16, ev, filt16)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         from . import f16scale
-        cat16, evp, filt16 = ctx.saved_tensors
+        cat16, ev, filt16 = ctx.saved_tensors
         site, (slope, ksize, B, Cin, C, H, W) = ctx.site, ctx.cfg
         book = f16scale.active_book()
         if book is None:
@@ -199,13 +198,11 @@ class KernelConvFacTrain(Function):
         dev = gout.device
         with torch.cuda.device_of(gout):
             st = N.stream_ptr(dev)
-            gevp = torch.empty_like(evp)
+            # grad wrt `ev` directly: the adjoint of the replicate padding is folded inside the kernel, in a fixed order
+            gev = torch.empty_like(ev) if ctx.needs_input_grad[1] else None
             gk16 = torch.empty_like(filt16)
-            N.check(lib.ebfi_fac_backward_p16(N.ptr(evp), N.ptr(filt16), sp("f"), N.ptr(gout), N.ptr(gevp), N.ptr(gk16), sp("g"), slope,
+            N.check(lib.ebfi_fac_backward_p16(N.ptr(ev), 1, N.ptr(filt16), sp("f"), N.ptr(gout), N.ptr(gev), N.ptr(gk16), sp("g"), slope,
                                               B, C, H, W, ksize, st), "ebfi_fac_backward_p16")
-            r = ksize // 2
-            # (adjoint of the replicate padding; `gout` only lends its shape [B, C, H, W])
-            gev = torch.ops.aten.replication_pad2d_backward(gevp, gout, [r, r, r, r]) if ctx.needs_input_grad[1] else None
             gw = torch.empty((site.M, Cin, 3, 3), dtype=torch.float32, device=dev)
             gb = torch.empty(site.M, dtype=torch.float32, device=dev)
             need = int(lib.ebfi_conv2d_backward_weight_workspace(B, Cin, H, W, site.M, 3, 1, 1, N.EBFI_F32))

@@ -148,3 +148,31 @@ def ed_head(ev, bl, gn):
             ev.shape[1] == gn.num_channels and not torch.is_autocast_enabled() and N.dev_env("EBFI_NO_EDHEAD") is None):
         return None
     return _EDHead.apply(ev, bl, gn.weight, gn.bias, gn.num_groups, gn.eps)
+
+
+class _ReflectPad2d(torch.autograd.Function):
+    """nn.ReflectionPad2d(p) whose BACKWARD is a gather in a fixed order (csrc/imgops.hip reflect_pad_bwd): torch's own
+    backward of the pad scatters with atomic adds, which made two runs of the same training step differ in the last bit (and,
+    amplified by the L1 / census kinks over a few optimiser steps, by percent in the smallest parameters)."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        ctx.p, ctx.shape = int(p), tuple(x.shape)
+        return torch.nn.functional.pad(x, (p, p, p, p), mode="reflect")
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W = ctx.shape
+        g = g.contiguous()
+        out = torch.empty(ctx.shape, dtype=g.dtype, device=g.device)
+        with torch.cuda.device_of(g):
+            rc = N.lib().ebfi_reflect_pad2d_backward(N.ptr(g), N.ptr(out), B * C, H, W, ctx.p, N.stream_ptr(g.device))
+        N.check(rc, "ebfi_reflect_pad2d_backward")
+        return out, None
+
+
+def reflect_pad2d(x, p):
+    """ReflectionPad2d(p) with the deterministic native adjoint on GPU fp32 tensors; plain F.pad otherwise."""
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and p < x.shape[-1] and p < x.shape[-2]:
+        return _ReflectPad2d.apply(x, p)
+    return torch.nn.functional.pad(x, (p, p, p, p), mode="reflect")

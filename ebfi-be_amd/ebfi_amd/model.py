@@ -418,7 +418,13 @@ class UNet3d_18(nn.Module):
         if isinstance(self.feature_fuse[1], identity) and conv.supported(y, ff.weight, ff.stride, ff.padding) and \
                 not torch.is_autocast_enabled():
             y = conv.conv_bias_act(y, ff.weight, None, 1, 0, conv.ACT_LEAKY, 0.2)  # 1x1 fuse + LeakyReLU(0.2)
-            return conv.conv_bias_act(self.outconv[0](y), oc.weight, oc.bias, 1, 0, conv.ACT_NONE, 0.0)
+            pad = self.outconv[0].padding
+            if isinstance(self.outconv[0], nn.ReflectionPad2d) and len(set(pad)) == 1:
+                from . import fused
+                yp = fused.reflect_pad2d(y, int(pad[0]))            # (deterministic adjoint: no atomics in the step's backward)
+            else:
+                yp = self.outconv[0](y)
+            return conv.conv_bias_act(yp, oc.weight, oc.bias, 1, 0, conv.ACT_NONE, 0.0)
         return self.outconv(self.lrelu(self.feature_fuse(y)))
 
 

@@ -329,11 +329,15 @@ int ebfi_conv2d_backward_weight_f16c_batch(int n, const void *const *input16, co
  * backward read them and the backward writes grad_kernel (times the LeakyReLU derivative) likewise; the weight / data
  * gradient of the convolution stage the planes (ebfi_conv2d_backward_weight_f16c grad_is_planar, ebfi_conv2d_packed_f16_c16
  * input_is_c16 = 2).  No fp32 [B, 1600, h, w] tensor is written or read. */
-int ebfi_fac_forward_p16(const float *input_pad, const void *filters16, const void *f_slot, float *output, int B, int C, int Ho,
-                         int Wo, int K, void *stream);
-int ebfi_fac_backward_p16(const float *input_pad, const void *filters16, const void *f_slot, const float *grad_output,
-                          float *grad_input_pad, void *grad_kernel16, void *g_slot, float kernel_leaky_slope, int B, int C,
-                          int Ho, int Wo, int K, void *stream);
+/* input_is_unpadded (round 5): `input` (and grad_input) are the UNPADDED [B, C, Ho, Wo] tensors and the replicate padding of
+ * KernelConv2D.py:82-86 (nn.ReplicationPad2d(K / 2)) is applied inside the kernels -- clamped reads in the forward; in the
+ * backward clamped reads plus the padding's ADJOINT folded into grad_input with a fixed summation order (no atomics: torch's
+ * replication_pad2d_backward adds atomically).  0: `input` is the padded [B, C, Ho+K-1, Wo+K-1] tensor as before. */
+int ebfi_fac_forward_p16(const float *input, int input_is_unpadded, const void *filters16, const void *f_slot, float *output, int B,
+                         int C, int Ho, int Wo, int K, void *stream);
+int ebfi_fac_backward_p16(const float *input, int input_is_unpadded, const void *filters16, const void *f_slot,
+                          const float *grad_output, float *grad_input, void *grad_kernel16, void *g_slot, float kernel_leaky_slope,
+                          int B, int C, int Ho, int Wo, int K, void *stream);
 int ebfi_scale_residual_cat_forward_c16(const float *a0, const float *s0, const float *a1, const float *s1, const float *x,
                                         float *out, void *out16, void *slot, int B, int C, int H, int W,
                                         int64_t a_batch_stride, void *stream);
@@ -477,6 +481,11 @@ int ebfi_laploss_forward(const float *pred_a, const float *pred_b, const float *
 int ebfi_laploss_backward(const float *grad_loss, float *workspace, float *grad_pred, int64_t planes, int H, int W,
                           int levels, void *stream);
 
+/* Adjoint of nn.ReflectionPad2d(pad) (the detail branch's output conv: ReflectionPad2d(3) + 7x7 convolution,
+ * models/Ours/model_singleframe.py:207): grad_padded [planes, H+2*pad, W+2*pad] -> grad_input [planes, H, W] as a gather in a
+ * fixed order (bit-reproducible; torch's backward of the pad accumulates with atomics).  pad < H, W. */
+int ebfi_reflect_pad2d_backward(const float *grad_padded, float *grad_input, int64_t planes, int H, int W, int pad, void *stream);
+
 /* Adam update (torch.optim.Adam of train_ours.py:276-277, amsgrad / weight decay off as in config/train_ours.yml:59-65)
  * over one flat fp32 buffer of n elements, in place: exp_avg <- exp_avg + (1-beta1)(grad - exp_avg);
  * exp_avg_sq <- beta2 exp_avg_sq + (1-beta2) grad^2; param <- param - lr/(1-beta1^t) * exp_avg / (sqrt(exp_avg_sq)/sqrt(1-beta2^t) + eps)
@@ -493,10 +502,13 @@ int ebfi_adam_step_guarded(float *param, const float *grad, float *exp_avg, floa
                            double lr, double beta1, double beta2, double eps, int *guard, const float *flag, void *stream);
 
 /* Gradient packing of a training step (replaces the bucket copy of DistributedDataParallel, train_ours.py:754, and the
- * 255-piece concatenation of earlier rounds): `table` = nseg device records {const float *src; int64 dst; int64 n} -- copy n
- * (<= 16384) floats from src (NULL: write zeros) to flat[dst ...]; then flat[numel] = (guard && guard[0] != 0) ? 1 : 0 and
- * flat[numel + 1 .. numel + pad - 1] = 0 (1 <= pad <= 256: the wire buffer's trailer).  One workgroup per record. */
-int ebfi_grad_gather(const void *table, int nseg, float *flat, int64_t numel, int pad, const int *guard, void *stream);
+ * 255-piece concatenation of earlier rounds): `grads` / `numels` are HOST arrays of `count` device pointers (NULL: that
+ * parameter has no gradient, its range is zero-filled) and element counts (sum = total); tensor k is copied to
+ * flat[sum of numels[0..k-1] ...].  Then flat[total] = (guard && guard[0] != 0) ? 1 : 0 and flat[total + 1 .. total + pad - 1]
+ * = 0 (1 <= pad <= 256: the wire buffer's trailer).  The pointers travel by value in the kernel arguments, 128 per launch:
+ * a captured launch replays with the addresses the capture saw (graph-pool allocations keep them). */
+int ebfi_grad_gather(const void *const *grads, const int64_t *numels, int count, float *flat, int64_t total, int pad,
+                     const int *guard, void *stream);
 
 
 /* ------------------------------------------------------------------ per-kernel device timing

@@ -311,15 +311,42 @@ def test_fac_on_fp16_filter_planes(B, C, H, W):
     fq = f16.float() / book.scale(sf)                      # what the kernels see
     lib, st = N.lib(), N.stream_ptr(xp.device)
     out = torch.empty(B, C, H, W, device="cuda")
-    N.check(lib.ebfi_fac_forward_p16(N.ptr(xp), N.ptr(f16), book.ptr(sf), N.ptr(out), B, C, H, W, K, st), "fac_forward_p16")
+    N.check(lib.ebfi_fac_forward_p16(N.ptr(xp), 0, N.ptr(f16), book.ptr(sf), N.ptr(out), B, C, H, W, K, st), "fac_forward_p16")
     assert torch.equal(out, fac_forward(xp, fq, K))
     gin = torch.empty_like(xp)
     gk16 = torch.empty(B, C * K * K, H, W, dtype=torch.float16, device="cuda")
-    N.check(lib.ebfi_fac_backward_p16(N.ptr(xp), N.ptr(f16), book.ptr(sf), N.ptr(go), N.ptr(gin), N.ptr(gk16), book.ptr(sg), 0.01,
+    N.check(lib.ebfi_fac_backward_p16(N.ptr(xp), 0, N.ptr(f16), book.ptr(sf), N.ptr(go), N.ptr(gin), N.ptr(gk16), book.ptr(sg), 0.01,
                                       B, C, H, W, K, st), "fac_backward_p16")
     rin, rk = fac_backward(xp, fq, K, go, kernel_leaky_slope=0.01)
     assert torch.equal(gin, rin)
     assert torch.equal(gk16, _p16(rk, 256.0)) and book.amax(sg) == rk.abs().max().item()
+    # ---- the replicate padding INSIDE the kernels (round 5): the unpadded tensor in, the gradient of the unpadded tensor out
+    ev = torch.randn(B, C, H, W).cuda()
+    evp = torch.nn.functional.pad(ev, (2, 2, 2, 2), mode="replicate")
+    ref_out, out_u = torch.empty_like(out), torch.empty_like(out)
+    N.check(lib.ebfi_fac_forward_p16(N.ptr(evp), 0, N.ptr(f16), book.ptr(sf), N.ptr(ref_out), B, C, H, W, K, st), "padded")
+    N.check(lib.ebfi_fac_forward_p16(N.ptr(ev), 1, N.ptr(f16), book.ptr(sf), N.ptr(out_u), B, C, H, W, K, st), "unpadded")
+    assert torch.equal(out_u, ref_out)
+    gp, gk_p = torch.empty_like(evp), torch.empty_like(gk16)
+    N.check(lib.ebfi_fac_backward_p16(N.ptr(evp), 0, N.ptr(f16), book.ptr(sf), N.ptr(go), N.ptr(gp), N.ptr(gk_p), book.ptr(sg), 0.01,
+                                      B, C, H, W, K, st), "padded bwd")
+    gu, gk_u = torch.full_like(ev, float("nan")), torch.empty_like(gk16)
+    N.check(lib.ebfi_fac_backward_p16(N.ptr(ev), 1, N.ptr(f16), book.ptr(sf), N.ptr(go), N.ptr(gu), N.ptr(gk_u), book.ptr(sg), 0.01,
+                                      B, C, H, W, K, st), "unpadded bwd")
+    assert torch.equal(gk_u, gk_p)
+    # the padding's adjoint in float64 from the padded gradient: interior elements are copies, border elements sums of <= 9 terms
+    ref_g = torch.zeros(B, C, H, W, dtype=torch.float64, device="cuda")
+    yy = torch.arange(H + 4, device="cuda").sub(2).clamp(0, H - 1)
+    xx = torch.arange(W + 4, device="cuda").sub(2).clamp(0, W - 1)
+    ref_g.index_put_((slice(None), slice(None), yy[:, None].expand(H + 4, W + 4), xx[None, :].expand(H + 4, W + 4)), gp.double(),
+                     accumulate=True)
+    assert torch.isfinite(gu).all()
+    assert torch.equal(gu[:, :, 1:-1, 1:-1], gp[:, :, 3:-3, 3:-3])
+    assert ((gu.double() - ref_g).abs().max() / ref_g.abs().max()).item() < 1e-6
+    gu2 = torch.empty_like(ev)                          # fixed summation order: bit-identical from run to run
+    N.check(lib.ebfi_fac_backward_p16(N.ptr(ev), 1, N.ptr(f16), book.ptr(sf), N.ptr(go), N.ptr(gu2), N.ptr(gk_u), book.ptr(sg), 0.01,
+                                      B, C, H, W, K, st), "unpadded bwd again")
+    assert torch.equal(gu, gu2)
 
 
 @pytest.mark.parametrize("B,Cin,H,W,Cout", [(2, 128, 16, 64, 200), (1, 64, 13, 36, 64)])
