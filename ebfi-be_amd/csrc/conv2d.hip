@@ -62,6 +62,16 @@ struct EpiExtra {
     // weight gradients): half the bytes of the fp32 tensor.  (A positive value below the fp16 denormal range of its scale
     // reads as 0 and takes the slope: 1e-8 of the tensor's |max|.)
     const _Float16 *mask16 = nullptr;
+    // round 5 (XM bit 2): the tail of a ResidualControl round folded into the epilogue of its grouped second-layer convolution
+    // (model_singleframe.py:130-133): with a = act(acc + bias) the kernel writes out = a * post_scale[b][co] +
+    // post_res[b][co % post_resC][pixel] (the exposure- / time-scaled residual: `cat(s_ex * a0 + x, s_t * a1 + x)`), out16 = the
+    // image of THAT, and pre16 = the image of `a` itself (scaled by pre_slot[0], |max| recorded there): what the fused backward
+    // stage reads for the scale gradients and the LeakyReLU mask.  No fp32 `a`, no separate scale / residual / concat launch.
+    const float *post_scale = nullptr;
+    const float *post_res = nullptr;
+    int post_resC = 0;
+    _Float16 *pre16 = nullptr;
+    float *pre_slot = nullptr;
 };
 
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
@@ -115,12 +125,12 @@ template <int MT, int XM = 0>
 __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const float *__restrict__ bias, const f32x16 (&acc)[MT][2],
                                                const ConvGeom &g, int b, int co_base, int yo, int x0, int lane, int act,
                                                float slope, EpiExtra ex = EpiExtra{nullptr, nullptr, 0, 0.f}, float oscale = 1.f,
-                                               float *amax16 = nullptr) {
+                                               float *amax16 = nullptr, float *amax_pre = nullptr) {
     // oscale: the accumulators are oscale-times too small (operands were scaled by powers of two: conv2d_f16.inc.hpp); 1 otherwise
     // amax16 (with ex.out16): running |max| of what this wave wrote into the fp16 image (recorded by the caller at the end)
     const int HWo = g.Ho * g.Wo;
     const unsigned plane = (unsigned)HWo * 4u;
-    constexpr bool EXTRA = XM != 0, XAM = (XM & 1) != 0, X16 = (XM & 2) != 0;
+    constexpr bool EXTRA = XM != 0, XAM = (XM & 1) != 0, X16 = (XM & 2) != 0, XRC = (XM & 4) != 0;
     if constexpr (EXTRA) {
         // Everything below is derived from `lane` and loop-invariant over the caller's tile walk: left alone, the compiler
         // computes the per-lane offsets and descriptors once at kernel start, keeps them live across the MFMA main loop (where
@@ -148,7 +158,17 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
               : const_cast<_Float16 *>(reinterpret_cast<const _Float16 *>(anyp)), 0,
         has16 ? (planar ? (unsigned)g.Cout * (unsigned)HWo * 2u : (unsigned)cb16 * (unsigned)HWo * 32u) : 0u, 0x00020000);
     const float s16 = has16 ? ex.slot16[0] : 1.f;
-    float am = 0.f;
+    // XRC: post-activation scale + residual, image of the activation output (see EpiExtra)
+    const bool has_rc = XRC && ex.post_scale != nullptr;
+    const __amdgpu_buffer_rsrc_t rps = make_rsrc(has_rc ? ex.post_scale + (int64_t)b * g.Cout : anyp, has_rc ? (unsigned)g.Cout * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rrs = make_rsrc(has_rc ? ex.post_res + (int64_t)b * ex.post_resC * HWo : anyp,
+                                                 has_rc ? (unsigned)ex.post_resC * plane : 0u);
+    const __amdgpu_buffer_rsrc_t rp16 = __builtin_amdgcn_make_buffer_rsrc(
+        has_rc ? ex.pre16 + (int64_t)b * cb16 * HWo * 16 : const_cast<_Float16 *>(reinterpret_cast<const _Float16 *>(anyp)), 0,
+        has_rc ? (unsigned)cb16 * (unsigned)HWo * 32u : 0u, 0x00020000);
+    const float sp16 = has_rc ? ex.pre_slot[0] : 1.f;
+    const int res_shift = has_rc ? co_base - co_base % ex.post_resC : 0;       // (channel blocks never straddle post_resC: both multiples of 64)
+    float am = 0.f, amp = 0.f;
     const int h = lane >> 5, l31 = lane & 31;
     auto emit = [&](auto actf) {
 #pragma unroll
@@ -215,6 +235,28 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
                                 }
                             }
                         }
+                        if constexpr (XRC) {
+                            if (has_rc) {
+                                const int cblk = ((co_base + m * 32) >> 4) + j;
+                                const unsigned o16 = (px_ok && cblk < cb16)
+                                                         ? ((unsigned)cblk * (unsigned)HWo * 2u + (unsigned)((yo * 2 + h) * g.Wo + xo)) * 16u : SENT;
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) amp = amax_acc(amp, u[i]);
+                                const u32x4_c16 q = c16_gather_halves(pack_f16(u[0] * sp16, u[1] * sp16), pack_f16(u[2] * sp16, u[3] * sp16),
+                                                                      pack_f16(u[4] * sp16, u[5] * sp16), pack_f16(u[6] * sp16, u[7] * sp16));
+                                __builtin_amdgcn_raw_buffer_store_b128(q, rp16, o16, 0, 0);
+                                float t[8];
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) t[i] = buf_ld(rps, (unsigned)(co_base + m * 32 + 4 * h) * 4u + row_off(i) * 4u);
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) u[i] *= t[i];
+                                const unsigned rbase = base == SENT ? SENT : base - (unsigned)res_shift * plane;
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) t[i] = buf_ld(rrs, rbase + row_off(i) * plane);
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) u[i] += t[i];
+                            }
+                        }
                         if (has32) {
 #pragma unroll
                             for (int i = 0; i < 8; ++i) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(u[i]), ro, base + row_off(i) * plane, 0, 0);
@@ -268,6 +310,9 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
         else emit([](float v) { return v; });
     }
     if (amax16) *amax16 = amax_acc(*amax16, am);
+    if constexpr (XRC) {
+        if (amax_pre) *amax_pre = amax_acc(*amax_pre, amp);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2446,7 +2491,7 @@ __global__ __launch_bounds__(NTWS) void conv_fwd_bf16x3_ws(const float *__restri
         for (int tap = 0; tap < KK; ++tap)
             fbits |= (unsigned)((((pbase + (tap / KS) * IW + (tap % KS)) >> 3) & 1) ^ hsel) << tap;
         bf16x8 ah[2][MT], al[2][MT], bh[2][2], bl[2][2];
-        [[maybe_unused]] float amax16 = 0.f;
+        [[maybe_unused]] float amax16 = 0.f, amax_pre = 0.f;
         if constexpr (EXTRA) saturate_fp16_conversions();       // (the fp16 side image of the epilogue: MODE.FP16_OVFL, see c16.hpp)
         auto tap_read = [&](const char *base, int tap, int set) {
             const int ky = tap / KS, kx = tap - ky * KS;
@@ -2502,7 +2547,7 @@ __global__ __launch_bounds__(NTWS) void conv_fwd_bf16x3_ws(const float *__restri
             int cb_, cy0, cx0;
             tile_coords(tcur, cb_, cy0, cx0);
             if constexpr (FAC) fac_epilogue_tile<MT>(out, bias, acc, g, fac, cb_, co_base, cy0 + wave, cx0, lane, slope);
-            else store_out_tile<MT, XM>(out, bias, acc, g, cb_, co_base, cy0 + wave, cx0, lane, act, slope, epi, 1.f, &amax16);
+            else store_out_tile<MT, XM>(out, bias, acc, g, cb_, co_base, cy0 + wave, cx0, lane, act, slope, epi, 1.f, &amax16, &amax_pre);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -2512,6 +2557,9 @@ __global__ __launch_bounds__(NTWS) void conv_fwd_bf16x3_ws(const float *__restri
         }
         if constexpr (EXTRA) {
             if (epi.out16 != nullptr) ScaleSlot{epi.slot16}.record(amax16);      // |max| of the fp16 side image this wave wrote
+            if constexpr ((XM & 4) != 0) {
+                if (epi.pre16 != nullptr) ScaleSlot{epi.pre_slot}.record(amax_pre);
+            }
         }
         return;
     }
@@ -2670,7 +2718,7 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
         // 16-byte input quads: rows must keep quads aligned, same-padding only; used where they pay (see the kernel's header)
         const bool vec4 = g.W % 4 == 0 && g.pad == KS / 2 && aligned16(x) && (!dact_y || aligned16(dact_y));
         const char *ws_env = dev_getenv("EBFI_CONV_WS");
-        const bool extra = epi.addend != nullptr || epi.mask_y != nullptr || epi.out16 != nullptr;
+        const bool extra = epi.addend != nullptr || epi.mask_y != nullptr || epi.out16 != nullptr || epi.post_scale != nullptr;
         // wave-specialised form (conv_fwd_bf16x3_ws): every 3x3 layer the quad-staging producers can serve (64-channel blocks, no
         // folded activation derivative); EBFI_CONV_WS=0 / 1 = never / only the long layers (development switch, A/B runs)
         const bool ws_long = ceil_div(g.Cout, 64) >= 8 || K16 >= 512;
@@ -2680,7 +2728,10 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
         if (epi.out16 != nullptr && !use_ws)
             return fail(EBFI_ERR_UNSUPPORTED, "conv2d: the fp16 side image is written by the wave-specialised 3x3 kernel only "
                         "(W %% 4 == 0, same padding, more than 32 output channels, 16-byte aligned input)");
-        if (use_ws) name = transposed ? "conv_fwd_bf16x3_ws/dgrad" : (epi.out16 ? "conv_fwd_bf16x3_ws/fwd_img" : "conv_fwd_bf16x3_ws/fwd");
+        if (epi.post_scale != nullptr && !use_ws)
+            return fail(EBFI_ERR_UNSUPPORTED, "conv2d: the ResidualControl epilogue is written by the wave-specialised 3x3 kernel only");
+        if (use_ws) name = transposed ? "conv_fwd_bf16x3_ws/dgrad" : (epi.post_scale ? "conv_fwd_bf16x3_ws/fwd_rc" :
+                                                                      (epi.out16 ? "conv_fwd_bf16x3_ws/fwd_img" : "conv_fwd_bf16x3_ws/fwd"));
         ProfScope ps(name, st, flops, conv_bytes_fwd(g, KS * KS, dact != 0));
 #define EBFI_LAUNCH_X3V(MT_, DA_, VEC_)                                                                                   \
     do {                                                                                                                 \
@@ -2714,7 +2765,11 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
                            (int)tiles, FacEpi{nullptr, 0});                                                               \
     } while (0)
                 const bool xam = epi.addend != nullptr || epi.mask_y != nullptr, x16 = epi.out16 != nullptr;
-                if (xam && x16) EBFI_LAUNCH_X3WS(3);
+                if (epi.post_scale != nullptr) {
+                    if (xam || !x16) return fail(EBFI_ERR_UNSUPPORTED, "conv2d: the ResidualControl epilogue comes with the output image and without addend / mask");
+                    EBFI_LAUNCH_X3WS(6);
+                }
+                else if (xam && x16) EBFI_LAUNCH_X3WS(3);
                 else if (x16) EBFI_LAUNCH_X3WS(2);
                 else if (xam) EBFI_LAUNCH_X3WS(1);
                 else EBFI_LAUNCH_X3WS(0);
@@ -3392,6 +3447,36 @@ extern "C" int ebfi_conv2d_packed_x3_c16(const void *input, const void *packed, 
     void *ws = const_cast<void *>(packed);
     if (ksize == 3) return launch_fwd_bf16<3>(st, x, nullptr, nullptr, bs, o, g, 0, act, slope, 0, 0.f, ws, packed_bytes, 1, epi);
     return launch_fwd_bf16<1>(st, x, nullptr, nullptr, bs, o, g, 0, act, slope, 0, 0.f, ws, packed_bytes, 1, epi);
+}
+
+// The grouped second-layer convolution of a ResidualControl round with the round's tail in its epilogue (EpiExtra, XM bit 2;
+// reference model_singleframe.py:127-133): a = LeakyReLU(conv3x3(input) + bias); pre16 = image(a); output = a * post_scale[b, co]
+// + post_res[b, co % res_channels]; out16 = image(output).  3x3, same padding, 64-channel blocks, W % 4 == 0.
+extern "C" int ebfi_conv2d_packed_x3_rc(const void *input, const void *packed, size_t packed_bytes, const void *bias, void *output,
+                                        int B, int Cin_per_group, int H, int W, int Cout, int groups, float slope,
+                                        const void *post_scale, const void *post_res, int res_channels, void *pre16, void *pre_slot,
+                                        void *out16, void *slot16, void *stream) {
+    if (!input || !packed || !post_scale || !post_res || !pre16 || !pre_slot || !out16 || !slot16)
+        return fail(EBFI_ERR_ARG, "conv2d_packed_x3_rc: null argument");
+    if (groups < 1 || Cout % groups != 0 || (Cout / groups) % 64 != 0 || res_channels < 64 || res_channels % 64 != 0 || Cout % res_channels != 0)
+        return fail(EBFI_ERR_ARG, "conv2d_packed_x3_rc: %d output channels in %d groups, residual of %d channels (multiples of 64)", Cout,
+                    groups, res_channels);
+    if (!aligned16(pre16) || !aligned16(out16)) return fail(EBFI_ERR_ARG, "conv2d_packed_x3_rc: 16-byte aligned images");
+    ConvGeom g;
+    if (int rc = make_geom(g, B, Cin_per_group, H, W, Cout, 3, 1, 1)) return rc;
+    if ((int64_t)groups * (Cin_per_group + 64) * H * W * 4 >= (1LL << 31) - (1LL << 26))
+        return fail(EBFI_ERR_ARG, "conv2d_packed_x3_rc: one sample exceeds the 2 GiB reach of 32-bit buffer offsets");
+    g.groups = groups;
+    if (B == 0) return EBFI_OK;
+    EpiExtra epi{nullptr, nullptr, 0, 0.f, static_cast<_Float16 *>(out16), static_cast<float *>(slot16), 0};
+    epi.post_scale = static_cast<const float *>(post_scale);
+    epi.post_res = static_cast<const float *>(post_res);
+    epi.post_resC = res_channels;
+    epi.pre16 = static_cast<_Float16 *>(pre16);
+    epi.pre_slot = static_cast<float *>(pre_slot);
+    return launch_fwd_bf16<3>(static_cast<hipStream_t>(stream), static_cast<const float *>(input), nullptr, nullptr,
+                              static_cast<const float *>(bias), static_cast<float *>(output), g, 0, ACT_LEAKY, slope, 0, 0.f,
+                              const_cast<void *>(packed), packed_bytes, 1, epi);
 }
 
 // KernelConv (3x3, Cin -> C*25 filters, LeakyReLU) fused with the FAC that consumes the filters: see fac_epilogue_tile.

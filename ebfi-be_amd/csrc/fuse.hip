@@ -225,12 +225,16 @@ __global__ __launch_bounds__(256) void src_fwd_c16_kernel(const float *__restric
 // channels instead of two fp32 tensors.  A workgroup owns 8 channels of one sample and one of `nslice` pixel slices; the
 // per-channel sums of grad*a (the gradients of the scales) leave as per-slice partials [nslice][B][C], summed in slice order by
 // the caller (fixed order: deterministic).
+// A16 (round 5): a0 is NOT an fp32 plane tensor but the c16 image of [a0 | a1] (2C channels, scaled by a_slot[0]) the forward
+// convolution's epilogue wrote (EpiExtra::pre16): four 16-byte pieces per thread and quad instead of eight 16-byte plane loads,
+// half the bytes, and the forward keeps no fp32 `a` at all.  The scale gradients see `a` rounded to fp16 (2^-11 per element).
+template <bool A16>
 __global__ __launch_bounds__(256) void src_bwd_c16_kernel(const float *__restrict__ gout, const float *__restrict__ a0,
                                                           const float *__restrict__ s0, const float *__restrict__ a1,
                                                           const float *__restrict__ s1, _Float16 *__restrict__ ga16,
                                                           float *__restrict__ slot, float *__restrict__ gx, float *__restrict__ gs0p,
                                                           float *__restrict__ gs1p, int B, int C, int64_t HW4, int W4, int64_t a_bs4,
-                                                          int nslice, float mask_slope) {
+                                                          int nslice, float mask_slope, const float *__restrict__ a_slot = nullptr) {
     saturate_fp16_conversions();
     __shared__ float red[4][16];
     const int G8 = C / 8;
@@ -252,27 +256,48 @@ __global__ __launch_bounds__(256) void src_bwd_c16_kernel(const float *__restric
     const f4 *g1 = reinterpret_cast<const f4 *>(gout) + ((int64_t)b * 2 * C + C + c) * HW4;
     const f4 *p0 = reinterpret_cast<const f4 *>(a0) + (int64_t)b * a_bs4 + (int64_t)c * HW4;
     const f4 *p1 = reinterpret_cast<const f4 *>(a1) + (int64_t)b * a_bs4 + (int64_t)c * HW4;
+    [[maybe_unused]] const _Float16 *img = reinterpret_cast<const _Float16 *>(a0);
+    [[maybe_unused]] const float ainv = A16 ? 1.f / a_slot[0] : 1.f;
+    // the four pieces (pixel j, 8 channels) of a quad -> per channel e the quad's four pixels, de-scaled
+    auto quad_from_image = [&](int64_t piece0, f4 (&v)[8]) {
+        u4 pc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pc[j] = *reinterpret_cast<const u4 *>(img + (piece0 + j) * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned wd = pc[j][e >> 1];
+                const _Float16 hv = __builtin_bit_cast(_Float16, (unsigned short)((e & 1) ? (wd >> 16) : (wd & 0xffffu)));
+                v[e][j] = (float)hv * ainv;
+            }
+        }
+    };
     f4 *ox = reinterpret_cast<f4 *>(gx) + ((int64_t)b * C + c) * HW4;
     for (int64_t q = q0 + threadIdx.x; q < q1; q += 256) {
-        f4 u0[8], u1[8], w[8];
+        f4 u0[8], u1[8], w[8], va[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) u0[e] = g0[e * HW4 + q], u1[e] = g1[e * HW4 + q];
 #pragma unroll
         for (int e = 0; e < 8; ++e) ox[e * HW4 + q] = u0[e] + u1[e];
+        const int64_t pc0 = c16_piece(b, 2 * C / 16, cg / 2, HW4, q, W4, cg & 1);
+        const int64_t pc1 = c16_piece(b, 2 * C / 16, (C + c) / 16, HW4, q, W4, ((C + c) >> 3) & 1);
+        if constexpr (A16) quad_from_image(pc0, va);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const f4 v = p0[e * HW4 + q];
+            const f4 v = A16 ? va[e] : p0[e * HW4 + q];
             d0[e] += (u0[e].x * v.x + u0[e].y * v.y) + (u0[e].z * v.z + u0[e].w * v.w);
             w[e] = u0[e] * k0[e] * dm(v);
         }
-        c16_store_quad(ga16, c16_piece(b, 2 * C / 16, cg / 2, HW4, q, W4, cg & 1), w, sc, amax);
+        c16_store_quad(ga16, pc0, w, sc, amax);
+        if constexpr (A16) quad_from_image(pc1, va);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const f4 v = p1[e * HW4 + q];
+            const f4 v = A16 ? va[e] : p1[e * HW4 + q];
             d1[e] += (u1[e].x * v.x + u1[e].y * v.y) + (u1[e].z * v.z + u1[e].w * v.w);
             w[e] = u1[e] * k1[e] * dm(v);
         }
-        c16_store_quad(ga16, c16_piece(b, 2 * C / 16, (C + c) / 16, HW4, q, W4, ((C + c) >> 3) & 1), w, sc, amax);
+        c16_store_quad(ga16, pc1, w, sc, amax);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e)
@@ -428,9 +453,34 @@ extern "C" int ebfi_scale_residual_cat_backward_c16(const float *grad_out, const
     const int nslice = ebfi_scale_residual_cat_backward_slices();
     {
         ProfScope ps("scale_residual_cat_bwd", st, 0.0, 24.0 * B * C * (double)HW);
-        hipLaunchKernelGGL(src_bwd_c16_kernel, dim3((unsigned)(B * (C / 8) * nslice)), dim3(256), 0, st, grad_out, a0, s0, a1, s1,
+        hipLaunchKernelGGL(src_bwd_c16_kernel<false>, dim3((unsigned)(B * (C / 8) * nslice)), dim3(256), 0, st, grad_out, a0, s0, a1, s1,
                            static_cast<_Float16 *>(grad_a16), static_cast<float *>(slot), grad_x, grad_s0_part, grad_s1_part, B, C,
-                           HW / 4, W / 4, a_batch_stride / 4, nslice, mask_slope);
+                           HW / 4, W / 4, a_batch_stride / 4, nslice, mask_slope, nullptr);
+    }
+    return check_launch("scale_residual_cat_bwd");
+}
+
+// The same stage with `a` given as the c16 IMAGE of [a0 | a1] (2C channels, scaled by a_slot[0]) that the forward convolution's
+// epilogue wrote (ebfi_conv2d_packed_x3_rc pre16): the forward keeps no fp32 copy of `a`.
+extern "C" int ebfi_scale_residual_cat_backward_c16a(const float *grad_out, const void *a16, const void *a_slot, const float *s0,
+                                                     const float *s1, void *grad_a16, void *slot, float *grad_x, float *grad_s0_part,
+                                                     float *grad_s1_part, int B, int C, int H, int W, float mask_slope, void *stream) {
+    const int64_t HW = (int64_t)H * W;
+    if (W % 4 != 0) return fail(EBFI_ERR_UNSUPPORTED, "scale_residual_cat_backward_c16a: W %% 4 != 0 (W = %d)", W);
+    if (!grad_out || !a16 || !a_slot || !s0 || !s1 || !grad_a16 || !slot || !grad_x || !grad_s0_part || !grad_s1_part)
+        return fail(EBFI_ERR_ARG, "scale_residual_cat_backward_c16a: null argument");
+    if (C % 16 != 0) return fail(EBFI_ERR_UNSUPPORTED, "scale_residual_cat_backward_c16a: %d channels (multiples of 16)", C);
+    if (!aligned16(a16) || !aligned16(grad_a16)) return fail(EBFI_ERR_ARG, "scale_residual_cat_backward_c16a: 16-byte aligned images");
+    if (int rc = check_planes("scale_residual_cat_backward_c16a", B, C, HW)) return rc;
+    if (B == 0) return EBFI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nslice = ebfi_scale_residual_cat_backward_slices();
+    {
+        ProfScope ps("scale_residual_cat_bwd", st, 0.0, 20.0 * B * C * (double)HW);
+        hipLaunchKernelGGL(src_bwd_c16_kernel<true>, dim3((unsigned)(B * (C / 8) * nslice)), dim3(256), 0, st, grad_out,
+                           static_cast<const float *>(a16), s0, static_cast<const float *>(a16), s1, static_cast<_Float16 *>(grad_a16),
+                           static_cast<float *>(slot), grad_x, grad_s0_part, grad_s1_part, B, C, HW / 4, W / 4, (int64_t)0, nslice,
+                           mask_slope, static_cast<const float *>(a_slot));
     }
     return check_launch("scale_residual_cat_bwd");
 }

@@ -84,6 +84,8 @@ SIGNATURES = {
     "ebfi_scale_residual_cat_forward_c16": (_i, [_vp] * 8 + [_i, _i, _i, _i, _i64, _vp]),
     "ebfi_scale_residual_cat_backward_slices": (_i, []),
     "ebfi_scale_residual_cat_backward_c16": (_i, [_vp] * 10 + [_i, _i, _i, _i, _i64, _c.c_float, _vp]),
+    "ebfi_scale_residual_cat_backward_c16a": (_i, [_vp] * 10 + [_i, _i, _i, _i, _c.c_float, _vp]),
+    "ebfi_conv2d_packed_x3_rc": (_i, [_vp, _vp, _sz, _vp, _vp] + [_i] * 6 + [_c.c_float, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "ebfi_kernelconv_fac_fused_x3": (_i, [_vp, _vp, _sz, _vp, _vp, _vp] + [_i] * 6 + [_c.c_float, _vp]),
     "ebfi_conv2d_packed_x3": (_i, [_vp, _vp, _sz, _vp, _vp] + [_i] * 8 + [_i, _c.c_float, _vp, _vp, _i, _c.c_float, _vp]),
     "ebfi_conv2d_backward_weight_x3g": (_i, [_vp] * 4 + [_i] * 8 + [_vp, _sz, _vp]),

@@ -135,6 +135,14 @@ def _slot_keys(sites):
     return keys
 
 
+def _tail_in_epilogue(book, sites):
+    """Round 5: the round's tail (scale, residual, concat) runs in the epilogue of its grouped convolution (csrc/conv2d.hip
+    EpiExtra post_scale / pre16) once the slot of the activation image `a` has been calibrated by the layer-wise form."""
+    if N.dev_env("EBFI_NO_RC_EPILOGUE", "0") == "1":          # (development switch: same-box A/B against the separate stage)
+        return False
+    return all(book.index.get((sb.key, "a")) in book.calibrated for _, sb, _ in sites)
+
+
 def images_usable(book, sites, W):
     """The image path needs every operand slot of the module calibrated (the layer-wise form below measures them just in time
     on the first eager pass and during the engine's calibration steps) and rows that split into 16-byte quads."""
@@ -233,7 +241,7 @@ class ResidualControlFn(Function):
         from . import c16, f16scale
         book = f16scale.active_book()
         images = keep and images_usable(book, sites, W)
-        ctx.images = images
+        ctx.images, ctx.tail = images, False
         if images:
             with torch.cuda.device_of(x):
                 st = N.stream_ptr(x.device)
@@ -242,11 +250,28 @@ class ResidualControlFn(Function):
                 sp = lambda site, role: book.ptr(book.slot((site.key, role)))
                 x16 = c16.to_c16(x, sp(sites[0][0], "x"))
                 f16fwd = f16scale.forward_level(book) >= 2 and all(t.fwd16_ptr() is not None for r in sites for t in r)
+                tail = not f16fwd and _tail_in_epilogue(book, sites)
+                ctx.tail = tail
+                s_cat = torch.cat([s_ex, s_t], 2).contiguous() if tail else None        # [step, B, 2C]: the epilogue's scales
                 for i, (sa, sb, sc) in enumerate(sites):
                     nxt = sites[i + 1][0] if i + 1 < len(sites) else None
-                    ya, a, xn = new(2 * C), new(2 * C), new(C)
+                    ya, xn = new(2 * C), new(C)
                     ya16, c16i = img(2 * C), img(2 * C)
                     xn16 = img(C) if nxt is not None else None
+                    if tail:
+                        # the grouped convolution's epilogue forms c = cat(s_ex * a0 + x, s_t * a1 + x) itself and leaves the
+                        # images of c (Conv5's weight gradient) and of a (the fused backward stage): no fp32 `a`, no stage launch
+                        c, a16 = new(2 * C), img(2 * C)
+                        _conv16(lib, st, x, sa, sa.bias(), ya, B, C, H, W, 2 * C, 1, slope, ya16, sp(sb, "x"))
+                        rc = lib.ebfi_conv2d_packed_x3_rc(N.ptr(ya), sb.fwd_ptr(), sb.fwd_bytes, N.ptr(sb.bias()), N.ptr(c), B, C, H, W,
+                                                          2 * C, 2, slope, N.ptr(s_cat[i]), N.ptr(x), C, N.ptr(a16), sp(sb, "a"),
+                                                          N.ptr(c16i), sp(sc, "x"), st)
+                        N.check(rc, "ebfi_conv2d_packed_x3_rc")
+                        _conv16(lib, st, c, sc, sc.bias(), xn, B, 2 * C, H, W, C, 1, slope, xn16, sp(nxt, "x") if nxt is not None else None)
+                        saved += [a16, x16, ya16, c16i]
+                        x, x16 = xn, xn16
+                        continue
+                    a = new(2 * C)
                     if f16fwd:
                         # fp16-operand forward: every convolution reads the image its producer wrote (the same images the
                         # weight gradients read later) -- one matrix-core product per tap instead of three, half the input bytes
@@ -279,6 +304,8 @@ class ResidualControlFn(Function):
                 ya, a, c, xn = new(2 * C), new(2 * C), new(2 * C), new(C)
                 _conv(lib, st, x, sa.fwd_ptr(), sa.fwd_bytes, sa.bias(), ya, B, C, H, W, 2 * C, 1, ACT, slope)
                 _conv(lib, st, ya, sb.fwd_ptr(), sb.fwd_bytes, sb.bias(), a, B, C, H, W, 2 * C, 2, ACT, slope)
+                if keep and book is not None:
+                    book.operand((sb.key, "a"), a)          # (scale of the image of `a` the epilogue form writes: measured here)
                 rc = lib.ebfi_scale_residual_cat_forward_ex(N.ptr(a), N.ptr(s_ex[i]), N._vp(a.data_ptr() + 4 * C * HW), N.ptr(s_t[i]),
                                                             N.ptr(x), N.ptr(c), B, C, HW, 2 * C * HW, st)
                 N.check(rc, "ebfi_scale_residual_cat_forward_ex")
@@ -329,9 +356,14 @@ class ResidualControlFn(Function):
                     gc = new(2 * C)
                     _dgrad16(lib, st, g5, sc, B, C, H, W, 2 * C, 1, 0.0, book, out=gc)
                     gb16, gxres = img(2 * C), new(C)
-                    rc = lib.ebfi_scale_residual_cat_backward_c16(
-                        N.ptr(gc), N.ptr(a), N.ptr(s_ex[i]), N._vp(a.data_ptr() + 4 * C * HW), N.ptr(s_t[i]), N.ptr(gb16), sp(sb, "g"),
-                        N.ptr(gxres), N.ptr(parts[0, i]), N.ptr(parts[1, i]), B, C, H, W, 2 * C * HW, slope, st)
+                    if ctx.tail:        # `a` is the image the forward epilogue wrote
+                        rc = lib.ebfi_scale_residual_cat_backward_c16a(
+                            N.ptr(gc), N.ptr(a), sp(sb, "a"), N.ptr(s_ex[i]), N.ptr(s_t[i]), N.ptr(gb16), sp(sb, "g"), N.ptr(gxres),
+                            N.ptr(parts[0, i]), N.ptr(parts[1, i]), B, C, H, W, slope, st)
+                    else:
+                        rc = lib.ebfi_scale_residual_cat_backward_c16(
+                            N.ptr(gc), N.ptr(a), N.ptr(s_ex[i]), N._vp(a.data_ptr() + 4 * C * HW), N.ptr(s_t[i]), N.ptr(gb16), sp(sb, "g"),
+                            N.ptr(gxres), N.ptr(parts[0, i]), N.ptr(parts[1, i]), B, C, H, W, 2 * C * HW, slope, st)
                     N.check(rc, "ebfi_scale_residual_cat_backward_c16")
                     if not batch:
                         gwb, gbb = _wgrad16(lib, st, ya16, gb16, B, C, H, W, 2 * C, 2, ws_cache, book, sb)

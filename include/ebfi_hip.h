@@ -60,7 +60,8 @@ extern "C" {
  *      sign of the c16 image instead of an fp32 tensor)
  *   8  ebfi_conv2d_backward_weight_f16g_ex: the weight gradient writes grad * act'(y) as a c16 image for the data gradient
  *   9  (round 5) ebfi_grad_gather (gradient packing + overflow flag in the wire buffer); ebfi_adam_step_guarded takes the
- *      all-reduced flag */
+ *      all-reduced flag; ebfi_fac_*_p16 take the unpadded input (replicate padding inside); ebfi_reflect_pad2d_backward;
+ *      ebfi_conv2d_packed_x3_rc / ebfi_scale_residual_cat_backward_c16a (ResidualControl's tail in the convolution's epilogue) */
 #define EBFI_ABI_VERSION 9
 
 typedef enum {
@@ -346,6 +347,19 @@ int ebfi_scale_residual_cat_backward_c16(const float *grad_out, const float *a0,
                                          const float *s1, void *grad_a16, void *slot, float *grad_x, float *grad_s0_part,
                                          float *grad_s1_part, int B, int C, int H, int W, int64_t a_batch_stride,
                                          float mask_slope, void *stream);
+/* ... with `a` as the c16 image of [a0 | a1] (2C channels, scale in a_slot) written by ebfi_conv2d_packed_x3_rc (round 5). */
+int ebfi_scale_residual_cat_backward_c16a(const float *grad_out, const void *a16, const void *a_slot, const float *s0, const float *s1,
+                                          void *grad_a16, void *slot, float *grad_x, float *grad_s0_part, float *grad_s1_part, int B,
+                                          int C, int H, int W, float mask_slope, void *stream);
+/* The grouped second-layer convolution of a ResidualControl round with the round's tail in its epilogue
+ * (models/Ours/model_singleframe.py:127-133): a = LeakyReLU(conv3x3(input) + bias); pre16 = c16 image of a (scale / |max| in
+ * pre_slot); output[b, co] = a * post_scale[b, co] + post_res[b, co % res_channels] -- the exposure- / time-scaled residual and
+ * concatenation `cat(s_ex * a0 + x, s_t * a1 + x)` -- and out16 = c16 image of output.  Replaces the separate
+ * ebfi_scale_residual_cat_forward_c16 launch; no fp32 `a` is written.  3x3, same padding, 64-channel blocks, W % 4 == 0. */
+int ebfi_conv2d_packed_x3_rc(const void *input, const void *packed, size_t packed_bytes, const void *bias, void *output, int B,
+                             int Cin_per_group, int H, int W, int Cout, int groups, float slope, const void *post_scale,
+                             const void *post_res, int res_channels, void *pre16, void *pre_slot, void *out16, void *slot16,
+                             void *stream);
 /* weight / bias gradient of such a (grouped) convolution from a pre-activation gradient: grad_weight
  * [Cout, Cin_per_group, k, k]; workspace as ebfi_conv2d_backward_weight_workspace(B, Cin_per_group, H, W, Cout, k, 1, pad) */
 int ebfi_conv2d_backward_weight_x3g(const void *input, const void *grad_output, void *grad_weight, void *grad_bias,

@@ -335,11 +335,10 @@ def test_fac_on_fp16_filter_planes(B, C, H, W):
                                       B, C, H, W, K, st), "unpadded bwd")
     assert torch.equal(gk_u, gk_p)
     # the padding's adjoint in float64 from the padded gradient: interior elements are copies, border elements sums of <= 9 terms
-    ref_g = torch.zeros(B, C, H, W, dtype=torch.float64, device="cuda")
     yy = torch.arange(H + 4, device="cuda").sub(2).clamp(0, H - 1)
     xx = torch.arange(W + 4, device="cuda").sub(2).clamp(0, W - 1)
-    ref_g.index_put_((slice(None), slice(None), yy[:, None].expand(H + 4, W + 4), xx[None, :].expand(H + 4, W + 4)), gp.double(),
-                     accumulate=True)
+    rows = torch.zeros(B, C, H, W + 4, dtype=torch.float64, device="cuda").index_add_(2, yy, gp.double())
+    ref_g = torch.zeros(B, C, H, W, dtype=torch.float64, device="cuda").index_add_(3, xx, rows)
     assert torch.isfinite(gu).all()
     assert torch.equal(gu[:, :, 1:-1, 1:-1], gp[:, :, 3:-3, 3:-3])
     assert ((gu.double() - ref_g).abs().max() / ref_g.abs().max()).item() < 1e-6
@@ -520,4 +519,71 @@ def test_one_nan_element_reaches_the_slot_and_raises_the_guard():
             N.check(lib.ebfi_conv2d_packed_x3_c16(N.ptr(inp), site.fwd_ptr(), site.fwd_bytes, N.ptr(site.bias()), N.ptr(out), 2, 64, 16, 64, 64,
                                                   3, 1, 1, 1, 0.01, N.ptr(None), N.ptr(None), 0, 0.0, N.ptr(img), bk.ptr(i), 0, st), "x3_c16")
         return fill
-    assert guard_after(fwd_img(x)) == 0 and guard_after(fwd_img(bad)) == 1
+    assert guard_after(fwd_img(x)) == 0
+    probe = torch.empty(2, 64, 16, 64, device="cuda")
+    N.check(lib.ebfi_conv2d_packed_x3(N.ptr(bad), site.fwd_ptr(), site.fwd_bytes, N.ptr(site.bias()), N.ptr(probe), 2, 64, 16, 64, 64, 3, 1,
+                                      1, 1, 0.01, N.ptr(None), N.ptr(None), 0, 0.0, st), "x3")
+    assert torch.isnan(probe).any(), "a NaN input element must reach the convolution's output"
+    assert guard_after(fwd_img(bad)) == 1
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 16, 64), (1, 64, 13, 36), (3, 64, 40, 132)])
+def test_residual_control_tail_in_the_convolution_epilogue(B, C, H, W):
+    """ebfi_conv2d_packed_x3_rc (round 5: scale + residual + concat of a ResidualControl round folded into the epilogue of its
+    grouped second-layer convolution) against the two launches it replaces -- the grouped convolution, then
+    ebfi_scale_residual_cat_forward_c16 -- bit for bit on the fp32 output and its image; the extra image of the activation output
+    `a` equals fp16(a * scale); the backward stage reading that image agrees with the one reading fp32 `a` to fp16 rounding."""
+    from ebfi_amd import c16, f16scale
+    torch.manual_seed(B * 7 + W)
+    w, b, bank, book, site = _banked(C, 2 * C, groups=2)
+    HW = H * W
+    ya = torch.randn(B, 2 * C, H, W).cuda()
+    x = torch.randn(B, C, H, W).cuda()
+    s_ex, s_t = torch.randn(B, C).cuda(), torch.randn(B, C).cuda()
+    lib, st = N.lib(), N.stream_ptr(x.device)
+    sc_, sa_ = book.slot("c"), book.slot("a")
+    book.slots[f16scale.SLOT_STRIDE * sc_] = 4.0
+    book.slots[f16scale.SLOT_STRIDE * sa_] = 8.0
+    # reference: convolution, then the fused stage
+    a = torch.empty(B, 2 * C, H, W, device="cuda")
+    N.check(lib.ebfi_conv2d_packed_x3(N.ptr(ya), site.fwd_ptr(), site.fwd_bytes, N.ptr(site.bias()), N.ptr(a), B, C, H, W, 2 * C, 3, 1, 2, 1,
+                                      0.01, N.ptr(None), N.ptr(None), 0, 0.0, st), "x3")
+    c_ref, c16_ref = torch.empty_like(a), c16.empty(B, 2 * C, H, W, "cuda")
+    a1p = N._vp(a.data_ptr() + 4 * C * HW)
+    N.check(lib.ebfi_scale_residual_cat_forward_c16(N.ptr(a), N.ptr(s_ex), a1p, N.ptr(s_t), N.ptr(x), N.ptr(c_ref), N.ptr(c16_ref),
+                                                    book.ptr(sc_), B, C, H, W, 2 * C * HW, st), "src_fwd_c16")
+    amax_c = book.amax(sc_)
+    book.slots[f16scale.SLOT_STRIDE * sc_ + f16scale.SLOT_AMAX] = 0.0
+    # the fused epilogue
+    s_cat = torch.cat([s_ex, s_t], 1).contiguous()
+    c_out = torch.full_like(a, float("nan"))
+    c16_out, a16 = c16.empty(B, 2 * C, H, W, "cuda").fill_(7.0), c16.empty(B, 2 * C, H, W, "cuda").fill_(7.0)
+    N.check(lib.ebfi_conv2d_packed_x3_rc(N.ptr(ya), site.fwd_ptr(), site.fwd_bytes, N.ptr(site.bias()), N.ptr(c_out), B, C, H, W, 2 * C, 2,
+                                         0.01, N.ptr(s_cat), N.ptr(x), C, N.ptr(a16), book.ptr(sa_), N.ptr(c16_out), book.ptr(sc_), st), "x3_rc")
+    # (a * s + x: the stage multiplies and adds in separate roundings or one fma depending on the compiler's contraction -- allow 1 ulp)
+    assert torch.allclose(c_out, c_ref, rtol=3e-7, atol=1e-7)
+    assert ((c16_out.float() - c16_ref.float()).abs().max() <= 4.0 * 2e-3 * c_ref.abs().max()).item()
+    assert torch.equal(c16_out, _ref_image(c_out, 4.0))
+    assert torch.equal(a16, _ref_image(a, 8.0))
+    assert book.amax(sa_) == a.abs().max().item() and abs(book.amax(sc_) - amax_c) <= 1e-6 * amax_c
+    # backward stage on the image of a
+    gc = torch.randn(B, 2 * C, H, W).cuda() * 1e-2
+    sg = book.slot("g")
+    book.slots[f16scale.SLOT_STRIDE * sg] = 512.0
+    S = int(lib.ebfi_scale_residual_cat_backward_slices())
+    outs = []
+    for mode in (0, 1):
+        ga16 = c16.empty(B, 2 * C, H, W, "cuda")
+        gx, p0, p1 = torch.empty(B, C, H, W, device="cuda"), torch.empty(S, B, C, device="cuda"), torch.empty(S, B, C, device="cuda")
+        if mode == 0:
+            N.check(lib.ebfi_scale_residual_cat_backward_c16(N.ptr(gc), N.ptr(a), N.ptr(s_ex), a1p, N.ptr(s_t), N.ptr(ga16), book.ptr(sg),
+                                                             N.ptr(gx), N.ptr(p0), N.ptr(p1), B, C, H, W, 2 * C * HW, 0.01, st), "bwd_c16")
+        else:
+            N.check(lib.ebfi_scale_residual_cat_backward_c16a(N.ptr(gc), N.ptr(a16), book.ptr(sa_), N.ptr(s_ex), N.ptr(s_t), N.ptr(ga16),
+                                                              book.ptr(sg), N.ptr(gx), N.ptr(p0), N.ptr(p1), B, C, H, W, 0.01, st), "bwd_c16a")
+        outs.append((ga16.clone(), gx.clone(), p0.sum(0), p1.sum(0)))
+    (g0, x0, q0, r0), (g1, x1, q1, r1) = outs
+    assert torch.equal(x0, x1)
+    # the mask only needs the SIGN of a (an element below the image's denormal range reads as 0: 1e-8 of |max|)
+    assert (g0 != g1).float().mean().item() < 1e-4
+    assert ((q0 - q1).abs().max() / q0.abs().max()).item() < 1e-3 and ((r0 - r1).abs().max() / r0.abs().max()).item() < 1e-3

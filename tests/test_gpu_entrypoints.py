@@ -237,7 +237,7 @@ def test_guarded_adam_skip_leaves_state_untouched(native, monkeypatch):
     params = [torch.nn.Parameter(torch.randn(300, 7).cuda()), torch.nn.Parameter(torch.randn(11).cuda())]
     opt = FlatAdam(params, lr=1e-2)
     if not native:
-        monkeypatch.setattr(FlatAdam, "_native_step", lambda self, g, guard=None: False)
+        monkeypatch.setattr(FlatAdam, "_native_step", lambda self, g, guard=None, flag=None: False)
     guard = torch.zeros(2, dtype=torch.int32, device="cuda")
     g = torch.randn(opt.flat.numel(), device="cuda")
     opt.step(g, guard=guard)                              # a clean step first (creates the state)

@@ -621,18 +621,30 @@ def test_training_step_is_bit_reproducible():
     fixed summation order (csrc/fac.hip CLAMP, csrc/imgops.hip reflect_pad_bwd).  Default widths at a reduced size."""
     from ebfi_amd.engine import Engine, synthetic_batch
     runs = []
+    names = None
     for _ in range(2):
         eng = Engine(dict(step=3), device="cuda", seed=21, graph=True, precision="bf16x3")
-        losses = []
+        names = [n for n, p in eng.model.named_parameters() if p.requires_grad]
+        sizes = [p.numel() for p in eng.bucket.params]
+        losses, grads = [], []
         for k in range(4):
             losses.append(eng.train_step(*synthetic_batch(2, 128, 128, device="cuda", seed=500 + k)).item())
+            grads.append(eng.bucket.flat.detach().clone())
         torch.cuda.synchronize()
-        runs.append((losses, eng.bucket.flat.detach().clone(), eng.optimizer.flat.detach().clone()))
+        runs.append((losses, grads, eng.optimizer.flat.detach().clone()))
         assert eng.book is not None and eng.book.skipped_steps() == 0 and len(eng._graphs) == 1
         del eng
     (la, ga, pa), (lb, gb, pb) = runs
+    for k in range(4):
+        if not torch.equal(ga[k], gb[k]):         # say WHERE the two runs part: the first step and the parameters that differ
+            bad, off = [], 0
+            for n, sz in zip(names, sizes):
+                a, b = ga[k][off:off + sz], gb[k][off:off + sz]
+                if not torch.equal(a, b):
+                    bad.append((n, ((a - b).abs().max() / a.abs().max().clamp_min(1e-30)).item()))
+                off += sz
+            raise AssertionError("step %d: %d of %d parameter gradients differ between two runs, e.g. %r" % (k, len(bad), len(names), bad[:12]))
     assert la == lb, (la, lb)
-    assert torch.equal(ga, gb), ((ga - gb).abs().max().item(), ga.abs().max().item())
     assert torch.equal(pa, pb)
 
 
