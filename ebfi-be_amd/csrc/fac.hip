@@ -222,10 +222,24 @@ __global__ __launch_bounds__(256) void fac_bwd_rows_f32(const float *__restrict_
             if (active) {
                 float inr[NS];
                 if (has_gk) {
+                    if constexpr (CLAMP) {
+                        if (x >= 4 && x + NS <= Wo) {
+                            // interior columns: the NS = 8 values start at x - 2, an 8-byte aligned address (rows are 16-byte aligned,
+                            // Wo % 4 == 0): four 8-byte loads instead of eight clamped dword loads with an address each
+                            const float2 *p2 = reinterpret_cast<const float2 *>(inrow + x - R2);
 #pragma unroll
-                    for (int j = 0; j < NS; ++j) {
-                        if constexpr (CLAMP) inr[j] = inrow[min(max(x + j - R2, 0), Wo - 1)];
-                        else inr[j] = inrow[x + j];   // x + j <= Wo - 4 + 3 + K - 1 < Wi
+                            for (int j = 0; j < NS / 2; ++j) {
+                                const float2 t = p2[j];
+                                inr[2 * j] = t.x;
+                                inr[2 * j + 1] = t.y;
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < NS; ++j) inr[j] = inrow[min(max(x + j - R2, 0), Wo - 1)];
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NS; ++j) inr[j] = inrow[x + j];   // x + j <= Wo - 4 + 3 + K - 1 < Wi
                     }
                 }
 #pragma unroll
@@ -271,22 +285,26 @@ __global__ __launch_bounds__(256) void fac_bwd_rows_f32(const float *__restrict_
                 if (ginrow != nullptr && yok && x < Wi) {
                     // padded columns x .. x + 3 -> output columns clamp(X - 2): the left border's three (X = 0, 1, 2 -> 0) sit in the
                     // thread with x == 0, the right border's three (X = Wo + 1 .. Wo + 3 -> Wo - 1) in the tail thread x == Wo
-                    float v[4];
-                    int xo[4], n;
-                    if (x == 0) { v[0] = (o[0] + o[1]) + o[2]; xo[0] = 0; v[1] = o[3]; xo[1] = 1; n = 2; }
-                    else if (x == Wo) { v[0] = o[0]; xo[0] = Wo - 2; v[1] = (o[1] + o[2]) + o[3]; xo[1] = Wo - 1; n = 2; }
-                    else {
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) { v[m] = o[m]; xo[m] = x - R2 + m; }
-                        n = 4;
-                    }
-#pragma unroll
-                    for (int m = 0; m < 4; ++m)
-                        if (m < n) {
-                            // (yi > 0 only in the first / last output row: this thread wrote the element in an earlier pass)
-                            if (yi == 0) ginrow[xo[m]] = v[m];
-                            else ginrow[xo[m]] += v[m];
+                    // (yi > 0 only in the first / last output row: this thread wrote the elements in an earlier pass and adds to them)
+                    if (x == 0) {
+                        const float v0 = (o[0] + o[1]) + o[2];
+                        if (yi == 0) { ginrow[0] = v0; ginrow[1] = o[3]; }
+                        else { ginrow[0] += v0; ginrow[1] += o[3]; }
+                    } else if (x == Wo) {
+                        const float v1 = (o[1] + o[2]) + o[3];
+                        if (yi == 0) { ginrow[Wo - 2] = o[0]; ginrow[Wo - 1] = v1; }
+                        else { ginrow[Wo - 2] += o[0]; ginrow[Wo - 1] += v1; }
+                    } else {
+                        float2 *g2 = reinterpret_cast<float2 *>(ginrow + x - R2);      // 8-byte aligned, like the input above
+                        if (yi == 0) {
+                            g2[0] = float2{o[0], o[1]};
+                            g2[1] = float2{o[2], o[3]};
+                        } else {
+                            const float2 a = g2[0], b = g2[1];
+                            g2[0] = float2{a.x + o[0], a.y + o[1]};
+                            g2[1] = float2{b.x + o[2], b.y + o[3]};
                         }
+                    }
                 }
             } else {
                 if (ginrow != nullptr && rowok) {

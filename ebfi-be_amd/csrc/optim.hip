@@ -102,7 +102,17 @@ __global__ __launch_bounds__(256) void grad_gather_kernel(GatherBatch bt, float 
         const int n4 = (n - head) >> 2;
         const float4 *a4 = reinterpret_cast<const float4 *>(a + head);
         float4 *d4 = reinterpret_cast<float4 *>(d + head);
-        for (int i = threadIdx.x; i < n4; i += 256) d4[i] = a4[i];
+        // eight 16-byte loads in flight per thread before the first store (a load-store pair per iteration made the copy wait
+        // for one memory round trip sixteen times: 34 us per launch for 11 MB)
+        for (int i0 = threadIdx.x; i0 < n4; i0 += 256 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (i0 + 256 * k < n4) v[k] = a4[i0 + 256 * k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (i0 + 256 * k < n4) d4[i0 + 256 * k] = v[k];
+        }
         for (int i = head + 4 * n4 + threadIdx.x; i < n; i += 256) d[i] = a[i];
     } else {
         for (int i = threadIdx.x; i < n; i += 256) d[i] = a[i];

@@ -513,18 +513,23 @@ def test_one_nan_element_reaches_the_slot_and_raises_the_guard():
     # the forward epilogue's side image (store_out_tile): a NaN in the conv's input reaches some outputs only
     w, b, bank, book0, site = _banked(64, 64)
 
+    seen = {}
+
     def fwd_img(inp):
         def fill(bk, i):
             out, img = torch.empty(2, 64, 16, 64, device="cuda"), c16.empty(2, 64, 16, 64, "cuda")
             N.check(lib.ebfi_conv2d_packed_x3_c16(N.ptr(inp), site.fwd_ptr(), site.fwd_bytes, N.ptr(site.bias()), N.ptr(out), 2, 64, 16, 64, 64,
                                                   3, 1, 1, 1, 0.01, N.ptr(None), N.ptr(None), 0, 0.0, N.ptr(img), bk.ptr(i), 0, st), "x3_c16")
+            torch.cuda.synchronize()
+            seen.update(out_nan=int(torch.isnan(out).sum()), img_nan=int(torch.isnan(img).sum()),
+                        amax_bits=hex(int(bk.slots[f16scale.SLOT_STRIDE * i + f16scale.SLOT_AMAX].view(torch.int32).item()) & 0xffffffff))
         return fill
     assert guard_after(fwd_img(x)) == 0
     probe = torch.empty(2, 64, 16, 64, device="cuda")
     N.check(lib.ebfi_conv2d_packed_x3(N.ptr(bad), site.fwd_ptr(), site.fwd_bytes, N.ptr(site.bias()), N.ptr(probe), 2, 64, 16, 64, 64, 3, 1,
                                       1, 1, 0.01, N.ptr(None), N.ptr(None), 0, 0.0, st), "x3")
     assert torch.isnan(probe).any(), "a NaN input element must reach the convolution's output"
-    assert guard_after(fwd_img(bad)) == 1
+    assert guard_after(fwd_img(bad)) == 1, seen
 
 
 @pytest.mark.parametrize("B,C,H,W", [(2, 64, 16, 64), (1, 64, 13, 36), (3, 64, 40, 132)])

@@ -643,7 +643,9 @@ def test_training_step_is_bit_reproducible():
                 if not torch.equal(a, b):
                     bad.append((n, ((a - b).abs().max() / a.abs().max().clamp_min(1e-30)).item()))
                 off += sz
-            raise AssertionError("step %d: %d of %d parameter gradients differ between two runs, e.g. %r" % (k, len(bad), len(names), bad[:12]))
+            same = [n for n in names if n not in {b[0] for b in bad}]
+            raise AssertionError("step %d: %d of %d parameter gradients differ between two runs (worst %.1e); DIFFERENT: %s; IDENTICAL: %s"
+                                 % (k, len(bad), len(names), max(b[1] for b in bad), " ".join(b[0] for b in bad), " ".join(same)))
     assert la == lb, (la, lb)
     assert torch.equal(pa, pb)
 
