@@ -106,6 +106,23 @@ constexpr unsigned SENT = 0x80000000u;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, bytes, 0x00020000);
 }
+// s_waitcnt vmcnt(N) with everything else left alone (gfx9 encoding: vmcnt = bits 15:14 | 3:0, expcnt 6:4, lgkmcnt 11:8).  Given
+// explicitly where a pipeline of register stages knows exactly which loads it needs: the wait-count pass honours an existing
+// s_waitcnt, so its own, more conservative guesses (a full drain around guarded stores or a re-used destination register)
+// become redundant.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_waitcnt(((N >> 4) << 14) | (0x7 << 4) | (0xf << 8) | (N & 15));
+}
+// A staging load's offset as a BRANCH-FREE select.  Written as `ok ? off : SENT`, hipcc may sink the offset arithmetic into a
+// branch and duplicate the load into both arms; the arm of the masked lanes then opens with s_waitcnt vmcnt(0) (it re-uses the
+// first destination register as the address temporary while the other arm's load is pending): every prefetch of a ragged
+// producer wave drained ALL the loads in flight (read off the ISA, round 5).  The empty asm pins `off` as computed for every lane.
+__device__ __forceinline__ unsigned sel_off(bool ok, unsigned off) {
+    asm volatile("" : "+v"(off));
+    return ok ? off : 0x80000000u;
+}
 __device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
 }

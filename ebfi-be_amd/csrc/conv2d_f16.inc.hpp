@@ -65,6 +65,8 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
     int ntiles_mine = 0;
     for (int t = blockIdx.x; t < tiles_total; t += G) ++ntiles_mine;
     const int nitems = ntiles_mine * nchunks;
+    constexpr int NSTG = IN16 ? 3 : 2;                             // register stages of the producers = phases per round of their loop
+    const int nitems_pad = (nitems + NSTG - 1) / NSTG * NSTG;
     const bool xcd_map = (gridDim.x & 7) == 0;
     auto tile_coords = [&](int tt, int &tb, int &ty0, int &tx0) {
         int u = xcd_map ? xcd_tile(tt, tiles_total) : tt;          // (neighbouring tiles on one XCD: shared halo lines hit its L2)
@@ -157,6 +159,9 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
 #pragma unroll
                         for (int e = 0; e < 16; ++e) acc[r][m][n][e] = 0.f;
         }
+        // The producers walk the items in groups of NSTG phases WITHOUT early exits (see there): the trailing dead phases' barriers
+        // are matched here.
+        for (int k = nitems; k < nitems_pad; ++k) __syncthreads();
         KB_STAMP(31);
         KB_FLUSH_SELF();
         if constexpr (EXTRA) {
@@ -167,6 +172,15 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
     // ---------------------------------------------------------------------- producers
     // 16-byte quads of 4 consecutive pixels x 8 channels (as conv_fwd_bf16x3_ws) and the chunk's weight pieces; two register
     // stages, so the loads of items i+2 and i+3 are in flight while item i+1 is converted and written.
+    //
+    // Round 5, read off the ISA: the rotating-stage loops below used to leave through `break` after any phase.  The structurizer
+    // merges such exits into the loop latch, so in the control-flow graph every phase's end is a predecessor of the loop header;
+    // the wait-count pass then has to assume that the stage committed FIRST in the loop body was issued LAST -- and emitted
+    // s_waitcnt vmcnt(10) .. vmcnt(0) there: once per round of stages the producers waited for EVERY load in flight, the two
+    // younger stages included.  The loops now run whole rounds (dead phases past the end stage empty descriptors and write a
+    // buffer nobody reads; the consumers match their barriers), and every commit opens with an explicit s_waitcnt for exactly
+    // its own stage, so that neither the guarded stores nor the re-use of a destination register as an address temporary makes
+    // the compiler insert a wider wait.
     KB_STAMP(20);
     const int ptid = tid - 64 * NCW;
     const unsigned img_bytes = (unsigned)KK * (unsigned)g.Cout * (unsigned)K16 * 2u;
@@ -241,6 +255,8 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
         };
         auto commit = [&](int buf, Stage16 &s) {
             char *base = smd + buf * BUFB;
+            // this stage's NPK + NWB loads are the oldest in flight, two younger stages behind them
+            wait_vmcnt<2 * (NPK + NWB)>();
 #pragma unroll
             for (int k = 0; k < NPK; ++k)
                 if (ptid + k * PT < NPIECE) *reinterpret_cast<u32x4 *>(base + p_dst[k]) = s.rq[k];
@@ -257,15 +273,13 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
         prefetch(sa);                          // item 3
         // steady state: before barrier (B) of item i the producers commit item i + 1 and request item i + 4; the stages rotate
         // sb -> sc -> sa (written out three times: a runtime stage index would move the registers to scratch)
-        for (int item = 0; item < nitems; item += 3) {
+        for (int item = 0; item < nitems_pad; item += 3) {
             commit((item + 1) & 1, sb);
             prefetch(sb);
             __syncthreads();                   // (B) item
-            if (item + 1 >= nitems) break;
             commit(item & 1, sc);
             prefetch(sc);
             __syncthreads();                   // (B) item + 1
-            if (item + 2 >= nitems) break;
             commit((item + 1) & 1, sa);
             prefetch(sa);
             __syncthreads();                   // (B) item + 2
@@ -354,6 +368,7 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
     };
     auto commit = [&](int buf, Stage &s) {
         char *base = smd + buf * BUFB;
+        wait_vmcnt<NIT * 8 + NWB>();           // this stage's loads are the oldest in flight, one younger stage behind them
 #pragma unroll
         for (int k = 0; k < NIT; ++k)
             if (ptid + k * PT < NITEM) {
@@ -396,13 +411,12 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
     __syncthreads();                       // (A)
     prefetch(sa);                          // item 2: two chunks of loads in flight from here on
     KB_STAMP(3);
-    for (int item = 0; item < nitems; item += 2) {
+    for (int item = 0; item < nitems_pad; item += 2) {
         if (item < 12) KB_STAMP(4 + 2 * item);
         commit((item + 1) & 1, sb);        // item + 1, while the consumers multiply item
         if (item < 12) KB_STAMP(5 + 2 * item);
         prefetch(sb);                      // item + 3 (past the end: empty descriptors, nothing is read)
         __syncthreads();                   // (B)
-        if (item + 1 >= nitems) break;
         if (item < 12) KB_STAMP(6 + 2 * item);
         commit(item & 1, sa);              // item + 2
         if (item < 12) KB_STAMP(7 + 2 * item);
@@ -778,6 +792,8 @@ __device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ x, const
                                               const int ci_blk, const int gpre_c16 = 0) {
     saturate_fp16_conversions();
     constexpr int KK = 9, PT = 256, NQ = 4;
+    constexpr int TR_NSTG = IN16 ? 3 : 1;          // the image-reading producers run whole rounds of 3 phases (padding barriers below)
+    constexpr bool WG_EXPLICIT_WAITS = false;
     constexpr int NXI = TRXR * TRXQ * 8, NXK = (NXI + PT - 1) / PT;          // input items (row, quad, 8-channel group): 480, 2 per thread
     static_assert(NXK == 2 && TRH * (TRW / 4) * 8 == PT, "one grad_out item and two input items per producer thread");
     extern __shared__ __attribute__((aligned(16))) char smt[];
@@ -831,7 +847,8 @@ __device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ x, const
         KB_STAMP(1);
         int cur = 0;
         [[maybe_unused]] int kb_i = 0;
-        for (int tile = split; tile < total_tiles; tile += G) {
+        int ntiles_done = 0;
+        for (int tile = split; tile < total_tiles; tile += G, ++ntiles_done) {
             const char *base = smt + cur * TR_BUFB;
             if (kb_i < 12) KB_STAMP(2 + 2 * kb_i);
             // Software pipeline over the 8 k-steps of a tile: the 14 transposing reads of step ks + 1 are issued BEFORE the 9 MFMAs
@@ -902,6 +919,9 @@ __device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ x, const
 #pragma unroll
             for (int m = 0; m < 2; ++m) store_block(acc[j][m], m, nq + NQ * j);
         store_block(accx, xm, xt);
+        // (the producers' stage loops run whole rounds of TR_NSTG phases without early exits -- conv_fwd_f16_ws explains why --
+        // and the barriers of their trailing dead phases are matched here)
+        for (int k = ntiles_done; k < (ntiles_done + TR_NSTG - 1) / TR_NSTG * TR_NSTG; ++k) __syncthreads();
         KB_STAMP(30);
         __syncthreads();                   // (C) the producers' bias partials are in LDS
         KB_STAMP(31);
@@ -978,14 +998,14 @@ __device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ x, const
             for (int k = 0; k < NXK16; ++k) {
                 const int yy = y0 - 1 + xr[k], xx = x0 - 1 + xc[k];
                 const bool ok = ptid + k * PT < NXP && xb[k] < cbx_rem && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
-                const unsigned o = ok ? (unsigned)((ci_base >> 4) + xb[k]) * xblk + (unsigned)((yy * 2 + xh[k]) * g.W + xx) * 16u : SENT;
+                const unsigned o = sel_off(ok, (unsigned)((ci_base >> 4) + xb[k]) * xblk + (unsigned)((yy * 2 + xh[k]) * g.W + xx) * 16u);
                 s.rx[k] = __builtin_amdgcn_raw_buffer_load_b128(rxi, o, 0, 0);
             }
             if constexpr (GP16) {
                 const __amdgpu_buffer_rsrc_t rgp = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<_Float16 *>(g16) + (int64_t)bb * g.Cout * HWo, 0, live ? (unsigned)g.Cout * gplane16 : 0u, 0x00020000);
                 const int gy = y0 + pg_y, gx = x0 + 4 * pg_q;
-                const unsigned o = (gy < g.Ho && gx + 3 < g.Wo) ? (unsigned)(co_base + 8 * chg) * gplane16 + (unsigned)(gy * g.Wo + gx) * 2u : SENT;
+                const unsigned o = sel_off(gy < g.Ho && gx + 3 < g.Wo, (unsigned)(co_base + 8 * chg) * gplane16 + (unsigned)(gy * g.Wo + gx) * 2u);
 #pragma unroll
                 for (int k = 0; k < NGK16; ++k) {          // channels 2k, 2k + 1 of the group in one register quad
                     const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(rgp, o + (unsigned)(2 * k) * gplane16, 0, 0);
@@ -998,7 +1018,7 @@ __device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ x, const
 #pragma unroll
                 for (int k = 0; k < NGK16; ++k) {
                     const int cb = (co_base >> 4) + k;
-                    const unsigned o = (gok && cb < cbo) ? (unsigned)cb * gblk + (unsigned)((gy * 2 + p_half) * g.Wo + gx) * 16u : SENT;
+                    const unsigned o = sel_off(gok && cb < cbo, (unsigned)cb * gblk + (unsigned)((gy * 2 + p_half) * g.Wo + gx) * 16u);
                     s.rg[k] = __builtin_amdgcn_raw_buffer_load_b128(rgo, o, 0, 0);
                 }
             }
@@ -1006,6 +1026,7 @@ __device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ x, const
         const float inv_sg = 1.f / sg;
         auto commit = [&](int buf, S16 &s) {
             char *img = smt + buf * TR_BUFB;
+            wait_vmcnt<2 * (NXK16 + (GP16 ? 2 * NGK16 : NGK16))>();      // this stage is the oldest of three in flight
 #pragma unroll
             for (int k = 0; k < NXK16; ++k)
                 if (ptid + k * PT < NXP) *reinterpret_cast<u32x4 *>(img + xd[k]) = s.rx[k];
@@ -1048,17 +1069,15 @@ __device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ x, const
         __syncthreads();                   // (A)
         prefetch(split + 3 * G, sa);
         int cur = 0;
-        for (int tile = split; tile < total_tiles; tile += 3 * G) {
+        for (int tile = split; tile < total_tiles; tile += 3 * G) {       // whole rounds: no early exit (see conv_fwd_f16_ws)
             commit(cur ^ 1, sb);           // tile + G
             prefetch(tile + 4 * G, sb);
             __syncthreads();               // (B)
             cur ^= 1;
-            if (tile + G >= total_tiles) break;
             commit(cur ^ 1, sc);           // tile + 2 G
             prefetch(tile + 5 * G, sc);
             __syncthreads();               // (B)
             cur ^= 1;
-            if (tile + 2 * G >= total_tiles) break;
             commit(cur ^ 1, sa);           // tile + 3 G
             prefetch(tile + 6 * G, sa);
             __syncthreads();               // (B)
@@ -1164,6 +1183,8 @@ __device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ x, const
     };
     auto commit_g = [&](int buf, int tile) {
         char *gi = smt + buf * TR_BUFB + TR_XB;
+        // grad_out (and the saved output) of this tile: the input quads of the NEXT tile were requested after them
+        if constexpr (WG_EXPLICIT_WAITS) wait_vmcnt<NXK * 8>();
         if constexpr (DACT != 0) {
 #pragma unroll
             for (int e = 0; e < 8; ++e)
@@ -1216,6 +1237,9 @@ __device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ x, const
     };
     auto commit_x = [&](int buf, XStage &s) {
         char *xi = smt + buf * TR_BUFB;
+        // this stage's input quads are the oldest loads in flight; behind them: one tile of grad_out quads (+ the saved output
+        // with a folded derivative) and, with two input stages, the other stage
+        if constexpr (WG_EXPLICIT_WAITS) wait_vmcnt<(DACT != 0 ? 16 : NXK * 8 + 8)>();
 #pragma unroll
         for (int k = 0; k < NXK; ++k)
             if (ptid + k * PT < NXI) {
@@ -1251,6 +1275,10 @@ __device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ x, const
         KB_STAMP(3);
         int cur = 0;
         [[maybe_unused]] int kb_i = 0;
+        // (This loop keeps its early exit between the phases, although the structurizer routes it through the loop latch and the
+        // wait-count pass then drains the other input stage once per round -- s_waitcnt vmcnt(17) .. (8) where vmcnt(33) would
+        // do; see conv_fwd_f16_ws.  Both cures that work for the image-reading producers -- dead padding phases, or whole rounds
+        // plus a tail phase after the loop -- push this 240-register variant into scratch: 166 / 223 spill instructions.)
         for (int tile = split; tile < total_tiles; tile += 2 * G) {
             if (kb_i < 6) KB_STAMP(4 + 4 * kb_i);
             commit_x(cur ^ 1, sb);         // tile + G, while the consumers multiply tile `tile` from image `cur`
