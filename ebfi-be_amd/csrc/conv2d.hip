@@ -187,126 +187,156 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
     const int res_shift = has_rc ? co_base - co_base % ex.post_resC : 0;       // (channel blocks never straddle post_resC: both multiples of 64)
     float am = 0.f, amp = 0.f;
     const int h = lane >> 5, l31 = lane & 31;
-    auto emit = [&](auto actf) {
+    // ---- EXTRA path: the tile is walked in blocks of 8 values = (row tile m, x half n, 16-channel block j); the per-pixel
+    // operands of a block (addend, mask, residual) are REQUESTED ONE BLOCK AHEAD into a second small register set.  Before
+    // round 5 every block loaded, waited and stored in turn -- sixteen dependent memory round trips per output row and wave
+    // (s_waitcnt vmcnt(7) .. vmcnt(0) sixteen times in the ISA): ~19 us of the 55 us of an image-writing data gradient.
+    struct BlockIn {
+        float add[8];                      // addend
+        float my[8];                       // mask_y (fp32 form)
+        unsigned m16[4];                   // mask16: the two 8-byte halves of this lane's piece pair
+        float res[8];                      // post_res (XRC)
+    };
+    auto blk_geom = [&](int m, int n, int j, bool &px_ok, unsigned &base, int &cblk, int &xo) {
+        xo = x0 + n * 32 + l31;
+        px_ok = yo < g.Ho && xo < g.Wo;
+        base = (px_ok && co_base + m * 32 + 4 * h < g.Cout) ? (unsigned)(co_base + m * 32 + 4 * h) * plane + (unsigned)(yo * g.Wo + xo) * 4u : SENT;
+        cblk = ((co_base + m * 32) >> 4) + j;
+    };
+    auto row_off = [](int j, int i) { return (unsigned)((i & 3) + 8 * (2 * j + (i >> 2))); };   // row of value i within the tile, minus 4h
+    [[maybe_unused]] auto issue = [&](int m, int n, int j, BlockIn &in) {
+        bool px_ok; unsigned base; int cblk, xo;
+        blk_geom(m, n, j, px_ok, base, cblk, xo);
+        if constexpr (XAM) {
+            if (has_a) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            [[maybe_unused]] float bvm[16];
-            if constexpr (!EXTRA) {        // (per 32-row tile: both tiles' biases up front cost 16 more live registers)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) bvm[r] = buf_ld(rb, (unsigned)(co_base + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 4u);
+                for (int i = 0; i < 8; ++i) in.add[i] = buf_ld(ra, base + row_off(j, i) * plane);
             }
+            if (has_m) {
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int xo = x0 + n * 32 + l31;
-                const bool px_ok = yo < g.Ho && xo < g.Wo;
-                const unsigned base = (px_ok && co_base + m * 32 + 4 * h < g.Cout)
-                                          ? (unsigned)(co_base + m * 32 + 4 * h) * plane + (unsigned)(yo * g.Wo + xo) * 4u : SENT;
-                if constexpr (EXTRA) {
-                    // Eight values (one 16-channel block of the 32-row tile) at a time, each extra inside its own uniform branch
-                    // with an 8-value temporary: with everything live next to the accumulators the kernels spilled registers to
-                    // scratch (round 4).
+                for (int i = 0; i < 8; ++i) in.my[i] = buf_ld(rm, base + row_off(j, i) * plane);
+            }
+            if (has_m16) {                 // this lane's 4 channels of either half-piece
+                typedef unsigned u32x2_m __attribute__((ext_vector_type(2)));
+                const unsigned om = (px_ok && cblk < cb16) ? ((unsigned)cblk * (unsigned)HWo * 2u + (unsigned)(yo * 2 * g.Wo + xo)) * 16u + 8u * (unsigned)h : SENT;
+                const u32x2_m lo = __builtin_amdgcn_raw_buffer_load_b64(rm16, om, 0, 0);
+                const u32x2_m hi = __builtin_amdgcn_raw_buffer_load_b64(rm16, om + (unsigned)g.Wo * 16u, 0, 0);
+                in.m16[0] = lo.x; in.m16[1] = lo.y; in.m16[2] = hi.x; in.m16[3] = hi.y;
+            }
+        }
+        if constexpr (XRC) {
+            if (has_rc) {
+                const unsigned rbase = base == SENT ? SENT : base - (unsigned)res_shift * plane;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        float u[8];
-                        auto row_off = [&](int i) { return (unsigned)((i & 3) + 8 * (2 * j + (i >> 2))); };   // row of value i within the tile, minus 4h
+                for (int i = 0; i < 8; ++i) in.res[i] = buf_ld(rrs, rbase + row_off(j, i) * plane);
+            }
+        }
+    };
+    [[maybe_unused]] auto finish = [&](int m, int n, int j, const BlockIn &in, auto actf) {
+        bool px_ok; unsigned base; int cblk, xo;
+        blk_geom(m, n, j, px_ok, base, cblk, xo);
+        float u[8];
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) u[i] = acc[m][n][8 * j + i] * oscale;
-                        if (bias != nullptr) {
-                            float t[8];
+        for (int i = 0; i < 8; ++i) u[i] = acc[m][n][8 * j + i] * oscale;
+        if (bias != nullptr) {             // (per-channel: the 32 pixel lanes of a half read one address -- served from L1)
+            float t[8];
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) t[i] = buf_ld(rb, (unsigned)(co_base + m * 32 + 4 * h) * 4u + row_off(i) * 4u);
+            for (int i = 0; i < 8; ++i) t[i] = buf_ld(rb, (unsigned)(co_base + m * 32 + 4 * h) * 4u + row_off(j, i) * 4u);
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) u[i] += t[i];
-                        }
-                        if constexpr (XAM) {
-                            if (has_a) {
-                                float t[8];
+            for (int i = 0; i < 8; ++i) u[i] += t[i];
+        }
+        if constexpr (XAM) {
+            if (has_a) {
 #pragma unroll
-                                for (int i = 0; i < 8; ++i) t[i] = buf_ld(ra, base + row_off(i) * plane);
+                for (int i = 0; i < 8; ++i) u[i] += in.add[i];
+            }
+        }
 #pragma unroll
-                                for (int i = 0; i < 8; ++i) u[i] += t[i];
-                            }
-                        }
+        for (int i = 0; i < 8; ++i) u[i] = actf(u[i]);
+        if constexpr (XAM) {
+            if (has_m) {                   // LeakyReLU masks only (the launchers refuse anything else with extras)
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) u[i] = actf(u[i]);
-                        if constexpr (XAM) {
-                            if (has_m) {           // LeakyReLU masks only (the launchers refuse anything else with extras)
-                                float t[8];
+                for (int i = 0; i < 8; ++i) u[i] *= in.my[i] > 0.f ? 1.f : ex.mask_slope;
+            }
+            if (has_m16) {                 // the same signs from the image
 #pragma unroll
-                                for (int i = 0; i < 8; ++i) t[i] = buf_ld(rm, base + row_off(i) * plane);
+                for (int i = 0; i < 8; ++i) {
+                    // positive = sign bit clear and not zero (fp16 bits; NaN cannot occur in a saturated image)
+                    const unsigned hbits = (in.m16[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+                    u[i] *= (hbits != 0u && hbits < 0x8000u) ? 1.f : ex.mask_slope;
+                }
+            }
+        }
+        if constexpr (XRC) {
+            if (has_rc) {
+                const unsigned o16 = (px_ok && cblk < cb16) ? ((unsigned)cblk * (unsigned)HWo * 2u + (unsigned)((yo * 2 + h) * g.Wo + xo)) * 16u : SENT;
 #pragma unroll
-                                for (int i = 0; i < 8; ++i) u[i] *= t[i] > 0.f ? 1.f : ex.mask_slope;
-                            }
-                            if (has_m16) {         // the same signs from the image: this lane's 4 channels of either half-piece
-                                typedef unsigned u32x2_m __attribute__((ext_vector_type(2)));
-                                const int cblk = ((co_base + m * 32) >> 4) + j;
-                                const unsigned om = (px_ok && cblk < cb16) ? ((unsigned)cblk * (unsigned)HWo * 2u + (unsigned)(yo * 2 * g.Wo + xo)) * 16u + 8u * (unsigned)h : SENT;
-                                const u32x2_m lo = __builtin_amdgcn_raw_buffer_load_b64(rm16, om, 0, 0);
-                                const u32x2_m hi = __builtin_amdgcn_raw_buffer_load_b64(rm16, om + (unsigned)g.Wo * 16u, 0, 0);
-                                const unsigned wds[4] = {lo.x, lo.y, hi.x, hi.y};
+                for (int i = 0; i < 8; ++i) amp = amax_acc(amp, u[i]);
+                const u32x4_c16 q = c16_gather_halves(pack_f16(u[0] * sp16, u[1] * sp16), pack_f16(u[2] * sp16, u[3] * sp16),
+                                                      pack_f16(u[4] * sp16, u[5] * sp16), pack_f16(u[6] * sp16, u[7] * sp16));
+                __builtin_amdgcn_raw_buffer_store_b128(q, rp16, o16, 0, 0);
+                float t[8];
 #pragma unroll
-                                for (int i = 0; i < 8; ++i) {
-                                    // positive = sign bit clear and not zero (fp16 bits; NaN cannot occur in a saturated image)
-                                    const unsigned hbits = (wds[i >> 1] >> (16 * (i & 1))) & 0xffffu;
-                                    u[i] *= (hbits != 0u && hbits < 0x8000u) ? 1.f : ex.mask_slope;
-                                }
-                            }
-                        }
-                        if constexpr (XRC) {
-                            if (has_rc) {
-                                const int cblk = ((co_base + m * 32) >> 4) + j;
-                                const unsigned o16 = (px_ok && cblk < cb16)
-                                                         ? ((unsigned)cblk * (unsigned)HWo * 2u + (unsigned)((yo * 2 + h) * g.Wo + xo)) * 16u : SENT;
+                for (int i = 0; i < 8; ++i) t[i] = buf_ld(rps, (unsigned)(co_base + m * 32 + 4 * h) * 4u + row_off(j, i) * 4u);
 #pragma unroll
-                                for (int i = 0; i < 8; ++i) amp = amax_acc(amp, u[i]);
-                                const u32x4_c16 q = c16_gather_halves(pack_f16(u[0] * sp16, u[1] * sp16), pack_f16(u[2] * sp16, u[3] * sp16),
-                                                                      pack_f16(u[4] * sp16, u[5] * sp16), pack_f16(u[6] * sp16, u[7] * sp16));
-                                __builtin_amdgcn_raw_buffer_store_b128(q, rp16, o16, 0, 0);
-                                float t[8];
+                for (int i = 0; i < 8; ++i) u[i] = u[i] * t[i] + in.res[i];
+            }
+        }
+        if (has32) {
 #pragma unroll
-                                for (int i = 0; i < 8; ++i) t[i] = buf_ld(rps, (unsigned)(co_base + m * 32 + 4 * h) * 4u + row_off(i) * 4u);
+            for (int i = 0; i < 8; ++i) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(u[i]), ro, base + row_off(j, i) * plane, 0, 0);
+        }
+        if constexpr (X16) {
+            if (has16) {
 #pragma unroll
-                                for (int i = 0; i < 8; ++i) u[i] *= t[i];
-                                const unsigned rbase = base == SENT ? SENT : base - (unsigned)res_shift * plane;
+                for (int i = 0; i < 8; ++i) am = amax_acc(am, u[i]);
+                if (planar) {
+                    // planes: one 2-byte store per value, lanes = consecutive pixels (64-byte runs per channel)
+                    const unsigned pb = (px_ok && co_base + m * 32 + 4 * h < g.Cout)
+                                            ? (unsigned)(co_base + m * 32 + 4 * h) * (unsigned)HWo * 2u + (unsigned)(yo * g.Wo + xo) * 2u : SENT;
 #pragma unroll
-                                for (int i = 0; i < 8; ++i) t[i] = buf_ld(rrs, rbase + row_off(i) * plane);
-#pragma unroll
-                                for (int i = 0; i < 8; ++i) u[i] += t[i];
-                            }
-                        }
-                        if (has32) {
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(u[i]), ro, base + row_off(i) * plane, 0, 0);
-                        }
-                        if constexpr (X16) {
-                            if (has16) {
-#pragma unroll
-                                for (int i = 0; i < 8; ++i) am = amax_acc(am, u[i]);
-                                if (planar) {
-                                    // planes: one 2-byte store per value, lanes = consecutive pixels (64-byte runs per channel)
-                                    const unsigned pb = (px_ok && co_base + m * 32 + 4 * h < g.Cout)
-                                                            ? (unsigned)(co_base + m * 32 + 4 * h) * (unsigned)HWo * 2u + (unsigned)(yo * g.Wo + xo) * 2u : SENT;
-#pragma unroll
-                                    for (int i = 0; i < 8; ++i) {
-                                        const _Float16 hv = (_Float16)(u[i] * s16);
-                                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), r16, pb + row_off(i) * (unsigned)HWo * 2u, 0, 0);
-                                    }
-                                } else {
-                                    const u32x4_c16 q = c16_gather_halves(pack_f16(u[0] * s16, u[1] * s16), pack_f16(u[2] * s16, u[3] * s16),
-                                                                          pack_f16(u[4] * s16, u[5] * s16), pack_f16(u[6] * s16, u[7] * s16));
-                                    const int cblk = ((co_base + m * 32) >> 4) + j;
-                                    // lower lanes: channels 0..7 of 32 consecutive pixels = one 512-byte run, upper lanes: channels 8..15
-                                    const unsigned o16 = (px_ok && cblk < cb16)
-                                                             ? ((unsigned)cblk * (unsigned)HWo * 2u + (unsigned)((yo * 2 + h) * g.Wo + xo)) * 16u : SENT;
-                                    __builtin_amdgcn_raw_buffer_store_b128(q, r16, o16, 0, 0);
-                                }
-                            }
-                        }
-                        // (keeps the scheduler from hoisting the next block's loads over this one: eight unrolled copies of the
-                        // body with their loads batched up front cost 13-19 spilled registers in the 168-register forward kernel)
-                        __builtin_amdgcn_sched_barrier(0);
+                    for (int i = 0; i < 8; ++i) {
+                        const _Float16 hv = (_Float16)(u[i] * s16);
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), r16, pb + row_off(j, i) * (unsigned)HWo * 2u, 0, 0);
                     }
                 } else {
+                    const u32x4_c16 q = c16_gather_halves(pack_f16(u[0] * s16, u[1] * s16), pack_f16(u[2] * s16, u[3] * s16),
+                                                          pack_f16(u[4] * s16, u[5] * s16), pack_f16(u[6] * s16, u[7] * s16));
+                    // lower lanes: channels 0..7 of 32 consecutive pixels = one 512-byte run, upper lanes: channels 8..15
+                    const unsigned o16 = (px_ok && cblk < cb16)
+                                             ? ((unsigned)cblk * (unsigned)HWo * 2u + (unsigned)((yo * 2 + h) * g.Wo + xo)) * 16u : SENT;
+                    __builtin_amdgcn_raw_buffer_store_b128(q, r16, o16, 0, 0);
+                }
+            }
+        }
+    };
+    auto emit = [&](auto actf) {
+        if constexpr (EXTRA) {
+            constexpr int NBLK = MT * 4;   // block id = (m * 2 + n) * 2 + j
+            BlockIn ia, ib;
+            issue(0, 0, 0, ia);
+#pragma unroll
+            for (int k = 0; k < NBLK; ++k) {
+                const int m = k >> 2, n = (k >> 1) & 1, j = k & 1;
+                // the NEXT block's operands are requested before this block waits for its own ...
+                if (k + 1 < NBLK) issue((k + 1) >> 2, ((k + 1) >> 1) & 1, (k + 1) & 1, (k & 1) ? ia : ib);
+                finish(m, n, j, (k & 1) ? ib : ia, actf);
+                // ... and nothing further ahead: eight unrolled copies of the body with all their loads batched up front cost 13-19
+                // spilled registers in the 168-register forward kernel
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                float bvm[16];             // (per 32-row tile: both tiles' biases up front cost 16 more live registers)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bvm[r] = buf_ld(rb, (unsigned)(co_base + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 4u);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int xo = x0 + n * 32 + l31;
+                    const bool px_ok = yo < g.Ho && xo < g.Wo;
+                    const unsigned base = (px_ok && co_base + m * 32 + 4 * h < g.Cout)
+                                              ? (unsigned)(co_base + m * 32 + 4 * h) * plane + (unsigned)(yo * g.Wo + xo) * 4u : SENT;
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(actf(acc[m][n][r] * oscale + bvm[r])), ro,

@@ -177,13 +177,16 @@ __global__ __launch_bounds__(CT *CT) void census_bwd_kernel(const float *__restr
     for (int c = 0; c < C; ++c) grad_x[((int64_t)b * C + c) * hw + (int64_t)py * W + px] = g;
 }
 
-// Adjoint of nn.ReflectionPad2d(p) (the detail branch's output conv, model_singleframe.py:207: ReflectionPad2d(3) before the
-// 7x7 convolution): grad_in[i][j] = sum of the padded gradient over the padded positions that reflect onto (i, j) -- the
-// position itself plus at most one mirror image per axis.  One thread per 4 output pixels, a GATHER in a fixed order
-// (own, row mirror, column mirror, corner): bit-reproducible, where torch's reflection_pad2d_backward scatters with atomic adds
-// and made the training step's trajectory differ from run to run in the last bit.
-__global__ __launch_bounds__(256) void reflect_pad_bwd_kernel(const float *__restrict__ gp, float *__restrict__ gx, int64_t planes,
-                                                              int H, int W, int p) {
+// Adjoints of nn.ReflectionPad2d(p) (the detail branch's output conv, model_singleframe.py:207: ReflectionPad2d(3) before the
+// 7x7 convolution) and nn.ReplicationPad2d(p) (the FAC module, KernelConv2D.py:82-86): grad_in[i][j] = sum of the padded
+// gradient over the padded positions that map onto (i, j).  One thread per output pixel, a GATHER in a fixed order:
+// bit-reproducible, where torch's reflection_pad2d_backward / replication_pad2d_backward scatter with atomic adds and made the
+// training step's trajectory differ from run to run in the last bit.
+//   reflect:   the position itself plus at most one mirror image per axis (own, row mirror, column mirror, corner)
+//   replicate: the position itself; the first / last row (column) also collects the p rows (columns) outside it
+template <bool REPLICATE>
+__global__ __launch_bounds__(256) void pad2d_bwd_kernel(const float *__restrict__ gp, float *__restrict__ gx, int64_t planes,
+                                                        int H, int W, int p) {
     const int Hp = H + 2 * p, Wp = W + 2 * p;
     const int64_t total = planes * H * W;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -192,36 +195,47 @@ __global__ __launch_bounds__(256) void reflect_pad_bwd_kernel(const float *__res
     const int i = (int)((idx / W) % H);
     const int64_t pl = idx / ((int64_t)W * H);
     const float *g = gp + pl * Hp * Wp;
-    // padded rows that reflect onto i: i + p; p - i (for 1 <= i <= p); 2 (H - 1) - i + p (for H - 1 - p <= i <= H - 2)
-    int ys[3], xs[3], ny = 0, nx = 0;
-    ys[ny++] = i + p;
-    if (i >= 1 && i <= p) ys[ny++] = p - i;
-    if (i <= H - 2 && i >= H - 1 - p) ys[ny++] = 2 * (H - 1) - i + p;
-    xs[nx++] = j + p;
-    if (j >= 1 && j <= p) xs[nx++] = p - j;
-    if (j <= W - 2 && j >= W - 1 - p) xs[nx++] = 2 * (W - 1) - j + p;
     float acc = 0.f;
-    for (int a = 0; a < ny; ++a)
-        for (int b = 0; b < nx; ++b) acc += g[(int64_t)ys[a] * Wp + xs[b]];
+    if constexpr (REPLICATE) {
+        const int ylo = i == 0 ? 0 : i + p, yhi = i == H - 1 ? H - 1 + 2 * p : i + p;
+        const int xlo = j == 0 ? 0 : j + p, xhi = j == W - 1 ? W - 1 + 2 * p : j + p;
+        for (int y = ylo; y <= yhi; ++y)
+            for (int x = xlo; x <= xhi; ++x) acc += g[(int64_t)y * Wp + x];
+    } else {
+        // padded rows that reflect onto i: i + p; p - i (for 1 <= i <= p); 2 (H - 1) - i + p (for H - 1 - p <= i <= H - 2)
+        int ys[3], xs[3], ny = 0, nx = 0;
+        ys[ny++] = i + p;
+        if (i >= 1 && i <= p) ys[ny++] = p - i;
+        if (i <= H - 2 && i >= H - 1 - p) ys[ny++] = 2 * (H - 1) - i + p;
+        xs[nx++] = j + p;
+        if (j >= 1 && j <= p) xs[nx++] = p - j;
+        if (j <= W - 2 && j >= W - 1 - p) xs[nx++] = 2 * (W - 1) - j + p;
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b) acc += g[(int64_t)ys[a] * Wp + xs[b]];
+    }
     gx[idx] = acc;
 }
 
 }  // namespace
 
-extern "C" int ebfi_reflect_pad2d_backward(const float *grad_padded, float *grad_input, int64_t planes, int H, int W, int pad,
-                                           void *stream) {
-    if (!grad_padded || !grad_input) return fail(EBFI_ERR_ARG, "reflect_pad2d_backward: null argument");
-    if (planes < 0 || H < 1 || W < 1 || pad < 0 || pad >= H || pad >= W)
-        return fail(EBFI_ERR_ARG, "reflect_pad2d_backward: pad %d needs pad < H, W (%d x %d)", pad, H, W);
+extern "C" int ebfi_pad2d_backward(const float *grad_padded, float *grad_input, int64_t planes, int H, int W, int pad, int replicate,
+                                   void *stream) {
+    if (!grad_padded || !grad_input) return fail(EBFI_ERR_ARG, "pad2d_backward: null argument");
+    if (planes < 0 || H < 1 || W < 1 || pad < 0 || (!replicate && (pad >= H || pad >= W)))
+        return fail(EBFI_ERR_ARG, "pad2d_backward: pad %d on %d x %d (reflection needs pad < H, W)", pad, H, W);
     if (planes == 0) return EBFI_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t total = planes * H * W;
     {
-        ProfScope ps("reflect_pad_bwd", st, 0.0, 4.0 * ((double)total + (double)planes * (H + 2 * pad) * (W + 2 * pad)));
-        hipLaunchKernelGGL(reflect_pad_bwd_kernel, dim3((unsigned)ceil_div(total, (int64_t)256)), dim3(256), 0, st, grad_padded, grad_input,
-                           planes, H, W, pad);
+        ProfScope ps(replicate ? "replicate_pad_bwd" : "reflect_pad_bwd", st, 0.0, 4.0 * ((double)total + (double)planes * (H + 2 * pad) * (W + 2 * pad)));
+        if (replicate)
+            hipLaunchKernelGGL(pad2d_bwd_kernel<true>, dim3((unsigned)ceil_div(total, (int64_t)256)), dim3(256), 0, st, grad_padded, grad_input,
+                               planes, H, W, pad);
+        else
+            hipLaunchKernelGGL(pad2d_bwd_kernel<false>, dim3((unsigned)ceil_div(total, (int64_t)256)), dim3(256), 0, st, grad_padded, grad_input,
+                               planes, H, W, pad);
     }
-    return check_launch("reflect_pad_bwd");
+    return check_launch("pad2d_bwd");
 }
 
 extern "C" int ebfi_gauss5_forward(const float *input, float *output, int64_t planes, int H, int W, float factor,

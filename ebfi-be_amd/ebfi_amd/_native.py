@@ -117,7 +117,7 @@ SIGNATURES = {
     "ebfi_conv2d_backward_data_s2_bf16x3": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ebfi_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64] + [_c.c_double] * 4 + [_vp]),
     "ebfi_adam_step_guarded": (_i, [_vp, _vp, _vp, _vp, _vp, _i64] + [_c.c_double] * 4 + [_vp, _vp, _vp]),
-    "ebfi_reflect_pad2d_backward": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp]),
+    "ebfi_pad2d_backward": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "ebfi_grad_gather": (_i, [_vp, _vp, _i, _vp, _i64, _i, _vp, _vp]),
     "ebfi_laploss_workspace_floats": (_i64, [_i64, _i, _i, _i]),
     "ebfi_laploss_partials": (_i64, [_i64, _i, _i, _i]),

@@ -124,7 +124,11 @@ class KernelConv2D(nn.Module):
         self.pad = nn.ReplicationPad2d([r, r, r, r])
 
     def forward(self, input, kernel, kernel_leaky_slope=None):
-        return KernelConv2DFunction.apply(self.pad(input), kernel, self.kernel_size, kernel_leaky_slope)
+        # (self.pad stays the module the reference has; on the GPU its padding runs through the op with the deterministic adjoint)
+        from . import fused
+        r = (self.kernel_size - 1) // 2
+        padded = fused.replicate_pad2d(input, r) if input.is_cuda and input.dtype == torch.float32 and input.dim() == 4 else self.pad(input)
+        return KernelConv2DFunction.apply(padded, kernel, self.kernel_size, kernel_leaky_slope)
 
 
 # ------------------------------------------------------------------------------------------------------------------------

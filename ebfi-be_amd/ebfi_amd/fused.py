@@ -150,15 +150,15 @@ def ed_head(ev, bl, gn):
     return _EDHead.apply(ev, bl, gn.weight, gn.bias, gn.num_groups, gn.eps)
 
 
-class _ReflectPad2d(torch.autograd.Function):
-    """nn.ReflectionPad2d(p) whose BACKWARD is a gather in a fixed order (csrc/imgops.hip reflect_pad_bwd): torch's own
-    backward of the pad scatters with atomic adds, which made two runs of the same training step differ in the last bit (and,
-    amplified by the L1 / census kinks over a few optimiser steps, by percent in the smallest parameters)."""
+class _Pad2d(torch.autograd.Function):
+    """nn.ReflectionPad2d(p) / nn.ReplicationPad2d(p) whose BACKWARD is a gather in a fixed order (csrc/imgops.hip pad2d_bwd):
+    torch's own backward of either pad scatters with atomic adds, which made two runs of the same training step differ in the
+    last bit (and, amplified by the L1 / census kinks over a few optimiser steps, by percent in the smallest parameters)."""
 
     @staticmethod
-    def forward(ctx, x, p):
-        ctx.p, ctx.shape = int(p), tuple(x.shape)
-        return torch.nn.functional.pad(x, (p, p, p, p), mode="reflect")
+    def forward(ctx, x, p, mode):
+        ctx.p, ctx.shape, ctx.mode = int(p), tuple(x.shape), mode
+        return torch.nn.functional.pad(x, (p, p, p, p), mode=mode)
 
     @staticmethod
     def backward(ctx, g):
@@ -166,13 +166,25 @@ class _ReflectPad2d(torch.autograd.Function):
         g = g.contiguous()
         out = torch.empty(ctx.shape, dtype=g.dtype, device=g.device)
         with torch.cuda.device_of(g):
-            rc = N.lib().ebfi_reflect_pad2d_backward(N.ptr(g), N.ptr(out), B * C, H, W, ctx.p, N.stream_ptr(g.device))
-        N.check(rc, "ebfi_reflect_pad2d_backward")
-        return out, None
+            rc = N.lib().ebfi_pad2d_backward(N.ptr(g), N.ptr(out), B * C, H, W, ctx.p, 1 if ctx.mode == "replicate" else 0,
+                                             N.stream_ptr(g.device))
+        N.check(rc, "ebfi_pad2d_backward")
+        return out, None, None
+
+
+def _native_pad_ok(x):
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
 
 
 def reflect_pad2d(x, p):
     """ReflectionPad2d(p) with the deterministic native adjoint on GPU fp32 tensors; plain F.pad otherwise."""
-    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and p < x.shape[-1] and p < x.shape[-2]:
-        return _ReflectPad2d.apply(x, p)
+    if _native_pad_ok(x) and p < x.shape[-1] and p < x.shape[-2]:
+        return _Pad2d.apply(x, p, "reflect")
     return torch.nn.functional.pad(x, (p, p, p, p), mode="reflect")
+
+
+def replicate_pad2d(x, p):
+    """ReplicationPad2d(p) with the deterministic native adjoint on GPU fp32 tensors; plain F.pad otherwise."""
+    if _native_pad_ok(x):
+        return _Pad2d.apply(x, p, "replicate")
+    return torch.nn.functional.pad(x, (p, p, p, p), mode="replicate")

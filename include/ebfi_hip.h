@@ -60,7 +60,7 @@ extern "C" {
  *      sign of the c16 image instead of an fp32 tensor)
  *   8  ebfi_conv2d_backward_weight_f16g_ex: the weight gradient writes grad * act'(y) as a c16 image for the data gradient
  *   9  (round 5) ebfi_grad_gather (gradient packing + overflow flag in the wire buffer); ebfi_adam_step_guarded takes the
- *      all-reduced flag; ebfi_fac_*_p16 take the unpadded input (replicate padding inside); ebfi_reflect_pad2d_backward;
+ *      all-reduced flag; ebfi_fac_*_p16 take the unpadded input (replicate padding inside); ebfi_pad2d_backward;
  *      ebfi_conv2d_packed_x3_rc / ebfi_scale_residual_cat_backward_c16a (ResidualControl's tail in the convolution's epilogue) */
 #define EBFI_ABI_VERSION 9
 
@@ -495,10 +495,12 @@ int ebfi_laploss_forward(const float *pred_a, const float *pred_b, const float *
 int ebfi_laploss_backward(const float *grad_loss, float *workspace, float *grad_pred, int64_t planes, int H, int W,
                           int levels, void *stream);
 
-/* Adjoint of nn.ReflectionPad2d(pad) (the detail branch's output conv: ReflectionPad2d(3) + 7x7 convolution,
- * models/Ours/model_singleframe.py:207): grad_padded [planes, H+2*pad, W+2*pad] -> grad_input [planes, H, W] as a gather in a
- * fixed order (bit-reproducible; torch's backward of the pad accumulates with atomics).  pad < H, W. */
-int ebfi_reflect_pad2d_backward(const float *grad_padded, float *grad_input, int64_t planes, int H, int W, int pad, void *stream);
+/* Adjoints of nn.ReflectionPad2d(pad) (the detail branch's output conv: ReflectionPad2d(3) + 7x7 convolution,
+ * models/Ours/model_singleframe.py:207; replicate = 0) and nn.ReplicationPad2d(pad) (the FAC module,
+ * models/FAC/kernelconv2d/KernelConv2D.py:82-86; replicate = 1): grad_padded [planes, H+2*pad, W+2*pad] -> grad_input
+ * [planes, H, W] as a gather in a fixed order (bit-reproducible; torch's backward of either pad accumulates with atomics).
+ * Reflection needs pad < H, W. */
+int ebfi_pad2d_backward(const float *grad_padded, float *grad_input, int64_t planes, int H, int W, int pad, int replicate, void *stream);
 
 /* Adam update (torch.optim.Adam of train_ours.py:276-277, amsgrad / weight decay off as in config/train_ours.yml:59-65)
  * over one flat fp32 buffer of n elements, in place: exp_avg <- exp_avg + (1-beta1)(grad - exp_avg);

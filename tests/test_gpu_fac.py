@@ -285,3 +285,25 @@ def test_kernelconv_fac_training_form_on_fp16_planes_vs_unfused_pair():
         assert err < 3e-3, (name, err)
     # what the node keeps for its backward: the fp16 image of the conv input, the padded feature map, the fp16 filter planes
     assert ((B, C * K * K, H, W), torch.float16) in saved and not any(dt == torch.float32 and len(sh) == 4 and sh[1] == C * K * K for sh, dt in saved)
+
+
+@pytest.mark.parametrize("mode,p", [("reflect", 3), ("replicate", 2), ("reflect", 1), ("replicate", 4)])
+def test_deterministic_pad_adjoints_match_torch(mode, p):
+    """csrc/imgops.hip pad2d_bwd (the adjoints of ReflectionPad2d / ReplicationPad2d as gathers in a fixed order) against torch's
+    backward of F.pad in float64 on the CPU, on shapes with short and long sides; twice the same bits."""
+    from ebfi_amd import fused
+    torch.manual_seed(p)
+    for shape in [(2, 3, 9, 14), (1, 16, 64, 40), (3, 2, 5, 5)]:
+        x = torch.randn(*shape, dtype=torch.float64, requires_grad=True)
+        g = torch.randn(shape[0], shape[1], shape[2] + 2 * p, shape[3] + 2 * p, dtype=torch.float64)
+        torch.nn.functional.pad(x, (p, p, p, p), mode=mode).backward(g)
+        fn = fused.reflect_pad2d if mode == "reflect" else fused.replicate_pad2d
+        outs = []
+        for _ in range(2):
+            xd = x.detach().float().cuda().requires_grad_()
+            y = fn(xd, p)
+            assert torch.equal(y, torch.nn.functional.pad(xd.detach(), (p, p, p, p), mode=mode))
+            y.backward(g.float().cuda())
+            outs.append(xd.grad.clone())
+        assert torch.equal(outs[0], outs[1])
+        assert torch.allclose(outs[0].cpu().double(), x.grad, rtol=1e-6, atol=1e-6), (mode, p, shape)
