@@ -73,45 +73,63 @@ struct GatherBatch {
     unsigned chunk0[GG_BATCH + 1];     // prefix sums of ceil(n / GG_CHUNK); chunk0[count] = workgroups of this launch
     int count;
     int trailer;                       // 1: one extra workgroup writes the trailer
+    unsigned chunks;                   // = chunk0[count] (a field of its own: no dynamic index into the kernarg table)
 };
 
 __global__ __launch_bounds__(256) void grad_gather_kernel(GatherBatch bt, float *__restrict__ flat, int64_t numel, int pad,
                                                           const int *__restrict__ guard) {
     const unsigned wg = blockIdx.x;
-    if (wg == bt.chunk0[bt.count]) {                // (only when bt.trailer: the grid has one workgroup more)
+    if (wg == bt.chunks) {                          // (only when bt.trailer: the grid has one workgroup more)
         if ((int)threadIdx.x < pad) flat[numel + threadIdx.x] = (threadIdx.x == 0 && guard != nullptr && guard[0] != 0) ? 1.f : 0.f;
         return;
     }
-    int lo = 0, hi = bt.count;                      // chunk0[lo] <= wg < chunk0[hi]
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (bt.chunk0[mid] <= wg) lo = mid; else hi = mid;
+    // this workgroup's tensor: the last k with chunk0[k] <= wg.  A linear walk with CONSTANT indices on purpose: the arguments
+    // live in the kernarg segment, and a bisection's dynamic index made the compiler copy the table into scratch memory first
+    // (144 bytes per lane); the walk is 128 scalar compare-and-select steps, uniform over the workgroup.
+    const float *src = nullptr;
+    long long dst0 = 0;
+    int cnt = 0;
+    unsigned c0 = 0;
+#pragma unroll
+    for (int k = 0; k < GG_BATCH; ++k) {
+        if (k < bt.count && wg >= bt.chunk0[k]) {
+            src = bt.src[k];
+            dst0 = bt.dst[k];
+            cnt = bt.n[k];
+            c0 = bt.chunk0[k];
+        }
     }
-    const int o = (int)(wg - bt.chunk0[lo]) * GG_CHUNK;
-    const int n = min(GG_CHUNK, bt.n[lo] - o);
-    float *__restrict__ d = flat + bt.dst[lo] + o;
-    if (bt.src[lo] == nullptr) {
+    const int o = (int)(wg - c0) * GG_CHUNK;
+    const int n = min(GG_CHUNK, cnt - o);
+    float *__restrict__ d = flat + dst0 + o;
+    if (src == nullptr) {
         for (int i = threadIdx.x; i < n; i += 256) d[i] = 0.f;
         return;
     }
-    const float *__restrict__ a = bt.src[lo] + o;
+    const float *__restrict__ a = src + o;
     // 16-byte accesses where source and destination are aligned alike (parameter offsets are arbitrary element counts)
     const int head = (int)((16u - ((unsigned)reinterpret_cast<uintptr_t>(d) & 15u)) & 15u) >> 2;
     if (((reinterpret_cast<uintptr_t>(a) ^ reinterpret_cast<uintptr_t>(d)) & 15u) == 0 && n >= head + 4) {
         if ((int)threadIdx.x < head) d[threadIdx.x] = a[threadIdx.x];
         const int n4 = (n - head) >> 2;
-        const float4 *a4 = reinterpret_cast<const float4 *>(a + head);
-        float4 *d4 = reinterpret_cast<float4 *>(d + head);
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 *a4 = reinterpret_cast<const f32x4 *>(a + head);
+        f32x4 *d4 = reinterpret_cast<f32x4 *>(d + head);
         // eight 16-byte loads in flight per thread before the first store (a load-store pair per iteration made the copy wait
-        // for one memory round trip sixteen times: 34 us per launch for 11 MB)
+        // for one memory round trip sixteen times: 34 us per launch for 11 MB).  The loads are UNCONDITIONAL on a clamped index and
+        // the values plain vector registers: guarded loads / HIP's float4 struct sent the eight-entry array to scratch memory.
         for (int i0 = threadIdx.x; i0 < n4; i0 += 256 * 8) {
-            float4 v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (i0 + 256 * k < n4) v[k] = a4[i0 + 256 * k];
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (i0 + 256 * k < n4) d4[i0 + 256 * k] = v[k];
+            const f32x4 v0 = a4[min(i0, n4 - 1)], v1 = a4[min(i0 + 256, n4 - 1)], v2 = a4[min(i0 + 512, n4 - 1)];
+            const f32x4 v3 = a4[min(i0 + 768, n4 - 1)], v4 = a4[min(i0 + 1024, n4 - 1)], v5 = a4[min(i0 + 1280, n4 - 1)];
+            const f32x4 v6 = a4[min(i0 + 1536, n4 - 1)], v7 = a4[min(i0 + 1792, n4 - 1)];
+            d4[i0] = v0;
+            if (i0 + 256 < n4) d4[i0 + 256] = v1;
+            if (i0 + 512 < n4) d4[i0 + 512] = v2;
+            if (i0 + 768 < n4) d4[i0 + 768] = v3;
+            if (i0 + 1024 < n4) d4[i0 + 1024] = v4;
+            if (i0 + 1280 < n4) d4[i0 + 1280] = v5;
+            if (i0 + 1536 < n4) d4[i0 + 1536] = v6;
+            if (i0 + 1792 < n4) d4[i0 + 1792] = v7;
         }
         for (int i = head + 4 * n4 + threadIdx.x; i < n; i += 256) d[i] = a[i];
     } else {
@@ -149,6 +167,7 @@ extern "C" int ebfi_grad_gather(const void *const *grads, const int64_t *numels,
             bytes += 8.0 * (double)numels[k0 + j];
         }
         bt.chunk0[bt.count] = chunks;
+        bt.chunks = chunks;
         for (int j = bt.count; j < GG_BATCH; ++j) bt.src[j] = nullptr, bt.dst[j] = 0, bt.n[j] = 0, bt.chunk0[j + 1] = chunks;
         if (chunks + (unsigned)bt.trailer == 0) continue;
         ProfScope ps("grad_gather", st, 0.0, bytes);
