@@ -238,6 +238,13 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
         float u[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) u[i] = acc[m][n][8 * j + i] * oscale;
+        [[maybe_unused]] float psc[8];     // XRC: the per-channel scales, requested together with the bias (one round trip, not two)
+        if constexpr (XRC) {
+            if (has_rc) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) psc[i] = buf_ld(rps, (unsigned)(co_base + m * 32 + 4 * h) * 4u + row_off(j, i) * 4u);
+            }
+        }
         if (bias != nullptr) {             // (per-channel: the 32 pixel lanes of a half read one address -- served from L1)
             float t[8];
 #pragma unroll
@@ -275,11 +282,8 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
                 const u32x4_c16 q = c16_gather_halves(pack_f16(u[0] * sp16, u[1] * sp16), pack_f16(u[2] * sp16, u[3] * sp16),
                                                       pack_f16(u[4] * sp16, u[5] * sp16), pack_f16(u[6] * sp16, u[7] * sp16));
                 __builtin_amdgcn_raw_buffer_store_b128(q, rp16, o16, 0, 0);
-                float t[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) t[i] = buf_ld(rps, (unsigned)(co_base + m * 32 + 4 * h) * 4u + row_off(j, i) * 4u);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) u[i] = u[i] * t[i] + in.res[i];
+                for (int i = 0; i < 8; ++i) u[i] = u[i] * psc[i] + in.res[i];
             }
         }
         if (has32) {

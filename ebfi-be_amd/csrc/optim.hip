@@ -107,34 +107,34 @@ __global__ __launch_bounds__(256) void grad_gather_kernel(GatherBatch bt, float 
         return;
     }
     const float *__restrict__ a = src + o;
-    // 16-byte accesses where source and destination are aligned alike (parameter offsets are arbitrary element counts)
-    const int head = (int)((16u - ((unsigned)reinterpret_cast<uintptr_t>(d) & 15u)) & 15u) >> 2;
-    if (((reinterpret_cast<uintptr_t>(a) ^ reinterpret_cast<uintptr_t>(d)) & 15u) == 0 && n >= head + 4) {
-        if ((int)threadIdx.x < head) d[threadIdx.x] = a[threadIdx.x];
-        const int n4 = (n - head) >> 2;
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        const f32x4 *a4 = reinterpret_cast<const f32x4 *>(a + head);
-        f32x4 *d4 = reinterpret_cast<f32x4 *>(d + head);
-        // eight 16-byte loads in flight per thread before the first store (a load-store pair per iteration made the copy wait
-        // for one memory round trip sixteen times: 34 us per launch for 11 MB).  The loads are UNCONDITIONAL on a clamped index and
-        // the values plain vector registers: guarded loads / HIP's float4 struct sent the eight-entry array to scratch memory.
-        for (int i0 = threadIdx.x; i0 < n4; i0 += 256 * 8) {
-            const f32x4 v0 = a4[min(i0, n4 - 1)], v1 = a4[min(i0 + 256, n4 - 1)], v2 = a4[min(i0 + 512, n4 - 1)];
-            const f32x4 v3 = a4[min(i0 + 768, n4 - 1)], v4 = a4[min(i0 + 1024, n4 - 1)], v5 = a4[min(i0 + 1280, n4 - 1)];
-            const f32x4 v6 = a4[min(i0 + 1536, n4 - 1)], v7 = a4[min(i0 + 1792, n4 - 1)];
-            d4[i0] = v0;
-            if (i0 + 256 < n4) d4[i0 + 256] = v1;
-            if (i0 + 512 < n4) d4[i0 + 512] = v2;
-            if (i0 + 768 < n4) d4[i0 + 768] = v3;
-            if (i0 + 1024 < n4) d4[i0 + 1024] = v4;
-            if (i0 + 1280 < n4) d4[i0 + 1280] = v5;
-            if (i0 + 1536 < n4) d4[i0 + 1536] = v6;
-            if (i0 + 1792 < n4) d4[i0 + 1792] = v7;
+    // 16-byte LOADS from the source as soon as it is 16-byte aligned (gradient tensors are: `sh` skips to the boundary), eight
+    // of them in flight per thread; 16-byte STORES when the destination happens to share that alignment, four dword stores per
+    // load otherwise -- parameter offsets are arbitrary element counts, and behind the first 3-element bias every destination
+    // is misaligned: the first version fell back to a dword-per-iteration loop there (64 dependent round trips, 33 us per launch).
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int sh = min(n, (int)((16u - ((unsigned)reinterpret_cast<uintptr_t>(a) & 15u)) & 15u) >> 2);
+    if ((int)threadIdx.x < sh) d[threadIdx.x] = a[threadIdx.x];
+    const int n4 = (n - sh) >> 2;
+    const f32x4 *a4 = reinterpret_cast<const f32x4 *>(a + sh);
+    float *dd = d + sh;
+    const bool dst16 = (reinterpret_cast<uintptr_t>(dd) & 15u) == 0;
+    for (int i0 = threadIdx.x; i0 < n4; i0 += 256 * 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = a4[min(i0 + 256 * k, n4 - 1)];          // (unconditional, clamped: stays in registers)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + 256 * k;
+            if (i < n4) {
+                if (dst16) {
+                    reinterpret_cast<f32x4 *>(dd)[i] = v[k];
+                } else {
+                    dd[4 * i] = v[k].x; dd[4 * i + 1] = v[k].y; dd[4 * i + 2] = v[k].z; dd[4 * i + 3] = v[k].w;
+                }
+            }
         }
-        for (int i = head + 4 * n4 + threadIdx.x; i < n; i += 256) d[i] = a[i];
-    } else {
-        for (int i = threadIdx.x; i < n; i += 256) d[i] = a[i];
     }
+    for (int i = sh + 4 * n4 + threadIdx.x; i < n; i += 256) d[i] = a[i];
 }
 
 }  // namespace

@@ -40,6 +40,42 @@ def get_compute_dtype():
     return _COMPUTE
 
 
+# ---- weight gradients on a side stream (round 5).  The detail branch (R3D-18 U-Net folded to 2-D) is 500 launches of 5-25 us on
+# 16-64 workgroups each: a launch leaves most of the 256 CUs idle, and half of the backward launches -- the weight gradients of the
+# activation-free layers with their slab reductions and fold gathers -- feed nothing but the optimiser.  Inside a marked region
+# (`side_wgrad_region`, the detail branch's forward) such a layer remembers the engine's side stream, and its backward issues the
+# weight-gradient launches there: they overlap with the data-gradient chain on the main stream.  The engine joins the streams after
+# backward (Engine._fwd_bwd), before the scale book's finish launch and the gradient packing; inside a hipGraph capture the fork /
+# join become graph edges.  (Round 4 tried this for the TRUNK's layers, whose kernels fill the chip: +0.3 ms.  Layers that fold
+# act'(y) into grad_out stay on the main stream: their data gradient consumes the weight-gradient launch's side output.)
+_SIDE_STREAM = None
+_SIDE_REGION = False
+
+
+def set_side_stream(stream):
+    """The stream weight gradients of marked regions may run on (None = everything on the current stream)."""
+    global _SIDE_STREAM
+    _SIDE_STREAM = stream
+
+
+def side_stream():
+    return _SIDE_STREAM
+
+
+class side_wgrad_region:
+    """with side_wgrad_region(): forward of layers whose activation-free weight gradients may leave the main stream."""
+
+    def __enter__(self):
+        global _SIDE_REGION
+        self.prev, _SIDE_REGION = _SIDE_REGION, _SIDE_STREAM is not None
+        return self
+
+    def __exit__(self, *exc):
+        global _SIDE_REGION
+        _SIDE_REGION = self.prev
+        return False
+
+
 def _bf16_ok(k, stride, mode=None):
     return (mode or _COMPUTE) == "bf16" and k in (1, 3) and stride == 1
 
@@ -232,6 +268,7 @@ class SiteConvBiasAct(Function):
         if grad_preact:                      # the incoming gradient is already that of the pre-activation
             act, slope = ACT_NONE, 0.0
         ctx.site, ctx.cfg, ctx.geo = site, (act, slope), geo
+        ctx.side = _SIDE_STREAM if (_SIDE_REGION and act == ACT_NONE) else None      # (see side_wgrad_region)
         ctx.save_for_backward(x, out if act != ACT_NONE else None)
         return out
 
@@ -257,34 +294,52 @@ class SiteConvBiasAct(Function):
         al16 = all(t is None or t.data_ptr() % 16 == 0 for t in (x, gout, y))
         f16_w = f16 and (Cin % 64 == 0 or (Cin >= 32 and W % 4 == 0 and al16 and N.dev_env("EBFI_WGRAD_TR", "1") != "0"))
         f16_x = f16 and W % 4 == 0 and Cin >= 48 and site.tr16_ptr() is not None
+        side = ctx.side if (need_p and getattr(ctx, "side", None) is not None) else None
+        gpre = None
+
+        def weight_gradients(st_w):
+            """weight / bias gradient launches (+ slab reduction, + fold gathers) on stream `st_w`; returns (pgrads, gpre)."""
+            gw2 = torch.empty((site.M, site.K, site.ks, site.ks), dtype=x.dtype, device=x.device)
+            gb2 = torch.empty(site.M, dtype=x.dtype, device=x.device) if site.has_bias else None
+            need = int(lib.ebfi_conv2d_backward_weight_workspace(*geo, N.EBFI_F32))
+            ws = torch.empty(max(need, 4), dtype=torch.uint8, device=x.device)
+            # grad * act' for the data gradient: as the fp16 image that kernel stages (ebfi_amd.c16) when both gradients run on fp16
+            # operands and the pixel-major weight-gradient kernel applies -- half the bytes written and read again
+            gpre16 = need_x and act != ACT_NONE and f16_w and f16_x and al16 and W % 4 == 0 and M % 16 == 0 and site.groups == 1 and \
+                N.dev_env("EBFI_NO_GPRE16", "0") != "1" and N.dev_env("EBFI_WGRAD_TR", "1") != "0"
+            gp = None
+            if need_x and act != ACT_NONE:
+                if gpre16:
+                    from . import c16
+                    gp = c16.empty(B, M, H, W, x.device)
+                else:
+                    gp = torch.empty_like(gout)
+            if f16_w:
+                rc = lib.ebfi_conv2d_backward_weight_f16g_ex(N.ptr(x), N.ptr(gout), N.ptr(y), N.ptr(gw2), N.ptr(gb2), N.ptr(gp),
+                                                             1 if gpre16 else 0, B, Cin, H, W, M, ks, pad, 1, act, slope,
+                                                             book.operand((site.key, "x"), x), book.operand((site.key, "g"), gout),
+                                                             N.ptr(ws), need, st_w)
+            else:
+                rc = lib.ebfi_conv2d_backward_weight_ex(N.ptr(x), N.ptr(gout), N.ptr(y), N.ptr(gw2), N.ptr(gb2), N.ptr(gp), *geo,
+                                                        act, slope, N.ptr(ws), need, N.EBFI_F32_BF16X3MMA, st_w)
+            N.check(rc, "ebfi_conv2d_backward_weight")
+            return _route_site_grads(site, gw2, gb2, st_w), gp
+
         with torch.cuda.device_of(x):
             st = N.stream_ptr(x.device)
-            gpre = None
-            if need_p:
-                gw2 = torch.empty((site.M, site.K, site.ks, site.ks), dtype=x.dtype, device=x.device)
-                gb2 = torch.empty(site.M, dtype=x.dtype, device=x.device) if site.has_bias else None
-                need = int(lib.ebfi_conv2d_backward_weight_workspace(*geo, N.EBFI_F32))
-                ws = torch.empty(max(need, 4), dtype=torch.uint8, device=x.device)
-                # grad * act' for the data gradient: as the fp16 image that kernel stages (ebfi_amd.c16) when both gradients run on fp16
-                # operands and the pixel-major weight-gradient kernel applies -- half the bytes written and read again
-                gpre16 = need_x and act != ACT_NONE and f16_w and f16_x and al16 and W % 4 == 0 and M % 16 == 0 and site.groups == 1 and \
-                    N.dev_env("EBFI_NO_GPRE16", "0") != "1" and N.dev_env("EBFI_WGRAD_TR", "1") != "0"
-                if need_x and act != ACT_NONE:
-                    if gpre16:
-                        from . import c16
-                        gpre = c16.empty(B, M, H, W, x.device)
-                    else:
-                        gpre = torch.empty_like(gout)
-                if f16_w:
-                    rc = lib.ebfi_conv2d_backward_weight_f16g_ex(N.ptr(x), N.ptr(gout), N.ptr(y), N.ptr(gw2), N.ptr(gb2), N.ptr(gpre),
-                                                                 1 if gpre16 else 0, B, Cin, H, W, M, ks, pad, 1, act, slope,
-                                                                 book.operand((site.key, "x"), x), book.operand((site.key, "g"), gout),
-                                                                 N.ptr(ws), need, st)
-                else:
-                    rc = lib.ebfi_conv2d_backward_weight_ex(N.ptr(x), N.ptr(gout), N.ptr(y), N.ptr(gw2), N.ptr(gb2), N.ptr(gpre), *geo,
-                                                            act, slope, N.ptr(ws), need, N.EBFI_F32_BF16X3MMA, st)
-                N.check(rc, "ebfi_conv2d_backward_weight")
-                pgrads = _route_site_grads(site, gw2, gb2, st)
+            if need_p and side is not None:
+                # fork: the side stream continues from here (grad_out and the saved input are complete on the main stream); both
+                # tensors are marked as in use there, so the allocator does not hand their memory out while the launches are pending
+                main = torch.cuda.current_stream(x.device)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                x.record_stream(side)
+                gout.record_stream(side)
+                with torch.cuda.stream(side):
+                    pgrads, gpre = weight_gradients(N.stream_ptr(x.device))
+            elif need_p:
+                pgrads, gpre = weight_gradients(st)
             if need_x:
                 gx = torch.empty_like(x)
                 src, sy, a = (gpre, None, ACT_NONE) if gpre is not None else (gout, y, act)

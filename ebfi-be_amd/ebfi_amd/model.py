@@ -406,6 +406,19 @@ class UNet3d_18(nn.Module):
                                           nn.BatchNorm2d(c0) if bn else identity())
         self.outconv = nn.Sequential(nn.ReflectionPad2d(3), nn.Conv2d(c0, 3, kernel_size=7, stride=1, padding=0))
 
+    @staticmethod
+    def _fuse_weight_on_depth_minor_channels(w):
+        """feature_fuse's 1x1 weight [c0, 2*c0, 1, 1] on the channel order of cat(unbind(y, 2), 1) (index d*c0 + c) -> the same
+        map on the channels of y's own memory, [B, c0, 2, H, W] == [B, 2*c0, H, W] with index c*2 + d: a permutation of the
+        weight's input columns (a 0/1 fold like the Conv3d ones: the bank applies it, autograd routes the gradient back)."""
+        co, c2 = w.shape[0], w.shape[1]
+        return w.reshape(co, 2, c2 // 2, 1, 1).permute(0, 2, 1, 3, 4).reshape(co, c2, 1, 1)
+
+    def _ebfi_bank_register(self, bank):
+        ff = self.feature_fuse[0]
+        if isinstance(self.feature_fuse[1], identity) and ff.bias is None and ff.kernel_size == (1, 1) and ff.in_channels % 2 == 0:
+            bank.register(ff.weight, None, "fuse_d2", self._fuse_weight_on_depth_minor_channels)
+
     def forward(self, img0, img1):
         skips = self.encoder(torch.stack((img0, img1), dim=2))
         y = skips[4]
@@ -413,8 +426,20 @@ class UNet3d_18(nn.Module):
         for stage, skip in zip(self.decoder[:4], (skips[3], skips[2], skips[1], skips[0])):
             y = torch.cat([stage(y, slope), skip], dim=1)          # LeakyReLU(0.2) fused into the stage's gate
         y = self.decoder[4](y, slope)
-        y = torch.cat(torch.unbind(y, 2), 1)
         ff, oc = self.feature_fuse[0], self.outconv[1]
+        from . import weightbank
+        site = weightbank.lookup(ff.weight, "fuse_d2")
+        if site is not None and y.is_contiguous() and conv.site_usable(site, y.reshape(y.shape[0], -1, y.shape[3], y.shape[4])) and \
+                not torch.is_autocast_enabled():
+            # cat(unbind(y, 2), 1) is a channel permutation of y's own memory: the 1x1 fuse reads y in place through the bank's
+            # column-permuted weight image instead of a 67 MB copy forward and another backward
+            y2 = y.reshape(y.shape[0], -1, y.shape[3], y.shape[4])
+            y = conv.conv_site(y2, site, 0, conv.ACT_LEAKY, 0.2, [ff.weight], [])          # 1x1 fuse + LeakyReLU(0.2)
+            pad = self.outconv[0].padding
+            from . import fused
+            yp = fused.reflect_pad2d(y, int(pad[0])) if isinstance(self.outconv[0], nn.ReflectionPad2d) and len(set(pad)) == 1 else self.outconv[0](y)
+            return conv.conv_bias_act(yp, oc.weight, oc.bias, 1, 0, conv.ACT_NONE, 0.0)
+        y = torch.cat(torch.unbind(y, 2), 1)
         if isinstance(self.feature_fuse[1], identity) and conv.supported(y, ff.weight, ff.stride, ff.padding) and \
                 not torch.is_autocast_enabled():
             y = conv.conv_bias_act(y, ff.weight, None, 1, 0, conv.ACT_LEAKY, 0.2)  # 1x1 fuse + LeakyReLU(0.2)
@@ -526,7 +551,11 @@ class EVFIAutoEx(BaseModel):
         Frame, frame_feat, event_feat, ex, cropper = state
         event_feat = self.ResidualControl(event_feat, ex, T)
         Sharp = self._reconstruct(self.Modification(frame_feat, event_feat))
-        Final = Sharp + self.Detail(img0=Frame, img1=Sharp) if self.DetailEnabled else Sharp
+        if self.DetailEnabled:
+            with conv.side_wgrad_region():          # (its small layers' weight gradients may run beside the backward chain)
+                Final = Sharp + self.Detail(img0=Frame, img1=Sharp)
+        else:
+            Final = Sharp
 
         if cropper is not None:
             Sharp = cropper.crop(Sharp).contiguous()

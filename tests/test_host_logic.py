@@ -309,6 +309,8 @@ def test_weight_bank_tables_reproduce_the_per_call_packing():
             W2, b2 = fold3d.fold_conv3d_weight(w), fold3d._rep2
         elif kind == "convT3d":
             W2, b2 = fold3d.fold_conv_transpose3d_weight(w), fold3d._rep8
+        elif kind == "fuse_d2":                  # UNet3d_18._ebfi_bank_register: feature_fuse on y's own channel order
+            W2, b2 = net.Detail._fuse_weight_on_depth_minor_channels(w), None
         elif kind == "cat34":
             W2, b2 = torch.cat([rc.Conv3[0][0].conv2d.weight, rc.Conv4[0][0].conv2d.weight]).detach(), None
         else:
@@ -323,15 +325,16 @@ def test_weight_bank_tables_reproduce_the_per_call_packing():
         assert torch.equal(packed[o:o + n], th) and torch.equal(packed[o + n:o + 2 * n], tl), kind
         kinds.add(kind)
         # adjoint of the fold: gradient of W2 routed back to the parameter
-        if kind in ("conv3d", "convT3d"):
+        if kind in ("conv3d", "convT3d", "fuse_d2"):
             wr = w.clone().requires_grad_()
-            fold = fold3d.fold_conv3d_weight if kind == "conv3d" else fold3d.fold_conv_transpose3d_weight
+            fold = {"conv3d": fold3d.fold_conv3d_weight, "convT3d": fold3d.fold_conv_transpose3d_weight,
+                    "fuse_d2": net.Detail._fuse_weight_on_depth_minor_channels}[kind]
             g2 = torch.randn(s.M, s.K, s.ks, s.ks)
             fold(wr).backward(g2)
             inv = s.w_inv[0].long()
             routed = torch.cat([g2.flatten(), torch.zeros(1)])[inv].sum(-1).view(w.shape)
             assert torch.allclose(routed, wr.grad, atol=1e-6), kind
-    assert kinds == {"id", "conv3d", "convT3d", "cat34", "rcA", "rcB"}
+    assert kinds == {"id", "conv3d", "convT3d", "cat34", "rcA", "rcB", "fuse_d2"}
     # folded biases: one Conv_3d of the decoder (bias=True) and the concatenated pair
     dec = net.Detail.decoder[0].conv[0]
     sb = bank.sites[(dec.weight.data_ptr(), "conv3d")]
