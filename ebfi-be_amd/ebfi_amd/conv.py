@@ -40,42 +40,6 @@ def get_compute_dtype():
     return _COMPUTE
 
 
-# ---- weight gradients on a side stream (round 5).  The detail branch (R3D-18 U-Net folded to 2-D) is 500 launches of 5-25 us on
-# 16-64 workgroups each: a launch leaves most of the 256 CUs idle, and half of the backward launches -- the weight gradients of the
-# activation-free layers with their slab reductions and fold gathers -- feed nothing but the optimiser.  Inside a marked region
-# (`side_wgrad_region`, the detail branch's forward) such a layer remembers the engine's side stream, and its backward issues the
-# weight-gradient launches there: they overlap with the data-gradient chain on the main stream.  The engine joins the streams after
-# backward (Engine._fwd_bwd), before the scale book's finish launch and the gradient packing; inside a hipGraph capture the fork /
-# join become graph edges.  (Round 4 tried this for the TRUNK's layers, whose kernels fill the chip: +0.3 ms.  Layers that fold
-# act'(y) into grad_out stay on the main stream: their data gradient consumes the weight-gradient launch's side output.)
-_SIDE_STREAM = None
-_SIDE_REGION = False
-
-
-def set_side_stream(stream):
-    """The stream weight gradients of marked regions may run on (None = everything on the current stream)."""
-    global _SIDE_STREAM
-    _SIDE_STREAM = stream
-
-
-def side_stream():
-    return _SIDE_STREAM
-
-
-class side_wgrad_region:
-    """with side_wgrad_region(): forward of layers whose activation-free weight gradients may leave the main stream."""
-
-    def __enter__(self):
-        global _SIDE_REGION
-        self.prev, _SIDE_REGION = _SIDE_REGION, _SIDE_STREAM is not None
-        return self
-
-    def __exit__(self, *exc):
-        global _SIDE_REGION
-        _SIDE_REGION = self.prev
-        return False
-
-
 def _bf16_ok(k, stride, mode=None):
     return (mode or _COMPUTE) == "bf16" and k in (1, 3) and stride == 1
 
@@ -268,7 +232,6 @@ class SiteConvBiasAct(Function):
         if grad_preact:                      # the incoming gradient is already that of the pre-activation
             act, slope = ACT_NONE, 0.0
         ctx.site, ctx.cfg, ctx.geo = site, (act, slope), geo
-        ctx.side = _SIDE_STREAM if (_SIDE_REGION and act == ACT_NONE) else None      # (see side_wgrad_region)
         ctx.save_for_backward(x, out if act != ACT_NONE else None)
         return out
 
@@ -294,7 +257,6 @@ class SiteConvBiasAct(Function):
         al16 = all(t is None or t.data_ptr() % 16 == 0 for t in (x, gout, y))
         f16_w = f16 and (Cin % 64 == 0 or (Cin >= 32 and W % 4 == 0 and al16 and N.dev_env("EBFI_WGRAD_TR", "1") != "0"))
         f16_x = f16 and W % 4 == 0 and Cin >= 48 and site.tr16_ptr() is not None
-        side = ctx.side if (need_p and getattr(ctx, "side", None) is not None) else None
         gpre = None
 
         def weight_gradients(st_w):
@@ -327,18 +289,7 @@ class SiteConvBiasAct(Function):
 
         with torch.cuda.device_of(x):
             st = N.stream_ptr(x.device)
-            if need_p and side is not None:
-                # fork: the side stream continues from here (grad_out and the saved input are complete on the main stream); both
-                # tensors are marked as in use there, so the allocator does not hand their memory out while the launches are pending
-                main = torch.cuda.current_stream(x.device)
-                ev = torch.cuda.Event()
-                ev.record(main)
-                side.wait_event(ev)
-                x.record_stream(side)
-                gout.record_stream(side)
-                with torch.cuda.stream(side):
-                    pgrads, gpre = weight_gradients(N.stream_ptr(x.device))
-            elif need_p:
+            if need_p:
                 pgrads, gpre = weight_gradients(st)
             if need_x:
                 gx = torch.empty_like(x)

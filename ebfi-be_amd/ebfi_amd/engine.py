@@ -113,9 +113,6 @@ class Engine:
         self.use_graph = bool(graph) and self.device.type == "cuda"
         self._graphs = {}
         self.graph_capture_failed, self.graph_capture_error = False, None    # set when a capture fell back to eager launches
-        from . import _native as _N
-        self.side_wgrad = _N.dev_env("EBFI_NO_SIDE_WGRAD", "0") != "1"
-        self._wside = None
         if strict_graph is None:
             from .dp import is_distributed
             strict_graph = is_distributed()
@@ -189,32 +186,15 @@ class Engine:
         return self.book.active()
 
     def _fwd_bwd(self, frame, event, t, gtex, target):
-        from . import conv
-        side = self._wgrad_side_stream()
         with self._autocast(), self._bank(), self._book() as book:
             if book is not None and self._steps_run < self.calibration_steps:
                 book.calibrated.clear()             # (measure every operand of this pass again, see __init__)
-            conv.set_side_stream(side)              # (weight gradients of the detail branch's small layers: ebfi_amd.conv)
-            try:
-                sharp_pre, sharp = self.model(frame, event, t, gtex)
-                loss = self.loss(sharp_pre.float(), sharp.float(), target, self.iteration, self.accu_step)
-                loss.backward()
-            finally:
-                conv.set_side_stream(None)
-            if side is not None:                    # join: everything the side stream was given is done before the scales'
-                torch.cuda.current_stream(self.device).wait_stream(side)   # finish launch and the gradient packing read it
+            sharp_pre, sharp = self.model(frame, event, t, gtex)
+            loss = self.loss(sharp_pre.float(), sharp.float(), target, self.iteration, self.accu_step)
+            loss.backward()
             if book is not None:
                 book.finish()                       # next step's operand scales from this pass's maxima; guard on overflow
         return loss.detach()
-
-    def _wgrad_side_stream(self):
-        """The stream the detail branch's activation-free weight gradients run on (split-precision mode on a GPU; None = off:
-        EBFI_NO_SIDE_WGRAD=1 with EBFI_DEV=1, for same-box A/B runs)."""
-        if self.device.type != "cuda" or self.precision != "bf16x3" or self.bank is None or not self.side_wgrad:
-            return None
-        if self._wside is None:
-            self._wside = torch.cuda.Stream(self.device)
-        return self._wside
 
     def _begin_micro_step(self):
         """Clears the fp16 overflow guard at the start of an accumulation window -- EAGERLY, never inside the captured

@@ -552,8 +552,7 @@ class EVFIAutoEx(BaseModel):
         event_feat = self.ResidualControl(event_feat, ex, T)
         Sharp = self._reconstruct(self.Modification(frame_feat, event_feat))
         if self.DetailEnabled:
-            with conv.side_wgrad_region():          # (its small layers' weight gradients may run beside the backward chain)
-                Final = Sharp + self.Detail(img0=Frame, img1=Sharp)
+            Final = Sharp + self.Detail(img0=Frame, img1=Sharp)
         else:
             Final = Sharp
 

@@ -775,9 +775,11 @@ def test_weight_bank_path_equals_per_call_packing(fix):
             return s.detach().clone(), f.detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters()}, prof
         s0, f0, g0, prof0 = run(None)
         bank = weightbank.build_for(net)
-        assert {k for _, k in bank.sites} == {"id", "conv3d", "convT3d", "rcA", "rcB"}
+        assert {k for _, k in bank.sites} == {"id", "conv3d", "convT3d", "rcA", "rcB", "fuse_d2"}
         s1, f1, g1, prof1 = run(bank)
-        assert torch.equal(s0, s1) and torch.equal(f0, f1)
+        # (not bit-equal since the bank's feature_fuse image sums its 64 input channels in the decoder's memory order,
+        # c*2 + d, where the per-call form sums them in cat(unbind) order: the same products, another fp32 summation order)
+        assert _rel(s1, s0) < 2e-6 and _rel(f1, f0) < 2e-6
         for n in g0:     # (PyTorch's replication / reflection pad backward accumulate with atomics: last-bit run-to-run noise)
             assert _rel(g1[n], g0[n]) < 5e-5, n
         assert prof0["conv_pack_w_bf16"][0] > 50 and "conv_pack_w_bf16" not in prof1 and prof1["pack_table_bf16"][0] == 1
@@ -787,7 +789,7 @@ def test_weight_bank_path_equals_per_call_packing(fix):
         s2, _, _, prof2 = run(bank)
         assert prof2["pack_table_bf16"][0] == 1 and not torch.equal(s2, s1)
         s3, _, _, _ = run(None)
-        assert torch.equal(s2, s3)
+        assert _rel(s2, s3) < 2e-6 and _rel(s2, s1) > 1e-4
     finally:
         conv.set_compute_dtype("fp32")
 
