@@ -180,10 +180,11 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
     const __amdgpu_buffer_rsrc_t rps = make_rsrc(has_rc ? ex.post_scale + (int64_t)b * g.Cout : anyp, has_rc ? (unsigned)g.Cout * 4u : 0u);
     const __amdgpu_buffer_rsrc_t rrs = make_rsrc(has_rc ? ex.post_res + (int64_t)b * ex.post_resC * HWo : anyp,
                                                  has_rc ? (unsigned)ex.post_resC * plane : 0u);
+    const bool has_p16 = has_rc && ex.pre16 != nullptr;        // (inference: scale + residual only, no image of `a`)
     const __amdgpu_buffer_rsrc_t rp16 = __builtin_amdgcn_make_buffer_rsrc(
-        has_rc ? ex.pre16 + (int64_t)b * cb16 * HWo * 16 : const_cast<_Float16 *>(reinterpret_cast<const _Float16 *>(anyp)), 0,
-        has_rc ? (unsigned)cb16 * (unsigned)HWo * 32u : 0u, 0x00020000);
-    const float sp16 = has_rc ? ex.pre_slot[0] : 1.f;
+        has_p16 ? ex.pre16 + (int64_t)b * cb16 * HWo * 16 : const_cast<_Float16 *>(reinterpret_cast<const _Float16 *>(anyp)), 0,
+        has_p16 ? (unsigned)cb16 * (unsigned)HWo * 32u : 0u, 0x00020000);
+    const float sp16 = has_p16 ? ex.pre_slot[0] : 1.f;
     const int res_shift = has_rc ? co_base - co_base % ex.post_resC : 0;       // (channel blocks never straddle post_resC: both multiples of 64)
     float am = 0.f, amp = 0.f;
     const int h = lane >> 5, l31 = lane & 31;
@@ -276,12 +277,14 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
         }
         if constexpr (XRC) {
             if (has_rc) {
-                const unsigned o16 = (px_ok && cblk < cb16) ? ((unsigned)cblk * (unsigned)HWo * 2u + (unsigned)((yo * 2 + h) * g.Wo + xo)) * 16u : SENT;
+                if (has_p16) {
+                    const unsigned o16 = (px_ok && cblk < cb16) ? ((unsigned)cblk * (unsigned)HWo * 2u + (unsigned)((yo * 2 + h) * g.Wo + xo)) * 16u : SENT;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) amp = amax_acc(amp, u[i]);
-                const u32x4_c16 q = c16_gather_halves(pack_f16(u[0] * sp16, u[1] * sp16), pack_f16(u[2] * sp16, u[3] * sp16),
-                                                      pack_f16(u[4] * sp16, u[5] * sp16), pack_f16(u[6] * sp16, u[7] * sp16));
-                __builtin_amdgcn_raw_buffer_store_b128(q, rp16, o16, 0, 0);
+                    for (int i = 0; i < 8; ++i) amp = amax_acc(amp, u[i]);
+                    const u32x4_c16 q = c16_gather_halves(pack_f16(u[0] * sp16, u[1] * sp16), pack_f16(u[2] * sp16, u[3] * sp16),
+                                                          pack_f16(u[4] * sp16, u[5] * sp16), pack_f16(u[6] * sp16, u[7] * sp16));
+                    __builtin_amdgcn_raw_buffer_store_b128(q, rp16, o16, 0, 0);
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) u[i] = u[i] * psc[i] + in.res[i];
             }
@@ -2760,7 +2763,8 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
     // 32 output channels per workgroup when 64 would leave more than half of the CUs without one (small feature maps of the
     // detail branch): twice the workgroups, each with half the matrix work per staged chunk
     // (a requested fp16 side image pins the 64-channel wave-specialised form: its epilogue is the one that writes it)
-    const bool few = x3 && epi.out16 == nullptr && tiles * ceil_div(g.Cout, 64) <= 128 && dev_getenv("EBFI_CONV_NO_MT1") == nullptr;
+    const bool few = x3 && epi.out16 == nullptr && epi.post_scale == nullptr && tiles * ceil_div(g.Cout, 64) <= 128 &&
+                     dev_getenv("EBFI_CONV_NO_MT1") == nullptr;
     const int mt = (g.Cout <= 32 || few) ? 1 : 2;
     dim3 grid((unsigned)tiles, (unsigned)ceil_div(g.Cout, 32 * mt));
     if (x3) {
@@ -2817,8 +2821,9 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
     } while (0)
                 const bool xam = epi.addend != nullptr || epi.mask_y != nullptr, x16 = epi.out16 != nullptr;
                 if (epi.post_scale != nullptr) {
-                    if (xam || !x16) return fail(EBFI_ERR_UNSUPPORTED, "conv2d: the ResidualControl epilogue comes with the output image and without addend / mask");
-                    EBFI_LAUNCH_X3WS(6);
+                    if (xam) return fail(EBFI_ERR_UNSUPPORTED, "conv2d: the ResidualControl epilogue comes without addend / mask");
+                    if (x16) EBFI_LAUNCH_X3WS(6);      // training: + the images of `a` and of the result
+                    else EBFI_LAUNCH_X3WS(4);          // inference: scale + residual only
                 }
                 else if (xam && x16) EBFI_LAUNCH_X3WS(3);
                 else if (x16) EBFI_LAUNCH_X3WS(2);
@@ -3507,12 +3512,14 @@ extern "C" int ebfi_conv2d_packed_x3_rc(const void *input, const void *packed, s
                                         int B, int Cin_per_group, int H, int W, int Cout, int groups, float slope,
                                         const void *post_scale, const void *post_res, int res_channels, void *pre16, void *pre_slot,
                                         void *out16, void *slot16, void *stream) {
-    if (!input || !packed || !post_scale || !post_res || !pre16 || !pre_slot || !out16 || !slot16)
-        return fail(EBFI_ERR_ARG, "conv2d_packed_x3_rc: null argument");
+    if (!input || !packed || !post_scale || !post_res || !output) return fail(EBFI_ERR_ARG, "conv2d_packed_x3_rc: null argument");
+    const bool images = pre16 || pre_slot || out16 || slot16;       // all four (training) or none (inference)
+    if (images && (!pre16 || !pre_slot || !out16 || !slot16))
+        return fail(EBFI_ERR_ARG, "conv2d_packed_x3_rc: the two images come with their slots, or none of the four is given");
     if (groups < 1 || Cout % groups != 0 || (Cout / groups) % 64 != 0 || res_channels < 64 || res_channels % 64 != 0 || Cout % res_channels != 0)
         return fail(EBFI_ERR_ARG, "conv2d_packed_x3_rc: %d output channels in %d groups, residual of %d channels (multiples of 64)", Cout,
                     groups, res_channels);
-    if (!aligned16(pre16) || !aligned16(out16)) return fail(EBFI_ERR_ARG, "conv2d_packed_x3_rc: 16-byte aligned images");
+    if (images && (!aligned16(pre16) || !aligned16(out16))) return fail(EBFI_ERR_ARG, "conv2d_packed_x3_rc: 16-byte aligned images");
     ConvGeom g;
     if (int rc = make_geom(g, B, Cin_per_group, H, W, Cout, 3, 1, 1)) return rc;
     if ((int64_t)groups * (Cin_per_group + 64) * H * W * 4 >= (1LL << 31) - (1LL << 26))

@@ -147,7 +147,10 @@ __device__ __forceinline__ float census_dterm(float dx, float dy) {
 }
 
 // grad_x[b,c,p] = (1/C) * scale * ( sum_k G(p-k, k) - sum_k G(p, k) ),  scale = grad_loss / (49*B*H*W),
-// G(q,k) = [q interior] * census_dterm(gx(q+k) - gx(q), gy(q+k) - gy(q))
+// G(q,k) = [q interior] * census_dterm(gx(q+k) - gx(q), gy(q+k) - gy(q)).
+// census_dterm is odd in (dx, dy) and the 49 taps are symmetric, so the first sum -- this pixel as tap k of the centre p - k --
+// is -sum_k [p+k interior] D(k) with D(k) = census_dterm(gx(p+k) - gx(p), gy(p+k) - gy(p)), the same 49 terms as the second:
+// grad = -scale/C * sum_k D(k) * ([p+k interior] + [p interior]) -- 49 evaluations (two rsqrt and a division each) instead of 98.
 __global__ __launch_bounds__(CT *CT) void census_bwd_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                             const float *__restrict__ grad_loss, float *__restrict__ grad_x,
                                                             int C, int H, int W, float norm) {
@@ -159,19 +162,20 @@ __global__ __launch_bounds__(CT *CT) void census_bwd_kernel(const float *__restr
     const int py = ty0 + ly, px = tx0 + lx;
     if (py >= H || px >= W) return;
     const float cx = gx[ly + CR][lx + CR], cy = gy[ly + CR][lx + CR];
-    const bool self_in = py >= CR && py < H - CR && px >= CR && px < W - CR;
+    const float self_in = (py >= CR && py < H - CR && px >= CR && px < W - CR) ? 1.f : 0.f;
     float acc = 0.f;
 #pragma unroll
-    for (int i = 0; i < 7; ++i)
+    for (int i = 0; i < 7; ++i) {
+        const int qy = py + (i - CR);
+        const bool row_in = qy >= CR && qy < H - CR;
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
-            // this pixel as the tap (i,j) of centre q = p - k, i.e. q = (py - (i-3), px - (j-3))
-            const int qy = py - (i - CR), qx = px - (j - CR);
-            if (qy >= CR && qy < H - CR && qx >= CR && qx < W - CR)
-                acc += census_dterm(cx - gx[ly + 2 * CR - i][lx + 2 * CR - j], cy - gy[ly + 2 * CR - i][lx + 2 * CR - j]);
-            // this pixel as the centre of its own 49 terms
-            if (self_in) acc -= census_dterm(gx[ly + i][lx + j] - cx, gy[ly + i][lx + j] - cy);
+            const int qx = px + (j - CR);
+            const float wgt = self_in + ((row_in && qx >= CR && qx < W - CR) ? 1.f : 0.f);
+            // (a tap outside the image has weight 0 whenever p is not interior, and the staged zero otherwise: as in the forward)
+            acc -= wgt * census_dterm(gx[ly + i][lx + j] - cx, gy[ly + i][lx + j] - cy);
         }
+    }
     const float g = acc * norm * grad_loss[0] / (float)C;
     const int64_t hw = (int64_t)H * W;
     for (int c = 0; c < C; ++c) grad_x[((int64_t)b * C + c) * hw + (int64_t)py * W + px] = g;

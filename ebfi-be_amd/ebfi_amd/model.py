@@ -428,7 +428,7 @@ class UNet3d_18(nn.Module):
         y = self.decoder[4](y, slope)
         ff, oc = self.feature_fuse[0], self.outconv[1]
         from . import weightbank
-        site = weightbank.lookup(ff.weight, "fuse_d2")
+        site = weightbank.lookup(ff.weight, "fuse_d2") if N.dev_env("EBFI_NO_FUSE_D2", "0") != "1" else None
         if site is not None and y.is_contiguous() and conv.site_usable(site, y.reshape(y.shape[0], -1, y.shape[3], y.shape[4])) and \
                 not torch.is_autocast_enabled():
             # cat(unbind(y, 2), 1) is a channel permutation of y's own memory: the 1x1 fuse reads y in place through the bank's

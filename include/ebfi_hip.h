@@ -355,7 +355,9 @@ int ebfi_scale_residual_cat_backward_c16a(const float *grad_out, const void *a16
  * (models/Ours/model_singleframe.py:127-133): a = LeakyReLU(conv3x3(input) + bias); pre16 = c16 image of a (scale / |max| in
  * pre_slot); output[b, co] = a * post_scale[b, co] + post_res[b, co % res_channels] -- the exposure- / time-scaled residual and
  * concatenation `cat(s_ex * a0 + x, s_t * a1 + x)` -- and out16 = c16 image of output.  Replaces the separate
- * ebfi_scale_residual_cat_forward_c16 launch; no fp32 `a` is written.  3x3, same padding, 64-channel blocks, W % 4 == 0. */
+ * ebfi_scale_residual_cat_forward_c16 launch; no fp32 `a` is written.  3x3, same padding, 64-channel blocks, W % 4 == 0.
+ * Inference form: pre16, pre_slot, out16 and slot16 all NULL -- only `output` is written (replaces the launch of
+ * ebfi_scale_residual_cat_forward_ex after the convolution, and the fp32 `a` between them). */
 int ebfi_conv2d_packed_x3_rc(const void *input, const void *packed, size_t packed_bytes, const void *bias, void *output, int B,
                              int Cin_per_group, int H, int W, int Cout, int groups, float slope, const void *post_scale,
                              const void *post_res, int res_channels, void *pre16, void *pre_slot, void *out16, void *slot16,

@@ -572,6 +572,14 @@ def test_residual_control_tail_in_the_convolution_epilogue(B, C, H, W):
     assert torch.equal(c16_out, _ref_image(c_out, 4.0))
     assert torch.equal(a16, _ref_image(a, 8.0))
     assert book.amax(sa_) == a.abs().max().item() and abs(book.amax(sc_) - amax_c) <= 1e-6 * amax_c
+    # inference form (no images): the same fp32 result, nothing else written; a partial set of image arguments is refused
+    c_inf = torch.full_like(a, float("nan"))
+    amax_before = (book.amax(sa_), book.amax(sc_))
+    N.check(lib.ebfi_conv2d_packed_x3_rc(N.ptr(ya), site.fwd_ptr(), site.fwd_bytes, N.ptr(site.bias()), N.ptr(c_inf), B, C, H, W, 2 * C, 2,
+                                         0.01, N.ptr(s_cat), N.ptr(x), C, N.ptr(None), N.ptr(None), N.ptr(None), N.ptr(None), st), "x3_rc (inference)")
+    assert torch.equal(c_inf, c_out) and (book.amax(sa_), book.amax(sc_)) == amax_before
+    assert lib.ebfi_conv2d_packed_x3_rc(N.ptr(ya), site.fwd_ptr(), site.fwd_bytes, N.ptr(site.bias()), N.ptr(c_inf), B, C, H, W, 2 * C, 2,
+                                        0.01, N.ptr(s_cat), N.ptr(x), C, N.ptr(a16), book.ptr(sa_), N.ptr(None), N.ptr(None), st) == -1      # EBFI_ERR_ARG
     # backward stage on the image of a
     gc = torch.randn(B, 2 * C, H, W).cuda() * 1e-2
     sg = book.slot("g")
