@@ -2734,6 +2734,7 @@ __global__ __launch_bounds__(NTWS) void conv_fwd_bf16x3_ws(const float *__restri
 }
 
 #include "conv2d_f16.inc.hpp"
+#include "conv2d_thin.inc.hpp"
 
 size_t bf16_pack_bytes(int M, int K, int ks) { return (size_t)ks * ks * M * (size_t)((K + 15) / 16 * 16) * 2; }
 
@@ -3379,7 +3380,10 @@ extern "C" size_t ebfi_conv2d_backward_weight_workspace(int B, int Cin, int H, i
     (void)dtype;
     ConvGeom g;
     if (make_geom(g, B, Cin, H, W, Cout, ksize, stride, pad) != EBFI_OK) return 0;
-    return (size_t)wgrad_splits(g, ksize, stride) * ((size_t)Cout * Cin * ksize * ksize + Cout) * sizeof(float);
+    int slabs = wgrad_splits(g, ksize, stride);
+    if (g.Wo % 4 == 0 && g.Wo <= 1024 && 256 % (g.Wo / 4) == 0 && thin_wgrad_slabs(g) > slabs)
+        slabs = thin_wgrad_slabs(g);            // (the thin-layer kernels write one slab per sample and row band: conv2d_thin.inc.hpp)
+    return (size_t)slabs * ((size_t)Cout * Cin * ksize * ksize + Cout) * sizeof(float);
 }
 
 // grad_weight[Cout,Cin,k,k] (and grad_bias[Cout] when non-NULL), both fully overwritten, deterministic.
@@ -3423,6 +3427,11 @@ extern "C" int ebfi_conv2d_backward_weight_ex(const void *input, const void *gra
     const float *x = static_cast<const float *>(input), *go = static_cast<const float *>(grad_output);
     const float *yo = static_cast<const float *>(saved_output);
     float *slab = static_cast<float *>(workspace);
+    // layers with <= 6 channels on one side: direct fp32 kernels that stream the thick tensor once (conv2d_thin.inc.hpp), whatever
+    // operand format was asked for (they are exact)
+    if (const ThinPlan tp = thin_wgrad_plan(g, ksize, stride, input, grad_output, saved_output, grad_preact_out); tp.kind != 0)
+        return launch_wgrad_thin(st, tp, x, go, yo, static_cast<float *>(grad_preact_out), slab, g, ksize, act, slope,
+                                 static_cast<float *>(grad_weight), static_cast<float *>(grad_bias));
     int nsplit = wgrad_splits(g, ksize, stride);
     if (x3) nsplit = wgrad_x3_splits(g, ksize);       // never more than the fp32 count the workspace is sized for
     if (bf16mma) {   // half-size channel blocks and short tiles: fewer, longer-lived workgroups (workspace is sized for the fp32 count)
@@ -3737,6 +3746,12 @@ extern "C" int ebfi_conv2d_backward_weight_f16g_ex(const void *input, const void
         return EBFI_OK;
     }
     float *slab = static_cast<float *>(workspace);
+    if (!gp16) {       // thin layers (64 -> 3, 64 -> 1): the direct fp32 kernel, no operand scaling involved
+        if (const ThinPlan tp = thin_wgrad_plan(g, 3, 1, input, grad_output, saved_output, grad_preact_out); tp.kind != 0)
+            return launch_wgrad_thin(st, tp, static_cast<const float *>(input), static_cast<const float *>(grad_output),
+                                     static_cast<const float *>(saved_output), static_cast<float *>(grad_preact_out), slab, g, 3, act, slope,
+                                     static_cast<float *>(grad_weight), static_cast<float *>(grad_bias));
+    }
     int nsplit = wgrad_x3_splits(g, 3);
     // pre-activation gradients on quad-aligned rows: the pixel-major kernel with transposing LDS reads (conv_wgrad_f16_tr)
     // (EBFI_WGRAD_TR=0 keeps the pair-word kernel for A/B runs.  A first in-step measurement had this kernel at 102 us against

@@ -72,6 +72,63 @@ def test_conv_forward_backward_vs_cpu(B, Cin, H, W, Cout, k, s, p, act, has_bias
         assert _rel(bd.grad, br.grad) < 5e-5
 
 
+THIN = [
+    # B, Cin, H, W, Cout, k, s, p, act, bias, kernel role      (>= 64 K output pixels: below that the matrix-core kernels keep the layer)
+    (1, 64, 256, 256, 3, 3, 1, 1, 2, True, "out"),       # last reconstruction conv at full size: Cout = 3, sigmoid
+    (2, 32, 128, 256, 1, 3, 1, 1, 0, True, "out"),       # ExposureDecision's 64 -> 1 (one thin channel, four thick per workgroup)
+    (1, 18, 256, 256, 4, 3, 1, 1, 1, False, "out"),      # 4 thin channels, thick count not a multiple of the block
+    (1, 4, 256, 256, 64, 3, 1, 1, 1, True, "in"),        # ExposureDecision's blur-level conv: Cin = 4
+    (1, 3, 256, 256, 17, 3, 1, 1, 1, True, "in"),        # Cin = 3, odd thick count
+    (1, 1, 256, 512, 16, 3, 1, 1, 0, False, "in"),       # Cin = 1, two workgroup rows per image row
+    (1, 16, 262, 262, 3, 7, 1, 0, 0, True, "out7"),      # detail-branch output conv on the reflection-padded map (ragged rows)
+    (2, 9, 134, 262, 2, 7, 1, 0, 1, False, "out7"),      # ... two thin channels, LeakyReLU, two samples
+    (4, 6, 256, 256, 32, 7, 2, 3, 1, False, "in7s2"),    # detail-branch stem: 7x7 stride 2
+    (4, 3, 256, 256, 64, 3, 2, 1, 1, True, "ins2"),      # FrameFeatExtract: 3x3 stride 2
+    (6, 4, 200, 256, 16, 3, 2, 1, 0, True, "ins2"),      # ragged last band
+]
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,s,p,act,has_bias,role", THIN)
+def test_thin_layer_weight_gradients_vs_cpu(B, Cin, H, W, Cout, k, s, p, act, has_bias, role, mode):
+    """csrc/conv2d_thin.inc.hpp: layers with <= 6 channels on one side take direct fp32 weight-gradient kernels that stream the
+    thick tensor once.  Against torch's CPU autograd at the sizes that select them; the launch is checked to BE the thin kernel,
+    and the by-product grad * act'(out) feeds the data gradient as before."""
+    from ebfi_amd import conv
+    from ebfi_amd import _native as N
+    torch.manual_seed(Cin * 7 + Cout + k + s)
+    x = torch.randn(B, Cin, H, W)
+    w = torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout) * 0.1 if has_bias else None
+    ref = _ref(x, w, b, s, p, act, 0.01)
+    g = torch.randn_like(ref)
+    conv.set_compute_dtype(mode)
+    try:
+        xd, wd = x.cuda().requires_grad_(), w.cuda().requires_grad_()
+        bd = b.cuda().requires_grad_() if has_bias else None
+        out = conv.conv_bias_act(xd, wd, bd, s, p, act, 0.01)
+        N.prof_reset()
+        N.prof_enable(True)
+        out.backward(g.cuda())
+        torch.cuda.synchronize()
+        N.prof_enable(False)
+        prof = N.prof_collect()
+    finally:
+        conv.set_compute_dtype("fp32")
+    assert "conv_wgrad_thin/" + role in prof, sorted(prof)
+    assert _rel(out.detach(), ref) < 2e-5
+    # the gradients of the op AS THE DEVICE EVALUATED IT: act' from the device's own output (a LeakyReLU output within rounding of
+    # zero may carry the other sign than the CPU's: a different, equally valid subgradient -- not what this test is about)
+    y = out.detach().cpu()
+    gp = g * (torch.where(y > 0, 1.0, 0.01) if act == 1 else (y * (1 - y) if act == 2 else torch.ones_like(y)))
+    gw_ref = torch.nn.grad.conv2d_weight(x, w.shape, gp, stride=s, padding=p)
+    gx_ref = torch.nn.grad.conv2d_input(x.shape, w, gp, stride=s, padding=p)
+    assert _rel(wd.grad, gw_ref) < 2e-5
+    if has_bias:
+        assert _rel(bd.grad, gp.sum((0, 2, 3))) < 2e-5
+    assert _rel(xd.grad, gx_ref) < (5e-5 if mode == "fp32" else 2e-4)
+
+
 def test_convlayer_uses_native_kernels_and_matches():
     from ebfi_amd import _native as N
     from ebfi_amd.model import ConvLayer
