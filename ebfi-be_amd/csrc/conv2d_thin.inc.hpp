@@ -1,28 +1,30 @@
-// THIN convolution layers (included by conv2d.hip inside its anonymous namespace, round 5).
+// THIN 3x3 layers: weight gradients as direct fp32 kernels (included by conv2d.hip inside its anonymous namespace, round 5).
 //
-// Seven layers of the model have <= 6 channels on one side at full resolution (B = 8, 256 x 256): the model's first and last
-// convolutions (3 -> 64 stride 2, 64 -> 3), ExposureDecision's (4 -> 64, 64 -> 1) and the detail branch's 7x7 stem / output
-// convolution (6 -> 32 stride 2, 16 -> 3 on the reflection-padded 262 x 262 map).  On the matrix-core kernels they pad the
-// thin side to a 32- or 64-row tile: the weight gradients alone took 70-160 us each for 6-130 MB of operands -- 1/6 of what
-// HBM delivers.  Work per pixel is ~1700 multiply-adds, which the VECTOR pipe does in the time the thick tensor streams in
-// once, so these kernels are direct convolutions in exact fp32 (no operand rounding at all: closer to the reference than the
-// split-precision or fp16 forms they replace):
+// Four 3x3 layers of the model have <= 4 channels on one side at full resolution (B = 8, 256 x 256): the model's first and last
+// convolutions (3 -> 64 stride 2, 64 -> 3) and ExposureDecision's (4 -> 64, 64 -> 1).  On the matrix-core kernels the thin side
+// is padded to a 32- or 64-row tile: their weight gradients took 72-144 us each for 6-130 MB of operands.  Work per pixel is
+// ~1700 multiply-adds, which the vector pipe does while the thick tensor streams in once, so these are direct convolutions in
+// exact fp32 (no operand rounding: closer to the reference than the split-precision / fp16 forms they replace):
 //
-//   weight gradient  gw[co][ci][ky][kx] = sum_{b,y,x} gp[b][co][y][x] * X[b][ci][y S + ky - P][x S + kx - P],  gp = grad * act'(out)
+//   gw[co][ci][ky][kx] = sum_{b,y,x} gp[b][co][y][x] * X[b][ci][y S + ky - 1][x S + kx - 1],   gp = grad * act'(out)
 //
 // A workgroup owns 1-4 channels of the THICK tensor, one sample and a band of output rows; a thread owns ONE COLUMN of quads
-// (4 consecutive output pixels) and walks THIN_RUN output rows down it with the KS input rows it needs in a sliding register
-// window (one new row per output row), keeping the NT x KS x KS partial sums of its channels against all thin channels in
-// registers.  The thick tensor is read once (halo rows of a run twice), the thin one -- a few MB -- from L2.  At the end: wave
-// reduction by lane exchange, the four waves through LDS in a fixed order, one slab per (sample, band) summed by
-// conv_wgrad_reduce_f32 in a fixed order: bit-reproducible like every other weight gradient here.
-//   THIN_OUT: thick = input (Cin), thin = grad_out (Cout <= 4)      THIN_IN: thick = grad_out (Cout), thin = input (Cin <= 6)
-//   KYSPLIT (7x7): ky is a grid dimension -- NT x 7 partial sums per thread instead of NT x 49.
-// Loads go through buffer descriptors (out-of-range rows read 0 = zero padding); rows whose width is a multiple of 4 floats
-// with a 16-byte aligned base are fetched as 16-byte quads aligned on the row, other widths (the 262-wide padded map) dword
-// by dword.
+// (4 consecutive output pixels) and walks THIN_RUN output rows down it with the 3 input rows it needs in a sliding register
+// window (the next step's rows are requested before the current step's products), keeping the NT x 3 x 3 partial sums of its
+// channels against all thin channels in registers.  The thick tensor is read once (halo rows of a run twice), the thin one
+// -- a few MB -- from L2.  At the end: wave sums on the DPP path, the four waves through LDS in a fixed order, one slab per
+// (sample, band) summed by conv_wgrad_reduce_f32 in a fixed order: bit-reproducible like every other weight gradient here.
+//   THIN_OUT: thick = input (Cin), thin = grad_out (Cout <= 4)      THIN_IN: thick = grad_out (Cout), thin = input (Cin <= 4)
+// Measured inside the step (B = 8, 256 x 256, entry point incl. the slab reduction): 64 -> 3  111 -> 79 us, 64 -> 1  103 -> 46,
+// 4 -> 64  144 -> 122, 3 -> 64 stride 2  72 -> 52.  These kernels issue at ~1/6 of the vector pipe's peak (two waves per SIMD,
+// chains of dependent packed FMAs), so there is room left; the first version -- a runtime `switch` on the activation inside
+// the loop, wave sums through ds_bpermute -- was SLOWER than the matrix-core kernels (125 us for 64 -> 3).  The same scheme
+// for the two 7x7 layers (16 -> 3 on the 262-wide padded map with ky as a grid dimension, 6 -> 32 stride 2) measured 192 and
+// 435 us against 159 and 88: dropped, they stay on the matrix cores.
+// Loads go through buffer descriptors (out-of-range rows read 0 = zero padding); rows are whole 16-byte quads (W % 4 == 0,
+// aligned base: launcher), the quad-filling columns come as 16-byte loads and the two ragged end columns as dwords.
 
-constexpr int THIN_RUN = 8;            // output rows a thread walks (one column of quads, input rows kept in a sliding register window)
+constexpr int THIN_RUN = 16;           // output rows a thread walks (one column of quads, input rows kept in a sliding register window)
 
 typedef float f32x4_thin __attribute__((ext_vector_type(4)));
 
@@ -33,53 +35,83 @@ struct ThinGeom {
     int bands, band_rows;               // band_rows = THIN_RUN * (256 / (Wo / 4)) output rows per workgroup
 };
 
-__device__ __forceinline__ float thin_dact(float g, float y, int act, float slope) {
-    if (act == ACT_LEAKY) return y > 0.f ? g : g * slope;
-    if (act == ACT_SIGMOID) return g * y * (1.f - y);
-    return g;
+// grad * act'(y) without a branch per element (a runtime `switch` on the activation compiled to a dozen scalar branches per quad,
+// each with its own s_waitcnt): act' = (c0 + y (c1 + c2 y)) * (y > 0 ? 1 : sl) with
+//   none: c = (1, 0, 0), sl = 1     LeakyReLU: c = (1, 0, 0), sl = slope     sigmoid: c = (0, 1, -1), sl = 1 (y in (0, 1))
+struct ThinAct {
+    float c0, c1, c2, sl;
+};
+__device__ __forceinline__ ThinAct thin_act(int act, float slope) {
+    ThinAct a;
+    const bool sg = act == ACT_SIGMOID;
+    a.c0 = sg ? 0.f : 1.f;
+    a.c1 = sg ? 1.f : 0.f;
+    a.c2 = sg ? -1.f : 0.f;
+    a.sl = act == ACT_LEAKY ? slope : 1.f;
+    return a;
+}
+__device__ __forceinline__ float thin_dact(float g, float y, const ThinAct &a) {
+    const float m = fmaf(y, fmaf(y, a.c2, a.c1), a.c0);
+    return g * m * (y > 0.f ? 1.f : a.sl);
 }
 
-// NG4 quads of one input row starting at column c0a (a multiple of 4, possibly negative): v[4 * q + e] = X[row][c0a + 4 q + e],
-// 0 outside the image.  ALIGNED: every quad lies wholly inside or outside [0, W) (W % 4 == 0) and is one 16-byte load.
-template <int NG4, bool ALIGNED>
-__device__ __forceinline__ void thin_load_row(const __amdgpu_buffer_rsrc_t r, unsigned chan_off, int row, int c0a, int H, int W,
-                                              float (&v)[NG4 * 4]) {
-    const bool row_ok = row >= 0 && row < H;
-    const unsigned rbase = chan_off + (unsigned)(row_ok ? row : 0) * (unsigned)W * 4u;
-    if constexpr (ALIGNED) {
-#pragma unroll
-        for (int q = 0; q < NG4; ++q) {
-            const int c = c0a + 4 * q;
-            const unsigned off = sel_off(row_ok && c >= 0 && c < W, rbase + (unsigned)c * 4u);
+// The NV = 3 S + KS input columns a quad of output pixels needs from one input row: v[i] = X[row][c0a + OFF + i], 0 outside the
+// image.  c0a is a multiple of 4 (possibly negative).  ALIGNED (W % 4 == 0, 16-byte aligned rows): the columns that fill whole
+// quads of the row come as 16-byte loads (a quad lies wholly inside or outside [0, W)), the ragged ends dword by dword.
+template <int I, int NV, int OFF, bool ALIGNED>
+__device__ __forceinline__ void thin_load_cols(const __amdgpu_buffer_rsrc_t r, unsigned rbase, bool row_ok, int c0a, int W, float (&v)[NV]) {
+    if constexpr (I < NV) {                     // (compile-time recursion: v[] must keep constant indices to stay in registers)
+        const int c = c0a + OFF + I;
+        const unsigned off = sel_off(row_ok && c >= 0 && c < W, rbase + (unsigned)c * 4u);
+        if constexpr (ALIGNED && (OFF + I) % 4 == 0 && I + 4 <= NV) {
             const f32x4_thin t = __builtin_bit_cast(f32x4_thin, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
-            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < NG4 * 4; ++e) {
-            const int c = c0a + e;
-            v[e] = buf_ld(r, sel_off(row_ok && c >= 0 && c < W, rbase + (unsigned)c * 4u));
+            v[I] = t.x; v[I + 1] = t.y; v[I + 2] = t.z; v[I + 3] = t.w;
+            thin_load_cols<I + 4, NV, OFF, ALIGNED>(r, rbase, row_ok, c0a, W, v);
+        } else {
+            v[I] = buf_ld(r, off);
+            thin_load_cols<I + 1, NV, OFF, ALIGNED>(r, rbase, row_ok, c0a, W, v);
         }
     }
 }
+template <int NV, int OFF, bool ALIGNED>
+__device__ __forceinline__ void thin_load_row(const __amdgpu_buffer_rsrc_t r, unsigned chan_off, int row, int c0a, int H, int W,
+                                              float (&v)[NV]) {
+    const bool row_ok = row >= 0 && row < H;
+    const unsigned rbase = chan_off + (unsigned)(row_ok ? row : 0) * (unsigned)W * 4u;
+    thin_load_cols<0, NV, OFF, ALIGNED>(r, rbase, row_ok, c0a, W, v);
+}
 
-// sum over the 64 lanes (every lane gets it), fixed exchange order
+// Sum over the 64 lanes as a wave-uniform value, in a fixed order, on the VALU's data-parallel-primitive path: an inclusive scan
+// along each row of 16 lanes (row_shr 1, 2, 4, 8), then row_bcast15 / row_bcast31 carry the row totals up; lane 63 holds the sum.
+// (The first version went through __shfl_xor = ds_bpermute: six LDS round trips with an s_waitcnt each per value, and with
+// 50-80 partial sums per thread the reduction took as long as the eight rows of products before it.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float thin_dpp_add(float v) {
+    const int sh = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
+    return v + __int_as_float(sh);
+}
 __device__ __forceinline__ float thin_wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = thin_dpp_add<0x111, 0xf>(v);           // row_shr:1
+    v = thin_dpp_add<0x112, 0xf>(v);           // row_shr:2
+    v = thin_dpp_add<0x114, 0xf>(v);           // row_shr:4
+    v = thin_dpp_add<0x118, 0xf>(v);           // row_shr:8  -> lane 15 of every row: the row's sum
+    v = thin_dpp_add<0x142, 0xa>(v);           // row_bcast:15 into rows 1 and 3
+    v = thin_dpp_add<0x143, 0xc>(v);           // row_bcast:31 into rows 2 and 3 -> lane 63: the wave's sum
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // KS x KS taps, stride S, padding P; NT thin channels (template: register arrays); NTH thick channels per workgroup.
-template <int KS, int S, int P, int NT, int NTH, bool THIN_OUT, bool KYSPLIT, bool ALIGNED>
+template <int S, int NT, int NTH, bool THIN_OUT>
 __global__ __launch_bounds__(256) void conv_wgrad_thin(const float *__restrict__ x, const float *__restrict__ gout,
                                                        const float *__restrict__ yact, float *__restrict__ gpre_out,
                                                        float *__restrict__ slab, ThinGeom g) {
-    constexpr int KYN = KYSPLIT ? 1 : KS;                       // ky handled by one workgroup
+    constexpr int KS = 3, P = 1;                                // 3x3 taps, padding 1 (the 7x7 layers stay on the matrix cores: see the header)
+    constexpr int KYN = KS;
+    constexpr bool ALIGNED = true;                              // rows are whole 16-byte quads (the launcher checks)
     constexpr int NKEEP = KYN > S ? KYN - S : 0;                // window rows that survive a step to the next output row
     constexpr int PA = (P + 3) / 4 * 4;                         // the row window starts PA columns left of the quad's first input column
     constexpr int OFF = PA - P;                                 // window index of tap kx = 0 of output pixel j = 0
-    constexpr int NG4 = (OFF + 3 * S + KS + 3) / 4;             // quads per row window
+    constexpr int NV = 3 * S + KS;                              // input columns a quad of output pixels touches in one row
     constexpr int NXC = THIN_OUT ? NTH : NT;                    // input channels this workgroup reads
     constexpr int NGP = THIN_OUT ? NT : NTH;                    // grad_out channels this workgroup reads
     constexpr int NACC = NTH * NT * KYN * KS;
@@ -88,8 +120,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin(const float *__restrict__
     const int thick = THIN_OUT ? g.Cin : g.Cout;
     const int nblk = (thick + NTH - 1) / NTH;
     int t = blockIdx.x;
-    int ky0 = 0;
-    if constexpr (KYSPLIT) { ky0 = t % KS; t /= KS; }
     const int cblk = t % nblk; t /= nblk;
     const int band = t % g.bands;
     const int b = t / g.bands;
@@ -97,11 +127,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin(const float *__restrict__
     const int HW = g.H * g.W, HWo = g.Ho * g.Wo;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (int64_t)b * g.Cin * HW, (unsigned)g.Cin * (unsigned)HW * 4u);
     const __amdgpu_buffer_rsrc_t rg = make_rsrc(gout + (int64_t)b * g.Cout * HWo, (unsigned)g.Cout * (unsigned)HWo * 4u);
-    const __amdgpu_buffer_rsrc_t ry = make_rsrc(yact ? yact + (int64_t)b * g.Cout * HWo : gout, yact ? (unsigned)g.Cout * (unsigned)HWo * 4u : 0u);
+    const bool has_y = yact != nullptr && g.act != ACT_NONE;
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(has_y ? yact + (int64_t)b * g.Cout * HWo : gout, has_y ? (unsigned)g.Cout * (unsigned)HWo * 4u : 0u);
     float *gp_out = gpre_out ? gpre_out + (int64_t)b * g.Cout * HWo : nullptr;
     // THIN_OUT: every workgroup needs gp of the NT output channels; the one with thick channel 0 (and ky 0) writes it out and
     // owns the bias sums.  THIN_IN: a workgroup's gp rows are its own thick channels: it writes them (ky 0) and sums its bias.
-    const bool owner = (KYSPLIT ? ky0 == 0 : true) && (THIN_OUT ? c0 == 0 : true);
+    const bool owner = (THIN_OUT ? c0 == 0 : true);
 
     float acc[NTH][NT][KYN][KS];
     float bsum[NGP];
@@ -129,42 +160,49 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin(const float *__restrict__
         const int cin = THIN_OUT ? c0 + ci : ci;
         xch[ci] = cin < g.Cin ? (unsigned)cin * (unsigned)HW * 4u : SENT;
     }
-    float xw[NXC][KYN][NG4 * 4];
-    // the window as it would be one output row earlier: its rows S .. KYN-1 are rows 0 .. KYN-S-1 of the first output row
-    if constexpr (NKEEP > 0) {
-        if (y_begin < y_end) {
-#pragma unroll
-            for (int ci = 0; ci < NXC; ++ci)
-#pragma unroll
-                for (int k = S; k < KYN; ++k) thin_load_row<NG4, ALIGNED>(rx, xch[ci], (y_begin - 1) * S + k - P, c0a, g.H, g.W, xw[ci][k]);
-        }
-    }
-    for (int yo = y_begin; yo < y_end; ++yo) {
-        // ---- input rows: shift the window by S rows, fetch the new ones
-#pragma unroll
-        for (int ci = 0; ci < NXC; ++ci) {
-#pragma unroll
-            for (int k = 0; k < NKEEP; ++k)
-#pragma unroll
-                for (int e = 0; e < NG4 * 4; ++e) xw[ci][k][e] = xw[ci][k + S][e];
-#pragma unroll
-            for (int k = NKEEP; k < KYN; ++k)
-                thin_load_row<NG4, ALIGNED>(rx, xch[ci], yo * S + (KYSPLIT ? ky0 : k) - P, c0a, g.H, g.W, xw[ci][k]);
-        }
-        // ---- gp of this quad: NT channels (THIN_OUT) or the NTH thick channels (THIN_IN)
-        float gp[NGP][4];
+    float xw[NXC][KYN][NV];
+    const ThinAct da = thin_act(g.act, g.slope);
+    // first output row: its whole window, grad_out and (for act') the saved output
+    auto load_g = [&](int yo, f32x4_thin (&gq)[NGP], f32x4_thin (&yq)[NGP]) {
 #pragma unroll
         for (int n = 0; n < NGP; ++n) {
             const int co = THIN_OUT ? n : c0 + n;
-            const unsigned off = sel_off(co < g.Cout, ((unsigned)co * (unsigned)HWo + (unsigned)(yo * g.Wo + xo)) * 4u);
-            const f32x4_thin gv = __builtin_bit_cast(f32x4_thin, __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0));
-            f32x4_thin yv = {0.f, 0.f, 0.f, 0.f};
-            if (g.act != ACT_NONE) yv = __builtin_bit_cast(f32x4_thin, __builtin_amdgcn_raw_buffer_load_b128(ry, off, 0, 0));
-            gp[n][0] = thin_dact(gv.x, yv.x, g.act, g.slope);
-            gp[n][1] = thin_dact(gv.y, yv.y, g.act, g.slope);
-            gp[n][2] = thin_dact(gv.z, yv.z, g.act, g.slope);
-            gp[n][3] = thin_dact(gv.w, yv.w, g.act, g.slope);
-            if (owner) {
+            const unsigned off = sel_off(co < g.Cout && yo < g.Ho, ((unsigned)co * (unsigned)HWo + (unsigned)(yo * g.Wo + xo)) * 4u);
+            gq[n] = __builtin_bit_cast(f32x4_thin, __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0));
+            yq[n] = __builtin_bit_cast(f32x4_thin, __builtin_amdgcn_raw_buffer_load_b128(ry, off, 0, 0));   // (no activation: empty descriptor, reads 0)
+        }
+    };
+    f32x4_thin gv[NGP], yv[NGP];
+#pragma unroll
+    for (int ci = 0; ci < NXC; ++ci)
+#pragma unroll
+        for (int k = 0; k < KYN; ++k)
+            thin_load_row<NV, OFF, ALIGNED>(rx, xch[ci], y_begin * S + k - P, c0a, g.H, g.W, xw[ci][k]);
+    load_g(y_begin, gv, yv);
+    constexpr int SN = KYN - NKEEP;                             // input rows that are new in every step
+    for (int yo = y_begin; yo < y_end; ++yo) {
+        // ---- the NEXT step's loads go out before this step's products: at two waves per SIMD nothing else hides the memory
+        // latency (a step is ~200 instructions)
+        float xn[NXC][SN][NV];
+        f32x4_thin gn[NGP], yn[NGP];
+#pragma unroll
+        for (int ci = 0; ci < NXC; ++ci)
+#pragma unroll
+            for (int k = 0; k < SN; ++k)
+                thin_load_row<NV, OFF, ALIGNED>(rx, xch[ci], (yo + 1) * S + (NKEEP + k) - P, c0a, g.H, g.W, xn[ci][k]);
+        load_g(yo + 1, gn, yn);
+        float gp[NGP][4];
+#pragma unroll
+        for (int n = 0; n < NGP; ++n) {
+            gp[n][0] = thin_dact(gv[n].x, yv[n].x, da);
+            gp[n][1] = thin_dact(gv[n].y, yv[n].y, da);
+            gp[n][2] = thin_dact(gv[n].z, yv[n].z, da);
+            gp[n][3] = thin_dact(gv[n].w, yv[n].w, da);
+        }
+        if (owner) {
+#pragma unroll
+            for (int n = 0; n < NGP; ++n) {
+                const int co = THIN_OUT ? n : c0 + n;
                 bsum[n] += (gp[n][0] + gp[n][1]) + (gp[n][2] + gp[n][3]);
                 if (gp_out != nullptr && co < g.Cout) {
                     const f32x4_thin o = {gp[n][0], gp[n][1], gp[n][2], gp[n][3]};
@@ -172,33 +210,47 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin(const float *__restrict__
                 }
             }
         }
-        // ---- the products
+        // ---- the products (pixel j outermost: consecutive multiply-adds go to different partial sums -- written sum by sum, the
+        // compiler emitted chains of 3-4 dependent packed FMAs)
 #pragma unroll
-        for (int k = 0; k < KYN; ++k)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int ci = 0; ci < NXC; ++ci)
+            for (int k = 0; k < KYN; ++k)
 #pragma unroll
-                for (int kx = 0; kx < KS; ++kx) {
-                    if constexpr (THIN_OUT) {
+                for (int ci = 0; ci < NXC; ++ci)
 #pragma unroll
-                        for (int n = 0; n < NT; ++n) {
-                            float s = acc[ci][n][k][kx];
+                    for (int kx = 0; kx < KS; ++kx) {
+                        const float xv = xw[ci][k][kx + j * S];
+                        if constexpr (THIN_OUT) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) s = fmaf(gp[n][j], xw[ci][k][OFF + kx + j * S], s);
-                            acc[ci][n][k][kx] = s;
-                        }
-                    } else {
+                            for (int n = 0; n < NT; ++n) acc[ci][n][k][kx] = fmaf(gp[n][j], xv, acc[ci][n][k][kx]);
+                        } else {
 #pragma unroll
-                        for (int a = 0; a < NTH; ++a) {
-                            float s = acc[a][ci][k][kx];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) s = fmaf(gp[a][j], xw[ci][k][OFF + kx + j * S], s);
-                            acc[a][ci][k][kx] = s;
+                            for (int a = 0; a < NTH; ++a) acc[a][ci][k][kx] = fmaf(gp[a][j], xv, acc[a][ci][k][kx]);
                         }
                     }
-                }
+        // ---- the window moves down by S rows (register copies: ~1/8 of the step's instructions; a rotating window unrolled over
+        // its period kept every slot live across the steps and cost more registers than it saved instructions)
+#pragma unroll
+        for (int ci = 0; ci < NXC; ++ci) {
+#pragma unroll
+            for (int k = 0; k < NKEEP; ++k)
+#pragma unroll
+                for (int e = 0; e < NV; ++e) xw[ci][k][e] = xw[ci][k + S][e];
+#pragma unroll
+            for (int k = 0; k < SN; ++k)
+#pragma unroll
+                for (int e = 0; e < NV; ++e) xw[ci][NKEEP + k][e] = xn[ci][k][e];
+        }
+#pragma unroll
+        for (int n = 0; n < NGP; ++n) { gv[n] = gn[n]; yv[n] = yn[n]; }
     }
-    // ---- reduction: lanes, then the four waves in a fixed order, then this workgroup's part of slab (b, band)
+    // ---- reduction: lanes (wave-uniform sums, value i parked in lane i % 64), then the four waves in a fixed order, then this
+    // workgroup's part of slab (b, band)
+    constexpr int NRED = NACC + NGP;
+    float park[(NRED + 63) / 64];
+#pragma unroll
+    for (int i = 0; i < (NRED + 63) / 64; ++i) park[i] = 0.f;
 #pragma unroll
     for (int a = 0; a < NTH; ++a)
 #pragma unroll
@@ -207,14 +259,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin(const float *__restrict__
             for (int k = 0; k < KYN; ++k)
 #pragma unroll
                 for (int q = 0; q < KS; ++q) {
+                    const int i = ((a * NT + n) * KYN + k) * KS + q;
                     const float s = thin_wave_sum(acc[a][n][k][q]);
-                    if (lane == 0) red[wave][((a * NT + n) * KYN + k) * KS + q] = s;
+                    park[i / 64] = lane == (i & 63) ? s : park[i / 64];
                 }
 #pragma unroll
     for (int a = 0; a < NGP; ++a) {
+        const int i = NACC + a;
         const float s = thin_wave_sum(bsum[a]);
-        if (lane == 0) red[wave][NACC + a] = s;
+        park[i / 64] = lane == (i & 63) ? s : park[i / 64];
     }
+#pragma unroll
+    for (int i = 0; i < (NRED + 63) / 64; ++i)
+        if (i * 64 + lane < NRED) red[wave][i * 64 + lane] = park[i];
     __syncthreads();
     const int64_t n_weight = (int64_t)g.Cout * g.Cin * KS * KS, n_total = n_weight + g.Cout;
     float *my = slab + (int64_t)(b * g.bands + band) * n_total;
@@ -225,7 +282,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin(const float *__restrict__
         const int k = r % KYN; r /= KYN;
         const int n = r % NT; r /= NT;
         const int a = r;
-        const int ky = KYSPLIT ? ky0 : k;
+        const int ky = k;
         const int co = THIN_OUT ? n : c0 + a, ci = THIN_OUT ? c0 + a : n;
         if (co < g.Cout && ci < g.Cin) my[(((int64_t)co * g.Cin + ci) * KS + ky) * KS + kx] = s;
     }
@@ -239,7 +296,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin(const float *__restrict__
 
 // Which shapes the thin weight gradient serves (everything else keeps the matrix-core kernels)
 struct ThinPlan {
-    int kind;      // 0 = none; 1 = thin out 3x3 s1 p1; 2 = thin in 3x3 s1 p1; 3 = thin out 7x7 s1 p0; 4 = thin in 7x7 s2 p3; 5 = thin in 3x3 s2 p1
+    int kind;      // 0 = none; 1 = thin out 3x3 s1 p1; 2 = thin in 3x3 s1 p1; 5 = thin in 3x3 s2 p1
     int nt;        // thin channels (register array size of the instance)
     bool aligned;
 };
@@ -257,29 +314,24 @@ inline ThinPlan thin_wgrad_plan(const ConvGeom &g, int ks, int stride, const voi
     if (ks == 3 && stride == 1 && g.pad == 1) {
         if (g.Cout <= 4 && g.Cin >= 16) { p.kind = 1; p.nt = g.Cout <= 1 ? 1 : (g.Cout <= 3 ? 3 : 4); }
         else if (g.Cin <= 4 && g.Cout >= 16) { p.kind = 2; p.nt = g.Cin <= 1 ? 1 : (g.Cin <= 3 ? 3 : 4); }
-    } else if (ks == 7 && stride == 1 && g.pad == 0 && g.Cout <= 3 && g.Cin >= 8) {
-        p.kind = 3; p.nt = 3;
-    } else if (ks == 7 && stride == 2 && g.pad == 3 && g.Cin <= 6 && g.Cout >= 16) {
-        p.kind = 4; p.nt = 6;
     } else if (ks == 3 && stride == 2 && g.pad == 1 && g.Cin <= 4 && g.Cout >= 16) {
         p.kind = 5; p.nt = g.Cin <= 3 ? 3 : 4;
     }
-    if (p.kind == 0) return p;
-    if (!p.aligned && p.kind != 3) p.kind = 0;          // (only the 7x7 output convolution's padded map has ragged rows)
+    if (!p.aligned) p.kind = 0;
     return p;
 }
 
 inline int thin_band_rows(const ConvGeom &g) { return THIN_RUN * (256 / (g.Wo / 4)); }
 inline int thin_wgrad_slabs(const ConvGeom &g) { return g.B * (int)ceil_div(g.Ho, thin_band_rows(g)); }
 
-template <int KS, int S, int P, int NT, int NTH, bool THIN_OUT, bool KYSPLIT, bool ALIGNED>
+template <int S, int NT, int NTH, bool THIN_OUT>
 int launch_wgrad_thin_i(hipStream_t st, const float *x, const float *go, const float *y, float *gp, float *slab, const ThinGeom &tg,
                         const char *label, double flops, double bytes) {
     const int thick = THIN_OUT ? tg.Cin : tg.Cout;
-    const int64_t wgs = (int64_t)tg.B * tg.bands * ceil_div(thick, NTH) * (KYSPLIT ? KS : 1);
+    const int64_t wgs = (int64_t)tg.B * tg.bands * ceil_div(thick, NTH);
     if (wgs > 2147483647LL) return fail(EBFI_ERR_ARG, "conv2d_backward_weight (thin): too many workgroups");
     ProfScope ps(label, st, flops, bytes);
-    hipLaunchKernelGGL((conv_wgrad_thin<KS, S, P, NT, NTH, THIN_OUT, KYSPLIT, ALIGNED>), dim3((unsigned)wgs), dim3(256), 0, st, x, go, y,
+    hipLaunchKernelGGL((conv_wgrad_thin<S, NT, NTH, THIN_OUT>), dim3((unsigned)wgs), dim3(256), 0, st, x, go, y,
                        gp, slab, tg);
     return check_launch(label);
 }
@@ -293,25 +345,18 @@ int launch_wgrad_thin(hipStream_t st, const ThinPlan &p, const float *x, const f
     int rc = EBFI_ERR_UNSUPPORTED;
     switch (p.kind) {
     case 1:
-        if (p.nt == 1) rc = launch_wgrad_thin_i<3, 1, 1, 1, 4, true, false, true>(st, x, go, y, gp, slab, tg, "conv_wgrad_thin/out", flops, bytes);
-        else if (p.nt == 3) rc = launch_wgrad_thin_i<3, 1, 1, 3, 2, true, false, true>(st, x, go, y, gp, slab, tg, "conv_wgrad_thin/out", flops, bytes);
-        else rc = launch_wgrad_thin_i<3, 1, 1, 4, 2, true, false, true>(st, x, go, y, gp, slab, tg, "conv_wgrad_thin/out", flops, bytes);
+        if (p.nt == 1) rc = launch_wgrad_thin_i<1, 1, 4, true>(st, x, go, y, gp, slab, tg, "conv_wgrad_thin/out", flops, bytes);
+        else if (p.nt == 3) rc = launch_wgrad_thin_i<1, 3, 2, true>(st, x, go, y, gp, slab, tg, "conv_wgrad_thin/out", flops, bytes);
+        else rc = launch_wgrad_thin_i<1, 4, 2, true>(st, x, go, y, gp, slab, tg, "conv_wgrad_thin/out", flops, bytes);
         break;
     case 2:
-        if (p.nt == 1) rc = launch_wgrad_thin_i<3, 1, 1, 1, 4, false, false, true>(st, x, go, y, gp, slab, tg, "conv_wgrad_thin/in", flops, bytes);
-        else if (p.nt == 3) rc = launch_wgrad_thin_i<3, 1, 1, 3, 2, false, false, true>(st, x, go, y, gp, slab, tg, "conv_wgrad_thin/in", flops, bytes);
-        else rc = launch_wgrad_thin_i<3, 1, 1, 4, 2, false, false, true>(st, x, go, y, gp, slab, tg, "conv_wgrad_thin/in", flops, bytes);
-        break;
-    case 3:
-        // (Wo = W - 6 and Wo % 4 == 0 leave W % 4 == 2: the rows of this layer's input are never quad-aligned -- dword loads)
-        rc = launch_wgrad_thin_i<7, 1, 0, 3, 1, true, true, false>(st, x, go, y, gp, slab, tg, "conv_wgrad_thin/out7", flops, bytes);
-        break;
-    case 4:
-        rc = launch_wgrad_thin_i<7, 2, 3, 6, 2, false, true, true>(st, x, go, y, gp, slab, tg, "conv_wgrad_thin/in7s2", flops, bytes);
+        if (p.nt == 1) rc = launch_wgrad_thin_i<1, 1, 4, false>(st, x, go, y, gp, slab, tg, "conv_wgrad_thin/in", flops, bytes);
+        else if (p.nt == 3) rc = launch_wgrad_thin_i<1, 3, 2, false>(st, x, go, y, gp, slab, tg, "conv_wgrad_thin/in", flops, bytes);
+        else rc = launch_wgrad_thin_i<1, 4, 1, false>(st, x, go, y, gp, slab, tg, "conv_wgrad_thin/in", flops, bytes);
         break;
     case 5:
-        if (p.nt == 3) rc = launch_wgrad_thin_i<3, 2, 1, 3, 2, false, false, true>(st, x, go, y, gp, slab, tg, "conv_wgrad_thin/ins2", flops, bytes);
-        else rc = launch_wgrad_thin_i<3, 2, 1, 4, 2, false, false, true>(st, x, go, y, gp, slab, tg, "conv_wgrad_thin/ins2", flops, bytes);
+        if (p.nt == 3) rc = launch_wgrad_thin_i<2, 3, 1, false>(st, x, go, y, gp, slab, tg, "conv_wgrad_thin/ins2", flops, bytes);
+        else rc = launch_wgrad_thin_i<2, 4, 1, false>(st, x, go, y, gp, slab, tg, "conv_wgrad_thin/ins2", flops, bytes);
         break;
     default:
         return fail(EBFI_ERR_UNSUPPORTED, "conv2d_backward_weight (thin): no kernel for this shape");
