@@ -2171,36 +2171,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16(const float *__restric
 // instead of hi = bf16(v); negative: structural zero).  The host lays the entries out as the conv kernels expect them
 // ([hi image | lo image] per weight, forward and transposed layouts, channel padding, folded 3-D kernels, concatenated
 // convolutions): ebfi_amd/weightbank.py.
-// (four consecutive elements per thread: one 16-byte table load, four gathers in flight, one 8-byte store -- the first form, an
-// element per thread with 2-byte stores, ran at 2.8 TB/s of its 10 bytes per element)
 __global__ __launch_bounds__(256) void pack_table_bf16_kernel(const float *__restrict__ src, const int32_t *__restrict__ table,
                                                               int64_t n, __bf16 *__restrict__ out) {
-    const int64_t e0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (e0 >= n) return;
-    auto one = [&](int32_t t) -> __bf16 {
-        float v = 0.f;
-        if (t >= 0) v = src[t & 0x3fffffff];
-        const __bf16 h = (__bf16)v;
-        return (t >= 0 && (t & 0x40000000)) ? (__bf16)(v - (float)h) : h;
-    };
-    if (e0 + 3 < n) {
-        typedef int i32x4_pk __attribute__((ext_vector_type(4)));
-        typedef __bf16 bf16x4_pk __attribute__((ext_vector_type(4)));
-        const i32x4_pk t = *reinterpret_cast<const i32x4_pk *>(table + e0);
-        float v[4];
-        const int32_t tt[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = tt[i] >= 0 ? src[tt[i] & 0x3fffffff] : 0.f;
-        bf16x4_pk o;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const __bf16 h = (__bf16)v[i];
-            o[i] = (tt[i] >= 0 && (tt[i] & 0x40000000)) ? (__bf16)(v[i] - (float)h) : h;
-        }
-        *reinterpret_cast<bf16x4_pk *>(out + e0) = o;
-    } else {
-        for (int64_t e = e0; e < n; ++e) out[e] = one(table[e]);
-    }
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int32_t t = table[e];
+    float v = 0.f;
+    if (t >= 0) v = src[t & 0x3fffffff];
+    const __bf16 h = (__bf16)v;
+    out[e] = (t >= 0 && (t & 0x40000000)) ? (__bf16)(v - (float)h) : h;
 }
 
 // 64 consecutive elements per workgroup, 4 thread rows each summing every 4th slab (4 loads in
@@ -3280,9 +3259,7 @@ extern "C" int ebfi_pack_table_bf16(const float *src, const int32_t *table, int6
     if (n == 0) return EBFI_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     ProfScope ps("pack_table_bf16", st, 0.0, 10.0 * (double)n);
-    if ((reinterpret_cast<uintptr_t>(table) & 15u) || (reinterpret_cast<uintptr_t>(out) & 7u))
-        return fail(EBFI_ERR_ARG, "pack_table_bf16: table must be 16-byte aligned, out 8-byte aligned");
-    hipLaunchKernelGGL(pack_table_bf16_kernel, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, st, src, table, n,
+    hipLaunchKernelGGL(pack_table_bf16_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, src, table, n,
                        static_cast<__bf16 *>(out));
     return check_launch("pack_table_bf16");
 }
@@ -3998,9 +3975,7 @@ extern "C" int ebfi_pack_table_f16(const float *src, const int32_t *table, int64
     if (n <= 0) return EBFI_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     ProfScope ps("pack_table_f16", st);
-    if ((reinterpret_cast<uintptr_t>(table) & 15u) || (reinterpret_cast<uintptr_t>(out) & 7u))
-        return fail(EBFI_ERR_ARG, "pack_table_f16: table must be 16-byte aligned, out 8-byte aligned");
-    hipLaunchKernelGGL(pack_table_f16_kernel, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, st, src, table, n,
+    hipLaunchKernelGGL(pack_table_f16_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, src, table, n,
                        static_cast<_Float16 *>(out), block_slot, static_cast<float *>(slots));
     return check_launch("pack_table_f16");
 }

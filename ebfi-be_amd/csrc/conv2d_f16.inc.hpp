@@ -721,38 +721,18 @@ __global__ __launch_bounds__(256) void f16_scales_finish_kernel(float *__restric
 // fp16 images from an index table (the bf16 pack launch's table format, hi entries only): packed[e] = fp16(src[table[e]] *
 // scale(slot of e)), 0 for table[e] < 0.  Every site's image starts on a 256-element boundary, so a workgroup lies inside one
 // image: block_slot[blockIdx.x] names its scale slot; |max| of the source values is recorded there (one atomic per wave).
-// (four consecutive elements per thread -- a wave = one 256-element block = one slot: block_slot[4 * blockIdx.x + wave])
 __global__ __launch_bounds__(256) void pack_table_f16_kernel(const float *__restrict__ src, const int32_t *__restrict__ table,
                                                              int64_t n, _Float16 *__restrict__ out,
                                                              const int32_t *__restrict__ block_slot, float *__restrict__ slots) {
     saturate_fp16_conversions();
-    const int64_t e0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (blk * 256 >= n) return;                // (whole wave)
-    float *slot = slots + (int64_t)SLOT_STRIDE * block_slot[blk];
-    const float sc = slot[0];
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (e0 + 3 < n) {
-        typedef int i32x4_pk __attribute__((ext_vector_type(4)));
-        typedef _Float16 f16x4_pk __attribute__((ext_vector_type(4)));
-        const i32x4_pk t = *reinterpret_cast<const i32x4_pk *>(table + e0);
-        const int32_t tt[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = tt[i] >= 0 ? src[tt[i] & 0x3fffffff] : 0.f;
-        f16x4_pk o;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = (_Float16)(v[i] * sc);
-        *reinterpret_cast<f16x4_pk *>(out + e0) = o;
-    } else {
-        for (int i = 0; i < 4 && e0 + i < n; ++i) {
-            const int32_t t = table[e0 + i];
-            v[i] = t >= 0 ? src[t & 0x3fffffff] : 0.f;
-            out[e0 + i] = (_Float16)(v[i] * sc);
-        }
-    }
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float *slot = slots + (int64_t)SLOT_STRIDE * block_slot[blockIdx.x];
+    const int32_t t = e < n ? table[e] : -1;
+    const float v = t >= 0 ? src[t & 0x3fffffff] : 0.f;
+    if (e < n) out[e] = (_Float16)(v * slot[0]);
     // |max| over the wave on the float BITS (non-negative floats order like unsigned integers, and a NaN weight -- which
     // fmaxf would drop -- stays the largest value and reaches the slot: the finish launch then raises the guard)
-    unsigned m = max(max(__float_as_uint(fabsf(v[0])), __float_as_uint(fabsf(v[1]))), max(__float_as_uint(fabsf(v[2])), __float_as_uint(fabsf(v[3]))));
+    unsigned m = __float_as_uint(fabsf(v));
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d, 64));
     if ((threadIdx.x & 63) == 0 && !(__uint_as_float(m) <= fmaxf(__builtin_nontemporal_load(slot + SLOT_AMAX), slot[SLOT_FLOOR])))

@@ -230,7 +230,10 @@ int ebfi_pack_table_bf16(const float *src, const int32_t *table, int64_t n, void
  *   addend      [B,Cout,Ho,Wo] added before the activation (NULL: none)
  *   mask_y      [B,Cout,Ho,Wo]: the result is multiplied by act'(mask_y) for activation mask_act / mask_slope (NULL: none)
  * out = act(conv(input) + bias + addend) * act'(mask_y); stride 1.  With transposed images it is the data gradient of a
- * layer; addend + mask then turn its output into the PRE-activation gradient of the layer below. */
+ * layer; addend + mask then turn its output into the PRE-activation gradient of the layer below.
+ * Restriction (since ABI 5): with addend or mask_y, `act` and `mask_act` must be none or LeakyReLU -- a sigmoid there returns
+ * EBFI_ERR_UNSUPPORTED (the epilogue with extras compiles ONE activation form, LeakyReLU with slope 1 = none; the model never
+ * combines a sigmoid layer with them).  Without addend / mask_y every activation is accepted. */
 int ebfi_conv2d_packed_x3(const void *input, const void *packed, size_t packed_bytes, const void *bias, void *output,
                           int B, int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups, int act,
                           float slope, const void *addend, const void *mask_y, int mask_act, float mask_slope, void *stream);

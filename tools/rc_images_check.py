@@ -1,5 +1,13 @@
-import sys, torch, time
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/ebfi-be_amd')
+"""ResidualControl with fp16 image storage against its layer-wise fp16 form: packed gradients of one training step (development)."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "ebfi-be_amd"))
 from ebfi_amd.engine import Engine, synthetic_batch, DEFAULT_MODEL_ARGS
 from ebfi_amd import rc_fused
 # image path vs layer-wise fp16 path: same engine weights, compare packed gradients
