@@ -3462,6 +3462,21 @@ extern "C" int ebfi_conv2d_backward_weight_ex(const void *input, const void *gra
     return check_launch("conv_wgrad_reduce_f32");
 }
 
+// The thin-layer forward (conv2d_thin.inc.hpp): a 3x3 stride-1 same-padded layer with <= 3 output channels from the fp32 weight
+// itself (the (co, tap)-row form needs its own operand layout, not a bank image).  Returns EBFI_ERR_UNSUPPORTED -- without
+// recording an error -- for every other shape: the caller then takes its usual entry point.
+extern "C" int ebfi_conv2d_thin_forward(const void *input, const void *weight, const void *bias, void *output, int B, int Cin, int H,
+                                        int W, int Cout, int ksize, int stride, int pad, int act, float slope, void *stream) {
+    if (!input || !weight || !output) return fail(EBFI_ERR_ARG, "conv2d_thin_forward: null argument");
+    if (ksize != 3 || stride != 1 || pad != 1 || Cout > 3 || Cin > 64) return EBFI_ERR_UNSUPPORTED;
+    if (act < 0 || act > 2) return fail(EBFI_ERR_ARG, "conv2d_thin_forward: activation %d", act);
+    ConvGeom g;
+    if (int rc = make_geom(g, B, Cin, H, W, Cout, ksize, stride, pad)) return rc;
+    if (!thin_out_fwd_ok(g, ksize, stride)) return EBFI_ERR_UNSUPPORTED;
+    return launch_thin_out_fwd(static_cast<hipStream_t>(stream), static_cast<const float *>(input), static_cast<const float *>(weight),
+                               static_cast<const float *>(bias), static_cast<float *>(output), g, act, slope);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Building blocks of hand-scheduled layer chains (ebfi_amd/rc_fused.py): a split-precision convolution on weights that
 // are ALREADY packed (weight bank), optionally grouped, with the epilogue extras of EpiExtra; and the matching grouped

@@ -370,3 +370,161 @@ int launch_wgrad_thin(hipStream_t st, const ThinPlan &p, const float *x, const f
     }
     return check_launch("conv_wgrad_reduce_f32");
 }
+
+// ====================================================================================================================
+// THIN-OUT 3x3 FORWARD on the matrix cores with the TAPS ON THE ROW AXIS.
+//
+// A 64 -> 3 convolution padded to a 32-row tile wastes 29 of 32 matrix rows, in each of 9 taps.  Written as
+//   Q[(co, tap)][p'] = sum_ci w[co][ci][tap] * x[ci][p']          -- a 1x1 convolution with 9 Cout <= 27 output rows, K = Cin
+//   out[co][p]       = act(bias[co] + sum_tap Q[(co, tap)][p + shift(tap)])
+// the same tile carries 27 useful rows of 32 and the contraction is only Cin long: a ninth of the matrix work, and the
+// B operand of v_mfma_f32_32x32x16_bf16 -- 8 consecutive k = 8 input CHANNELS of one pixel per lane -- comes straight from
+// global memory (lanes = 32 consecutive pixels of a row: coalesced per channel plane), split into bf16 hi / lo in
+// registers.  No LDS staging of the input at all; LDS only holds Q over the tile's window (8 x 64 pixels + halo = 10 x 66
+// positions) for the shift-and-add.  Split precision like every forward convolution here (three products per k-step).
+// Measured (B = 8, 256 x 256, 64 input channels): 48-50 us per launch against 72 us (64 -> 3) and 63 us (64 -> 1) on the padded
+// 32-row tiles.  Ablations on the same box: without the loads (all out of range) 22 us -- 1250 vector instructions per wave for
+// three column tiles, 16 waves per CU: the issue rate of the vector pipe, mostly the hi / lo split of the input (pairwise
+// v_cvt_pk_bf16_f32: 1700 -> 1250 instructions) and per-load address arithmetic; the loads add 27 us on top instead of hiding
+// behind that (one or two tiles of lookahead, 8 or 16 waves per CU: all the same) -- not understood yet, and the reason the
+// data-gradient / weight-gradient forms of the same idea were not built.
+constexpr int TF_TY = 8, TF_TX = 64, TF_WC = TF_TX + 2, TF_WPX = (TF_TY + 2) * TF_WC;        // window: 10 x 66 = 660 positions
+constexpr int TF_NTILES = (TF_WPX + 31) / 32, TF_PITCH = TF_NTILES * 32, TF_ROWS = 27;       // 21 column tiles of 32
+constexpr int TF_LDS = TF_ROWS * TF_PITCH * 4;                                               // 72.6 KB: two workgroups per CU
+constexpr int TF_THREADS = 512, TF_WAVES = TF_THREADS / 64;                                  // 16 waves per CU keep enough loads in flight
+
+// eight fp32 values -> their bf16 leading parts and bf16 remainders, PAIRWISE (v_cvt_pk_bf16_f32 converts two values per
+// instruction and its result is already the packed pair the matrix fragment holds): ~3 vector instructions per value, where
+// split_word + peel (one value at a time, then two byte permutes per pair) cost ~7 and made this kernel VALU-bound.
+__device__ __forceinline__ void thin_split8(const float (&v)[8], bf16x8 &hi, bf16x8 &lo) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    unsigned hw[4], lw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2_t p = {v[2 * i], v[2 * i + 1]};
+        const bf16x2_t hp = __builtin_convertvector(p, bf16x2_t);
+        const unsigned hb = __builtin_bit_cast(unsigned, hp);
+        const f32x2_t hf = {__uint_as_float(hb << 16), __uint_as_float(hb & 0xffff0000u)};
+        const bf16x2_t lp = __builtin_convertvector(p - hf, bf16x2_t);
+        hw[i] = hb;
+        lw[i] = __builtin_bit_cast(unsigned, lp);
+    }
+    const u32x4 hv = {hw[0], hw[1], hw[2], hw[3]}, lv = {lw[0], lw[1], lw[2], lw[3]};
+    hi = __builtin_bit_cast(bf16x8, hv);
+    lo = __builtin_bit_cast(bf16x8, lv);
+}
+
+__device__ __forceinline__ float thin_act_fwd(float v, int act, float slope) {
+    const float lk = v > 0.f ? v : v * slope;
+    const float sg = 1.f / (1.f + __expf(-v));
+    return act == ACT_SIGMOID ? sg : (act == ACT_LEAKY ? lk : v);
+}
+
+template <int KSTEPS>                    // ceil(Cin / 16) <= KSTEPS: the weight fragments of every k-step live in registers
+__global__ __launch_bounds__(TF_THREADS, 4) void conv_thin_out_fwd(const float *__restrict__ x, const float *__restrict__ w,
+                                                            const float *__restrict__ bias, float *__restrict__ out, ThinGeom g,
+                                                            int tiles_x, int tiles_y) {
+    extern __shared__ __attribute__((aligned(16))) float sQ[];                              // [27][TF_PITCH]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    int t = blockIdx.x;
+    const int txi = t % tiles_x; t /= tiles_x;
+    const int tyi = t % tiles_y;
+    const int b = t / tiles_y;
+    const int y0 = tyi * TF_TY, x0 = txi * TF_TX;
+    const int HW = g.H * g.W;
+    const unsigned plane = (unsigned)HW * 4u;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (int64_t)b * g.Cin * HW, (unsigned)g.Cin * plane);   // channels >= Cin: out of range, read 0
+    const int rows_used = 9 * g.Cout;
+    // ---- weight fragments: row i = lane & 31 = (co, tap), k = 16 ks + 8 h + e = input channel
+    bf16x8 ah[KSTEPS], al[KSTEPS];
+    {
+        const int co = l31 / 9, tap = l31 - 9 * co;
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(w, (unsigned)g.Cout * (unsigned)g.Cin * 36u);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            float wd[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ci = 16 * ks + 8 * h + e;
+                wd[e] = buf_ld(rw, sel_off(l31 < rows_used && ci < g.Cin, (unsigned)((co * g.Cin + ci) * 9 + tap) * 4u));
+            }
+            thin_split8(wd, ah[ks], al[ks]);
+        }
+    }
+    // ---- phase 1: Q over the window, a wave = every eighth column tile; the next tile's 32 loads go out before the current
+    // tile is split and multiplied (two tiles ahead; without any prefetch the six tiles of a wave were six exposed memory round trips)
+    auto issue = [&](int n, unsigned (&xw)[KSTEPS][8]) {
+        const int p = 32 * n + l31;
+        const int wr = p / TF_WC, wc = p - wr * TF_WC;
+        const int yy = y0 - 1 + wr, xx = x0 - 1 + wc;
+        const bool ok = n < TF_NTILES && p < TF_WPX && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+        const unsigned base = sel_off(ok, (unsigned)(yy * g.W + xx) * 4u + (unsigned)(8 * h) * plane);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xw[ks][e] = __builtin_amdgcn_raw_buffer_load_b32(rx, base + (unsigned)(16 * ks + e) * plane, 0, 0);
+    };
+    constexpr int TPW = (TF_NTILES + TF_WAVES - 1) / TF_WAVES;  // column tiles per wave (3)
+    unsigned xw[2][KSTEPS][8];                                  // one tile ahead: two register sets
+    issue(wave, xw[0]);
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int n = wave + TF_WAVES * i;
+        if (n < TF_NTILES) {
+            if (i + 1 < TPW) issue(n + TF_WAVES, xw[(i + 1) & 1]);
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                float xv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[e] = __uint_as_float(xw[i & 1][ks][e]);
+                bf16x8 bh, bl;
+                thin_split8(xv, bh, bl);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh, acc, 0, 0, 0);
+            }
+            const int p = 32 * n + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < TF_ROWS) sQ[row * TF_PITCH + p] = acc[r];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: shift and add, bias, activation; a thread = one output pixel of the 8 x 64 tile
+    const int HWo = g.Ho * g.Wo;
+    for (int q = tid; q < TF_TY * TF_TX; q += TF_THREADS) {
+        const int ty = q >> 6, tx = q & 63;
+        const int yo = y0 + ty, xo = x0 + tx;
+        if (yo >= g.Ho || xo >= g.Wo) continue;
+        for (int co = 0; co < g.Cout; ++co) {
+            float s = bias ? bias[co] : 0.f;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) s += sQ[(co * 9 + tap) * TF_PITCH + (ty + tap / 3) * TF_WC + tx + tap % 3];
+            out[((int64_t)b * g.Cout + co) * HWo + (int64_t)yo * g.Wo + xo] = thin_act_fwd(s, g.act, g.slope);
+        }
+    }
+}
+
+// 3x3, stride 1, padding 1, Cout <= 3, Cin <= 64, at least 64 K output pixels: the tap-row forward
+inline bool thin_out_fwd_ok(const ConvGeom &g, int ks, int stride) {
+    return ks == 3 && stride == 1 && g.pad == 1 && g.groups == 1 && g.Cout <= 3 && g.Cin >= 16 && g.Cin <= 64 &&
+           (int64_t)g.B * g.Ho * g.Wo >= 64 * 1024 && dev_getenv("EBFI_NO_THIN") == nullptr && dev_getenv("EBFI_NO_THIN_FWD") == nullptr;
+}
+
+int launch_thin_out_fwd(hipStream_t st, const float *x, const float *w, const float *bias, float *out, const ConvGeom &g, int act,
+                        float slope) {
+    ThinGeom tg{g.B, g.Cin, g.H, g.W, g.Cout, g.Ho, g.Wo, act, slope, 0, 0};
+    const int tiles_x = ceil_div(g.Wo, TF_TX), tiles_y = ceil_div(g.Ho, TF_TY);
+    const int64_t tiles = (int64_t)g.B * tiles_x * tiles_y;
+    if (tiles > 2147483647LL) return fail(EBFI_ERR_ARG, "conv2d (thin forward): too many tiles");
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_thin_out_fwd<4>), TF_LDS)) return rc;
+    ProfScope ps("conv_thin_out_fwd", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * 9, conv_bytes_fwd(g, 9, false));
+    hipLaunchKernelGGL((conv_thin_out_fwd<4>), dim3((unsigned)tiles), dim3(TF_THREADS), TF_LDS, st, x, w, bias, out, tg, tiles_x, tiles_y);
+    return check_launch("conv_thin_out_fwd");
+}

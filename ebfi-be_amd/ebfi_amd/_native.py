@@ -30,7 +30,8 @@ HEADER = os.path.join(REPO_ROOT, "include", "ebfi_hip.h")
 BUILD_SCRIPT = os.path.join(PKG_ROOT, "csrc", "build.sh")
 
 EBFI_F32, EBFI_F32_BF16MMA, EBFI_F32_BF16X3MMA = 0, 2, 3
-ABI_VERSION = 9          # include/ebfi_hip.h EBFI_ABI_VERSION
+EBFI_ERR_UNSUPPORTED = -3   # include/ebfi_hip.h ebfi_status
+ABI_VERSION = 10         # include/ebfi_hip.h EBFI_ABI_VERSION
 
 
 class EbfiNativeError(RuntimeError):
@@ -86,6 +87,7 @@ SIGNATURES = {
     "ebfi_scale_residual_cat_backward_c16": (_i, [_vp] * 10 + [_i, _i, _i, _i, _i64, _c.c_float, _vp]),
     "ebfi_scale_residual_cat_backward_c16a": (_i, [_vp] * 10 + [_i, _i, _i, _i, _c.c_float, _vp]),
     "ebfi_conv2d_packed_x3_rc": (_i, [_vp, _vp, _sz, _vp, _vp] + [_i] * 6 + [_c.c_float, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ebfi_conv2d_thin_forward": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_i, _c.c_float, _vp]),
     "ebfi_kernelconv_fac_fused_x3": (_i, [_vp, _vp, _sz, _vp, _vp, _vp] + [_i] * 6 + [_c.c_float, _vp]),
     "ebfi_conv2d_packed_x3": (_i, [_vp, _vp, _sz, _vp, _vp] + [_i] * 8 + [_i, _c.c_float, _vp, _vp, _i, _c.c_float, _vp]),
     "ebfi_conv2d_backward_weight_x3g": (_i, [_vp] * 4 + [_i] * 8 + [_vp, _sz, _vp]),

@@ -97,6 +97,19 @@ def supported(x, weight, stride, padding, dilation=(1, 1), groups=1):
     return ok
 
 
+def _thin_forward(x, weight, bias, out, geo, act, slope):
+    """The tap-row forward of a 3x3 layer with <= 3 output channels (csrc/conv2d_thin.inc.hpp) when the shape is one: True if it
+    ran.  (The C entry point decides; the test here only spares the call for the shapes that cannot qualify.)"""
+    B, Cin, H, W, Cout, k, stride, pad = geo
+    if not (k == 3 and stride == 1 and pad == 1 and Cout <= 3 and 16 <= Cin <= 64 and B * H * W >= 65536 and _COMPUTE == "bf16x3"):
+        return False
+    rc = N.lib().ebfi_conv2d_thin_forward(N.ptr(x), N.ptr(weight), N.ptr(bias), N.ptr(out), *geo, act, slope, N.stream_ptr(x.device))
+    if rc == N.EBFI_ERR_UNSUPPORTED:
+        return False
+    N.check(rc, "ebfi_conv2d_thin_forward")
+    return True
+
+
 def _geo(x, weight, stride, pad):
     B, Cin, H, W = x.shape
     return [int(B), int(Cin), int(H), int(W), int(weight.shape[0]), int(weight.shape[-1]), int(stride), int(pad)]
@@ -115,7 +128,9 @@ class ConvBiasAct(Function):
         lib = N.lib()
         bptr = N.ptr(bias.contiguous() if bias is not None else None)
         with torch.cuda.device_of(x):
-            if _bf16_ok(k, stride) or _x3_ok(k, stride, geo[4]):
+            if _thin_forward(x, weight, bias.contiguous() if bias is not None else None, out, geo, act, slope):
+                rc = 0
+            elif _bf16_ok(k, stride) or _x3_ok(k, stride, geo[4]):
                 ws, need = _bf16_ws(lib, geo, x.device)
                 fn = lib.ebfi_conv2d_forward_bf16mma if _COMPUTE == "bf16" else lib.ebfi_conv2d_forward_bf16x3
                 rc = fn(N.ptr(x), N.ptr(weight), bptr, N.ptr(out), *geo, act, slope, N.ptr(ws), need, N.stream_ptr(x.device))
@@ -226,8 +241,13 @@ class SiteConvBiasAct(Function):
         Ho, Wo = H + 2 * pad - site.ks + 1, W + 2 * pad - site.ks + 1
         out = torch.empty((B, site.M, Ho, Wo), dtype=x.dtype, device=x.device)
         with torch.cuda.device_of(x):
-            rc = N.lib().ebfi_conv2d_forward_bf16x3(N.ptr(x), N.ptr(None), N.ptr(site.bias()), N.ptr(out), *geo, act, slope,
-                                                    site.fwd_ptr(), site.fwd_bytes, N.stream_ptr(x.device))
+            # (a plain single-weight site of a thin layer: the tap-row kernel reads the fp32 weight itself)
+            if site.kind == "id" and len(site.w_shapes) == 1 and site.groups == 1 and \
+                    _thin_forward(x, params[0].contiguous(), site.bias(), out, geo, act, slope):
+                rc = 0
+            else:
+                rc = N.lib().ebfi_conv2d_forward_bf16x3(N.ptr(x), N.ptr(None), N.ptr(site.bias()), N.ptr(out), *geo, act, slope,
+                                                        site.fwd_ptr(), site.fwd_bytes, N.stream_ptr(x.device))
         N.check(rc, "ebfi_conv2d_forward_bf16x3 (packed)")
         if grad_preact:                      # the incoming gradient is already that of the pre-activation
             act, slope = ACT_NONE, 0.0

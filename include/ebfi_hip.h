@@ -61,8 +61,9 @@ extern "C" {
  *   8  ebfi_conv2d_backward_weight_f16g_ex: the weight gradient writes grad * act'(y) as a c16 image for the data gradient
  *   9  (round 5) ebfi_grad_gather (gradient packing + overflow flag in the wire buffer); ebfi_adam_step_guarded takes the
  *      all-reduced flag; ebfi_fac_*_p16 take the unpadded input (replicate padding inside); ebfi_pad2d_backward;
- *      ebfi_conv2d_packed_x3_rc / ebfi_scale_residual_cat_backward_c16a (ResidualControl's tail in the convolution's epilogue) */
-#define EBFI_ABI_VERSION 9
+ *      ebfi_conv2d_packed_x3_rc / ebfi_scale_residual_cat_backward_c16a (ResidualControl's tail in the convolution's epilogue)
+ *  10  ebfi_conv2d_thin_forward (3x3 layers with <= 3 output channels: taps on the matrix row axis) */
+#define EBFI_ABI_VERSION 10
 
 typedef enum {
     EBFI_OK = 0,
@@ -222,6 +223,15 @@ size_t ebfi_conv2d_packed_bytes(int Cin, int Cout, int ksize, int transposed);
 int ebfi_conv2d_pack_bf16x3(const void *weight, int Cin, int Cout, int ksize, int transposed, void *packed,
                             size_t packed_bytes, void *stream);
 int ebfi_pack_table_bf16(const float *src, const int32_t *table, int64_t n, void *out, void *stream);
+
+/* 3x3, stride 1, padding 1, Cout <= 3, 16 <= Cin <= 64, >= 64 K output pixels (the model's last convolution 64 -> 3 + sigmoid,
+ * ExposureDecision's 64 -> 1; reference model_misc/submodules.py:159-200 ConvLayer): Q[(co, tap)][p] = sum_ci w[co][ci][tap] x[ci][p]
+ * on the matrix cores (27 of 32 rows used, K = Cin; the input's channel fragments straight from global memory, split into
+ * bf16 hi / lo in registers: three products per k-step like every forward convolution here), then out = act(bias + sum_tap
+ * Q shifted by the tap) from LDS.  `weight` is the fp32 [Cout, Cin, 3, 3] tensor.  Any other shape: EBFI_ERR_UNSUPPORTED without an
+ * error record -- the caller takes ebfi_conv2d_forward_bf16x3 instead. */
+int ebfi_conv2d_thin_forward(const void *input, const void *weight, const void *bias, void *output, int B, int Cin, int H, int W,
+                             int Cout, int ksize, int stride, int pad, int act, float slope, void *stream);
 
 /* Split-precision convolution on packed weight images with the options hand-scheduled layer chains need
  * (ebfi_amd/rc_fused.py; ResidualControl, reference models/Ours/model_singleframe.py:115-136):

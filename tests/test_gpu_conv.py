@@ -103,9 +103,9 @@ def test_thin_layer_weight_gradients_vs_cpu(B, Cin, H, W, Cout, k, s, p, act, ha
     try:
         xd, wd = x.cuda().requires_grad_(), w.cuda().requires_grad_()
         bd = b.cuda().requires_grad_() if has_bias else None
-        out = conv.conv_bias_act(xd, wd, bd, s, p, act, 0.01)
         N.prof_reset()
         N.prof_enable(True)
+        out = conv.conv_bias_act(xd, wd, bd, s, p, act, 0.01)
         out.backward(g.cuda())
         torch.cuda.synchronize()
         N.prof_enable(False)
@@ -113,6 +113,8 @@ def test_thin_layer_weight_gradients_vs_cpu(B, Cin, H, W, Cout, k, s, p, act, ha
     finally:
         conv.set_compute_dtype("fp32")
     assert "conv_wgrad_thin/" + role in prof, sorted(prof)
+    # the forward of the thin-OUT layers (<= 3 output channels) in the split-precision mode: taps on the matrix row axis
+    assert ("conv_thin_out_fwd" in prof) == (mode == "bf16x3" and role == "out" and Cout <= 3 and 16 <= Cin <= 64), sorted(prof)
     assert _rel(out.detach(), ref) < 2e-5
     # the gradients of the op AS THE DEVICE EVALUATED IT: act' from the device's own output (a LeakyReLU output within rounding of
     # zero may carry the other sign than the CPU's: a different, equally valid subgradient -- not what this test is about)

@@ -25,7 +25,7 @@ GEO = {"ebfi_conv2d_forward_bf16x3": slice(4, 12), "ebfi_conv2d_backward_data_bf
        "ebfi_conv2d_backward_weight_x3g": slice(4, 12), "ebfi_conv2d_forward": slice(4, 12), "ebfi_conv2d_backward_data": slice(4, 12),
        # fp16 backward of the generic (non-ResidualControl) layers: (x, gout, y, gw, gb, gpre, gpre_is_c16, B, Cin, H, W, M, ks, pad, ..)
        "ebfi_conv2d_backward_weight_f16g_ex": slice(7, 15), "ebfi_conv2d_packed_f16": slice(5, 13),
-       "ebfi_conv2d_packed_f16_c16": slice(6, 14)}
+       "ebfi_conv2d_packed_f16_c16": slice(6, 14), "ebfi_conv2d_thin_forward": slice(4, 12)}
 
 
 def wrap(name):
