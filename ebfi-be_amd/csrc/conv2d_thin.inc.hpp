@@ -382,12 +382,15 @@ int launch_wgrad_thin(hipStream_t st, const ThinPlan &p, const float *x, const f
 // global memory (lanes = 32 consecutive pixels of a row: coalesced per channel plane), split into bf16 hi / lo in
 // registers.  No LDS staging of the input at all; LDS only holds Q over the tile's window (8 x 64 pixels + halo = 10 x 66
 // positions) for the shift-and-add.  Split precision like every forward convolution here (three products per k-step).
-// Measured (B = 8, 256 x 256, 64 input channels): 48-50 us per launch against 72 us (64 -> 3) and 63 us (64 -> 1) on the padded
-// 32-row tiles.  Ablations on the same box: without the loads (all out of range) 22 us -- 1250 vector instructions per wave for
-// three column tiles, 16 waves per CU: the issue rate of the vector pipe, mostly the hi / lo split of the input (pairwise
-// v_cvt_pk_bf16_f32: 1700 -> 1250 instructions) and per-load address arithmetic; the loads add 27 us on top instead of hiding
-// behind that (one or two tiles of lookahead, 8 or 16 waves per CU: all the same) -- not understood yet, and the reason the
-// data-gradient / weight-gradient forms of the same idea were not built.
+// Measured (B = 8, 256 x 256, 64 input channels; tools/thinfwd_time.py): 37 us (64 -> 3) and 33 us (64 -> 1) per launch against 72
+// and 63 us on the padded 32-row tiles.  On the way: 58 us first; one / two tiles of lookahead and 16 instead of 8 waves per CU
+// changed nothing; the pairwise hi / lo split (1700 -> 1250 vector instructions per wave) 50 us; then the two that mattered
+// together, 50 -> 37 us: workgroup ids mapped so that an XCD owns a contiguous run of tiles (the halo rows / columns that
+// neighbouring tiles share were fetched into two L2s: 176 MB of HBM reads for a 134 MB tensor) and the channel plane offset
+// moved into the loads' scalar offset.  Ablation at the 50 us stage: 22 us without the loads (vector-pipe issue), 27 us more
+// with them.  The same idea with the THIN tensor on the contraction axis (forward of 4 -> 64, data gradient of 64 -> 3) was
+// built and measured slower than the kernels it would replace (139 vs 42 us, 56 vs 41 us: eight shifted, bounds-checked
+// reads and a store address per output row cost more vector instructions than the padded tile wastes matrix work): removed.
 constexpr int TF_TY = 8, TF_TX = 64, TF_WC = TF_TX + 2, TF_WPX = (TF_TY + 2) * TF_WC;        // window: 10 x 66 = 660 positions
 constexpr int TF_NTILES = (TF_WPX + 31) / 32, TF_PITCH = TF_NTILES * 32, TF_ROWS = 27;       // 21 column tiles of 32
 constexpr int TF_LDS = TF_ROWS * TF_PITCH * 4;                                               // 72.6 KB: two workgroups per CU
@@ -421,13 +424,15 @@ __device__ __forceinline__ float thin_act_fwd(float v, int act, float slope) {
     return act == ACT_SIGMOID ? sg : (act == ACT_LEAKY ? lk : v);
 }
 
-template <int KSTEPS>                    // ceil(Cin / 16) <= KSTEPS: the weight fragments of every k-step live in registers
+template <int KSTEPS>                    // Cin / 16 (Cin % 16 == 0): the weight fragments of every k-step live in registers
 __global__ __launch_bounds__(TF_THREADS, 4) void conv_thin_out_fwd(const float *__restrict__ x, const float *__restrict__ w,
                                                             const float *__restrict__ bias, float *__restrict__ out, ThinGeom g,
                                                             int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(16))) float sQ[];                              // [27][TF_PITCH]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
-    int t = blockIdx.x;
+    // (workgroup ids congruent mod 8 share an XCD and its L2: give each XCD a contiguous eighth of the tile sequence, so that the
+    // halo rows / columns neighbouring tiles share are fetched into one L2 instead of two)
+    int t = (gridDim.x & 7) == 0 ? xcd_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     const int txi = t % tiles_x; t /= tiles_x;
     const int tyi = t % tiles_y;
     const int b = t / tiles_y;
@@ -461,9 +466,13 @@ __global__ __launch_bounds__(TF_THREADS, 4) void conv_thin_out_fwd(const float *
         const bool ok = n < TF_NTILES && p < TF_WPX && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
         const unsigned base = sel_off(ok, (unsigned)(yy * g.W + xx) * 4u + (unsigned)(8 * h) * plane);
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks)
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            // the channel's plane offset is wave-uniform: it rides in the instruction's SCALAR offset (one vector add less per load).
+            // The scalar offset is not part of the descriptor's range check: KSTEPS is exactly Cin / 16 (launcher), no channel
+            // past the sample is ever addressed.
 #pragma unroll
-            for (int e = 0; e < 8; ++e) xw[ks][e] = __builtin_amdgcn_raw_buffer_load_b32(rx, base + (unsigned)(16 * ks + e) * plane, 0, 0);
+            for (int e = 0; e < 8; ++e) xw[ks][e] = __builtin_amdgcn_raw_buffer_load_b32(rx, base, (unsigned)(16 * ks + e) * plane, 0);
+        }
     };
     constexpr int TPW = (TF_NTILES + TF_WAVES - 1) / TF_WAVES;  // column tiles per wave (3)
     unsigned xw[2][KSTEPS][8];                                  // one tile ahead: two register sets
@@ -513,7 +522,7 @@ __global__ __launch_bounds__(TF_THREADS, 4) void conv_thin_out_fwd(const float *
 
 // 3x3, stride 1, padding 1, Cout <= 3, Cin <= 64, at least 64 K output pixels: the tap-row forward
 inline bool thin_out_fwd_ok(const ConvGeom &g, int ks, int stride) {
-    return ks == 3 && stride == 1 && g.pad == 1 && g.groups == 1 && g.Cout <= 3 && g.Cin >= 16 && g.Cin <= 64 &&
+    return ks == 3 && stride == 1 && g.pad == 1 && g.groups == 1 && g.Cout <= 3 && g.Cin >= 16 && g.Cin <= 64 && g.Cin % 16 == 0 &&
            (int64_t)g.B * g.Ho * g.Wo >= 64 * 1024 && dev_getenv("EBFI_NO_THIN") == nullptr && dev_getenv("EBFI_NO_THIN_FWD") == nullptr;
 }
 
@@ -523,8 +532,20 @@ int launch_thin_out_fwd(hipStream_t st, const float *x, const float *w, const fl
     const int tiles_x = ceil_div(g.Wo, TF_TX), tiles_y = ceil_div(g.Ho, TF_TY);
     const int64_t tiles = (int64_t)g.B * tiles_x * tiles_y;
     if (tiles > 2147483647LL) return fail(EBFI_ERR_ARG, "conv2d (thin forward): too many tiles");
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_thin_out_fwd<4>), TF_LDS)) return rc;
     ProfScope ps("conv_thin_out_fwd", st, 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * 9, conv_bytes_fwd(g, 9, false));
-    hipLaunchKernelGGL((conv_thin_out_fwd<4>), dim3((unsigned)tiles), dim3(TF_THREADS), TF_LDS, st, x, w, bias, out, tg, tiles_x, tiles_y);
+#define EBFI_LAUNCH_TF(KS_)                                                                                                        \
+    do {                                                                                                                           \
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_thin_out_fwd<KS_>), TF_LDS)) return rc_;             \
+        hipLaunchKernelGGL((conv_thin_out_fwd<KS_>), dim3((unsigned)tiles), dim3(TF_THREADS), TF_LDS, st, x, w, bias, out, tg, tiles_x, \
+                           tiles_y);                                                                                               \
+    } while (0)
+    switch (g.Cin / 16) {
+    case 1: EBFI_LAUNCH_TF(1); break;
+    case 2: EBFI_LAUNCH_TF(2); break;
+    case 3: EBFI_LAUNCH_TF(3); break;
+    default: EBFI_LAUNCH_TF(4); break;
+    }
+#undef EBFI_LAUNCH_TF
     return check_launch("conv_thin_out_fwd");
 }
+

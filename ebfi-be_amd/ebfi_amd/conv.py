@@ -101,7 +101,7 @@ def _thin_forward(x, weight, bias, out, geo, act, slope):
     """The tap-row forward of a 3x3 layer with <= 3 output channels (csrc/conv2d_thin.inc.hpp) when the shape is one: True if it
     ran.  (The C entry point decides; the test here only spares the call for the shapes that cannot qualify.)"""
     B, Cin, H, W, Cout, k, stride, pad = geo
-    if not (k == 3 and stride == 1 and pad == 1 and Cout <= 3 and 16 <= Cin <= 64 and B * H * W >= 65536 and _COMPUTE == "bf16x3"):
+    if not (k == 3 and stride == 1 and pad == 1 and Cout <= 3 and 16 <= Cin <= 64 and Cin % 16 == 0 and B * H * W >= 65536 and _COMPUTE == "bf16x3"):
         return False
     rc = N.lib().ebfi_conv2d_thin_forward(N.ptr(x), N.ptr(weight), N.ptr(bias), N.ptr(out), *geo, act, slope, N.stream_ptr(x.device))
     if rc == N.EBFI_ERR_UNSUPPORTED:
