@@ -2897,7 +2897,7 @@ __global__ __launch_bounds__(NTB) void conv7_x3_kernel(const float *__restrict__
     extern __shared__ __attribute__((aligned(16))) char smd[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = (Wo + TX - 1) / TX, tiles_y = (Ho + TYB - 1) / TYB;
-    int t = blockIdx.x;
+    int t = (gridDim.x & 7) == 0 ? xcd_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;   // (halo lines of neighbouring tiles in one L2)
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const int b = t / tiles_y;
@@ -3038,7 +3038,7 @@ __global__ __launch_bounds__(NTB) void conv7s2_dgrad_x3_kernel(const float *__re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Hu = (H + 1) / 2, Wu = (W + 1) / 2;          // grid of (u, v): output pixels (2u + py, 2v + px)
     const int tiles_x = (Wu + TX - 1) / TX, tiles_y = (Hu + TYB - 1) / TYB;
-    int t = blockIdx.x;
+    int t = (gridDim.x & 7) == 0 ? xcd_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;   // (halo lines of neighbouring tiles in one L2)
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const int b = t / tiles_y;
