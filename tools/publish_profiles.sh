@@ -15,8 +15,9 @@ python3 - "$S/pmc_traffic_summary.json" "$2" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
 d = {"_comment": "HBM-side bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --no-graph`, "
-                 "mean over all launches of a kernel; FETCH_SIZE doubled for the kernels that stage with 16-byte-per-lane loads as "
-                 "MI355X_MICROARCH.md prescribes: fetch_correction); source: profiles/%s/bench_final_pmc_traffic_summary.json" % sys.argv[2], **d}
+                 "mean over all launches of a kernel; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes -- calibrated here for "
+                 "coalesced 4-, 8- and 16-byte-per-lane reads alike (profiles/r05/fetch_size_calibration.txt); the DCNv2 gather kernels "
+                 "are reported as counted: fetch_correction); source: profiles/%s/bench_final_pmc_traffic_summary.json" % sys.argv[2], **d}
 json.dump(d, open("profiles/pmc_traffic.json", "w"), indent=1)
 PY
 cp $S/kbench.log $D/kbench_final.log
