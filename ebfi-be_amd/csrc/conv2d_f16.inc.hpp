@@ -80,6 +80,10 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
     KB_STAMP(0);
 
     if (wave < NCW) {
+        // static priority for the matrix-issuing waves: VALU issue is arbitrated by priority, then age (MI355X_MICROARCH.md, "two
+        // waves per SIMD"); with the consumers above the converting producer wave of their SIMD the kernel measured 0.5-0.7 % faster,
+        // with the producers above the consumers 2 % slower (same box, round 5)
+        __builtin_amdgcn_s_setprio(1);
         // ------------------------------------------------------------------ consumers: output rows 2*wave, 2*wave + 1
         f32x16 acc[RW][MT][2];
 #pragma unroll
