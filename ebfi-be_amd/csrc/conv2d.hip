@@ -3385,7 +3385,7 @@ extern "C" size_t ebfi_conv2d_backward_weight_workspace(int B, int Cin, int H, i
     ConvGeom g;
     if (make_geom(g, B, Cin, H, W, Cout, ksize, stride, pad) != EBFI_OK) return 0;
     int slabs = wgrad_splits(g, ksize, stride);
-    if (g.Wo % 4 == 0 && g.Wo <= 1024 && 256 % (g.Wo / 4) == 0 && thin_wgrad_slabs(g) > slabs)
+    if (thin_wgrad_geometry(g, ksize, stride).kind != 0 && thin_wgrad_slabs(g) > slabs)
         slabs = thin_wgrad_slabs(g);            // (the thin-layer kernels write one slab per sample and row band: conv2d_thin.inc.hpp)
     return (size_t)slabs * ((size_t)Cout * Cin * ksize * ksize + Cout) * sizeof(float);
 }

@@ -301,23 +301,32 @@ struct ThinPlan {
     bool aligned;
 };
 
-inline ThinPlan thin_wgrad_plan(const ConvGeom &g, int ks, int stride, const void *x, const void *go, const void *y, const void *gp) {
+// The geometry half of the plan -- channels, kernel, stride, padding, pixel count: everything known without the operand
+// pointers.  Shared by thin_wgrad_plan and by ebfi_conv2d_backward_weight_workspace, which must size the slabs for exactly the
+// layers the plan can select (a wide 512x512 layer at Wo = 32 used to get B * bands slabs it never touches: round-5 advisory).
+inline ThinPlan thin_wgrad_geometry(const ConvGeom &g, int ks, int stride) {
     ThinPlan p{0, 0, false};
     if (g.groups != 1 || g.Wo % 4 != 0 || g.B < 1) return p;
     const int tpr = g.Wo / 4;
     if (tpr > 256 || 256 % tpr != 0) return p;          // a thread = one column of quads: 256 threads are whole rows of them
-    if (!aligned16(go) || (y && !aligned16(y)) || (gp && !aligned16(gp))) return p;
-    if (dev_getenv("EBFI_NO_THIN") != nullptr) return p;
-    p.aligned = g.W % 4 == 0 && aligned16(x);
     const int64_t px = (int64_t)g.B * g.Ho * g.Wo;
     if (px < 64 * 1024) return p;                       // small maps: the matrix-core kernels' fixed costs are not the problem
+    if (g.W % 4 != 0) return p;
     if (ks == 3 && stride == 1 && g.pad == 1) {
         if (g.Cout <= 4 && g.Cin >= 16) { p.kind = 1; p.nt = g.Cout <= 1 ? 1 : (g.Cout <= 3 ? 3 : 4); }
         else if (g.Cin <= 4 && g.Cout >= 16) { p.kind = 2; p.nt = g.Cin <= 1 ? 1 : (g.Cin <= 3 ? 3 : 4); }
     } else if (ks == 3 && stride == 2 && g.pad == 1 && g.Cin <= 4 && g.Cout >= 16) {
         p.kind = 5; p.nt = g.Cin <= 3 ? 3 : 4;
     }
-    if (!p.aligned) p.kind = 0;
+    return p;
+}
+
+inline ThinPlan thin_wgrad_plan(const ConvGeom &g, int ks, int stride, const void *x, const void *go, const void *y, const void *gp) {
+    ThinPlan p = thin_wgrad_geometry(g, ks, stride);
+    if (p.kind == 0) return p;
+    p.aligned = aligned16(x);
+    if (!aligned16(go) || (y && !aligned16(y)) || (gp && !aligned16(gp)) || !p.aligned || dev_getenv("EBFI_NO_THIN") != nullptr)
+        p.kind = 0;
     return p;
 }
 

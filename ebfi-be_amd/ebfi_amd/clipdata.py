@@ -59,6 +59,39 @@ def period_items(num_imgs, frames_per_period, frames_per_blurry=None, exposure_m
     return items
 
 
+def sequence_items(num_periods, periods_per_seq=1, sliding_window_seq=1, periods_per_load=1, sliding_window_load=1):
+    """set_items (h5dataset.py:166-186): the dataset's items are SEQUENCES of loads, a load = [first period, last period].
+    Sequence starts step by `sliding_window_seq`; a sequence that would run past the last period is dropped; inside a sequence
+    loads start every `sliding_window_load` periods and a load that would cross the sequence's end is dropped.  Returns the
+    list of sequences, each a list of (left, right) period indices -- infer_ours.py walks them in this order."""
+    S, ws, Lp, wl = int(periods_per_seq), int(sliding_window_seq), int(periods_per_load), int(sliding_window_load)
+    assert S >= 1, "Number of period per seq must >= 1!"
+    assert 0 <= ws <= S, "Sliding window seq must be in [0, number of period per seq]"
+    assert Lp >= 1, "Number of period per Load must >= 1!"
+    assert 0 <= wl <= Lp, "Sliding window Load must be in [0, number of period per Load]"
+    assert Lp <= S, "Number of period per load must <= Number of period per seq"
+    if ws == 0 or wl == 0:
+        raise ValueError("a sliding window of 0 never advances (numpy.arange raises in the reference too)")
+    seqs = []
+    for start in range(0, int(num_periods), ws):
+        end = start + S - 1
+        if end <= num_periods - 1:
+            seqs.append([(i, i + Lp - 1) for i in range(start, end + 1, wl) if i + Lp - 1 <= end])
+    return seqs
+
+
+def add_noise(data, seed, noise_std=1.0, noise_fraction=0.1):
+    """add_noise of the reference (h5dataset.py:455-463) on an event stack: `|N(0, std)|` truncated to an integer at a
+    `noise_fraction` of the cells, drawn on the HOST from a generator seeded like the reference seeds torch's global one
+    (`torch.manual_seed(seed)`; same engine, same draw order: one normal and one uniform per cell over the contiguous shape) --
+    bit-identical counts for the same seed (tests/test_clipdata.py, fixture case 'noise').  The sum is formed on data's device."""
+    g = torch.Generator(device="cpu").manual_seed(int(seed))
+    noise = (noise_std * torch.randn(tuple(data.shape), generator=g)).abs().int()
+    if noise_fraction < 1.0:
+        noise.masked_fill_(torch.rand(tuple(data.shape), generator=g) >= noise_fraction, 0)
+    return data + noise.to(data.device)
+
+
 def normalise_events(xs, ys, ts, ps):
     """GetEventsIndex (h5dataset.py:327-336): an empty slice becomes the single event (0, 0, 0, 0); timestamps become
     (t - t0) / (tN - t0 + 1e-6).  Returns float64 arrays (the reference concatenates into one float64 [4, N] tensor)."""
@@ -152,16 +185,19 @@ class ClipDataset:
 
     def __init__(self, paths, time_bins=16, frames_per_period=16, frames_per_blurry=16, exposure_method="Fixed",
                  exposure_time=None, crop=None, crop_mode="random", flips=False, device="cuda", seed=0,
-                 flip_probs=(0.5, 0.5), center_crop=None):
+                 flip_probs=(0.5, 0.5), center_crop=None, noise=None):
         """crop / crop_mode: the first crop of AugmentData's list (RandomCrop when enabled, else CenterCrop); center_crop: a
         CenterCrop applied AFTER a random crop when the config enables both (the reference walks its `augment` list in order,
-        h5dataset.py:410-433); flip_probs: (horizontal_prob, vertical_prob) of data_augment.flip."""
+        h5dataset.py:410-433); flip_probs: (horizontal_prob, vertical_prob) of data_augment.flip; noise: None or
+        (noise_std, noise_fraction) of data_augment.noise -- applied to the event stack after crops and flips with the item's
+        seed + 3, like AugmentData does ('Noise' sits behind the crops and flips in the shipped `augment` order)."""
         self.clips = [open_clip(p) for p in (list_clips(paths) if isinstance(paths, str) else list(paths))]
         if not self.clips:
             raise ValueError("no clips under %r" % (paths,))
         self.time_bins, self.P = int(time_bins), int(frames_per_period)
         self.crop, self.crop_mode, self.flips = crop, crop_mode, bool(flips)
         self.flip_probs, self.center_crop = (float(flip_probs[0]), float(flip_probs[1])), center_crop
+        self.noise = None if noise is None else (float(noise[0]), float(noise[1]))
         self.device = torch.device(device)
         self.items = []
         for ci, clip in enumerate(self.clips):
@@ -225,6 +261,8 @@ class ClipDataset:
         stack = events_to_stack(to(xs, torch.float64), to(ys, torch.float64), to(ts, torch.float64), to(ps, torch.float32),
                                 self.time_bins, sensor_size=res).transpose(0, 1)                # [TB,2,H,W]
         sharp, blur, stack = self.augment([sharp.to(dev), blur.to(dev), stack], res, seed)
+        if self.noise is not None:
+            stack = add_noise(stack[None], seed + 3, *self.noise)[0]          # (drawn over [L=1, TB, 2, H, W] like the reference)
         return self.assemble(sharp, blur, stack, duty)
 
 
@@ -234,12 +272,10 @@ SUPPORTED_AUGMENT_ORDER = ["RandomCrop", "CenterCrop", "HorizontalFlip", "Vertiv
 def dataset_args_from_config(ds_cfg):
     """The reference's `train_dataloader.dataset` keys (config/train_ours.yml:115-150) -> ClipDataset keyword arguments.
     Everything the keys can ask for that this reader does NOT do is refused here instead of being ignored silently
-    (round-4 advisory): noise on the event stacks (h5dataset.py:455-463; its values come from torch's global CPU generator
-    on a strided view and are not reproduced), another `augment` order than the shipped one (crops, then flips), and
-    scale / ori_scale pairs whose ground truth is not the 'ori' groups of a clip.  hot_pixel needs no code: the
+    (round-4 advisory): another `augment` order than the shipped one (crops, then flips, then noise) and scale / ori_scale pairs whose ground truth is not the 'ori' groups of a clip.  hot_pixel needs no code: the
     reference's own test `type == [...]` (h5dataset.py:436) is never true, so it never adds hot pixels."""
     aug = ds_cfg.get("data_augment") or {}
-    out = dict(crop=None, crop_mode="random", center_crop=None, flips=False, flip_probs=(0.5, 0.5))
+    out = dict(crop=None, crop_mode="random", center_crop=None, flips=False, flip_probs=(0.5, 0.5), noise=None)
     # the tensors the model sees come from the reference's `gt_prex` groups (h5dataset.py:36-100): 'ori' exactly when `scale`
     # equals the factor `ori_scale` names -- the shipped pair (2, 'down2') and (1, 'ori') among them; any other pair reads
     # down-scaled groups this reader does not open
@@ -255,9 +291,9 @@ def dataset_args_from_config(ds_cfg):
     if known != [m for m in SUPPORTED_AUGMENT_ORDER if m in known] or len(known) != len(order):
         raise NotImplementedError("data_augment.augment %r: supported is the shipped order %r (crops before flips) or a "
                                   "sub-list of it" % (order, SUPPORTED_AUGMENT_ORDER))
-    if (aug.get("noise") or {}).get("enabled") and "Noise" in order:
-        raise NotImplementedError("data_augment.noise.enabled: event-stack noise is not implemented by this reader "
-                                  "(the shipped config has NoiseEnabled: False)")
+    nz = aug.get("noise") or {}
+    if nz.get("enabled") and "Noise" in order:          # (h5dataset.py:432-433: defaults of add_noise where a key is absent)
+        out["noise"] = (float(nz.get("noise_std", 1.0)), float(nz.get("noise_fraction", 0.1)))
     rc, cc = aug.get("random_crop") or {}, aug.get("center_crop") or {}
     if rc.get("enabled") and "RandomCrop" in order:
         out["crop"], out["crop_mode"] = rc["size"], "random"

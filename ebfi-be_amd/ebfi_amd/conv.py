@@ -73,28 +73,33 @@ _LEFT_NATIVE = set()
 
 
 def supported(x, weight, stride, padding, dilation=(1, 1), groups=1):
-    """True when the convolution runs on libebfi_hip.so.  A GPU convolution that does NOT (dilation, groups through nn.Conv2d,
-    k outside {1, 3, 7}, stride > 2, non-fp32 tensors: none occur in the default model) goes to torch -- i.e. MIOpen, which
-    compiles a kernel per unusual shape for minutes on a fresh machine.  That must not happen silently: the first time a shape
-    leaves the native path one line goes to stderr; with EBFI_STRICT_NATIVE=1 it is an EbfiNativeError instead."""
+    """True when the convolution runs on libebfi_hip.so.  A pure predicate (model code asks it to choose a path): what happens
+    when a GPU convolution is actually handed to torch is `left_native`'s business, at the one place that does it."""
     k = weight.shape[-1]
-    ok = (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and
-          weight.shape[-2] == k and k in (1, 3, 7) and stride[0] == stride[1] and stride[0] in (1, 2) and
-          not (k == 1 and stride[0] != 1) and padding[0] == padding[1] and 0 <= padding[0] <= k and
-          tuple(dilation) == (1, 1) and groups == 1 and x.shape[-1] * x.shape[-2] >= 2)
-    if not ok and x.is_cuda:
-        key = (tuple(weight.shape), tuple(stride), tuple(padding), tuple(dilation), int(groups), x.dtype, weight.dtype)
-        msg = ("ebfi_amd.conv: convolution weight %s stride %s padding %s dilation %s groups %d (%s) is outside the native kernels' "
-               "shapes and runs on torch / MIOpen" % (tuple(weight.shape), tuple(stride), tuple(padding), tuple(dilation),
-                                                      int(groups), str(x.dtype).replace("torch.", "")))
-        import os
-        if os.environ.get("EBFI_STRICT_NATIVE") == "1":
-            raise N.EbfiNativeError(msg + " (EBFI_STRICT_NATIVE=1)")
-        if key not in _LEFT_NATIVE:
-            _LEFT_NATIVE.add(key)
-            import sys
-            print(msg + "; set EBFI_STRICT_NATIVE=1 to make this an error", file=sys.stderr, flush=True)
-    return ok
+    return bool(x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and
+                weight.shape[-2] == k and k in (1, 3, 7) and stride[0] == stride[1] and stride[0] in (1, 2) and
+                not (k == 1 and stride[0] != 1) and padding[0] == padding[1] and 0 <= padding[0] <= k and
+                tuple(dilation) == (1, 1) and groups == 1 and x.shape[-1] * x.shape[-2] >= 2)
+
+
+def left_native(x, weight, stride, padding, dilation=(1, 1), groups=1):
+    """Called where a GPU convolution is DISPATCHED to torch (dilation, groups through nn.Conv2d, k outside {1, 3, 7}, stride > 2,
+    non-fp32 / autocast tensors: none occur in the default model) -- i.e. to MIOpen, which compiles a kernel per unusual shape
+    for minutes on a fresh machine.  That must not happen silently: the first time a shape leaves the native path one line goes
+    to stderr; with EBFI_STRICT_NATIVE=1 it is an EbfiNativeError instead."""
+    if not x.is_cuda:
+        return
+    key = (tuple(weight.shape), tuple(stride), tuple(padding), tuple(dilation), int(groups), x.dtype, weight.dtype)
+    msg = ("ebfi_amd.conv: convolution weight %s stride %s padding %s dilation %s groups %d (%s) is outside the native kernels' "
+           "shapes and runs on torch / MIOpen" % (tuple(weight.shape), tuple(stride), tuple(padding), tuple(dilation),
+                                                  int(groups), str(x.dtype).replace("torch.", "")))
+    import os
+    if os.environ.get("EBFI_STRICT_NATIVE") == "1":
+        raise N.EbfiNativeError(msg + " (EBFI_STRICT_NATIVE=1)")
+    if key not in _LEFT_NATIVE and len(_LEFT_NATIVE) < 256:
+        _LEFT_NATIVE.add(key)
+        import sys
+        print(msg + "; set EBFI_STRICT_NATIVE=1 to make this an error", file=sys.stderr, flush=True)
 
 
 def _thin_forward(x, weight, bias, out, geo, act, slope):

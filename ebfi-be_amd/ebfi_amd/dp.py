@@ -136,15 +136,18 @@ class FlatGradBucket:
             if g is not None and (g.dtype != self.dtype or not g.is_contiguous()):
                 g = g.to(self.dtype).contiguous()
             grads.append(g)
-        if dev.type != "cuda":
-            flag = torch.zeros(WIRE_PAD, dtype=self.dtype)
+        if dev.type != "cuda" or self.dtype != torch.float32:
+            # CPU parameters (host tests, gloo rehearsals) and bucket dtypes the native launch does not pack: one concatenation
+            flag = torch.zeros(WIRE_PAD, dtype=self.dtype, device=dev)
             if guard is not None:
                 flag[0] = 1.0 if int(guard[0]) != 0 else 0.0
-            pieces = [(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(grads, self.params)]
+            pieces = [(g if g is not None else torch.zeros_like(p, dtype=self.dtype)).reshape(-1) for g, p in zip(grads, self.params)]
             self.adopt(torch.cat(pieces + [flag]))
         else:
-            if self.dtype != torch.float32:
-                raise NotImplementedError("the native gradient gather packs float32 gradients")
+            if guard is not None and not (guard.is_cuda and guard.device == dev and guard.dtype == torch.int32):
+                # (the kernel dereferences this pointer: a host tensor -- the gloo tests pass one with CPU parameters -- or
+                # another dtype must be staged, never handed over as it is)
+                guard = guard.to(device=dev, dtype=torch.int32)
             import ctypes
             from . import _native as N
             n = len(self.params)

@@ -72,6 +72,7 @@ class ConvLayer(nn.Module):
         if x.shape[-2:] == (1, 1) and c.kernel_size == (1, 1) and c.groups == 1:
             y = F.linear(x.flatten(1), c.weight.flatten(1), c.bias)[:, :, None, None]   # scalar-conditioned scales
         else:
+            conv.left_native(x, c.weight, c.stride, c.padding, c.dilation, c.groups)   # (one line on stderr, or an error if strict)
             y = c(x)   # shapes the gfx950 conv kernels do not cover: PyTorch-ROCm conv (still GPU)
         if self.norm in ("BN", "IN"):
             y = self.norm_layer(y)
@@ -450,6 +451,7 @@ class UNet3d_18(nn.Module):
             else:
                 yp = self.outconv[0](y)
             return conv.conv_bias_act(yp, oc.weight, oc.bias, 1, 0, conv.ACT_NONE, 0.0)
+        conv.left_native(y, ff.weight, ff.stride, ff.padding)        # (autocast / a fuse layer with a norm: torch convolutions)
         return self.outconv(self.lrelu(self.feature_fuse(y)))
 
 

@@ -100,13 +100,18 @@ def main():
     cfgs = {
         "fixed": dict(NumFramePerPeriod=8, NumFramePerBlurry=5, ExposureMethod="Fixed", ExposureTime=[1], crop=None),
         "custom": dict(NumFramePerPeriod=6, NumFramePerBlurry=6, ExposureMethod="Custom", ExposureTime=[3, 4, 6], crop=[16, 16]),
+        # event-stack noise (AugmentData 'Noise' -> add_noise, h5dataset.py:432-433, :455-463) after a centre crop: what
+        # infer_ours.py runs with unless --noise_enabled is given (the flag is store_false there)
+        "noise": dict(NumFramePerPeriod=8, NumFramePerBlurry=3, ExposureMethod="Fixed", ExposureTime=[1], crop=[16, 24],
+                      noise=dict(enabled=True, noise_std=1.0, noise_fraction=0.05)),
     }
     for tag, c in cfgs.items():
         config = dict(scale=1, ori_scale="ori", time_bins=4, NumFramePerPeriod=c["NumFramePerPeriod"],
                       NumFramePerBlurry=c["NumFramePerBlurry"], NumPeriodPerSeq=1, SlidingWindowSeq=1, NumPeriodPerLoad=1,
                       SlidingWindowLoad=1, ExposureMethod=c["ExposureMethod"], ExposureTime=c["ExposureTime"],
-                      data_augment=dict(enabled=c["crop"] is not None, augment=["CenterCrop"],
-                                        center_crop=dict(enabled=True, size=c["crop"] or [0, 0])))
+                      data_augment=dict(enabled=c["crop"] is not None, augment=["CenterCrop", "Noise"],
+                                        center_crop=dict(enabled=True, size=c["crop"] or [0, 0]),
+                                        noise=c.get("noise", dict(enabled=False))))
         ds = h5d.H5Dataset.__new__(h5d.H5Dataset)
         ds.config, ds.h5_file_path = config, "<memory>"
         ds.h5_file = as_file(clip)

@@ -13,7 +13,9 @@ import torch
 from ebfi_amd import clipdata
 
 CFGS = {"fixed": dict(frames_per_period=8, frames_per_blurry=5, exposure_method="Fixed", exposure_time=[1], crop=None),
-        "custom": dict(frames_per_period=6, frames_per_blurry=6, exposure_method="Custom", exposure_time=[3, 4, 6], crop=[16, 16])}
+        "custom": dict(frames_per_period=6, frames_per_blurry=6, exposure_method="Custom", exposure_time=[3, 4, 6], crop=[16, 16]),
+        "noise": dict(frames_per_period=8, frames_per_blurry=3, exposure_method="Fixed", exposure_time=[1], crop=[16, 24],
+                      noise=(1.0, 0.05))}
 
 
 @pytest.fixture(scope="module")
@@ -29,7 +31,7 @@ def _dataset(path, tag, device="cpu"):
     return clipdata.ClipDataset(path, time_bins=4, crop_mode="center", flips=False, device=device, **c)
 
 
-@pytest.mark.parametrize("tag", ["fixed", "custom"])
+@pytest.mark.parametrize("tag", ["fixed", "custom", "noise"])
 def test_items_match_the_reference_dataset_on_the_host(fixture, tag):
     from oracle import events_ref
     z, path = fixture
@@ -40,6 +42,11 @@ def test_items_match_the_reference_dataset_on_the_host(fixture, tag):
         sharp, blur, (xs, ys, ts, ps), duty = ds.host_item(i)
         stack = torch.from_numpy(events_ref.events_to_stack(xs, ys, ts, ps.astype(np.float32), 4, (H, W))).transpose(0, 1)
         sharp, blur, stack = ds.augment([sharp, blur, stack], (H, W), seed=5)
+        if ds.noise is not None:
+            assert tag == "noise"
+            clean = stack
+            stack = clipdata.add_noise(stack[None], 5 + 3, *ds.noise)[0]
+            assert 0 < (stack != clean).float().mean() <= 0.05        # (|N(0,1)| truncates to 0 for two thirds of the drawn cells)
         item = ds.assemble(sharp, blur, stack, duty)
         for k in ("SeqLatentF", "SeqBlurryF", "SeqHREv", "RelativeLatentTs", "SeqExposureDuty"):
             ref = z["%s.%d.%s" % (tag, i, k)]
@@ -57,6 +64,19 @@ def test_period_rules():
         clipdata.period_items(40, 8, exposure_method="Custom", exposure_time=[9])
     auto = clipdata.period_items(100, 10, exposure_method="Auto", seed=3)
     assert all(1 <= len(b) < 10 for _, b, _ in auto)
+
+
+def test_sequence_items_follow_set_items():
+    """h5dataset.py:166-186 by hand: 5 periods, sequences of 2 stepping by 2, loads of 1 stepping by 1 (scripts/infer_ours.sh)."""
+    assert clipdata.sequence_items(5, 2, 2, 1, 1) == [[(0, 0), (1, 1)], [(2, 2), (3, 3)]]      # the start at 4 would end at 5 > 4
+    assert clipdata.sequence_items(5, 1, 1, 1, 1) == [[(i, i)] for i in range(5)]
+    assert clipdata.sequence_items(6, 3, 1, 2, 1) == [[(s, s + 1), (s + 1, s + 2)] for s in range(4)]   # the load at s+2 would cross
+    assert clipdata.sequence_items(4, 2, 2, 2, 2) == [[(0, 1)], [(2, 3)]]
+    assert clipdata.sequence_items(1, 2, 2, 1, 1) == []
+    with pytest.raises(AssertionError):
+        clipdata.sequence_items(4, 1, 1, 2, 1)
+    with pytest.raises(ValueError):
+        clipdata.sequence_items(4, 2, 0, 1, 1)
 
 
 def test_event_normalisation_edge_cases():
@@ -113,7 +133,7 @@ def test_h5_clip_without_h5py_is_a_clear_error(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["fixed", "custom"])
+@pytest.mark.parametrize("tag", ["fixed", "custom", "noise"])
 def test_items_match_the_reference_dataset_on_the_device(fixture, tag):
     z, path = fixture
     ds = _dataset(path, tag, device="cuda")
@@ -168,8 +188,10 @@ def test_dataset_config_keys_are_honoured_or_refused():
     c["data_augment"]["center_crop"].update(enabled=True, size=[64, 64])
     b = clipdata.dataset_args_from_config(c)
     assert b["flip_probs"] == (1.0, 0.0) and b["center_crop"] == [64, 64]
-    for breaker in (lambda d: d["data_augment"]["noise"].update(enabled=True),
-                    lambda d: d["data_augment"].update(augment=["HorizontalFlip", "RandomCrop"]),
+    c = copy.deepcopy(cfg)
+    c["data_augment"]["noise"].update(enabled=True)
+    assert clipdata.dataset_args_from_config(c)["noise"] == (1.0, 0.05) and a["noise"] is None
+    for breaker in (lambda d: d["data_augment"].update(augment=["HorizontalFlip", "RandomCrop"]),
                     lambda d: d.update(scale=2, ori_scale="down4"),
                     lambda d: d.update(scale=1, ori_scale="down2")):
         c = copy.deepcopy(cfg)

@@ -47,14 +47,15 @@ def test_train_resume_infer(tmp_path):
     assert r.returncode == 0 and "interpolated 6 frames" in r.stdout, r.stderr[-2000:]
 
 
-def test_bench_two_rank_rehearsal():
+def test_bench_two_rank_rehearsal(tmp_path):
     """bench.py's multi-rank path (barrier, flat-bucket gradient all-reduce, max-over-ranks timing, rank-0 JSON)
     rehearsed with 2 ranks sharing the one GPU over gloo (EBFI_BENCH_REHEARSAL=1); the real N>1 runs use RCCL."""
     import json
+    detail = str(tmp_path / "detail.json")
     env = dict(os.environ, EBFI_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29631", os.path.join(ROOT, "bench.py"),
-                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-bf16-leg"],
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-bf16-leg", "--detail", detail],
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -63,9 +64,11 @@ def test_bench_two_rank_rehearsal():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["cpu_baseline"] is None and d["roofline"]["kernel"].startswith("conv_")
     assert d["config"]["world_size"] == 2 and d["config"]["collective_backend"] == "gloo"
-    assert d["config"]["replica_param_checksum"]["ranks_identical"] is True
+    assert len(lines[0]) < 4096                     # the line the driver parses stays small; the tables are in the detail file
+    full = json.load(open(detail))
+    assert full["config"]["replica_param_checksum"]["ranks_identical"] is True
     # every launch of the profiled pass was timed: per-step launch counts are whole numbers
-    for name, k in d["kernels"].items():
+    for name, k in full["kernels"].items():
         assert float(k["launches_per_step"]).is_integer(), (name, k["launches_per_step"])
 
 
@@ -109,7 +112,7 @@ def test_bench_plain_form_launches_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["config"]["global_batch"] == 16
     assert d["config"]["collectives_per_step"] == 1 and d["config"]["graph_capture_failed"] is False
-    assert "hipGraph replay" in d["config"]["launch"] and d["config"]["replica_param_checksum"]["ranks_identical"] is True
+    assert "hipGraph replay" in d["config"]["launch"]
     # a mismatch between --gpus and the launcher's world size is an error, not a silent 1-rank run
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), timeout=300)
@@ -131,7 +134,7 @@ def test_bench_single_rank_over_rccl():
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["config"]["collective_backend"] == "nccl" and d["config"]["collectives_per_step"] == 1
     assert "hipGraph replay" in d["config"]["launch"] and d["config"]["graph_capture_failed"] is False
-    assert d["config"]["fp16_overflow_guard"]["optimiser_steps_skipped"] == 0
+    assert d["config"]["fp16_steps_skipped"] == 0
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs on the node (the round's GPU box has one)")
@@ -147,8 +150,7 @@ def test_bench_two_gpus_rccl():
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
-    assert d["n_gpus"] == 2 and d["config"]["collective_backend"] == "nccl"
-    assert d["config"]["replica_param_checksum"]["ranks_identical"] is True
+    assert d["n_gpus"] == 2 and d["config"]["collective_backend"] == "nccl"      # (bench.py exits non-zero if replicas diverge)
     assert "hipGraph replay" in d["config"]["launch"]
 
 
