@@ -326,6 +326,77 @@ int check_planes(const char *who, int B, int C, int64_t HW) {
     return EBFI_OK;
 }
 
+
+// ---- scalar-conditioned channel scales (ebfi_scalar_conv_*): a bank of S 1x1 convolutions on [B,K,1,1] inputs --------------
+constexpr int SC_MAX_LAYERS = 32, SC_MAX_K = 8;
+struct ScalarBank {                        // by value in the kernel arguments: a captured launch carries the pointers
+    const float *w[SC_MAX_LAYERS];
+    const float *b[SC_MAX_LAYERS];
+};
+
+__global__ __launch_bounds__(256) void scalar_conv_fwd_kernel(ScalarBank bank, const float *__restrict__ v, float *__restrict__ out,
+                                                              int B, int K, int C, float slope) {
+    const int s = blockIdx.x;
+    // (constant-index walk over the by-value table: a runtime index would put the struct in scratch, see optim.hip)
+    const float *w = nullptr, *bias = nullptr;
+#pragma unroll
+    for (int j = 0; j < SC_MAX_LAYERS; ++j)
+        if (j == s) { w = bank.w[j]; bias = bank.b[j]; }
+    for (int i = threadIdx.x; i < B * C; i += 256) {
+        const int b = i / C, c = i - b * C;
+        float acc = bias ? bias[c] : 0.f;
+        for (int k = 0; k < K; ++k) acc = fmaf(v[b * K + k], w[c * K + k], acc);
+        out[((int64_t)s * B + b) * C + c] = acc > 0.f ? acc : acc * slope;
+    }
+}
+
+// one workgroup for the whole bank (S*B*C values: 6144 for the default model): every sum in a fixed order
+__global__ __launch_bounds__(256) void scalar_conv_bwd_kernel(ScalarBank bank, const float *__restrict__ v, const float *__restrict__ out,
+                                                              const float *__restrict__ gout, float *__restrict__ gw, float *__restrict__ gb,
+                                                              float *__restrict__ gv, int S, int B, int K, int C, float slope) {
+    // grad_weight / grad_bias: thread = (layer, channel), walks the samples
+    for (int i = threadIdx.x; i < S * C; i += 256) {
+        const int s = i / C, c = i - s * C;
+        float aw[SC_MAX_K], ab = 0.f;
+#pragma unroll
+        for (int k = 0; k < SC_MAX_K; ++k) aw[k] = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const int64_t o = ((int64_t)s * B + b) * C + c;
+            const float gp = gout[o] * (out[o] > 0.f ? 1.f : slope);
+            ab += gp;
+#pragma unroll
+            for (int k = 0; k < SC_MAX_K; ++k)
+                if (k < K) aw[k] = fmaf(gp, v[b * K + k], aw[k]);
+        }
+        if (gb) gb[i] = ab;
+        if (gw) {
+#pragma unroll
+            for (int k = 0; k < SC_MAX_K; ++k)
+                if (k < K) gw[(int64_t)i * K + k] = aw[k];
+        }
+    }
+    // grad_v[b][k] = sum over (layer, channel): one wave per (b, k) pair, lanes stride the S*C terms, butterfly in fixed order
+    if (gv) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int p = wave; p < B * K; p += 4) {
+            const int b = p / K, k = p - b * K;
+            float acc = 0.f;
+            for (int s = 0; s < S; ++s) {
+                const float *w = nullptr;
+#pragma unroll
+                for (int j = 0; j < SC_MAX_LAYERS; ++j)
+                    if (j == s) w = bank.w[j];
+                for (int c = lane; c < C; c += 64) {
+                    const int64_t o = ((int64_t)s * B + b) * C + c;
+                    acc = fmaf(gout[o] * (out[o] > 0.f ? 1.f : slope), w[c * K + k], acc);
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+            if (lane == 0) gv[p] = acc;
+        }
+    }
+}
 }  // namespace
 
 // out [B,2C,H,W]: out[:, :C] = s0[b,c]*a0 + x, out[:, C:] = s1[b,c]*a1 + x   (x == NULL: no residual; s1 == NULL: s1 = 1)
@@ -524,4 +595,45 @@ extern "C" int ebfi_prodmean_backward(const float *a, const float *b, const floa
                            HW / 4, total4);
     }
     return check_launch("prodmean_bwd");
+}
+
+static int scalar_bank(ScalarBank &bank, const void *const *weights, const void *const *biases, int S, int B, int K, int C, const char *what) {
+    if (!weights || S < 1 || S > SC_MAX_LAYERS || K < 1 || K > SC_MAX_K || B < 0 || C < 1 || (int64_t)S * B * C > (1 << 20))
+        return fail(EBFI_ERR_ARG, "%s: S = %d layers (<= %d), K = %d (<= %d), B = %d, C = %d", what, S, SC_MAX_LAYERS, K, SC_MAX_K, B, C);
+    for (int j = 0; j < SC_MAX_LAYERS; ++j) {
+        bank.w[j] = j < S ? static_cast<const float *>(weights[j]) : nullptr;
+        bank.b[j] = (j < S && biases) ? static_cast<const float *>(biases[j]) : nullptr;
+        if (j < S && !bank.w[j]) return fail(EBFI_ERR_ARG, "%s: weight %d is NULL", what, j);
+    }
+    return EBFI_OK;
+}
+
+extern "C" int ebfi_scalar_conv_forward(const float *v, const void *const *weights, const void *const *biases, float *out, int S, int B,
+                                        int K, int C, float slope, void *stream) {
+    ScalarBank bank;
+    if (int rc = scalar_bank(bank, weights, biases, S, B, K, C, "scalar_conv_forward")) return rc;
+    if (!v || !out) return fail(EBFI_ERR_ARG, "scalar_conv_forward: null argument");
+    if (B == 0) return EBFI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    {
+        ProfScope ps("scalar_conv_fwd", st, 2.0 * S * B * C * K, 4.0 * (S * (double)C * (K + 1) + B * K + (double)S * B * C));
+        hipLaunchKernelGGL(scalar_conv_fwd_kernel, dim3((unsigned)S), dim3(256), 0, st, bank, v, out, B, K, C, slope);
+    }
+    return check_launch("scalar_conv_fwd");
+}
+
+extern "C" int ebfi_scalar_conv_backward(const float *v, const void *const *weights, const float *out, const float *grad_out,
+                                         float *grad_weight, float *grad_bias, float *grad_v, int S, int B, int K, int C, float slope,
+                                         void *stream) {
+    ScalarBank bank;
+    if (int rc = scalar_bank(bank, weights, nullptr, S, B, K, C, "scalar_conv_backward")) return rc;
+    if (!v || !out || !grad_out) return fail(EBFI_ERR_ARG, "scalar_conv_backward: null argument");
+    if (B == 0) return EBFI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    {
+        ProfScope ps("scalar_conv_bwd", st, 4.0 * S * B * C * K, 4.0 * (2.0 * S * B * C + 2.0 * S * C * (K + 1) + 2.0 * B * K));
+        hipLaunchKernelGGL(scalar_conv_bwd_kernel, dim3(1), dim3(256), 0, st, bank, v, out, grad_out, grad_weight, grad_bias, grad_v,
+                           S, B, K, C, slope);
+    }
+    return check_launch("scalar_conv_bwd");
 }

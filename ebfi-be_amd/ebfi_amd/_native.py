@@ -31,7 +31,7 @@ BUILD_SCRIPT = os.path.join(PKG_ROOT, "csrc", "build.sh")
 
 EBFI_F32, EBFI_F32_BF16MMA, EBFI_F32_BF16X3MMA = 0, 2, 3
 EBFI_ERR_UNSUPPORTED = -3   # include/ebfi_hip.h ebfi_status
-ABI_VERSION = 10         # include/ebfi_hip.h EBFI_ABI_VERSION
+ABI_VERSION = 11         # include/ebfi_hip.h EBFI_ABI_VERSION
 
 
 class EbfiNativeError(RuntimeError):
@@ -93,6 +93,8 @@ SIGNATURES = {
     "ebfi_conv2d_backward_weight_x3g": (_i, [_vp] * 4 + [_i] * 8 + [_vp, _sz, _vp]),
     "ebfi_scale_residual_cat_forward_ex": (_i, [_vp] * 6 + [_i, _i, _i64, _i64, _vp]),
     "ebfi_scale_residual_cat_backward_ex": (_i, [_vp] * 10 + [_i, _i, _i64, _i64, _i64, _i, _c.c_float, _vp]),
+    "ebfi_scalar_conv_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _c.c_float, _vp]),
+    "ebfi_scalar_conv_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _c.c_float, _vp]),
     "ebfi_events_workspace": (_sz, [_i]),
     "ebfi_events_to_stack": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ebfi_frame2lap": (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -43,6 +43,76 @@ class _ScaleResidualCat(torch.autograd.Function):
         return ga0, gs0.view(s0_shape), ga1, (gs1.view(s1_shape) if gs1 is not None else None), gx
 
 
+class _ScalarConvBank(torch.autograd.Function):
+    """A bank of S ConvLayer(k=1) + LeakyReLU layers on one [B, K] input in ONE launch each way (csrc/fuse.hip scalar_conv_*):
+    ResidualControl's scalar-conditioned channel scales Conv1[i](Ex) / Conv2[i](T) (model_singleframe.py:85-94, :127-129).
+    forward(v, slope, w_0, b_0, ..., w_{S-1}, b_{S-1}) -> [S, B, C]; the gradients of the S weights / biases are views of two
+    packed tensors."""
+
+    @staticmethod
+    def forward(ctx, v, slope, *params):
+        import ctypes
+        ws, bs = params[0::2], params[1::2]
+        S, (B, K), C = len(ws), v.shape, ws[0].shape[0]
+        v = v.contiguous()
+        # (the kernel indexes weight_s[c * K + k]: a [C, K, 1, 1] conv weight as it is stored)
+        ws = [w.contiguous() for w in ws]
+        bs = [None if b is None else b.contiguous() for b in bs]
+        wp = (ctypes.c_void_p * S)(*[w.data_ptr() for w in ws])
+        bp = (ctypes.c_void_p * S)(*[None if b is None else b.data_ptr() for b in bs])
+        out = torch.empty(S, B, C, dtype=v.dtype, device=v.device)
+        with torch.cuda.device_of(v):
+            rc = N.lib().ebfi_scalar_conv_forward(N.ptr(v), wp, bp, N.ptr(out), S, B, K, C, float(slope), N.stream_ptr(v.device))
+        N.check(rc, "ebfi_scalar_conv_forward")
+        ctx.save_for_backward(v, out, *ws)
+        ctx.meta = (float(slope), [w.shape for w in params[0::2]], [b is not None for b in bs])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        v, out = ctx.saved_tensors[:2]
+        ws = ctx.saved_tensors[2:]
+        slope, wshapes, has_b = ctx.meta
+        S, (B, K), C = len(ws), v.shape, out.shape[2]
+        g = g.contiguous()
+        wp = (ctypes.c_void_p * S)(*[w.data_ptr() for w in ws])
+        gw = torch.empty(S, C, K, dtype=v.dtype, device=v.device) if any(ctx.needs_input_grad[2::2]) else None
+        gb = torch.empty(S, C, dtype=v.dtype, device=v.device) if any(ctx.needs_input_grad[3::2]) else None
+        gv = torch.empty_like(v) if ctx.needs_input_grad[0] else None
+        with torch.cuda.device_of(g):
+            rc = N.lib().ebfi_scalar_conv_backward(N.ptr(v), wp, N.ptr(out), N.ptr(g), N.ptr(gw), N.ptr(gb), N.ptr(gv), S, B, K, C, slope,
+                                                   N.stream_ptr(g.device))
+        N.check(rc, "ebfi_scalar_conv_backward")
+        grads = []
+        for s in range(S):
+            grads.append(gw[s].view(wshapes[s]) if gw is not None and ctx.needs_input_grad[2 + 2 * s] else None)
+            grads.append(gb[s] if gb is not None and has_b[s] and ctx.needs_input_grad[3 + 2 * s] else None)
+        return (gv, None) + tuple(grads)
+
+
+def scalar_conv_usable(v, weights):
+    """[B, K] fp32 GPU input with K <= 8 into <= 32 layers of one shape [C, K(,1,1)]: what ebfi_scalar_conv_* takes."""
+    w0 = weights[0]
+    return (v.is_cuda and v.dtype == torch.float32 and v.dim() == 2 and 1 <= v.shape[1] <= 8 and 1 <= len(weights) <= 32 and
+            all(w.dtype == torch.float32 and w.is_cuda and w.shape == w0.shape and w.numel() == w0.shape[0] * v.shape[1] for w in weights) and
+            len(weights) * v.shape[0] * w0.shape[0] <= (1 << 20) and not torch.is_autocast_enabled())
+
+
+def scalar_conv_bank(v, weights, biases, slope):
+    """leaky_relu(bias_s + v @ weight_s^T, slope) for every layer s of the bank -> [S, B, C]."""
+    if scalar_conv_usable(v, weights):
+        params = []
+        for w, b in zip(weights, biases):
+            params += [w, b]
+        return _ScalarConvBank.apply(v, slope, *params)
+    w = torch.stack([x.flatten(1) for x in weights])                     # [S, C, K]
+    s = torch.einsum("bk,sck->sbc", v, w)
+    if biases[0] is not None:
+        s = s + torch.stack(list(biases))[:, None, :]
+    return torch.nn.functional.leaky_relu(s, slope)
+
+
 def _fusable(a0, a1, s0):
     return (a0.is_cuda and a0.dtype == torch.float32 and a1.dtype == torch.float32 and a0.dim() == 4 and a0.shape == a1.shape and
             (a0.shape[2] * a0.shape[3]) % 4 == 0 and s0.numel() == a0.shape[0] * a0.shape[1] and not torch.is_autocast_enabled())

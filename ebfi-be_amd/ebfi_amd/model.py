@@ -70,7 +70,12 @@ class ConvLayer(nn.Module):
         if grad_is_preact:
             raise RuntimeError("grad_is_preact needs the fused native conv kernel")
         if x.shape[-2:] == (1, 1) and c.kernel_size == (1, 1) and c.groups == 1:
-            y = F.linear(x.flatten(1), c.weight.flatten(1), c.bias)[:, :, None, None]   # scalar-conditioned scales
+            # scalar-conditioned scales (ResidualControl's Conv1 / Conv2 on Ex / T): an outer product + bias
+            v = x.flatten(1)
+            leaky = isinstance(self.activation, nn.LeakyReLU) and self.norm not in ("BN", "IN")
+            if leaky and fused.scalar_conv_usable(v, [c.weight]):
+                return fused.scalar_conv_bank(v, [c.weight], [c.bias], float(self.activation.negative_slope))[0][:, :, None, None]
+            y = F.linear(v, c.weight.flatten(1), c.bias)[:, :, None, None]
         else:
             conv.left_native(x, c.weight, c.stride, c.padding, c.dilation, c.groups)   # (one line on stderr, or an error if strict)
             y = c(x)   # shapes the gfx950 conv kernels do not cover: PyTorch-ROCm conv (still GPU)

@@ -442,12 +442,12 @@ def residual_control(rc, data, Ex, T):
     if sites is None:
         return None
     slope = float(rc.Conv5[0][0].activation.negative_slope)
-    # per-round channel scales Conv1[i](Ex), Conv2[i](T) for all rounds at once: [step, B, C]
+    # per-round channel scales Conv1[i](Ex), Conv2[i](T) for all rounds at once: [step, B, C] -- one native launch per bank
+    # (csrc/fuse.hip scalar_conv_*; before round 6: stack + einsum + add + leaky_relu through torch, ~30 tiny launches per step)
     def scales(bank_modules, v):
-        w = torch.stack([m[0].conv2d.weight.flatten(1) for m in bank_modules])          # [step, C, Cin]
-        b = torch.stack([m[0].conv2d.bias for m in bank_modules])                        # [step, C]
-        s = torch.einsum("bk,sck->sbc", v, w) + b[:, None, :]
-        return torch.nn.functional.leaky_relu(s, float(bank_modules[0][0].activation.negative_slope))
+        from . import fused
+        return fused.scalar_conv_bank(v, [m[0].conv2d.weight for m in bank_modules], [m[0].conv2d.bias for m in bank_modules],
+                                      float(bank_modules[0][0].activation.negative_slope))
     s_ex, s_t = scales(rc.Conv1, Ex), scales(rc.Conv2, T)
     params = []
     for i in range(rc.step):

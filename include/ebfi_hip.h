@@ -62,8 +62,10 @@ extern "C" {
  *   9  (round 5) ebfi_grad_gather (gradient packing + overflow flag in the wire buffer); ebfi_adam_step_guarded takes the
  *      all-reduced flag; ebfi_fac_*_p16 take the unpadded input (replicate padding inside); ebfi_pad2d_backward;
  *      ebfi_conv2d_packed_x3_rc / ebfi_scale_residual_cat_backward_c16a (ResidualControl's tail in the convolution's epilogue)
- *  10  ebfi_conv2d_thin_forward (3x3 layers with <= 3 output channels: taps on the matrix row axis) */
-#define EBFI_ABI_VERSION 10
+ *  10  ebfi_conv2d_thin_forward (3x3 layers with <= 3 output channels: taps on the matrix row axis)
+ *  11  ebfi_scalar_conv_forward / _backward (ResidualControl's scalar-conditioned channel scales: a bank of 1x1 convolutions on
+ *      [B,K,1,1] inputs in one launch each way) */
+#define EBFI_ABI_VERSION 11
 
 typedef enum {
     EBFI_OK = 0,
@@ -396,6 +398,20 @@ int ebfi_events_to_stack(const double *xs, const double *ys, const double *ts, c
 int ebfi_frame2lap(const float *frame, float *out, int B, int H, int W, void *stream);
 int ebfi_frame2dcp(const float *frame, float *out, float *scratch /* [B,H,W] */, int B, int H, int W,
                    int window, void *stream);
+
+/* ------------------------------------------------------------------ scalar-conditioned channel scales
+ * ResidualControl's Conv1[i](Ex) / Conv2[i](T) (models/Ours/model_singleframe.py:85-94, :127-129: ConvLayer(k=1) + LeakyReLU on a
+ * [B,K,1,1] input, reference submodules.py:159-200) for a BANK of S such layers in one launch:
+ *   out[s][b][c] = leaky_relu(bias_s[c] + sum_k v[b][k] * weight_s[c][k], slope)        v [B,K], weight_s [C,K], out [S,B,C]
+ * weights / biases: host arrays of S device pointers (the layers' own parameter tensors; bias entries may be NULL); they are
+ * copied into the kernel arguments, so a captured launch keeps them.  S <= 32, K <= 8, S*B*C <= 2^20.
+ * backward: grad_weight [S,C,K], grad_bias [S,C], grad_v [B,K] (each may be NULL), all fully overwritten, fixed summation
+ * order (bit-reproducible); `out` is the forward's output (its sign selects the LeakyReLU derivative). */
+int ebfi_scalar_conv_forward(const float *v, const void *const *weights, const void *const *biases, float *out, int S, int B,
+                             int K, int C, float slope, void *stream);
+int ebfi_scalar_conv_backward(const float *v, const void *const *weights, const float *out, const float *grad_out,
+                              float *grad_weight, float *grad_bias, float *grad_v, int S, int B, int K, int C, float slope,
+                              void *stream);
 
 /* ------------------------------------------------------------------ fused stages between the convolutions
  * One round of ResidualControl (models/Ours/model_singleframe.py:124-134):
