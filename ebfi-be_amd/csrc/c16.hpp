@@ -30,7 +30,15 @@ __device__ __forceinline__ unsigned pack_f16(float a, float b) {   // v_cvt_pk_f
 // stay what they are).  A scale that is too large for this step's data is caught by f16_scales_finish_kernel from the
 // recorded maximum either way; saturating keeps the step's wrong gradients FINITE, so the maxima recorded further down the
 // backward chain stay usable and every scale is repaired by that one finish launch instead of one layer per step.
-__device__ __forceinline__ void saturate_fp16_conversions() { __builtin_amdgcn_s_setreg(1 | (23 << 6), 1); }
+//
+// ROUND 6 -- the bit is NOT confined to conversions.  While MODE.FP16_OVFL is set the MATRIX CORES stop propagating non-finite
+// operands: one NaN / +Inf / -Inf element in an operand of v_mfma_f32_32x32x16_bf16 or _f16 gives 32 non-finite results in the
+// default mode and NONE with the bit set (tools/mfma_nan_probe.hip, profiles/r06/mfma_fp16_ovfl_nonfinite_probe.log).  That is
+// the "NaN the forward kernel swallows" of round 5: the consumer waves of the image-writing forward ran their whole MFMA loop
+// with the bit set for the sake of the epilogue's fp16 stores.  Rule: a wave that issues MFMAs sets the bit only AROUND its own
+// fp16 conversions (saturate_fp16_conversions(true) ... (false) around an epilogue) and never across a matrix loop; waves that
+// only convert (producers, elementwise kernels) may set it for good.
+__device__ __forceinline__ void saturate_fp16_conversions(bool on = true) { __builtin_amdgcn_s_setreg(1 | (23 << 6), on ? 1u : 0u); }
 
 // Scale slot: 64 floats (256 bytes); [0] = scale (power of two), [32] = running |max| of the fp32 values staged through it
 // (float bits, ordered as unsigned for non-negative floats).  The two words sit in different 128-byte lines on purpose: the

@@ -388,7 +388,8 @@ struct FacEpi {
 template <int MT>
 __device__ __forceinline__ void fac_epilogue_tile(float *__restrict__ out, const float *__restrict__ bias, const f32x16 (&acc)[MT][2],
                                                   const ConvGeom &g, const FacEpi &fac, int b, int co_base, int yo, int x0, int lane,
-                                                  float slope) {
+                                                  float slope, float oscale = 1.f) {
+    // oscale: the accumulators are oscale-times too small (fp16 operands scaled by powers of two, conv2d_f16.inc.hpp); 1 otherwise
     constexpr int K = 5, R = 2;
     const int HW = g.Ho * g.Wo;                       // same-padded 3x3: output size = input size = the size of ev
     const int h = lane >> 5, l31 = lane & 31;
@@ -425,7 +426,7 @@ __device__ __forceinline__ void fac_epilogue_tile(float *__restrict__ out, const
             float sum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float f = acc[m][n][r] + bv[r];
+                float f = acc[m][n][r] * oscale + bv[r];
                 f = f > 0.f ? f : f * slope;
                 sum = fmaf(f, e[r], sum);
             }
@@ -2550,7 +2551,6 @@ __global__ __launch_bounds__(NTWS) void conv_fwd_bf16x3_ws(const float *__restri
             fbits |= (unsigned)((((pbase + (tap / KS) * IW + (tap % KS)) >> 3) & 1) ^ hsel) << tap;
         bf16x8 ah[2][MT], al[2][MT], bh[2][2], bl[2][2];
         [[maybe_unused]] float amax16 = 0.f, amax_pre = 0.f;
-        if constexpr (EXTRA) saturate_fp16_conversions();       // (the fp16 side image of the epilogue: MODE.FP16_OVFL, see c16.hpp)
         auto tap_read = [&](const char *base, int tap, int set) {
             const int ky = tap / KS, kx = tap - ky * KS;
             const char *bp = base + pbase * 32 + (int)(((fbits >> tap) & 1u) << 4) + (ky * IW + kx) * 32;
@@ -2604,8 +2604,15 @@ __global__ __launch_bounds__(NTWS) void conv_fwd_bf16x3_ws(const float *__restri
             }
             int cb_, cy0, cx0;
             tile_coords(tcur, cb_, cy0, cx0);
-            if constexpr (FAC) fac_epilogue_tile<MT>(out, bias, acc, g, fac, cb_, co_base, cy0 + wave, cx0, lane, slope);
-            else store_out_tile<MT, XM>(out, bias, acc, g, cb_, co_base, cy0 + wave, cx0, lane, act, slope, epi, 1.f, &amax16, &amax_pre);
+            if constexpr (FAC) {
+                fac_epilogue_tile<MT>(out, bias, acc, g, fac, cb_, co_base, cy0 + wave, cx0, lane, slope);
+            } else {
+                // the fp16 side images of the epilogue saturate instead of overflowing (MODE.FP16_OVFL) -- set for the epilogue ONLY:
+                // under that bit the matrix cores drop non-finite operands (c16.hpp, round 6), and the loop above must pass them on
+                if constexpr ((XM & 6) != 0) saturate_fp16_conversions(true);
+                store_out_tile<MT, XM>(out, bias, acc, g, cb_, co_base, cy0 + wave, cx0, lane, act, slope, epi, 1.f, &amax16, &amax_pre);
+                if constexpr ((XM & 6) != 0) saturate_fp16_conversions(false);
+            }
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -3605,6 +3612,49 @@ extern "C" int ebfi_kernelconv_fac_fused_x3(const void *input, const void *packe
     return check_launch("conv_fwd_bf16x3_ws/kernelconv_fac");
 }
 
+// The same fused pair on fp16 OPERANDS (round 6; inference): conv_fwd_f16_ws<.., FAC> -- one matrix-core product per tap instead
+// of three.  `input` stays fp32 NCHW: the producers multiply by in_slot's power of two while converting (the caller sets that
+// scale from the tensor itself right before the launch: ebfi_amd.fac) and record |max| there; `packed16` is the "facrows" fp16
+// image [tap][C * 32][K16] of the layer's weight, scaled by w_slot[0] (ebfi_pack_table_f16).  The training step runs this
+// layer on fp16 operands since round 4 (Sharp / Final within 4e-4 of the fp32 result against the path's 1e-3 bar).
+extern "C" int ebfi_kernelconv_fac_fused_f16(const void *input, const void *packed16, size_t packed_bytes, const void *bias32,
+                                             const void *feat, void *output, int B, int Cin, int H, int W, int C, int fac_ksize,
+                                             float slope, void *in_slot, const void *w_slot, void *stream) {
+    if (!input || !packed16 || !bias32 || !feat || !output || !in_slot || !w_slot)
+        return fail(EBFI_ERR_ARG, "kernelconv_fac_fused_f16: null argument");
+    if (fac_ksize != 5) return fail(EBFI_ERR_UNSUPPORTED, "kernelconv_fac_fused_f16: FAC kernel size %d (5 is built)", fac_ksize);
+    if (C < 1) return fail(EBFI_ERR_ARG, "kernelconv_fac_fused_f16: %d channels", C);
+    ConvGeom g;
+    if (int rc = make_geom(g, B, Cin, H, W, C * 32, 3, 1, 1)) return rc;
+    if ((int64_t)(Cin + 64) * H * W * 4 >= (1LL << 31) - (1LL << 26))
+        return fail(EBFI_ERR_ARG, "kernelconv_fac_fused_f16: one sample exceeds the 2 GiB reach of 32-bit buffer offsets");
+    const int K16 = (Cin + 15) / 16 * 16;
+    const size_t need = (size_t)9 * g.Cout * K16 * 2;
+    if (packed_bytes < need) return fail(EBFI_ERR_WORKSPACE, "kernelconv_fac_fused_f16: packed image %zu bytes < required %zu", packed_bytes, need);
+    if (W % 4 != 0 || !aligned16(input))
+        return fail(EBFI_ERR_UNSUPPORTED, "kernelconv_fac_fused_f16: needs W %% 4 == 0 and a 16-byte aligned input (W = %d)", W);
+    if (B == 0) return EBFI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t tiles = (int64_t)B * ceil_div(g.Ho, TYB) * ceil_div(g.Wo, TX);
+    if (tiles > 2147483647LL) return fail(EBFI_ERR_ARG, "kernelconv_fac_fused_f16: too many tiles");
+    constexpr int PSX = (TYB - 1 + 3) * (TX - 1 + 3);
+    const size_t lds = (size_t)2 * (PSX * 32 + 9 * 64 * 32) + KB_LDS_BYTES;
+    const int64_t co_blocks = ceil_div(g.Cout, 64);
+    int64_t gx = 256 / co_blocks;
+    if (gx < 1) gx = 1;
+    if (gx > tiles) gx = tiles;
+    const double flops = 2.0 * B * g.Ho * g.Wo * (double)(C * 25) * Cin * 9 + 2.0 * B * g.Ho * g.Wo * (double)C * 25;
+    const double bytes = 4.0 * B * (double)g.Ho * g.Wo * (Cin + 2.0 * C);      // conv input + feature map + output: no filter tensor
+    ProfScope ps("conv_fwd_f16_ws/kernelconv_fac", st, flops, bytes);
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_f16_ws<false, false, false, true>), 160 * 1024)) return rc;
+    hipLaunchKernelGGL((conv_fwd_f16_ws<false, false, false, true>), dim3((unsigned)gx, (unsigned)co_blocks), dim3(NTF16), lds, st,
+                       static_cast<const float *>(input), static_cast<const _Float16 *>(packed16), static_cast<const float *>(bias32),
+                       static_cast<float *>(output), g, K16, ACT_LEAKY, slope, EpiExtra{nullptr, nullptr, 0, 0.f}, (int)tiles,
+                       ScaleSlot{static_cast<float *>(in_slot)}, static_cast<const float *>(w_slot),
+                       FacEpi{static_cast<const float *>(feat), C});
+    return check_launch("conv_fwd_f16_ws/kernelconv_fac");
+}
+
 // ------------------------------------------------------------------------------------------------
 // fp16 single-product forms for the BACKWARD pass of the training step (conv2d_f16.inc.hpp): the data gradient as a
 // convolution of the (pre-activation) gradient with packed fp16 TRANSPOSED weight images, and the weight gradient, both
@@ -3696,13 +3746,13 @@ extern "C" int ebfi_conv2d_packed_f16_c16(const void *input, int input_is_c16, c
     do {                                                                                                                 \
         if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_f16_ws<EX_, IN_>), 160 * 1024)) return rc_; \
         hipLaunchKernelGGL((conv_fwd_f16_ws<EX_, IN_>), grid, dim3(NTF16), lds, st, x, wp, bs, o, g, K16, act, slope, epi,   \
-                           (int)tiles, isl, static_cast<const float *>(w_slot));                                        \
+                           (int)tiles, isl, static_cast<const float *>(w_slot), FacEpi{nullptr, 0});                    \
     } while (0)
     if (input_is_c16 == 2) {
         if (extra) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_f16: planar fp16 input with epilogue extras");
         if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_f16_ws<false, false, true>), 160 * 1024)) return rc_;
         hipLaunchKernelGGL((conv_fwd_f16_ws<false, false, true>), grid, dim3(NTF16), lds, st, x, wp, bs, o, g, K16, act, slope, epi,
-                           (int)tiles, isl, static_cast<const float *>(w_slot));
+                           (int)tiles, isl, static_cast<const float *>(w_slot), FacEpi{nullptr, 0});
     } else if (extra && input_is_c16) EBFI_LAUNCH_F16WS(true, true);
     else if (extra) EBFI_LAUNCH_F16WS(true, false);
     else if (input_is_c16) EBFI_LAUNCH_F16WS(false, true);

@@ -40,12 +40,18 @@ constexpr int NTF16 = 512;
 //   INP16:  x is a PLANAR fp16 tensor [B, groups*Cin, H, W] scaled by in_slot's scale (the grad_kernel of the FAC op, written by
 //           fac_bwd_rows_f32<.., H16>): the quad staging of the fp32 form with 8-byte loads and byte permutes instead of
 //           conversions, half the bytes; in_slot is only read
-template <bool EXTRA, bool IN16 = false, bool INP16 = false>
+//   FAC (round 6; inference, with EXTRA = IN16 = INP16 = false): the output rows are the per-pixel 5x5 filters of the filter-adaptive
+//           convolution that follows (weight rows in the "facrows" layout: one FAC channel per 32-row tile); the epilogue applies
+//           them to `fac.ev` and stores ONE value per pixel and channel (fac_epilogue_tile, conv2d.hip): the fused
+//           KernelConv -> FAC kernel of conv_fwd_bf16x3_ws<0, true> at one matrix-core product per tap instead of three
+template <bool EXTRA, bool IN16 = false, bool INP16 = false, bool FAC = false>
 __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict__ x, const _Float16 *__restrict__ wp,
                                                          const float *__restrict__ bias, float *__restrict__ out, ConvGeom g, int K16,
                                                          int act, float slope, EpiExtra epi, int tiles_total, ScaleSlot in_slot,
-                                                         const float *__restrict__ w_slot) {
-    saturate_fp16_conversions();
+                                                         const float *__restrict__ w_slot, FacEpi fac) {
+    static_assert(!FAC || (!EXTRA && !IN16 && !INP16), "the FAC epilogue comes with fp32 input staging and no extras");
+    // (MODE.FP16_OVFL: the producers, which convert, set it for good below; the consumers only around their epilogue -- while it is
+    //  set the matrix cores drop non-finite operands, c16.hpp)
     constexpr int KS = 3, KK = 9, MT = 2, RW = 2;              // RW: output rows per consumer wave
     constexpr int IH = TYB - 1 + KS, IW = TX - 1 + KS, PS = IH * IW, COS = 32 * MT;
     constexpr int NCW = TYB / RW, PT = 256;
@@ -152,8 +158,15 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
             // (written out per row: as a loop the EXTRA variant was not unrolled, `acc[r]` became a runtime index and the whole
             // accumulator array moved to scratch memory -- 410 instead of 45 us per launch)
             static_assert(RW == 2, "epilogue is written out for two rows");
-            store_out_tile<MT, EXTRA ? 3 : 0>(out, bias, acc[0], g, cb_, co_base, cy0 + RW * wave, cx0, lane, act, slope, epi, oscale, &amax16);
-            store_out_tile<MT, EXTRA ? 3 : 0>(out, bias, acc[1], g, cb_, co_base, cy0 + RW * wave + 1, cx0, lane, act, slope, epi, oscale, &amax16);
+            if constexpr (FAC) {
+                fac_epilogue_tile<MT>(out, bias, acc[0], g, fac, cb_, co_base, cy0 + RW * wave, cx0, lane, slope, oscale);
+                fac_epilogue_tile<MT>(out, bias, acc[1], g, fac, cb_, co_base, cy0 + RW * wave + 1, cx0, lane, slope, oscale);
+            } else {
+                if constexpr (EXTRA) saturate_fp16_conversions(true);      // (the epilogue's fp16 image stores; never across the MFMA loop)
+                store_out_tile<MT, EXTRA ? 3 : 0>(out, bias, acc[0], g, cb_, co_base, cy0 + RW * wave, cx0, lane, act, slope, epi, oscale, &amax16);
+                store_out_tile<MT, EXTRA ? 3 : 0>(out, bias, acc[1], g, cb_, co_base, cy0 + RW * wave + 1, cx0, lane, act, slope, epi, oscale, &amax16);
+                if constexpr (EXTRA) saturate_fp16_conversions(false);
+            }
 #pragma unroll
             for (int r = 0; r < RW; ++r)
 #pragma unroll
@@ -174,6 +187,7 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
         return;
     }
     // ---------------------------------------------------------------------- producers
+    saturate_fp16_conversions();           // (these waves convert and issue no MFMA)
     // 16-byte quads of 4 consecutive pixels x 8 channels (as conv_fwd_bf16x3_ws) and the chunk's weight pieces; two register
     // stages, so the loads of items i+2 and i+3 are in flight while item i+1 is converted and written.
     //
@@ -451,7 +465,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_ws(const float *__restrict
                                                          const float *__restrict__ yact, float *__restrict__ slab,
                                                          float *__restrict__ gpre_out, ConvGeom g, float dslope, int total_tiles,
                                                          int need_bias, ScaleSlot x_slot, ScaleSlot g_slot) {
-    saturate_fp16_conversions();
     using C = WCfg<3, 1, 32>;
     constexpr int KS = 3, KK = 9, WTX = C::WTX, IH = C::IH, IW = C::IW;
     constexpr int IWP = 32, EXC = IW - IWP, CIB = 64, CP = CIB / 2, PS = C::PS, IWS = C::IWS;
@@ -570,6 +583,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_f16_ws(const float *__restrict
         return;
     }
     // ---------------------------------------------------------------------- producers
+    saturate_fp16_conversions();           // (MODE.FP16_OVFL in the converting waves only: under it the matrix cores drop non-finite operands, c16.hpp)
     const int ptid = tid - 64 * NQ;
     const int gslot = ptid & 63, gpy = gslot >> 5, gpx = gslot & 31, gco = ptid >> 6;
     const int icol = ptid & (IWP - 1), irow = ptid / IWP;
@@ -794,7 +808,6 @@ __device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ x, const
                                               const ConvGeom &g, float dslope, const int split, const int G, const int total_tiles,
                                               const bool xcd_map, int need_bias, ScaleSlot x_slot, ScaleSlot g_slot, const int co_blk,
                                               const int ci_blk, const int gpre_c16 = 0) {
-    saturate_fp16_conversions();
     constexpr int KK = 9, PT = 256, NQ = 4;
     constexpr int TR_NSTG = IN16 ? 3 : 1;          // the image-reading producers run whole rounds of 3 phases (padding barriers below)
     constexpr bool WG_EXPLICIT_WAITS = false;
@@ -938,6 +951,7 @@ __device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ x, const
         return;
     }
     // ---------------------------------------------------------------------- producers
+    saturate_fp16_conversions();           // (MODE.FP16_OVFL in the converting waves only, c16.hpp)
     const int ptid = tid - 64 * NQ;
     if constexpr (IN16) {
         static_assert(DACT == 0, "fp16 c16 operands: pre-activation gradients only");

@@ -322,15 +322,22 @@ class ClipInterpolator:
     (tests/test_gpu_model.py::test_hoisted_inference_is_bit_identical).  precision 'bf16x3' packs the conv weight images once
     (inference weight bank, incl. the fused KernelConv -> FAC layout)."""
 
-    def __init__(self, model, precision="bf16x3", graph=True, hoist=True):
+    def __init__(self, model, precision="bf16x3", graph=True, hoist=True, filters_f16=True):
+        """filters_f16 (precision 'bf16x3' only; default on): the fused KernelConv(128 -> 1600) -> FAC kernel -- a third of the
+        model's multiply-adds -- reads fp16 operands, one matrix-core product per tap instead of the split precision's three,
+        with exact power-of-two operand scales (the input's measured on the device before every launch).  It is the one
+        convolution the TRAINING step runs on fp16 operands too (Engine(forward_f16='filters')): outputs stay within 4e-4 of the
+        exact fp32 mode against the path's 1e-3 (tests/test_gpu_model.py, tests/test_infer_cli.py); False keeps split precision."""
         # (inference needs eval mode; the caller's model is NOT switched for good: its mode is restored after every call)
         self.model = model
         self.precision, self.graph, self.hoist = precision, bool(graph), bool(hoist)
         self.graph_capture_failed, self.graph_capture_error = False, None    # as Engine: a failed capture continues eagerly
-        self.bank = None
+        self.bank = self.book = None
         if precision == "bf16x3" and next(model.parameters()).is_cuda:
-            from . import weightbank
-            self.bank = weightbank.build_for(model, inference=True)
+            from . import f16scale, weightbank
+            if filters_f16:
+                self.book = f16scale.ScaleBook(next(model.parameters()).device, capacity=64)
+            self.bank = weightbank.build_for(model, inference=True, book=self.book)
             self.bank.refresh()
         self._captured = {}
 

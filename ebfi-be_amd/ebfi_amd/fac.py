@@ -78,6 +78,24 @@ def kernelconv_fac_fused(cat, feat, site, kernel_size, slope):
         raise RuntimeError("fused KernelConv -> FAC: packed weight [%d,%d] does not match input %s / feature %s"
                            % (site.M, site.K, tuple(cat.shape), tuple(feat.shape)))
     out = torch.empty_like(feat)
+    book = site.bank.book
+    if book is not None and site.fwd16_ptr() is not None and N.dev_env("EBFI_NO_FAC_F16", "0") != "1":
+        # fp16 operands (round 6): ONE matrix-core product per tap.  The input's power-of-two scale is set from the tensor itself
+        # right here (no delayed scale: an inference call has no previous step to trust) -- one min/max pass over `cat` and a
+        # handful of scalar launches on the stream, all capturable; the weight image carries its own exact scale (bank refresh).
+        from . import f16scale
+        i = book.slot((site.key, "x"))
+        lo, hi = torch.aminmax(cat)
+        amax = torch.maximum(-lo, hi).float()
+        e = torch.floor(torch.log2(amax.clamp_min(1e-37))) + 1.0          # amax = m * 2^e, m in [0.5, 1)
+        scale = torch.where((amax > 0) & torch.isfinite(amax), torch.exp2(f16scale.TARGET_EXP - e), torch.ones_like(amax))
+        book.slots[f16scale.SLOT_STRIDE * i:f16scale.SLOT_STRIDE * i + 1].copy_(scale.reshape(1))
+        with torch.cuda.device_of(cat):
+            rc = N.lib().ebfi_kernelconv_fac_fused_f16(N.ptr(cat), site.fwd16_ptr(), site.fwd16_bytes, N.ptr(site.bias()), N.ptr(feat),
+                                                       N.ptr(out), B, Cin, H, W, C, int(kernel_size), float(slope), book.ptr(i),
+                                                       site.w_slot_ptr(), N.stream_ptr(cat.device))
+        N.check(rc, "ebfi_kernelconv_fac_fused_f16")
+        return out
     with torch.cuda.device_of(cat):
         rc = N.lib().ebfi_kernelconv_fac_fused_x3(N.ptr(cat), site.fwd_ptr(), site.fwd_bytes, N.ptr(site.bias()), N.ptr(feat),
                                                   N.ptr(out), B, Cin, H, W, C, int(kernel_size), float(slope),

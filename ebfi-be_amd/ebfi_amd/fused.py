@@ -94,6 +94,8 @@ class _ScalarConvBank(torch.autograd.Function):
 def scalar_conv_usable(v, weights):
     """[B, K] fp32 GPU input with K <= 8 into <= 32 layers of one shape [C, K(,1,1)]: what ebfi_scalar_conv_* takes."""
     w0 = weights[0]
+    if N.dev_env("EBFI_NO_SCALAR_CONV", "0") == "1":       # (development switch: the torch einsum form, for A/B runs)
+        return False
     return (v.is_cuda and v.dtype == torch.float32 and v.dim() == 2 and 1 <= v.shape[1] <= 8 and 1 <= len(weights) <= 32 and
             all(w.dtype == torch.float32 and w.is_cuda and w.shape == w0.shape and w.numel() == w0.shape[0] * v.shape[1] for w in weights) and
             len(weights) * v.shape[0] * w0.shape[0] <= (1 << 20) and not torch.is_autocast_enabled())

@@ -213,7 +213,9 @@ class Modification(BaseModel):
         c = kc.conv2d
         if bank.inference and k == 5 and kc.norm is None and isinstance(kc.activation, nn.LeakyReLU) and c.bias is not None and \
                 c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.out_channels % (k * k) == 0:
-            bank.register(c.weight, c.bias, "facrows", fac.fac_rows_fold_weight, fac.fac_rows_fold_bias, need_tr=False)
+            # (with a scale book on the bank the site also gets an fp16 image: the fused kernel then runs one product per tap)
+            bank.register(c.weight, c.bias, "facrows", fac.fac_rows_fold_weight, fac.fac_rows_fold_bias, need_tr=False,
+                          fwd16=bank.book is not None)
 
     def _fused_filters_apply(self, ev, cat):
         """FAC(ev, LeakyReLU(KernelConv(cat))) as one kernel, or None when the fused form does not apply (training, other

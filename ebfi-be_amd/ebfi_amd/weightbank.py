@@ -166,8 +166,16 @@ class WeightBank:
         s.key, s.weights = key, weights
         s.fwd16_tag = fwd16 if isinstance(fwd16, str) else None
         s.tr_off, s.tr_bytes, s.tr16_off, s.tr16_bytes, s.w_slot, s.fwd16_off, s.fwd16_bytes = 0, 0, 0, 0, -1, 0, 0
-        if need_tr and ks == 3:           # fp16 images (scaled by the site's weight slot); images start on 256-element bounds
-            for name, img in (("tr16", tr), ("fwd16", fwd)) if (fwd16 or self.fwd16 == "all") else (("tr16", tr),):
+        # fp16 images (scaled by the site's weight slot; images start on 256-element bounds): the transposed one for the fp16 data
+        # gradient of a training bank, a forward one where asked for -- an inference bank keeps forward images only (round 6: the
+        # fused KernelConv -> FAC kernel on fp16 operands)
+        images16 = []
+        if ks == 3 and need_tr and not self.inference:
+            images16.append(("tr16", tr))
+        if ks == 3 and (fwd16 or (self.fwd16 == "all" and need_tr)):
+            images16.append(("fwd16", fwd))
+        if images16:
+            for name, img in images16:
                 setattr(s, name + "_off", self._n16)
                 setattr(s, name + "_bytes", 2 * img.numel())
                 padn = (-img.numel()) % 256
@@ -250,6 +258,8 @@ class WeightBank:
                         "ebfi_gather_sum")
             if self.packed16 is not None:
                 for _, site in self._segs:       # first refresh: the weight scales from the weights themselves (later: delayed)
+                    if self.inference:           # (no optimiser step follows that would move a delayed scale along: exact every time)
+                        self.book.calibrated.discard(site.w_slot)
                     self.book.calibrate(site.w_slot, *site.weights)
                 N.check(lib.ebfi_pack_table_f16(N.ptr(self.flat), N.ptr(self.table16), self.table16.numel(), N.ptr(self.packed16),
                                                 N.ptr(self.block_slot), N.ptr(self.book.slots), st), "ebfi_pack_table_f16")
@@ -269,14 +279,18 @@ class WeightBank:
             _ACTIVE = prev
 
 
-def build_for(model, flat=None, params=None, inference=False, fwd16=None):
+def build_for(model, flat=None, params=None, inference=False, fwd16=None, book=None):
     """A bank over every eligible convolution of `model` (nn.Conv2d 1x1 / 3x3 stride 1; the depth-2 Conv3d /
-    ConvTranspose3d of the detail branch), plus the concatenations modules declare through `_ebfi_bank_register(bank)`."""
+    ConvTranspose3d of the detail branch), plus the concatenations modules declare through `_ebfi_bank_register(bank)`.
+    `book` (inference banks): a ScaleBook attached before the sites register, so that sites asking for an fp16 forward image
+    (the fused KernelConv -> FAC layout) get one."""
     import torch.nn as nn
 
     from . import fold3d
     params = list(params) if params is not None else [p for p in model.parameters()]
     bank = WeightBank(params, flat, inference=inference, fwd16=fwd16)
+    if book is not None:
+        bank.attach_scale_book(book)
     known = set(p.data_ptr() for p in params)
     ok = lambda *ts: all(t is None or t.data_ptr() in known for t in ts)
     for m in model.modules():

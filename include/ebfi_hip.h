@@ -64,7 +64,8 @@ extern "C" {
  *      ebfi_conv2d_packed_x3_rc / ebfi_scale_residual_cat_backward_c16a (ResidualControl's tail in the convolution's epilogue)
  *  10  ebfi_conv2d_thin_forward (3x3 layers with <= 3 output channels: taps on the matrix row axis)
  *  11  ebfi_scalar_conv_forward / _backward (ResidualControl's scalar-conditioned channel scales: a bank of 1x1 convolutions on
- *      [B,K,1,1] inputs in one launch each way) */
+ *      [B,K,1,1] inputs in one launch each way); ebfi_kernelconv_fac_fused_f16 (the fused KernelConv -> FAC kernel of inference
+ *      on fp16 operands) */
 #define EBFI_ABI_VERSION 11
 
 typedef enum {
@@ -263,6 +264,15 @@ int ebfi_conv2d_packed_x3(const void *input, const void *packed, size_t packed_b
 int ebfi_kernelconv_fac_fused_x3(const void *input, const void *packed, size_t packed_bytes, const void *bias32,
                                  const void *feat, void *output, int B, int Cin, int H, int W, int C, int fac_ksize,
                                  float slope, void *stream);
+
+/* The same fused pair on fp16 operands (round 6; ABI 11): one matrix-core product per tap.  `input` fp32 NCHW, multiplied by
+ * in_slot[0] (a power of two the caller sets from the tensor right before the launch) while it is staged, |max| recorded in
+ * in_slot; `packed16`: the "facrows" fp16 image [tap][C*32][K16] scaled by w_slot[0] (ebfi_pack_table_f16).  Replaces the same
+ * reference lines as ebfi_kernelconv_fac_fused_x3 (model_singleframe.py:161-162, KernelConv2D.py:82-87,
+ * KernelConv2D_kernel.cu:25-53) for inference. */
+int ebfi_kernelconv_fac_fused_f16(const void *input, const void *packed16, size_t packed_bytes, const void *bias32,
+                                  const void *feat, void *output, int B, int Cin, int H, int W, int C, int fac_ksize,
+                                  float slope, void *in_slot, const void *w_slot, void *stream);
 /* ------------------------------------------------------------------ fp16 single-product backward (training step)
  * The data gradient and the weight gradient of the 3x3 layers with ONE fp16 MFMA per product (the forward keeps the
  * split-precision kernels: DESIGN.md section 4).  Every operand is scaled by a power of two kept in a device SLOT of

@@ -510,27 +510,70 @@ def test_one_nan_element_reaches_the_slot_and_raises_the_guard():
     gbad = gc.clone()
     gbad[0, 100, 3, 7] = float("nan")
     assert guard_after(src_bwd(gc)) == 0 and guard_after(src_bwd(gbad)) == 1
-    # the forward epilogue's side image (store_out_tile): one NaN BIAS element makes one output channel NaN -- the epilogue's own
-    # |max| has to carry it into the slot.  (Injected through the bias on purpose: it reaches the epilogue whatever the matrix
-    # cores do with a NaN operand; a NaN planted in the convolution's INPUT was observed NOT to come out of the wave-specialised
-    # forward kernel on this hardware, while the double-buffered kernel of small shapes passes it on -- noted in DESIGN.md.)
+    # the forward epilogue's side image (store_out_tile): ONE NaN in the convolution's INPUT must come out of the kernel -- in the
+    # fp32 output, in the fp16 image and in the slot's |max| (-> guard).  Round 5 planted the NaN in the bias instead: a NaN in the
+    # input did not come out of the wave-specialised kernel.  Cause (round 6, tools/mfma_nan_probe.hip): its matrix-issuing waves
+    # ran with MODE.FP16_OVFL set for the epilogue's fp16 stores, and under that bit the matrix cores drop non-finite operands;
+    # the bit is now set around the epilogue only (csrc/c16.hpp).
     w, b, bank, book0, site = _banked(64, 64)
-    bias_ok = site.bias().clone()
-    bias_bad = bias_ok.clone()
-    bias_bad[13] = float("nan")
     seen = {}
 
-    def fwd_img(bias):
+    def fwd_img(xin):
         def fill(bk, i):
             out, img = torch.empty(2, 64, 16, 64, device="cuda"), c16.empty(2, 64, 16, 64, "cuda")
-            N.check(lib.ebfi_conv2d_packed_x3_c16(N.ptr(x), site.fwd_ptr(), site.fwd_bytes, N.ptr(bias), N.ptr(out), 2, 64, 16, 64, 64,
+            N.check(lib.ebfi_conv2d_packed_x3_c16(N.ptr(xin), site.fwd_ptr(), site.fwd_bytes, N.ptr(site.bias()), N.ptr(out), 2, 64, 16, 64, 64,
                                                   3, 1, 1, 1, 0.01, N.ptr(None), N.ptr(None), 0, 0.0, N.ptr(img), bk.ptr(i), 0, st), "x3_c16")
             torch.cuda.synchronize()
             seen.update(out_nan=int(torch.isnan(out).sum()), img_nan=int(torch.isnan(img).sum()),
                         amax_bits=hex(int(bk.slots[f16scale.SLOT_STRIDE * i + f16scale.SLOT_AMAX].view(torch.int32).item()) & 0xffffffff))
         return fill
-    assert guard_after(fwd_img(bias_ok)) == 0
-    assert guard_after(fwd_img(bias_bad)) == 1, seen
+    assert guard_after(fwd_img(x)) == 0 and seen["out_nan"] == 0 and seen["img_nan"] == 0, seen
+    assert guard_after(fwd_img(bad)) == 1, seen
+    assert seen["out_nan"] == 64 * 9 and seen["img_nan"] == 64 * 9, seen      # the 3x3 neighbourhood of (5, 11) in every output channel
+
+
+@pytest.mark.parametrize("special", [float("nan"), float("inf"), float("-inf")])
+@pytest.mark.parametrize("B,Cin,Cout,H,W,form", [(2, 64, 64, 16, 64, "image"), (4, 64, 64, 128, 256, "plain"), (4, 64, 128, 128, 128, "plain"),
+                                                 (2, 64, 64, 8, 8, "plain")])
+def test_non_finite_input_comes_out_where_the_fp32_kernel_puts_it(B, Cin, Cout, H, W, form, special):
+    """NaN and +-Inf in the INPUT of the split-precision forward come out exactly at the output positions where the exact fp32
+    kernel (conv_fwd_f32) has non-finite values -- in the wave-specialised kernel (large shapes; pinned at any size by the
+    image-writing form), in the double-buffered one (small shapes) -- and nowhere else.  (Kind: a NaN stays NaN; an Inf becomes
+    NaN in split precision, because its low part Inf - bf16(Inf) is NaN -- non-finite either way, reference ConvLayer
+    submodules.py:159-200 on fp32 propagates Inf.)"""
+    from ebfi_amd import c16, f16scale
+    torch.manual_seed(Cout + H)
+    w, b, bank, book, site = _banked(Cin, Cout)
+    lib, st = N.lib(), N.stream_ptr(torch.device("cuda"))
+    x = torch.randn(B, Cin, H, W).cuda()
+    for pos in ((B - 1, 37, 5, min(11, W - 1)), (0, 0, 0, 0), (B - 1, Cin - 1, H - 1, W - 1)):
+        xb = x.clone()
+        xb[pos] = special
+        ref = torch.zeros(B, Cout, H, W, device="cuda")
+        N.check(lib.ebfi_conv2d_forward(N.ptr(xb), N.ptr(w.detach()), N.ptr(b.detach()), N.ptr(ref), B, Cin, H, W, Cout, 3, 1, 1, 1, 0.01,
+                                        N.EBFI_F32, st), "f32")
+        out = torch.zeros_like(ref)
+        N.prof_reset()
+        N.prof_enable(True)
+        if form == "image":
+            img = c16.empty(B, Cout, H, W, "cuda")
+            N.check(lib.ebfi_conv2d_packed_x3_c16(N.ptr(xb), site.fwd_ptr(), site.fwd_bytes, N.ptr(site.bias()), N.ptr(out), B, Cin, H, W, Cout,
+                                                  3, 1, 1, 1, 0.01, N.ptr(None), N.ptr(None), 0, 0.0, N.ptr(img), book.ptr(book.slot("t")), 0, st), "x3_c16")
+        else:
+            N.check(lib.ebfi_conv2d_packed_x3(N.ptr(xb), site.fwd_ptr(), site.fwd_bytes, N.ptr(site.bias()), N.ptr(out), B, Cin, H, W, Cout,
+                                              3, 1, 1, 1, 0.01, N.ptr(None), N.ptr(None), 0, 0.0, st), "x3")
+        torch.cuda.synchronize()
+        N.prof_enable(False)
+        ran = {k.split("/")[0] for k, v in N.prof_collect().items() if v[0] > 0}
+        assert ("conv_fwd_bf16x3_ws" in ran) == (form == "image" or H * W >= 16384), ran        # (which kernel the shape selected)
+        bad_ref, bad_out = ~torch.isfinite(ref), ~torch.isfinite(out)
+        assert int(bad_ref.sum()) >= 4 * Cout and torch.equal(bad_ref, bad_out), (pos, int(bad_ref.sum()), int(bad_out.sum()))
+        if special != special:
+            assert torch.equal(torch.isnan(ref), torch.isnan(out))
+        if form == "image":
+            # (image layout [B][C/16][H][2][W][8]: the non-finite pixels of the image are those of the output)
+            bad_img = ~torch.isfinite(c16.from_c16(img, 1.0))
+            assert torch.equal(bad_img, bad_out)
 
 
 @pytest.mark.parametrize("B,C,H,W", [(2, 64, 16, 64), (1, 64, 13, 36), (3, 64, 40, 132)])

@@ -8,6 +8,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from oracle import ref_ops  # noqa: E402
+from ebfi_amd import _native as N  # noqa: E402
 
 
 def _rel(a, b):
@@ -191,6 +192,76 @@ def test_fused_kernelconv_fac_vs_unfused_pair_and_oracle(B, C, Cin, H, W):
         conv.set_compute_dtype("fp32")
     assert _rel(out.cpu(), pair.cpu()) < 2e-6          # same filter bits, another summation order over the 25 taps
     assert _rel(out.cpu(), ref) < 1e-4                 # split-precision conv vs fp32 conv (path tolerance: 1e-3)
+
+
+@pytest.mark.parametrize("B,C,Cin,H,W", FUSED_CASES)
+@pytest.mark.parametrize("magnitude", [1.0, 1e-12, 3e4])
+def test_fused_kernelconv_fac_on_fp16_operands(B, C, Cin, H, W, magnitude):
+    """Round 6: the same fused kernel with fp16 operands (conv_fwd_f16_ws<.., FAC>: one matrix-core product per tap; inference).
+    The weight image carries an exact power-of-two scale from the bank, the input's scale is measured on the device before the
+    launch -- so inputs at 1e-12 or 3e4 (outside fp16's range unscaled) give the same relative error as O(1) ones.  Against the
+    split-precision fused kernel and the CPU oracle: operands rounded to 11 bits move a 25-tap x (9 x Cin)-term result by ~3e-4."""
+    from ebfi_amd import conv, f16scale, weightbank
+    from ebfi_amd.fac import fac_rows_fold_bias, fac_rows_fold_weight, kernelconv_fac_fused
+    torch.manual_seed(B * 1000 + C * 10 + H + W)
+    K, slope = 5, 0.01
+    w = torch.randn(C * K * K, Cin, 3, 3) * (1.0 / (Cin * 9) ** 0.5)
+    b = torch.randn(C * K * K) * 0.1 * magnitude
+    cat, feat = torch.randn(B, Cin, H, W) * magnitude, torch.randn(B, C, H, W)
+    filt = F.leaky_relu(F.conv2d(cat.double(), w.double(), b.double(), 1, 1), slope)
+    ref = ref_ops.fac_forward(F.pad(feat, (2, 2, 2, 2), mode="replicate").double(), filt.contiguous(), K).float()
+    wd, bd = torch.nn.Parameter(w.cuda()), torch.nn.Parameter(b.cuda())
+    outs = {}
+    for tag, book in (("x3", None), ("f16", f16scale.ScaleBook("cuda", capacity=8))):
+        bank = weightbank.WeightBank([wd, bd], inference=True)
+        if book is not None:
+            bank.attach_scale_book(book)
+        site = bank.register(wd, bd, "facrows", fac_rows_fold_weight, fac_rows_fold_bias, need_tr=False, fwd16=book is not None)
+        bank.refresh()
+        assert (site.fwd16_ptr() is not None) == (book is not None)
+        N.prof_reset()
+        N.prof_enable(True)
+        with torch.no_grad():
+            outs[tag] = kernelconv_fac_fused(cat.cuda(), feat.cuda(), site, K, slope).cpu()
+        torch.cuda.synchronize()
+        N.prof_enable(False)
+        ran = {k for k, v in N.prof_collect().items() if v[0] > 0}
+        assert ("conv_fwd_f16_ws/kernelconv_fac" in ran) == (book is not None) and ("conv_fwd_bf16x3_ws/kernelconv_fac" in ran) == (book is None), ran
+    assert torch.isfinite(outs["f16"]).all()
+    assert _rel(outs["x3"], ref) < 1e-4
+    assert _rel(outs["f16"], ref) < 1e-3, _rel(outs["f16"], ref)
+    assert _rel(outs["f16"], outs["x3"]) < 1e-3
+
+
+def test_clip_interpolator_takes_the_fp16_fused_kernel():
+    """ClipInterpolator (what infer_ours.py runs) in the default split-precision mode: Modification's KernelConv -> FAC pair is ONE
+    launch of the fp16-operand fused kernel per timestamp (filters_f16=False: of the split-precision one); Final within 1e-3 of the
+    exact fp32 mode either way."""
+    from ebfi_amd.engine import DEFAULT_MODEL_ARGS, ClipInterpolator, synthetic_batch
+    from ebfi_amd.model import EVFIAutoEx
+    torch.manual_seed(23)
+    net = EVFIAutoEx(**dict(DEFAULT_MODEL_ARGS, step=2, channels=[8, 8, 16, 16])).cuda().eval()
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() > 1:
+                p.copy_(torch.randn_like(p) * (1.2 / p[0].numel() ** 0.5))
+            else:
+                p.add_(0.05 * torch.randn_like(p))
+    frame, event, _, gtex, _ = synthetic_batch(2, 64, 96, 16, device="cuda", seed=5)
+    stamps = [0.25, 0.75]
+    exact = ClipInterpolator(net, precision="fp32", graph=False)(frame, event, gtex, stamps)
+    for f16, graph in ((True, False), (True, True), (False, False)):
+        interp = ClipInterpolator(net, precision="bf16x3", graph=graph, filters_f16=f16)
+        N.prof_reset()
+        N.prof_enable(not graph)
+        got = interp(frame, event, gtex, stamps)
+        torch.cuda.synchronize()
+        N.prof_enable(False)
+        if not graph:
+            ran = {k: v[0] for k, v in N.prof_collect().items() if v[0] > 0}
+            want, other = ("conv_fwd_f16_ws/kernelconv_fac", "conv_fwd_bf16x3_ws/kernelconv_fac")[::1 if f16 else -1]
+            assert ran.get(want) == len(stamps) and other not in ran and not any(k.startswith("fac_fwd") for k in ran), ran
+        assert exact.std() > 1e-3 and _rel(got.cpu(), exact.cpu()) < 1e-3, (f16, graph, _rel(got.cpu(), exact.cpu()))
 
 
 def test_inference_bank_runs_modification_fused():

@@ -430,7 +430,10 @@ def test_fp16_backward_takes_every_step_from_the_reference_initialisation():
 def _oracle_packed_gradient(sd, names, batch, iteration=0):
     sdo = {k: v.detach().cpu().clone().requires_grad_(k in names) for k, v in sd.items()}
     s, f = model_ref.evfi_forward(sdo, DEFAULT_ARGS_FULL, *batch[:3])
-    assert s.std() > 0.01
+    # (sanity only: the output carries signal.  After the five lr = 1e-3 steps on random targets of test_benchmarked_step_vs_oracle
+    #  the std of Sharp sits at 0.0097-0.0103 depending on the last digit of the trajectory -- profiles/r06/std_probe_benchmarked_step.log;
+    #  the bounds that matter are relative to the loss and to the gradient norms)
+    assert s.std() > 5e-3
     loss = loss_ref.train_loss(s, f, batch[4], iteration=iteration)
     loss.backward()
     return loss.item(), torch.cat([sdo[n].grad.reshape(-1) for n in names]), {n: sdo[n].numel() for n in names}
