@@ -320,17 +320,21 @@ def inference_block(device):
             per_kernel, _ = kernel_table(k, 1.0, 2)
             top = sorted(per_kernel.items(), key=lambda kv: -kv[1]["total_ms"])[:5]
             entry["top_kernels_ms_per_timestamp"] = {n: round(v["total_ms"] / 2, 4) for n, v in top}
-            fused = k.get("conv_fwd_bf16x3_ws/kernelconv_fac")
-            if fused and fused[0]:
-                n, ms, flops, nbytes = fused
+            # the fused KernelConv -> FAC launch: fp16 operands (one matrix-core product per tap; round 6) or split precision (three)
+            label = next((l for l in ("conv_fwd_f16_ws/kernelconv_fac_img", "conv_fwd_f16_ws/kernelconv_fac",
+                                      "conv_fwd_bf16x3_ws/kernelconv_fac") if k.get(l) and k[l][0]), None)
+            if label is not None:
+                n, ms, flops, nbytes = k[label]
                 secs = ms * 1e-3
-                t_mfma, t_hbm = 3 * flops / (BF16_MFMA_PEAK_TFS * 1e12), nbytes / (HBM_PEAK_GBS * 1e9)
+                mult = 3 if "x3" in label else 1
+                t_mfma, t_hbm = mult * flops / (BF16_MFMA_PEAK_TFS * 1e12), nbytes / (HBM_PEAK_GBS * 1e9)
                 entry["kernelconv_fac_fused"] = {
-                    "kernel": "conv_fwd_bf16x3_ws/kernelconv_fac", "launches": n, "avg_ms": round(ms / n, 4),
+                    "kernel": label, "launches": n, "avg_ms": round(ms / n, 4),
                     "bound": "mfma" if t_mfma >= t_hbm else "hbm", "algorithmic_flops_per_launch": flops / n,
                     "algorithmic_bytes_per_launch": nbytes / n, "achieved": round(flops / secs / 1e12, 2), "peak": BF16_MFMA_PEAK_TFS,
                     "unit": "TFLOP/s", "frac": round(flops / secs / 1e12 / BF16_MFMA_PEAK_TFS, 4),
-                    "executed": round(3 * flops / secs / 1e12, 2), "frac_executed": round(3 * flops / secs / 1e12 / BF16_MFMA_PEAK_TFS, 4),
+                    "matrix_flops_per_algorithmic_flop": mult, "executed": round(mult * flops / secs / 1e12, 2),
+                    "frac_executed": round(mult * flops / secs / 1e12 / BF16_MFMA_PEAK_TFS, 4),
                     "GBps": round(nbytes / secs / 1e9, 1), "frac_hbm": round(nbytes / secs / 1e9 / HBM_PEAK_GBS, 4)}
             del eager
         out[tag] = entry

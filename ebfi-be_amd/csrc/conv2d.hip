@@ -3613,13 +3613,13 @@ extern "C" int ebfi_kernelconv_fac_fused_x3(const void *input, const void *packe
 }
 
 // The same fused pair on fp16 OPERANDS (round 6; inference): conv_fwd_f16_ws<.., FAC> -- one matrix-core product per tap instead
-// of three.  `input` stays fp32 NCHW: the producers multiply by in_slot's power of two while converting (the caller sets that
-// scale from the tensor itself right before the launch: ebfi_amd.fac) and record |max| there; `packed16` is the "facrows" fp16
+// of three.  `input`: fp32 NCHW -- the producers multiply by in_slot's power of two while converting (the caller sets that scale
+// from the tensor itself right before the launch: ebfi_amd.fac) and record |max| there -- or its c16 image; `packed16` is the "facrows" fp16
 // image [tap][C * 32][K16] of the layer's weight, scaled by w_slot[0] (ebfi_pack_table_f16).  The training step runs this
 // layer on fp16 operands since round 4 (Sharp / Final within 4e-4 of the fp32 result against the path's 1e-3 bar).
-extern "C" int ebfi_kernelconv_fac_fused_f16(const void *input, const void *packed16, size_t packed_bytes, const void *bias32,
-                                             const void *feat, void *output, int B, int Cin, int H, int W, int C, int fac_ksize,
-                                             float slope, void *in_slot, const void *w_slot, void *stream) {
+extern "C" int ebfi_kernelconv_fac_fused_f16(const void *input, int input_is_c16, const void *packed16, size_t packed_bytes,
+                                             const void *bias32, const void *feat, void *output, int B, int Cin, int H, int W, int C,
+                                             int fac_ksize, float slope, void *in_slot, const void *w_slot, void *stream) {
     if (!input || !packed16 || !bias32 || !feat || !output || !in_slot || !w_slot)
         return fail(EBFI_ERR_ARG, "kernelconv_fac_fused_f16: null argument");
     if (fac_ksize != 5) return fail(EBFI_ERR_UNSUPPORTED, "kernelconv_fac_fused_f16: FAC kernel size %d (5 is built)", fac_ksize);
@@ -3633,6 +3633,11 @@ extern "C" int ebfi_kernelconv_fac_fused_f16(const void *input, const void *pack
     if (packed_bytes < need) return fail(EBFI_ERR_WORKSPACE, "kernelconv_fac_fused_f16: packed image %zu bytes < required %zu", packed_bytes, need);
     if (W % 4 != 0 || !aligned16(input))
         return fail(EBFI_ERR_UNSUPPORTED, "kernelconv_fac_fused_f16: needs W %% 4 == 0 and a 16-byte aligned input (W = %d)", W);
+    // input_is_c16: the input as the scaled fp16 image of the tensor (c16.hpp; written by ebfi_to_c16 with in_slot's scale): the
+    // producers copy 16-byte pieces -- half the bytes per staged chunk, no conversion.  It pays here because the layer has 25
+    // output-channel blocks and every one of them stages the whole input again.
+    if (input_is_c16 != 0 && input_is_c16 != 1) return fail(EBFI_ERR_ARG, "kernelconv_fac_fused_f16: input storage %d", input_is_c16);
+    if (input_is_c16 && Cin % 16 != 0) return fail(EBFI_ERR_UNSUPPORTED, "kernelconv_fac_fused_f16: an fp16 input image needs Cin %% 16 == 0");
     if (B == 0) return EBFI_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t tiles = (int64_t)B * ceil_div(g.Ho, TYB) * ceil_div(g.Wo, TX);
@@ -3644,14 +3649,21 @@ extern "C" int ebfi_kernelconv_fac_fused_f16(const void *input, const void *pack
     if (gx < 1) gx = 1;
     if (gx > tiles) gx = tiles;
     const double flops = 2.0 * B * g.Ho * g.Wo * (double)(C * 25) * Cin * 9 + 2.0 * B * g.Ho * g.Wo * (double)C * 25;
-    const double bytes = 4.0 * B * (double)g.Ho * g.Wo * (Cin + 2.0 * C);      // conv input + feature map + output: no filter tensor
-    ProfScope ps("conv_fwd_f16_ws/kernelconv_fac", st, flops, bytes);
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_f16_ws<false, false, false, true>), 160 * 1024)) return rc;
-    hipLaunchKernelGGL((conv_fwd_f16_ws<false, false, false, true>), dim3((unsigned)gx, (unsigned)co_blocks), dim3(NTF16), lds, st,
-                       static_cast<const float *>(input), static_cast<const _Float16 *>(packed16), static_cast<const float *>(bias32),
-                       static_cast<float *>(output), g, K16, ACT_LEAKY, slope, EpiExtra{nullptr, nullptr, 0, 0.f}, (int)tiles,
-                       ScaleSlot{static_cast<float *>(in_slot)}, static_cast<const float *>(w_slot),
-                       FacEpi{static_cast<const float *>(feat), C});
+    // conv input (in the element size it is stored in) + feature map + output: no filter tensor
+    const double bytes = B * (double)g.Ho * g.Wo * ((input_is_c16 ? 2.0 : 4.0) * Cin + 8.0 * C);
+    ProfScope ps(input_is_c16 ? "conv_fwd_f16_ws/kernelconv_fac_img" : "conv_fwd_f16_ws/kernelconv_fac", st, flops, bytes);
+#define EBFI_LAUNCH_FACF16(IN_)                                                                                          \
+    do {                                                                                                                 \
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_f16_ws<false, IN_, false, true>), 160 * 1024)) return rc; \
+        hipLaunchKernelGGL((conv_fwd_f16_ws<false, IN_, false, true>), dim3((unsigned)gx, (unsigned)co_blocks), dim3(NTF16), lds, st, \
+                           static_cast<const float *>(input), static_cast<const _Float16 *>(packed16),                   \
+                           static_cast<const float *>(bias32), static_cast<float *>(output), g, K16, ACT_LEAKY, slope,   \
+                           EpiExtra{nullptr, nullptr, 0, 0.f}, (int)tiles, ScaleSlot{static_cast<float *>(in_slot)},    \
+                           static_cast<const float *>(w_slot), FacEpi{static_cast<const float *>(feat), C});             \
+    } while (0)
+    if (input_is_c16) EBFI_LAUNCH_FACF16(true);
+    else EBFI_LAUNCH_FACF16(false);
+#undef EBFI_LAUNCH_FACF16
     return check_launch("conv_fwd_f16_ws/kernelconv_fac");
 }
 

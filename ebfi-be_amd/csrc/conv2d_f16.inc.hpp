@@ -40,7 +40,7 @@ constexpr int NTF16 = 512;
 //   INP16:  x is a PLANAR fp16 tensor [B, groups*Cin, H, W] scaled by in_slot's scale (the grad_kernel of the FAC op, written by
 //           fac_bwd_rows_f32<.., H16>): the quad staging of the fp32 form with 8-byte loads and byte permutes instead of
 //           conversions, half the bytes; in_slot is only read
-//   FAC (round 6; inference, with EXTRA = IN16 = INP16 = false): the output rows are the per-pixel 5x5 filters of the filter-adaptive
+//   FAC (round 6; inference, with EXTRA = INP16 = false): the output rows are the per-pixel 5x5 filters of the filter-adaptive
 //           convolution that follows (weight rows in the "facrows" layout: one FAC channel per 32-row tile); the epilogue applies
 //           them to `fac.ev` and stores ONE value per pixel and channel (fac_epilogue_tile, conv2d.hip): the fused
 //           KernelConv -> FAC kernel of conv_fwd_bf16x3_ws<0, true> at one matrix-core product per tap instead of three
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
                                                          const float *__restrict__ bias, float *__restrict__ out, ConvGeom g, int K16,
                                                          int act, float slope, EpiExtra epi, int tiles_total, ScaleSlot in_slot,
                                                          const float *__restrict__ w_slot, FacEpi fac) {
-    static_assert(!FAC || (!EXTRA && !IN16 && !INP16), "the FAC epilogue comes with fp32 input staging and no extras");
+    static_assert(!FAC || (!EXTRA && !INP16), "the FAC epilogue comes without epilogue extras (input: fp32 planes or a c16 image)");
     // (MODE.FP16_OVFL: the producers, which convert, set it for good below; the consumers only around their epilogue -- while it is
     //  set the matrix cores drop non-finite operands, c16.hpp)
     constexpr int KS = 3, KK = 9, MT = 2, RW = 2;              // RW: output rows per consumer wave

@@ -89,7 +89,7 @@ SIGNATURES = {
     "ebfi_conv2d_packed_x3_rc": (_i, [_vp, _vp, _sz, _vp, _vp] + [_i] * 6 + [_c.c_float, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "ebfi_conv2d_thin_forward": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_i, _c.c_float, _vp]),
     "ebfi_kernelconv_fac_fused_x3": (_i, [_vp, _vp, _sz, _vp, _vp, _vp] + [_i] * 6 + [_c.c_float, _vp]),
-    "ebfi_kernelconv_fac_fused_f16": (_i, [_vp, _vp, _sz, _vp, _vp, _vp] + [_i] * 6 + [_c.c_float, _vp, _vp, _vp]),
+    "ebfi_kernelconv_fac_fused_f16": (_i, [_vp, _i, _vp, _sz, _vp, _vp, _vp] + [_i] * 6 + [_c.c_float, _vp, _vp, _vp]),
     "ebfi_conv2d_packed_x3": (_i, [_vp, _vp, _sz, _vp, _vp] + [_i] * 8 + [_i, _c.c_float, _vp, _vp, _i, _c.c_float, _vp]),
     "ebfi_conv2d_backward_weight_x3g": (_i, [_vp] * 4 + [_i] * 8 + [_vp, _sz, _vp]),
     "ebfi_scale_residual_cat_forward_ex": (_i, [_vp] * 6 + [_i, _i, _i64, _i64, _vp]),

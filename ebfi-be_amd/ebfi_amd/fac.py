@@ -90,9 +90,15 @@ def kernelconv_fac_fused(cat, feat, site, kernel_size, slope):
         e = torch.floor(torch.log2(amax.clamp_min(1e-37))) + 1.0          # amax = m * 2^e, m in [0.5, 1)
         scale = torch.where((amax > 0) & torch.isfinite(amax), torch.exp2(f16scale.TARGET_EXP - e), torch.ones_like(amax))
         book.slots[f16scale.SLOT_STRIDE * i:f16scale.SLOT_STRIDE * i + 1].copy_(scale.reshape(1))
+        src, is_img = cat, 0
+        if Cin % 16 == 0 and N.dev_env("EBFI_NO_FAC_IMG", "0") != "1":
+            # the layer has C / 2 output-channel blocks and each of them stages the whole input: written once as the scaled fp16
+            # image (one pass), every staging reads half the bytes and converts nothing
+            from . import c16
+            src, is_img = c16.to_c16(cat, book.ptr(i)), 1
         with torch.cuda.device_of(cat):
-            rc = N.lib().ebfi_kernelconv_fac_fused_f16(N.ptr(cat), site.fwd16_ptr(), site.fwd16_bytes, N.ptr(site.bias()), N.ptr(feat),
-                                                       N.ptr(out), B, Cin, H, W, C, int(kernel_size), float(slope), book.ptr(i),
+            rc = N.lib().ebfi_kernelconv_fac_fused_f16(N.ptr(src), is_img, site.fwd16_ptr(), site.fwd16_bytes, N.ptr(site.bias()),
+                                                       N.ptr(feat), N.ptr(out), B, Cin, H, W, C, int(kernel_size), float(slope), book.ptr(i),
                                                        site.w_slot_ptr(), N.stream_ptr(cat.device))
         N.check(rc, "ebfi_kernelconv_fac_fused_f16")
         return out

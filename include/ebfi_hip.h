@@ -267,12 +267,13 @@ int ebfi_kernelconv_fac_fused_x3(const void *input, const void *packed, size_t p
 
 /* The same fused pair on fp16 operands (round 6; ABI 11): one matrix-core product per tap.  `input` fp32 NCHW, multiplied by
  * in_slot[0] (a power of two the caller sets from the tensor right before the launch) while it is staged, |max| recorded in
- * in_slot; `packed16`: the "facrows" fp16 image [tap][C*32][K16] scaled by w_slot[0] (ebfi_pack_table_f16).  Replaces the same
+ * in_slot -- or, input_is_c16 = 1, the c16 image of that tensor written by ebfi_to_c16 with in_slot's scale (Cin % 16 == 0: half
+ * the bytes per staged chunk; every one of the C / 2 output-channel blocks stages the whole input); `packed16`: the "facrows" fp16 image [tap][C*32][K16] scaled by w_slot[0] (ebfi_pack_table_f16).  Replaces the same
  * reference lines as ebfi_kernelconv_fac_fused_x3 (model_singleframe.py:161-162, KernelConv2D.py:82-87,
  * KernelConv2D_kernel.cu:25-53) for inference. */
-int ebfi_kernelconv_fac_fused_f16(const void *input, const void *packed16, size_t packed_bytes, const void *bias32,
-                                  const void *feat, void *output, int B, int Cin, int H, int W, int C, int fac_ksize,
-                                  float slope, void *in_slot, const void *w_slot, void *stream);
+int ebfi_kernelconv_fac_fused_f16(const void *input, int input_is_c16, const void *packed16, size_t packed_bytes,
+                                  const void *bias32, const void *feat, void *output, int B, int Cin, int H, int W, int C,
+                                  int fac_ksize, float slope, void *in_slot, const void *w_slot, void *stream);
 /* ------------------------------------------------------------------ fp16 single-product backward (training step)
  * The data gradient and the weight gradient of the 3x3 layers with ONE fp16 MFMA per product (the forward keeps the
  * split-precision kernels: DESIGN.md section 4).  Every operand is scaled by a power of two kept in a device SLOT of

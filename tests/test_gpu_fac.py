@@ -226,7 +226,9 @@ def test_fused_kernelconv_fac_on_fp16_operands(B, C, Cin, H, W, magnitude):
         torch.cuda.synchronize()
         N.prof_enable(False)
         ran = {k for k, v in N.prof_collect().items() if v[0] > 0}
-        assert ("conv_fwd_f16_ws/kernelconv_fac" in ran) == (book is not None) and ("conv_fwd_bf16x3_ws/kernelconv_fac" in ran) == (book is None), ran
+        # (the fp16 form reads the input as a c16 image when Cin is a multiple of 16, else it converts the fp32 planes while staging)
+        f16_label = "conv_fwd_f16_ws/kernelconv_fac_img" if Cin % 16 == 0 else "conv_fwd_f16_ws/kernelconv_fac"
+        assert (f16_label in ran) == (book is not None) and ("conv_fwd_bf16x3_ws/kernelconv_fac" in ran) == (book is None), ran
     assert torch.isfinite(outs["f16"]).all()
     assert _rel(outs["x3"], ref) < 1e-4
     assert _rel(outs["f16"], ref) < 1e-3, _rel(outs["f16"], ref)
@@ -259,7 +261,7 @@ def test_clip_interpolator_takes_the_fp16_fused_kernel():
         N.prof_enable(False)
         if not graph:
             ran = {k: v[0] for k, v in N.prof_collect().items() if v[0] > 0}
-            want, other = ("conv_fwd_f16_ws/kernelconv_fac", "conv_fwd_bf16x3_ws/kernelconv_fac")[::1 if f16 else -1]
+            want, other = ("conv_fwd_f16_ws/kernelconv_fac_img", "conv_fwd_bf16x3_ws/kernelconv_fac")[::1 if f16 else -1]
             assert ran.get(want) == len(stamps) and other not in ran and not any(k.startswith("fac_fwd") for k in ran), ran
         assert exact.std() > 1e-3 and _rel(got.cpu(), exact.cpu()) < 1e-3, (f16, graph, _rel(got.cpu(), exact.cpu()))
 
