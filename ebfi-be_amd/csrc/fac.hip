@@ -320,6 +320,149 @@ __global__ __launch_bounds__(256) void fac_bwd_rows_f32(const float *__restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// fac_bwd_rows_p16x8 (round 6): fac_bwd_rows_f32<5, TPR, H16, CLAMP> -- the training step's FAC backward on fp16 filter /
+// grad_kernel planes and the unpadded input -- with EIGHT pixels per thread instead of four.  The two big streams of the op
+// (25 filter planes read, 25 grad_kernel planes written) are fp16: four pixels are an 8-byte access per lane, and at 8 bytes
+// per lane the kernel ran at 0.44 of the HBM peak where its fp32 twin, at 16 bytes per lane, runs at 0.73.  Eight pixels
+// make every plane access 16 bytes again (Wo % 8 == 0).  Same arithmetic in the same order per output element: the partial
+// sums of grad_input, the hand-over of the K - 1 = 4 upper partials to the next lane (carried across chunks), the replicate
+// padding's adjoint folded in a fixed order, grad_kernel times the LeakyReLU derivative of the filters, |max| recorded.
+typedef _Float16 f16x8_fac __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_fac __attribute__((ext_vector_type(4)));
+template <int TPR>
+__global__ __launch_bounds__(256) void fac_bwd_rows_p16x8(const float *__restrict__ in, Str4 is, const _Float16 *__restrict__ kern,
+                                                          Str4 ks, const float *__restrict__ gout, Str4 gs,
+                                                          float *__restrict__ gin, Str4 gis, _Float16 *__restrict__ gkern,
+                                                          Str4 gks, int C, int Ho, int Wo, float kslope,
+                                                          const float *__restrict__ f_slot, float *__restrict__ g_slot) {
+    saturate_fp16_conversions();           // (no matrix instructions in this kernel)
+    constexpr int K = 5, PX = 8, NS = PX + K - 1, NU = K - 1, R2 = K / 2;
+    constexpr int RPW = 64 / TPR, ROWS = 4 * RPW;
+    const float finv = 1.f / f_slot[0], gsc = g_slot[0];
+    float gk_amax = 0.f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane / TPR, tx = lane % TPR;
+    const int row = blockIdx.x * ROWS + wave * RPW + r;   // output row
+    const int b = blockIdx.y / C, c = blockIdx.y % C;
+    const int Wi = Wo + K - 1;
+    const int nxp = Wo / PX;
+    const bool rowok = row < Ho;
+    const int nchunks = nxp / TPR + 1;     // the lane right after the last loading lane writes the tail
+    const int Ylo = row == 0 ? 0 : row + R2;
+    const int Yhi = row == Ho - 1 ? Ho - 1 + 2 * R2 : row + R2;
+    const float *inpl = in + (int64_t)b * is.s0 + (int64_t)c * is.s1;
+    const int64_t kbase = (int64_t)b * ks.s0 + (int64_t)c * K * K * ks.s1;
+    const float *gbase = gout + (int64_t)b * gs.s0 + (int64_t)c * gs.s1;
+    const int64_t gkbase = (int64_t)b * gks.s0 + (int64_t)c * K * K * gks.s1;
+    float *ginpl = gin ? gin + (int64_t)b * gis.s0 + (int64_t)c * gis.s1 : nullptr;
+
+    for (int yi = 0; yi < K; ++yi) {
+        const int Y = Ylo + yi;
+        const bool yok = rowok && Y <= Yhi;
+        if (__builtin_amdgcn_ballot_w64(yok) == 0) break;          // (wave-uniform: the shuffles below need every lane)
+        const float *inrow = inpl + (int64_t)min(max(Y - R2, 0), Ho - 1) * is.s2;
+        float *ginrow = ginpl ? ginpl + (int64_t)row * gis.s2 : nullptr;
+        float carry[NU];
+#pragma unroll
+        for (int m = 0; m < NU; ++m) carry[m] = 0.f;
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const int xp = chunk * TPR + tx;
+            const int x = xp * PX;
+            const bool active = yok && xp < nxp;
+            float s[NS];
+#pragma unroll
+            for (int j = 0; j < NS; ++j) s[j] = 0.f;
+            if (active) {
+                float inr[NS];             // padded columns x .. x + 11 = input columns clamp(x + j - 2)
+                if (x >= PX && x + NS <= Wo) {
+                    const float2 *p2 = reinterpret_cast<const float2 *>(inrow + x - R2);     // 8-byte aligned (x % 8 == 0, rows 16-byte aligned)
+#pragma unroll
+                    for (int j = 0; j < NS / 2; ++j) {
+                        const float2 t = p2[j];
+                        inr[2 * j] = t.x;
+                        inr[2 * j + 1] = t.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) inr[j] = inrow[min(max(x + j - R2, 0), Wo - 1)];
+                }
+#pragma unroll
+                for (int ky = 0; ky < K; ++ky) {
+                    const int y = Y - ky;
+                    if (y < 0 || y >= Ho) continue;
+                    const float4 ga = *reinterpret_cast<const float4 *>(gbase + (int64_t)y * gs.s2 + x);
+                    const float4 gb = *reinterpret_cast<const float4 *>(gbase + (int64_t)y * gs.s2 + x + 4);
+                    const float g[PX] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) {
+                        const int t = ky * K + kx;
+                        const u32x4_fac q = __builtin_nontemporal_load(
+                            reinterpret_cast<const u32x4_fac *>(kern + kbase + (int64_t)t * ks.s1 + (int64_t)y * ks.s2 + x));
+                        const f16x8_fac wh = __builtin_bit_cast(f16x8_fac, q);
+                        float p[PX];
+#pragma unroll
+                        for (int i = 0; i < PX; ++i) {
+                            const float w = (float)wh[i] * finv;
+                            p[i] = inr[kx + i] * g[i] * (w > 0.f ? 1.f : kslope);
+                            gk_amax = amax_acc(gk_amax, p[i]);
+                            s[kx + i] = fmaf(w, g[i], s[kx + i]);
+                        }
+                        const u32x4_fac o = {pack_f16(p[0] * gsc, p[1] * gsc), pack_f16(p[2] * gsc, p[3] * gsc),
+                                             pack_f16(p[4] * gsc, p[5] * gsc), pack_f16(p[6] * gsc, p[7] * gsc)};
+                        __builtin_nontemporal_store(o, reinterpret_cast<u32x4_fac *>(gkern + gkbase + (int64_t)t * gks.s1 + (int64_t)y * gks.s2 + x));
+                    }
+                }
+            }
+            // hand the K - 1 upper partials to the lane that owns those columns (all lanes take part)
+            float o[PX];
+#pragma unroll
+            for (int i = 0; i < PX; ++i) o[i] = s[i];
+#pragma unroll
+            for (int m = 0; m < NU; ++m) {
+                float left = __shfl_up(s[PX + m], 1, TPR);
+                if (tx == 0) left = carry[m];
+                const float last = __shfl(s[PX + m], TPR - 1, TPR);
+                o[m] += left;
+                carry[m] = last;
+            }
+            if (ginrow != nullptr && yok && x < Wi) {
+                // padded columns x .. x + 7 -> output columns clamp(X - 2): the left border's three (X = 0, 1, 2 -> 0) sit in the thread
+                // with x == 0, the right border's three (X = Wo + 1 .. Wo + 3 -> Wo - 1) in the tail thread x == Wo (which holds only
+                // the four carried partials).  yi > 0 (first / last output row): this thread wrote the elements in an earlier pass.
+                if (x == 0) {
+                    const float v0 = (o[0] + o[1]) + o[2];
+                    if (yi == 0) {
+                        ginrow[0] = v0; ginrow[1] = o[3];
+#pragma unroll
+                        for (int i = 4; i < PX; ++i) ginrow[i - 2] = o[i];
+                    } else {
+                        ginrow[0] += v0; ginrow[1] += o[3];
+#pragma unroll
+                        for (int i = 4; i < PX; ++i) ginrow[i - 2] += o[i];
+                    }
+                } else if (x == Wo) {
+                    const float v1 = (o[1] + o[2]) + o[3];
+                    if (yi == 0) { ginrow[Wo - 2] = o[0]; ginrow[Wo - 1] = v1; }
+                    else { ginrow[Wo - 2] += o[0]; ginrow[Wo - 1] += v1; }
+                } else {
+                    float2 *g2 = reinterpret_cast<float2 *>(ginrow + x - R2);
+#pragma unroll
+                    for (int i = 0; i < PX / 2; ++i) {
+                        if (yi == 0) {
+                            g2[i] = float2{o[2 * i], o[2 * i + 1]};
+                        } else {
+                            const float2 a = g2[i];
+                            g2[i] = float2{a.x + o[2 * i], a.y + o[2 * i + 1]};
+                        }
+                    }
+                }
+            }
+        }
+    }
+    ScaleSlot{g_slot}.record(gk_amax);
+}
+
 __global__ void fac_bwd_input_generic_f32(const float *__restrict__ kern, Str4 ks,
                                           const float *__restrict__ gout, Str4 gs, float *__restrict__ gin,
                                           Str4 gis, int64_t total, int C, int Ho, int Wo, int K) {
@@ -568,7 +711,23 @@ extern "C" int ebfi_fac_backward_p16(const float *input, int input_is_unpadded, 
     if (B == 0) return EBFI_OK;
     const int64_t Hi = Ho + K - 1, Wi = Wo + K - 1, HW = (int64_t)Ho * Wo;
     const Str4 ks{(int64_t)C * K * K * HW, HW, Wo, 1}, gs{C * HW, HW, Wo, 1};
-    if (input_is_unpadded) {
+    if (input_is_unpadded && grad_kernel16 && Wo % 8 == 0 && Wo >= 16 && dev_getenv("EBFI_FAC_BWD_X4") == nullptr) {
+        // the step's configuration: eight pixels per thread, 16-byte accesses of the fp16 planes (fac_bwd_rows_p16x8)
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        const int nxp = Wo / 8;
+        const double px = (double)B * C * Ho * Wo;
+        ProfScope ps("fac_bwd_rows_f32/p16", st, 4.0 * px * K * K, px * (2.0 * K * K + 4.0 + 4.0 + (grad_input ? 4.0 : 0.0) + 2.0 * K * K));
+#define EBFI_LAUNCH_FACB8(TPR_)                                                                                          \
+    hipLaunchKernelGGL((fac_bwd_rows_p16x8<TPR_>), dim3((unsigned)ceil_div(Ho, 4 * (64 / TPR_)), (unsigned)(B * C)), dim3(256), 0, st, \
+                       input, gs, static_cast<const _Float16 *>(filters16), ks, grad_output, gs, grad_input, gs,         \
+                       static_cast<_Float16 *>(grad_kernel16), ks, C, Ho, Wo, kernel_leaky_slope,                        \
+                       static_cast<const float *>(f_slot), static_cast<float *>(g_slot))
+        if (nxp <= 8) EBFI_LAUNCH_FACB8(8);
+        else if (nxp <= 16) EBFI_LAUNCH_FACB8(16);
+        else if (nxp <= 32) EBFI_LAUNCH_FACB8(32);
+        else EBFI_LAUNCH_FACB8(64);
+#undef EBFI_LAUNCH_FACB8
+    } else if (input_is_unpadded) {
         launch_bwd_rows<5, true, true>(static_cast<hipStream_t>(stream), input, gs, filters16, ks, grad_output, gs, grad_input, gs,
                                        grad_kernel16, ks, B, C, Ho, Wo, kernel_leaky_slope, static_cast<const float *>(f_slot),
                                        static_cast<float *>(g_slot));

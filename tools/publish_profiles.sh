@@ -6,6 +6,10 @@ cd "$(dirname "$0")/.."
 S=gpurun_out/$1; D=profiles/$2
 mkdir -p "$D"
 cp $S/bench.json $D/bench_final.json
+[ -s $S/bench_detail.json ] && cp $S/bench_detail.json $D/bench_final_detail.json || true      # (round 6: the line is compact, the tables are here)
+[ -s $S/bench_prof_detail.json ] && cp $S/bench_prof_detail.json $D/bench_final_profiled_run_detail.json || true
+[ -s $S/bench_2rank_rehearsal_detail.json ] && cp $S/bench_2rank_rehearsal_detail.json $D/bench_final_2rank_rehearsal_detail.json || true
+f=$(find $S/prof_ops -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp $f $D/opbench_dcn_fac_kernel_stats.csv || true
 cp $S/bench_prof.json $D/bench_final_profiled_run.json
 cp $S/prof/bench_kernel_stats.csv $D/bench_final_kernel_stats.csv
 cp $S/graph_replay_timeline.txt $D/graph_replay_timeline_final.txt
