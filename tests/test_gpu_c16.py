@@ -333,14 +333,22 @@ def test_fac_on_fp16_filter_planes(B, C, H, W):
     gu, gk_u = torch.full_like(ev, float("nan")), torch.empty_like(gk16)
     N.check(lib.ebfi_fac_backward_p16(N.ptr(ev), 1, N.ptr(f16), book.ptr(sf), N.ptr(go), N.ptr(gu), N.ptr(gk_u), book.ptr(sg), 0.01,
                                       B, C, H, W, K, st), "unpadded bwd")
-    assert torch.equal(gk_u, gk_p)
+    # grad_kernel: where the filter is > 0 the two kernels form the same product (bit-equal); where it is <= 0 the 8-pixel kernel of
+    # the unpadded path multiplies in * (grad_out * slope) and the 4-pixel one (in * grad_out) * slope -- one fp32 rounding apart
+    # before the fp16 rounding: a few elements in a thousand differ by one fp16 ulp
+    pos = (f16 > 0)
+    assert torch.equal(gk_u[pos], gk_p[pos])
+    dk = (gk_u.float() - gk_p.float()).abs()
+    assert (dk > 0).float().mean().item() < 5e-3 and (dk <= gk_p.float().abs() * 2.0 ** -10 + 1e-12).all()
     # the padding's adjoint in float64 from the padded gradient: interior elements are copies, border elements sums of <= 9 terms
     yy = torch.arange(H + 4, device="cuda").sub(2).clamp(0, H - 1)
     xx = torch.arange(W + 4, device="cuda").sub(2).clamp(0, W - 1)
     rows = torch.zeros(B, C, H, W + 4, dtype=torch.float64, device="cuda").index_add_(2, yy, gp.double())
     ref_g = torch.zeros(B, C, H, W, dtype=torch.float64, device="cuda").index_add_(3, xx, rows)
     assert torch.isfinite(gu).all()
-    assert torch.equal(gu[:, :, 1:-1, 1:-1], gp[:, :, 3:-3, 3:-3])
+    # (interior elements are the same sums; the 8-pixel kernel adds a column's terms in another association than the 4-pixel one --
+    #  neighbouring threads' partial sums meet at other places -- so the comparison is to fp32 rounding, not bit for bit)
+    assert ((gu[:, :, 1:-1, 1:-1] - gp[:, :, 3:-3, 3:-3]).abs().max() / gp.abs().max()).item() < 1e-6
     assert ((gu.double() - ref_g).abs().max() / ref_g.abs().max()).item() < 1e-6
     gu2 = torch.empty_like(ev)                          # fixed summation order: bit-identical from run to run
     N.check(lib.ebfi_fac_backward_p16(N.ptr(ev), 1, N.ptr(f16), book.ptr(sf), N.ptr(go), N.ptr(gu2), N.ptr(gk_u), book.ptr(sg), 0.01,

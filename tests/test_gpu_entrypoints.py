@@ -119,6 +119,30 @@ def test_bench_plain_form_launches_its_own_ranks():
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr + r.stdout
 
 
+def test_bench_form_stays_native_under_strict(tmp_path):
+    """The driver's bench form (`python bench.py --gpus 1 ...`: default widths, the split-precision leg with the fp16 backward, the
+    exact-fp32 leg, the three inference legs) with EBFI_STRICT_NATIVE=1: a convolution of the default model dispatched to torch /
+    MIOpen anywhere on these paths raises EbfiNativeError and fails the run (round 5: ResidualControl's scalar 1x1 convolutions
+    still printed 'runs on torch' here).  Also what the driver needs from stdout: ONE line, < 4 KB, with roofline and config."""
+    import json
+    env = dict(os.environ, EBFI_STRICT_NATIVE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "EBFI_BENCH_REHEARSAL", "EBFI_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    detail = str(tmp_path / "detail.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-ops", "--detail", detail], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "runs on torch" not in r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    d = json.loads(lines[0])
+    assert d["roofline"]["kernel"].startswith("conv_") and d["config"]["graph_capture_failed"] is False
+    assert set(d["inference_frames_per_s"]) == {"config2_fp32", "config2_bf16x3", "config5_hd_bf16x3"}
+    full = json.load(open(detail))
+    assert full["inference"]["config5_hd_bf16x3"]["kernelconv_fac_fused"]["kernel"] == "conv_fwd_f16_ws/kernelconv_fac_img"
+    assert full["fp32_exact_mode"]["ms_per_step"] > d["ms_per_step"]
+
+
 def test_bench_single_rank_over_rccl():
     """What a one-GPU box can exercise of the RCCL path: bench.py as ONE rank with the process group initialised on backend
     'nccl' (= RCCL), its watchdog thread alive during the hipGraph capture (strict), and the step's collective -- the
