@@ -727,7 +727,8 @@ extern "C" int ebfi_fac_backward_p16(const float *input, int input_is_unpadded, 
         hipStream_t st = static_cast<hipStream_t>(stream);
         const int nxp = Wo / 8;
         const double px = (double)B * C * Ho * Wo;
-        ProfScope ps("fac_bwd_rows_f32/p16", st, 4.0 * px * K * K, px * (2.0 * K * K + 4.0 + 4.0 + (grad_input ? 4.0 : 0.0) + 2.0 * K * K));
+        // (label = kernel symbol / role: bench.py looks the launch's PMC traffic up by the symbol)
+        ProfScope ps("fac_bwd_rows_p16x8/p16", st, 4.0 * px * K * K, px * (2.0 * K * K + 4.0 + 4.0 + (grad_input ? 4.0 : 0.0) + 2.0 * K * K));
 #define EBFI_LAUNCH_FACB8(TPR_)                                                                                          \
     hipLaunchKernelGGL((fac_bwd_rows_p16x8<TPR_>), dim3((unsigned)ceil_div(Ho, 4 * (64 / TPR_)), (unsigned)(B * C)), dim3(256), 0, st, \
                        input, gs, static_cast<const _Float16 *>(filters16), ks, grad_output, gs, grad_input, gs,         \

@@ -282,6 +282,13 @@ class ResidualControlFn(Function):
                         c = new(2 * C)
                         _conv16(lib, st, x, sa, sa.bias(), ya, B, C, H, W, 2 * C, 1, slope, ya16, sp(sb, "x"))
                         _conv(lib, st, ya, sb.fwd_ptr(), sb.fwd_bytes, sb.bias(), a, B, C, H, W, 2 * C, 2, ACT, slope)
+                        # the epilogue-tail form above needs the slot of the image of `a`, which only the layer-wise form used to
+                        # measure: slots restored from an earlier state, or a first pass run with EBFI_NO_RC_EPILOGUE=1, left this
+                        # path on the separate stage for good (round-5 advisory).  Measured here while the fp32 `a` still exists
+                        # (eager passes only: a first use cannot be calibrated inside a graph capture).
+                        if book.index.get((sb.key, "a")) not in book.calibrated and not torch.cuda.is_current_stream_capturing() \
+                                and N.dev_env("EBFI_NO_RC_EPILOGUE", "0") != "1":
+                            book.operand((sb.key, "a"), a)
                     rc = lib.ebfi_scale_residual_cat_forward_c16(N.ptr(a), N.ptr(s_ex[i]), N._vp(a.data_ptr() + 4 * C * HW), N.ptr(s_t[i]),
                                                                  N.ptr(x), N.ptr(c), N.ptr(c16i), sp(sc, "x"), B, C, H, W, 2 * C * HW, st)
                     N.check(rc, "ebfi_scale_residual_cat_forward_c16")

@@ -37,6 +37,9 @@ timeout -k 10 300 python ebfi-be_amd/infer_ours.py --rand-init --batch 4 --heigh
 timeout -k 10 300 python ebfi-be_amd/infer_ours.py --rand-init --batch 4 --height 256 --width 256 > $OUT/config2_x3.log 2>&1; tail -1 $OUT/config2_x3.log
 timeout -k 10 400 python ebfi-be_amd/infer_ours.py --rand-init --batch 8 --height 720 --width 1280 --num_ts 4 > $OUT/config5.log 2>&1; tail -1 $OUT/config5.log
 EBFI_DEV=1 EBFI_NO_FAC_FUSION=1 timeout -k 10 400 python ebfi-be_amd/infer_ours.py --rand-init --batch 8 --height 720 --width 1280 --num_ts 4 > $OUT/config5_unfused.log 2>&1; tail -1 $OUT/config5_unfused.log
+# (round 6: the fused kernel runs on fp16 operands by default; the split-precision form of it for comparison)
+EBFI_DEV=1 EBFI_NO_FAC_F16=1 timeout -k 10 400 python ebfi-be_amd/infer_ours.py --rand-init --batch 8 --height 720 --width 1280 --num_ts 4 > $OUT/config5_fused_x3.log 2>&1; tail -1 $OUT/config5_fused_x3.log
+EBFI_DEV=1 EBFI_NO_FAC_F16=1 timeout -k 10 300 python ebfi-be_amd/infer_ours.py --rand-init --batch 4 --height 256 --width 256 > $OUT/config2_fused_x3.log 2>&1; tail -1 $OUT/config2_fused_x3.log
 echo "[6b] rocprofv3 kernel stats of the inference configs 2 and 5 (eager launches: a replayed graph is traced the same way)"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c2 -o c2 -- python3 ebfi-be_amd/infer_ours.py --rand-init --batch 4 --height 256 --width 256 --num_ts 8 > $OUT/config2_prof.log 2>&1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c5 -o c5 -- python3 ebfi-be_amd/infer_ours.py --rand-init --batch 8 --height 720 --width 1280 --num_ts 4 > $OUT/config5_prof.log 2>&1

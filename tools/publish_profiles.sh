@@ -28,7 +28,7 @@ cp $S/kbench.log $D/kbench_final.log
 cp $S/opbench_x3.jsonl $D/opbench_final_bf16x3.jsonl
 cp $S/opbench_fp32.jsonl $D/opbench_final_fp32.jsonl
 cp $S/opbench_dcn_fac.jsonl $D/opbench_dcn_fac_final.jsonl
-cat $S/config1.log $S/config2_fp32.log $S/config2_x3.log $S/config5.log $S/config5_unfused.log | grep -v amdgpu.ids > $D/configs_final.log
+( for f in config1 config2_fp32 config2_x3 config2_fused_x3 config5 config5_fused_x3 config5_unfused; do [ -s $S/$f.log ] && { echo "== $f"; grep -v amdgpu.ids $S/$f.log; }; done ) > $D/configs_final.log
 cp $(find $S/prof_c2 -name "*kernel_stats.csv" | head -1) $D/infer_config2_kernel_stats.csv
 cp $(find $S/prof_c5 -name "*kernel_stats.csv" | head -1) $D/infer_config5_kernel_stats.csv
 grep -v amdgpu.ids $S/train_ours_1gpu.log > $D/train_ours_1gpu.log
