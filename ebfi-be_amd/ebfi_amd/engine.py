@@ -322,8 +322,16 @@ class ClipInterpolator:
     (tests/test_gpu_model.py::test_hoisted_inference_is_bit_identical).  precision 'bf16x3' packs the conv weight images once
     (inference weight bank, incl. the fused KernelConv -> FAC layout)."""
 
-    def __init__(self, model, precision="bf16x3", graph=True, hoist=True, filters_f16=True):
-        """filters_f16 (precision 'bf16x3' only; default on): the fused KernelConv(128 -> 1600) -> FAC kernel -- a third of the
+    GROUP_PIXELS = 16 * 256 * 256      # auto grouping: timestamps per pass so that B * k * H * W stays at or below this
+
+    def __init__(self, model, precision="bf16x3", graph=True, hoist=True, filters_f16=True, group=None):
+        """group (round 6; with hoist): how many latent timestamps ONE pass of the per-timestamp network computes.  The prefix's
+        outputs are the same for every timestamp, so k timestamps are a batch of k * B samples that differ only in T (samples are
+        independent: no BatchNorm, per-sample GroupNorm / pooling).  None = as many as keep B * k * H * W <= GROUP_PIXELS (4 at
+        BASELINE config 2, B=4 256x256: the launches of a B=4 pass are mostly at their latency floor; 1 at config 5); 1 = one
+        timestamp per pass, bit-identical to the reference loop's per-timestamp module call.  Grouped passes agree with that to
+        fp32 rounding (the kernels pick tile geometries by problem size; tests/test_gpu_entrypoints.py).
+        filters_f16 (precision 'bf16x3' only; default on): the fused KernelConv(128 -> 1600) -> FAC kernel -- a third of the
         model's multiply-adds -- reads fp16 operands, one matrix-core product per tap instead of the split precision's three,
         with exact power-of-two operand scales (the input's measured on the device before every launch).  It is the one
         convolution the TRAINING step runs on fp16 operands too (Engine(forward_f16='filters')): outputs stay within 4e-4 of the
@@ -331,6 +339,7 @@ class ClipInterpolator:
         # (inference needs eval mode; the caller's model is NOT switched for good: its mode is restored after every call)
         self.model = model
         self.precision, self.graph, self.hoist = precision, bool(graph), bool(hoist)
+        self.group = None if group is None else max(1, int(group))
         self.graph_capture_failed, self.graph_capture_error = False, None    # as Engine: a failed capture continues eagerly
         self.bank = self.book = None
         if precision == "bf16x3" and next(model.parameters()).is_cuda:
@@ -389,21 +398,45 @@ class ClipInterpolator:
             if ev:
                 ev[1].record()
             result = out
+            n = len(timestamps)
+            k = 1
+            if self.hoist:
+                k = self.group if self.group is not None else max(1, self.GROUP_PIXELS // max(1, B * frame.shape[-2] * frame.shape[-1]))
+                k = max(1, min(k, n))
+            self.last_group = k
 
-            def put(i, value):
+            def put(i, value, count=1):
+                """value: [count * B, 3, H, W] (pass-major: sample b of timestamp j at row j * B + b) -> result[:, i : i + count]"""
                 nonlocal result
+                shape = (B, n) + tuple(value.shape[1:])
                 if result is None:
-                    result = torch.empty((B, len(timestamps)) + tuple(value.shape[1:]), dtype=value.dtype, device=value.device)
-                elif i == 0 and (tuple(result.shape) != (B, len(timestamps)) + tuple(value.shape[1:]) or result.dtype != value.dtype
-                                 or result.device != value.device):
-                    raise ValueError("ClipInterpolator: out must be a %s tensor of shape %r on %s"
-                                     % (value.dtype, (B, len(timestamps)) + tuple(value.shape[1:]), value.device))
-                result[:, i].copy_(value)
+                    result = torch.empty(shape, dtype=value.dtype, device=value.device)
+                elif i == 0 and (tuple(result.shape) != shape or result.dtype != value.dtype or result.device != value.device):
+                    raise ValueError("ClipInterpolator: out must be a %s tensor of shape %r on %s" % (value.dtype, shape, value.device))
+                if count == 1:
+                    result[:, i].copy_(value[:B])
+                else:
+                    result[:, i:i + count].copy_(value[:count * B].view((count, B) + tuple(value.shape[1:])).transpose(0, 1))
+
+            def t_tensor(chunk, rows):
+                """[rows * B, 1]: T of every sample of a pass (a short last chunk repeats its last timestamp; the extra rows are dropped)"""
+                cols = []
+                for j in range(rows):
+                    ts = chunk[min(j, len(chunk) - 1)]
+                    cols.append(ts.reshape(B, 1).to(dev) if torch.is_tensor(ts) else torch.full((B, 1), float(ts), device=dev))
+                return torch.cat(cols, 0)
+
+            def replicated(st, rows):
+                return tuple(torch.cat([v] * rows, 0) if torch.is_tensor(v) and rows > 1 else v for v in st) if self.hoist else st
 
             def eager():
-                for i, ts in enumerate(timestamps):
-                    t = ts if torch.is_tensor(ts) else torch.full((B, 1), float(ts), device=dev)
-                    put(i, self._step(state, frame, event, gtex, t))
+                rep = replicated(state, k) if self.hoist else None
+                for i0 in range(0, n, k):
+                    chunk = timestamps[i0:i0 + k]
+                    if self.hoist:
+                        put(i0, self.model.decode(rep, t_tensor(chunk, k))[-1], len(chunk))
+                    else:
+                        put(i0, self._step(state, frame, event, gtex, t_tensor(chunk, 1)))
 
             def done():
                 if ev:
@@ -415,13 +448,13 @@ class ClipInterpolator:
             if not self.graph or dev.type != "cuda":
                 eager()
                 return done()
-            key = (tuple(frame.shape), tuple(event.shape), gtex is not None)
+            key = (tuple(frame.shape), tuple(event.shape), gtex is not None, k)
             ent = self._captured.get(key)
             if ent is None:
-                # static inputs of the captured graph: the prefix's outputs (hoisted) or the raw inputs, plus T
-                st_in = [v.clone() if torch.is_tensor(v) else v for v in state] if self.hoist else \
+                # static inputs of the captured graph: the prefix's outputs, replicated k times (hoisted), or the raw inputs; plus T
+                st_in = list(replicated(tuple(v.clone() if torch.is_tensor(v) else v for v in state), k)) if self.hoist else \
                     [frame.clone(), event.clone(), None if gtex is None else gtex.clone()]
-                t_static = torch.zeros(B, 1, device=dev)
+                t_static = torch.zeros(k * B, 1, device=dev)
                 call = (lambda: self.model.decode(tuple(st_in), t_static)[-1]) if self.hoist else \
                     (lambda: self.model(st_in[0], st_in[1], t_static, st_in[2])[-1])
                 side = torch.cuda.Stream(dev)
@@ -447,12 +480,13 @@ class ClipInterpolator:
             src = state if self.hoist else (frame, event, gtex)
             for dst, v in zip(st_in, src):
                 if torch.is_tensor(dst):
-                    dst.copy_(v)
-            for i, ts in enumerate(timestamps):
-                if torch.is_tensor(ts):
-                    t_static.copy_(ts)
-                else:
-                    t_static.fill_(float(ts))
+                    if dst.shape[0] == v.shape[0]:
+                        dst.copy_(v)
+                    else:                                   # k replicas of the prefix's output, pass-major
+                        dst.view((k,) + tuple(v.shape)).copy_(v.unsqueeze(0).expand((k,) + tuple(v.shape)))
+            for i0 in range(0, n, k):
+                chunk = timestamps[i0:i0 + k]
+                t_static.copy_(t_tensor(chunk, k))
                 g.replay()
-                put(i, out_static)
+                put(i0, out_static, len(chunk))
             return done()
