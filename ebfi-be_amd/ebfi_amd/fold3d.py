@@ -147,19 +147,74 @@ def fold_conv_transpose3d_weight(wt):
     return w8.reshape(8 * Co, 2 * Ci, 3, 3)
 
 
-def conv_transpose3d_d2(x, m):
-    """x [B,Ci,2,H,W] through nn.ConvTranspose3d `m` -> [B,Co,2,2H,2W]."""
+def _conv_transpose3d_unshuffled(x, m):
+    """x [B,Ci,2,H,W] through nn.ConvTranspose3d `m` as the folded 3x3 convolution: [B, 8*Co, H, W], channel = (co, d, py, px)."""
     B, Ci, D, H, W = x.shape
     assert D == 2 and m.kernel_size == (3, 4, 4) and m.stride == (1, 2, 2) and m.padding == (1, 1, 1)
     assert m.output_padding == (0, 0, 0) and m.dilation == (1, 1, 1) and m.groups == 1
     site = weightbank.lookup(m.weight, "convT3d")
     if conv.site_usable(site, x.reshape(B, 2 * Ci, H, W)):
-        y = conv.conv_site(x.reshape(B, 2 * Ci, H, W), site, 1, conv.ACT_NONE, 0.0, [m.weight], [m.bias] if m.bias is not None else [])
-        return F.pixel_shuffle(y, 2).view(B, m.out_channels, 2, 2 * H, 2 * W)
+        return conv.conv_site(x.reshape(B, 2 * Ci, H, W), site, 1, conv.ACT_NONE, 0.0, [m.weight], [m.bias] if m.bias is not None else [])
     b8 = folded("rep8", _rep8, m.bias) if m.bias is not None else None
-    y = conv.conv_bias_act(x.reshape(B, 2 * Ci, H, W), folded("convT3d", fold_conv_transpose3d_weight, m.weight), b8, 1, 1,
-                           conv.ACT_NONE, 0.0)
-    return F.pixel_shuffle(y, 2).view(B, m.out_channels, 2, 2 * H, 2 * W)
+    return conv.conv_bias_act(x.reshape(B, 2 * Ci, H, W), folded("convT3d", fold_conv_transpose3d_weight, m.weight), b8, 1, 1,
+                              conv.ACT_NONE, 0.0)
+
+
+def conv_transpose3d_d2(x, m):
+    """x [B,Ci,2,H,W] through nn.ConvTranspose3d `m` -> [B,Co,2,2H,2W]."""
+    B, Ci, D, H, W = x.shape
+    return F.pixel_shuffle(_conv_transpose3d_unshuffled(x, m), 2).view(B, m.out_channels, 2, 2 * H, 2 * W)
+
+
+class _SEGateShuffled(torch.autograd.Function):
+    """_SEGate on the UNSHUFFLED output of a folded transposed convolution: y2 [B, 8C, h, w] -> act(gate * shuffle(y2))
+    [B, C, 2, 2h, 2w]; the gradient returns in y2's layout (csrc/segate.hip, PsGeom).  The PixelShuffle copy never runs."""
+
+    @staticmethod
+    def forward(ctx, y2, weight, bias, act, slope):
+        y2 = y2.contiguous()
+        B, C8, h, w = (int(v) for v in y2.shape)
+        C = C8 // 8
+        n = 8 * h * w
+        w2 = weight.reshape(C, C).contiguous()
+        out = torch.empty(B, C, 2, 2 * h, 2 * w, dtype=y2.dtype, device=y2.device)
+        mean = torch.empty(B * C, dtype=y2.dtype, device=y2.device)
+        gate = torch.empty(B * C, dtype=y2.dtype, device=y2.device)
+        ws = torch.empty(max(int(N.lib().ebfi_se_gate_workspace(B, C, n)), 1), dtype=y2.dtype, device=y2.device)
+        with torch.cuda.device_of(y2):
+            rc = N.lib().ebfi_se_gate_forward_ps(N.ptr(y2), N.ptr(w2), N.ptr(bias), N.ptr(out), N.ptr(mean), N.ptr(gate), N.ptr(ws),
+                                                 B, C, h, w, act, slope, N.stream_ptr(y2.device))
+        N.check(rc, "ebfi_se_gate_forward_ps")
+        ctx.cfg = (B, C, h, w, act, slope, bias is not None, weight.shape)
+        ctx.save_for_backward(y2, w2, gate, mean, out if act != 0 else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        y2, w2, gate, mean, out = ctx.saved_tensors
+        B, C, h, w, act, slope, has_bias, wshape = ctx.cfg
+        g = g.contiguous()
+        gy = torch.empty_like(y2)
+        gw = torch.empty_like(w2)
+        gb = torch.empty(C, dtype=y2.dtype, device=y2.device) if has_bias else None
+        ws = torch.empty(max(int(N.lib().ebfi_se_gate_workspace(B, C, 8 * h * w)), 1), dtype=y2.dtype, device=y2.device)
+        with torch.cuda.device_of(y2):
+            rc = N.lib().ebfi_se_gate_backward_ps(N.ptr(g), N.ptr(out), N.ptr(y2), N.ptr(w2), N.ptr(gate), N.ptr(mean), N.ptr(gy),
+                                                  N.ptr(gw), N.ptr(gb), N.ptr(ws), B, C, h, w, act, slope, N.stream_ptr(y2.device))
+        N.check(rc, "ebfi_se_gate_backward_ps")
+        return gy, gw.view(wshape), gb, None, None
+
+
+def conv_transpose3d_se(x, m, attn_conv, act=0, slope=0.0):
+    """upConv3D's transposed convolution + SEGating (+ LeakyReLU) (model_3DUnet / resnet_3D upConv3D; the decoder stages of
+    UNet3d_18, model_singleframe.py:200-221): the gate reads the folded convolution's output through the pixel shuffle."""
+    B, Ci, D, H, W = x.shape
+    C = m.out_channels
+    if N.dev_env("EBFI_NO_SEGATE_SHUFFLE", "0") != "1" and N.dev_env("EBFI_NO_SEGATE", "0") != "1" and x.is_cuda \
+            and x.dtype == torch.float32 and W % 2 == 0 and B * C <= 4096 and attn_conv.in_channels == attn_conv.out_channels == C \
+            and not torch.is_autocast_enabled():
+        return _SEGateShuffled.apply(_conv_transpose3d_unshuffled(x, m), attn_conv.weight, attn_conv.bias, int(act), float(slope))
+    return se_gate(conv_transpose3d_d2(x, m), attn_conv, None, act, slope)
 
 
 class _SEGate(torch.autograd.Function):

@@ -389,7 +389,7 @@ class upConv3D(nn.Module):
 
     def forward(self, x, post_act=None):
         if fold3d.usable(x) and self.upmode == "transpose" and isinstance(self.upconv[2], identity):
-            return self.upconv[1](fold3d.conv_transpose3d_d2(x, self.upconv[0]), None, post_act)
+            return fold3d.conv_transpose3d_se(x, self.upconv[0], self.upconv[1].attn_layer[0], 0 if post_act is None else 1, post_act or 0.0)
         y = self.upconv(x)
         return y if post_act is None else F.leaky_relu(y, post_act)
 

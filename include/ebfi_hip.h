@@ -65,8 +65,10 @@ extern "C" {
  *  10  ebfi_conv2d_thin_forward (3x3 layers with <= 3 output channels: taps on the matrix row axis)
  *  11  ebfi_scalar_conv_forward / _backward (ResidualControl's scalar-conditioned channel scales: a bank of 1x1 convolutions on
  *      [B,K,1,1] inputs in one launch each way); ebfi_kernelconv_fac_fused_f16 (the fused KernelConv -> FAC kernel of inference
- *      on fp16 operands) */
-#define EBFI_ABI_VERSION 11
+ *      on fp16 operands)
+ *  12  ebfi_se_gate_forward_ps / _backward_ps (the squeeze-excite gate of an up-convolution stage reading the transposed
+ *      convolution's output through the pixel shuffle) */
+#define EBFI_ABI_VERSION 12
 
 typedef enum {
     EBFI_OK = 0,
@@ -470,6 +472,17 @@ int ebfi_se_gate_forward(const float *x, const float *weight, const float *bias,
 int ebfi_se_gate_backward(const float *grad_out, const float *out, const float *x, const float *weight, const float *gate,
                           const float *mean, float *grad_x, float *grad_res, float *grad_weight, float *grad_bias,
                           float *workspace, int B, int C, int64_t N, int act, float slope, void *stream);
+
+/* Round 6 (ABI 12): the same gate behind a transposed convolution whose output has NOT been pixel-shuffled yet -- upConv3D of the
+ * detail branch (model_singleframe.py:200-223, resnet_3D / model_3DUnet upConv3D: ConvTranspose3d (3,4,4)/(1,2,2) -> SEGating ->
+ * LeakyReLU), run here as a 3x3 convolution to 8*C channels.  x: that convolution's output [B, 8*C, h, w] (channel = (c, d, py, px));
+ * out / grad_out: [B, C, 2, 2h, 2w]; grad_x in x's layout.  The gate kernels address x through the shuffle: the PixelShuffle copy
+ * of the stage's largest tensor (forward and backward) never runs.  w even; no residual input. */
+int ebfi_se_gate_forward_ps(const float *x, const float *weight, const float *bias, float *out, float *mean, float *gate,
+                            float *workspace, int B, int C, int h, int w, int act, float slope, void *stream);
+int ebfi_se_gate_backward_ps(const float *grad_out, const float *out, const float *x, const float *weight, const float *gate,
+                             const float *mean, float *grad_x, float *grad_weight, float *grad_bias, float *workspace, int B, int C,
+                             int h, int w, int act, float slope, void *stream);
 
 /* ------------------------------------------------------------------ GroupNorm (exposure-decision head)
  * nn.GroupNorm(groups, C) on contiguous NCHW fp32 (reference models/Ours/model_singleframe.py:36,66-67).

@@ -849,6 +849,65 @@ def test_fused_residual_control_equals_layerwise():
         conv.set_compute_dtype("fp32")
 
 
+def test_se_gate_through_the_pixel_shuffle_vs_torch_cpu():
+    """csrc/segate.hip (round 6): the gate of an up-convolution stage reads the folded transposed convolution's output THROUGH the
+    pixel shuffle.  (a) the gate alone on a random unshuffled tensor against pixel_shuffle + the reference formulation on the CPU;
+    (b) a whole upConv3D stage (ConvTranspose3d (3,4,4)/(1,2,2) -> SEGating -> LeakyReLU(0.2): model_singleframe.py:200-221)
+    against torch's own modules on the CPU, output and all gradients; and the stage takes the new kernels."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from ebfi_amd import _native as N
+    from ebfi_amd import fold3d
+    from ebfi_amd.model import SEGating, upConv3D
+    torch.manual_seed(29)
+    for (B, C, h, w, act) in [(2, 16, 6, 10, 0.2), (1, 8, 5, 8, None), (3, 4, 64, 96, 0.2), (1, 32, 3, 2, 0.2), (70, 4, 2, 4, None)]:
+        gate = SEGating(C)
+        with torch.no_grad():
+            gate.attn_layer[0].weight.copy_(torch.randn_like(gate.attn_layer[0].weight) * 0.5)
+            gate.attn_layer[0].bias.copy_(torch.randn(C) * 0.3)
+        y2 = torch.randn(B, 8 * C, h, w, requires_grad=True)
+        x = F.pixel_shuffle(y2, 2).view(B, C, 2, 2 * h, 2 * w)
+        y = x * torch.sigmoid(gate.attn_layer[0](gate.pool(x)))
+        if act is not None:
+            y = F.leaky_relu(y, act)
+        g = torch.randn_like(y)
+        y.backward(g)
+        gd = SEGating(C).cuda()
+        gd.load_state_dict(gate.state_dict())
+        y2d = y2.detach().cuda().requires_grad_()
+        conv1 = gd.attn_layer[0]
+        yd = fold3d._SEGateShuffled.apply(y2d, conv1.weight, conv1.bias, 0 if act is None else 1, act or 0.0)
+        yd.backward(g.cuda())
+        assert yd.shape == y.shape and _rel(yd.detach(), y.detach()) < 1e-5
+        assert _rel(y2d.grad, y2.grad) < 2e-5
+        assert _rel(conv1.weight.grad, gate.attn_layer[0].weight.grad) < 5e-5
+        assert _rel(conv1.bias.grad, gate.attn_layer[0].bias.grad) < 5e-5
+    for (B, Ci, Co, H, W) in [(2, 16, 8, 6, 10), (1, 24, 16, 16, 32)]:
+        up = upConv3D(Ci, Co, kernel_size=(3, 4, 4), stride=(1, 2, 2), padding=(1, 1, 1), upmode="transpose", bn=False)
+        with torch.no_grad():
+            up.upconv[1].attn_layer[0].weight.mul_(3.0)
+            up.upconv[1].attn_layer[0].bias.copy_(torch.randn(Co) * 0.3)
+        x = torch.randn(B, Ci, 2, H, W, requires_grad=True)
+        y = F.leaky_relu(up.upconv(x), 0.2)          # torch's ConvTranspose3d + pool + 1x1x1 conv + sigmoid on the CPU
+        g = torch.randn_like(y)
+        y.backward(g)
+        ud = upConv3D(Ci, Co, kernel_size=(3, 4, 4), stride=(1, 2, 2), padding=(1, 1, 1), upmode="transpose", bn=False).cuda()
+        ud.load_state_dict(up.state_dict())
+        xd = x.detach().cuda().requires_grad_()
+        N.prof_reset()
+        N.prof_enable(True)
+        yd = ud(xd, 0.2)
+        yd.backward(g.cuda())
+        torch.cuda.synchronize()
+        N.prof_enable(False)
+        prof = N.prof_collect()
+        assert prof["se_gate_fwd/shuffle"][0] == 1 and prof["se_gate_bwd/shuffle"][0] == 1
+        assert _rel(yd.detach(), y.detach()) < 2e-5
+        assert _rel(xd.grad, x.grad) < 5e-5
+        for (n, p), (_, q) in zip(ud.named_parameters(), up.named_parameters()):
+            assert _rel(p.grad, q.grad) < 1e-4, n
+
+
 def test_se_gate_kernels_vs_torch_cpu():
     """csrc/segate.hip: SEGating (+ residual + ReLU / LeakyReLU) against the reference formulation
     x * sigmoid(Conv3d_1x1x1(AdaptiveAvgPool3d(1)(x))) on the CPU (resnet_3D.py:89-105,:137-141): output and all gradients."""
