@@ -38,6 +38,15 @@ struct ConvGeom {
     int B, Cin, H, W, Cout, Ho, Wo, pad;
     int groups = 1;    // grouped convolution (split-precision kernels only): Cin = input channels PER GROUP, Cout = all output
                        // channels; output channel co reads input channels [grp*Cin, (grp+1)*Cin), grp = co / (Cout/groups)
+    // round 6: where the fp32 output goes (store_out_tile; the matrix-core kernels of launch_fwd_bf16 and conv_fwd_f16_ws):
+    //   0  out[B][Cout][Ho][Wo]
+    //   1  THROUGH PixelShuffle(2): out[B][Cout/4][2Ho][2Wo], channel 4c + 2py + px of pixel (y, x) -> (c, 2y + py, 2x + px)
+    //      (Cout % 4 == 0) -- the reconstruction head's 64 -> 256 convolution (model_singleframe.py:257-260) hands the next
+    //      layer its input without the PixelShuffle copy
+    //   2  through its INVERSE: out[B][4Cout][Ho/2][Wo/2], channel c of pixel (Y, X) -> (4c + 2(Y&1) + (X&1), Y/2, X/2)
+    //      (Ho, Wo even) -- the data gradient of the layer that READ a shuffled tensor hands the gradient back in the layout of
+    //      the convolution that wrote it.  Addend / mask / residual operands stay in the kernel's natural layout.
+    int store = 0;
 };
 
 // Optional extras of the split-precision forward / data-gradient epilogue: out = act(acc + bias + addend) * act'(mask_y)
@@ -137,7 +146,8 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, unsigned byte_o
 // activation is selected outside the element loop.  The previous per-element `if` chain compiled to ~70 instructions and a
 // dependent bias load per element (4500 instructions per thread), several microseconds per workgroup.
 // XM: which epilogue extras are compiled in (so that a launch pays registers only for what it can use): bit 0 = addend / mask,
-// bit 1 = the fp16 side output (image or planes).  0 = the plain epilogue; `true` from older call sites means bit 0.
+// bit 1 = the fp16 side output (image or planes), bit 2 = the ResidualControl tail, bit 3 = the shuffled output layouts of
+// ConvGeom::store (a kernel built without it ignores g.store: its launcher refuses).  0 = the plain epilogue; `true` from older call sites means bit 0.
 template <int MT, int XM = 0>
 __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const float *__restrict__ bias, const f32x16 (&acc)[MT][2],
                                                const ConvGeom &g, int b, int co_base, int yo, int x0, int lane, int act,
@@ -147,7 +157,8 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
     // amax16 (with ex.out16): running |max| of what this wave wrote into the fp16 image (recorded by the caller at the end)
     const int HWo = g.Ho * g.Wo;
     const unsigned plane = (unsigned)HWo * 4u;
-    constexpr bool EXTRA = XM != 0, XAM = (XM & 1) != 0, X16 = (XM & 2) != 0, XRC = (XM & 4) != 0;
+    constexpr bool EXTRA = (XM & 7) != 0, XAM = (XM & 1) != 0, X16 = (XM & 2) != 0, XRC = (XM & 4) != 0;
+    constexpr bool XST = (XM & 8) != 0;                             // the shuffled output layouts (ConvGeom::store) are compiled in
     if constexpr (EXTRA) {
         // Everything below is derived from `lane` and loop-invariant over the caller's tile walk: left alone, the compiler
         // computes the per-lane offsets and descriptors once at kernel start, keeps them live across the MFMA main loop (where
@@ -197,6 +208,13 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
         float my[8];                       // mask_y (fp32 form)
         unsigned m16[4];                   // mask16: the two 8-byte halves of this lane's piece pair
         float res[8];                      // post_res (XRC)
+    };
+    // g.store != 0 (ConvGeom): byte offsets of this lane's first channel (co_base + 32m + 4h) in the shuffled / unshuffled output
+    auto shuffled_base = [&](int m) { return (unsigned)(((co_base + m * 32) >> 2) + h) * 4u * plane; };    // + pixel (2yo, 2xo) of the 2Wo-wide plane
+    auto unshuffled_base = [&](int m, bool px_ok, int xo) {
+        return px_ok ? (unsigned)(4 * (co_base + m * 32 + 4 * h) + 2 * (yo & 1) + (xo & 1)) * (plane >> 2) +
+                           (unsigned)((yo >> 1) * (g.Wo >> 1) + (xo >> 1)) * 4u
+                     : SENT;
     };
     auto blk_geom = [&](int m, int n, int j, bool &px_ok, unsigned &base, int &cblk, int &xo) {
         xo = x0 + n * 32 + l31;
@@ -290,8 +308,24 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
             }
         }
         if (has32) {
+            if (XST && g.store == 1) {     // through the pixel shuffle: this lane's 4 consecutive channels are one 2x2 output block
+                const unsigned b1 = px_ok ? shuffled_base(m) + (unsigned)(2 * yo * 2 * g.Wo + 2 * xo) * 4u : SENT;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(u[i]), ro, base + row_off(j, i) * plane, 0, 0);
+                for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                    for (int py = 0; py < 2; ++py) {
+                        typedef float f32x2_st __attribute__((ext_vector_type(2)));
+                        typedef unsigned u32x2_st __attribute__((ext_vector_type(2)));
+                        const f32x2_st v{u[4 * q + 2 * py], u[4 * q + 2 * py + 1]};
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_st, v), ro,
+                                                              b1 + (unsigned)(2 * (2 * j + q)) * 4u * plane + (unsigned)(py * 2 * g.Wo) * 4u, 0, 0);
+                    }
+                }
+            } else {
+                const unsigned sb = (XST && g.store == 2) ? unshuffled_base(m, px_ok, xo) : base;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(u[i]), ro, sb + row_off(j, i) * plane, 0, 0);
+            }
         }
         if constexpr (X16) {
             if (has16) {
@@ -342,7 +376,24 @@ __device__ __forceinline__ void store_out_tile(float *__restrict__ out, const fl
                 for (int n = 0; n < 2; ++n) {
                     const int xo = x0 + n * 32 + l31;
                     const bool px_ok = yo < g.Ho && xo < g.Wo;
-                    const unsigned base = (px_ok && co_base + m * 32 + 4 * h < g.Cout)
+                    if (XST && g.store == 1) {    // through the pixel shuffle (see `finish`): 8 eight-byte stores instead of 16 dwords
+                        const unsigned b1 = px_ok ? shuffled_base(m) + (unsigned)(2 * yo * 2 * g.Wo + 2 * xo) * 4u : SENT;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                            for (int py = 0; py < 2; ++py) {
+                                typedef float f32x2_st __attribute__((ext_vector_type(2)));
+                                typedef unsigned u32x2_st __attribute__((ext_vector_type(2)));
+                                const int r = 4 * k + 2 * py;
+                                const f32x2_st v{actf(acc[m][n][r] * oscale + bvm[r]), actf(acc[m][n][r + 1] * oscale + bvm[r + 1])};
+                                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_st, v), ro,
+                                                                      b1 + (unsigned)(2 * k) * 4u * plane + (unsigned)(py * 2 * g.Wo) * 4u, 0, 0);
+                            }
+                        }
+                        continue;
+                    }
+                    const unsigned base = (XST && g.store == 2) ? unshuffled_base(m, px_ok, xo)
+                                          : (px_ok && co_base + m * 32 + 4 * h < g.Cout)
                                               ? (unsigned)(co_base + m * 32 + 4 * h) * plane + (unsigned)(yo * g.Wo + xo) * 4u : SENT;
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
@@ -2503,7 +2554,7 @@ template <int XM, bool FAC = false>
 __global__ __launch_bounds__(NTWS) void conv_fwd_bf16x3_ws(const float *__restrict__ x, const __bf16 *__restrict__ wp,
                                                            const float *__restrict__ bias, float *__restrict__ out, ConvGeom g, int K16,
                                                            int act, float slope, EpiExtra epi, int tiles_total, FacEpi fac) {
-    constexpr bool EXTRA = XM != 0;                            // XM: epilogue extras compiled in (store_out_tile)
+    constexpr bool EXTRA = (XM & 7) != 0;                      // XM: epilogue extras compiled in (store_out_tile; bit 3 = output layouts)
     constexpr int KS = 3, KK = 9, MT = 2;
     constexpr int IH = TYB - 1 + KS, IW = TX - 1 + KS, PS = IH * IW, COS = 32 * MT;
     constexpr int NCW = 8, PT = 256;                           // consumer waves (one output row each); producer threads
@@ -2775,10 +2826,11 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
     // 32 output channels per workgroup when 64 would leave more than half of the CUs without one (small feature maps of the
     // detail branch): twice the workgroups, each with half the matrix work per staged chunk
     // (a requested fp16 side image pins the 64-channel wave-specialised form: its epilogue is the one that writes it)
-    const bool few = x3 && epi.out16 == nullptr && epi.post_scale == nullptr && tiles * ceil_div(g.Cout, 64) <= 128 &&
+    const bool few = x3 && epi.out16 == nullptr && epi.post_scale == nullptr && g.store == 0 && tiles * ceil_div(g.Cout, 64) <= 128 &&
                      dev_getenv("EBFI_CONV_NO_MT1") == nullptr;
     const int mt = (g.Cout <= 32 || few) ? 1 : 2;
     dim3 grid((unsigned)tiles, (unsigned)ceil_div(g.Cout, 32 * mt));
+    if (g.store != 0 && !x3) return fail(EBFI_ERR_UNSUPPORTED, "conv2d: shuffled output layouts are written by the split-precision kernels only");
     if (x3) {
         constexpr int PSX = (TYB - 1 + KS) * (TX - 1 + KS);
         const size_t lds = (size_t)2 * (2 * PSX * 32 + 2 * KS * KS * 32 * mt * 32) + KB_LDS_BYTES;   // two buffers of unpadded hi/lo images
@@ -2797,8 +2849,12 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
                         "(W %% 4 == 0, same padding, more than 32 output channels, 16-byte aligned input)");
         if (epi.post_scale != nullptr && !use_ws)
             return fail(EBFI_ERR_UNSUPPORTED, "conv2d: the ResidualControl epilogue is written by the wave-specialised 3x3 kernel only");
+        if (g.store != 0 && (!use_ws || extra))
+            return fail(EBFI_ERR_UNSUPPORTED, "conv2d: a shuffled output layout is written by the wave-specialised 3x3 kernel only (W %% 4 == 0, "
+                        "same padding, more than 32 output channels, 16-byte aligned input), without epilogue extras");
         if (use_ws) name = transposed ? "conv_fwd_bf16x3_ws/dgrad" : (epi.post_scale ? "conv_fwd_bf16x3_ws/fwd_rc" :
-                                                                      (epi.out16 ? "conv_fwd_bf16x3_ws/fwd_img" : "conv_fwd_bf16x3_ws/fwd"));
+                                                                      (epi.out16 ? "conv_fwd_bf16x3_ws/fwd_img" :
+                                                                       (g.store ? "conv_fwd_bf16x3_ws/fwd_shuffle" : "conv_fwd_bf16x3_ws/fwd")));
         ProfScope ps(name, st, flops, conv_bytes_fwd(g, KS * KS, dact != 0));
 #define EBFI_LAUNCH_X3V(MT_, DA_, VEC_)                                                                                   \
     do {                                                                                                                 \
@@ -2837,6 +2893,7 @@ int launch_fwd_bf16(hipStream_t st, const float *x, const float *dact_y, const f
                     if (x16) EBFI_LAUNCH_X3WS(6);      // training: + the images of `a` and of the result
                     else EBFI_LAUNCH_X3WS(4);          // inference: scale + residual only
                 }
+                else if (g.store != 0) EBFI_LAUNCH_X3WS(8);        // output through PixelShuffle(2) / its inverse (ConvGeom::store)
                 else if (xam && x16) EBFI_LAUNCH_X3WS(3);
                 else if (x16) EBFI_LAUNCH_X3WS(2);
                 else if (xam) EBFI_LAUNCH_X3WS(1);
@@ -3508,10 +3565,47 @@ extern "C" int ebfi_conv2d_packed_x3(const void *input, const void *packed, size
 // Same, plus the output as a scaled fp16 image in the c16 layout (c16.hpp; out16 [B][Cout/16][Ho][Wo][16], scale and |max|
 // record in slot16): what the fp16 weight gradient of the NEXT layer stages.  3x3 layers on the wave-specialised kernel only
 // (quad-aligned rows, 64-channel blocks); anything else is refused rather than silently skipping the side image.
+namespace {
+// out_layout (ConvGeom::store): 0 = NCHW, 1 = through PixelShuffle(2), 2 = through its inverse -- fp32 output only
+int check_out_layout(const char *who, int out_layout, int Cout, int Ho, int Wo, const void *output, const void *addend, const void *out16) {
+    if (out_layout == 0) return EBFI_OK;
+    if (out_layout < 0 || out_layout > 2) return fail(EBFI_ERR_ARG, "%s: output layout %d (0 plain, 1 pixel-shuffled, 2 unshuffled)", who, out_layout);
+    if (!output || addend || out16) return fail(EBFI_ERR_UNSUPPORTED, "%s: a shuffled output is the fp32 tensor alone (no addend, no fp16 side output)", who);
+    if (out_layout == 1 && Cout % 4 != 0) return fail(EBFI_ERR_UNSUPPORTED, "%s: pixel-shuffled output needs Cout %% 4 == 0 (Cout = %d)", who, Cout);
+    if (out_layout == 2 && ((Ho | Wo) & 1)) return fail(EBFI_ERR_UNSUPPORTED, "%s: unshuffled output needs even sizes (%d x %d)", who, Ho, Wo);
+    if (((int64_t)Cout + 128) * Ho * Wo * 4 >= (1LL << 31) - (1LL << 26))
+        return fail(EBFI_ERR_ARG, "%s: one output sample exceeds the 2 GiB reach of 32-bit buffer offsets", who);
+    return EBFI_OK;
+}
+
+int packed_x3_impl(const void *input, const void *packed, size_t packed_bytes, const void *bias, void *output,
+                   int B, int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups, int act,
+                   float slope, const void *addend, const void *mask_y, int mask_act, float mask_slope,
+                   void *out16, void *slot16, int out16_planar, int out_layout, void *stream);
+}  // namespace
+
 extern "C" int ebfi_conv2d_packed_x3_c16(const void *input, const void *packed, size_t packed_bytes, const void *bias, void *output,
                                          int B, int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups, int act,
                                          float slope, const void *addend, const void *mask_y, int mask_act, float mask_slope,
                                          void *out16, void *slot16, int out16_planar, void *stream) {
+    return packed_x3_impl(input, packed, packed_bytes, bias, output, B, Cin_per_group, H, W, Cout, ksize, pad, groups, act, slope, addend,
+                          mask_y, mask_act, mask_slope, out16, slot16, out16_planar, 0, stream);
+}
+
+// The same convolution with its fp32 output stored THROUGH PixelShuffle(2) (out_layout 1: output [B, Cout/4, 2H', 2W']) or through
+// its inverse (2: [B, 4Cout, H'/2, W'/2]) -- ConvGeom::store.  Round 6: the reconstruction head (model_singleframe.py:257-260:
+// conv 64 -> 256, PixelShuffle(2), LeakyReLU) writes the shuffled tensor itself.
+extern "C" int ebfi_conv2d_packed_x3_shuffled(const void *input, const void *packed, size_t packed_bytes, const void *bias, void *output,
+                                              int B, int Cin, int H, int W, int Cout, int act, float slope, int out_layout, void *stream) {
+    return packed_x3_impl(input, packed, packed_bytes, bias, output, B, Cin, H, W, Cout, 3, 1, 1, act, slope, nullptr, nullptr, 0, 0.f,
+                          nullptr, nullptr, 0, out_layout, stream);
+}
+
+namespace {
+int packed_x3_impl(const void *input, const void *packed, size_t packed_bytes, const void *bias, void *output,
+                   int B, int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups, int act,
+                   float slope, const void *addend, const void *mask_y, int mask_act, float mask_slope,
+                   void *out16, void *slot16, int out16_planar, int out_layout, void *stream) {
     // out16_planar != 0: out16 is a planar fp16 tensor [B, Cout, H, W] (the FAC op's filters) instead of a c16 image; `output`
     // may be NULL when out16 is given (the fp16 tensor alone)
     if (!input || !packed || (!output && !out16)) return fail(EBFI_ERR_ARG, "conv2d_packed_x3: null argument");
@@ -3527,6 +3621,8 @@ extern "C" int ebfi_conv2d_packed_x3_c16(const void *input, const void *packed, 
     if ((int64_t)groups * (Cin_per_group + 64) * H * W * 4 >= (1LL << 31) - (1LL << 26))
         return fail(EBFI_ERR_ARG, "conv2d_packed_x3: one sample exceeds the 2 GiB reach of 32-bit buffer offsets");
     g.groups = groups;
+    if (int rc = check_out_layout("conv2d_packed_x3", out_layout, Cout, g.Ho, g.Wo, output, addend, out16)) return rc;
+    g.store = out_layout;
     if (B == 0) return EBFI_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if ((addend || mask_y || out16) && (act == ACT_SIGMOID || mask_act == ACT_SIGMOID))
@@ -3539,6 +3635,7 @@ extern "C" int ebfi_conv2d_packed_x3_c16(const void *input, const void *packed, 
     if (ksize == 3) return launch_fwd_bf16<3>(st, x, nullptr, nullptr, bs, o, g, 0, act, slope, 0, 0.f, ws, packed_bytes, 1, epi);
     return launch_fwd_bf16<1>(st, x, nullptr, nullptr, bs, o, g, 0, act, slope, 0, 0.f, ws, packed_bytes, 1, epi);
 }
+}  // namespace
 
 // The grouped second-layer convolution of a ResidualControl round with the round's tail in its epilogue (EpiExtra, XM bit 2;
 // reference model_singleframe.py:127-133): a = LeakyReLU(conv3x3(input) + bias); pre16 = image(a); output = a * post_scale[b, co]
@@ -3691,11 +3788,41 @@ extern "C" int ebfi_conv2d_packed_f16(const void *input, const void *packed16, s
 // out16_planar != 0: as PLANAR fp16 [B][Cout][H][W] instead (the FAC filters; `output` must then be NULL).
 // With a site's FORWARD fp16 weight image this is the fp16-operand forward convolution (bias + LeakyReLU in the epilogue).
 // mask_is_c16 != 0: mask_y is the c16 IMAGE of the mask tensor (Cout % 16 == 0; only its signs are read).
+namespace {
+int packed_f16_impl(const void *input, int input_is_c16, const void *packed16, size_t packed_bytes,
+                    const void *bias, void *output, int B, int Cin_per_group, int H, int W, int Cout, int ksize,
+                    int pad, int groups, int act, float slope, const void *addend, const void *mask_y,
+                    int mask_act, float mask_slope, void *in_slot, const void *w_slot, void *out16,
+                    void *slot16, int out16_planar, int mask_is_c16, int out_layout, void *stream);
+}  // namespace
+
 extern "C" int ebfi_conv2d_packed_f16_c16(const void *input, int input_is_c16, const void *packed16, size_t packed_bytes,
                                           const void *bias, void *output, int B, int Cin_per_group, int H, int W, int Cout, int ksize,
                                           int pad, int groups, int act, float slope, const void *addend, const void *mask_y,
                                           int mask_act, float mask_slope, void *in_slot, const void *w_slot, void *out16,
                                           void *slot16, int out16_planar, int mask_is_c16, void *stream) {
+    return packed_f16_impl(input, input_is_c16, packed16, packed_bytes, bias, output, B, Cin_per_group, H, W, Cout, ksize, pad, groups, act,
+                           slope, addend, mask_y, mask_act, mask_slope, in_slot, w_slot, out16, slot16, out16_planar, mask_is_c16, 0, stream);
+}
+
+// The fp16-operand convolution with its fp32 output stored through PixelShuffle(2) or its inverse (ConvGeom::store; see
+// ebfi_conv2d_packed_x3_shuffled).  With a site's TRANSPOSED image, out_layout 2 and mask_y = the layer's own (shuffled) input this
+// is the data gradient of the layer behind a PixelShuffle + LeakyReLU, handed back as the pre-activation gradient of the
+// convolution in front of the shuffle, in that convolution's layout: no pixel-unshuffle copy, no mask pass.
+extern "C" int ebfi_conv2d_packed_f16_shuffled(const void *input, int input_is_c16, const void *packed16, size_t packed_bytes,
+                                               const void *bias, void *output, int B, int Cin, int H, int W, int Cout, int act, float slope,
+                                               const void *mask_y, int mask_act, float mask_slope, void *in_slot, const void *w_slot,
+                                               int out_layout, void *stream) {
+    return packed_f16_impl(input, input_is_c16, packed16, packed_bytes, bias, output, B, Cin, H, W, Cout, 3, 1, 1, act, slope, nullptr, mask_y,
+                           mask_act, mask_slope, in_slot, w_slot, nullptr, nullptr, 0, 0, out_layout, stream);
+}
+
+namespace {
+int packed_f16_impl(const void *input, int input_is_c16, const void *packed16, size_t packed_bytes,
+                    const void *bias, void *output, int B, int Cin_per_group, int H, int W, int Cout, int ksize,
+                    int pad, int groups, int act, float slope, const void *addend, const void *mask_y,
+                    int mask_act, float mask_slope, void *in_slot, const void *w_slot, void *out16,
+                    void *slot16, int out16_planar, int mask_is_c16, int out_layout, void *stream) {
     if (!input || !packed16 || (!output && !out16)) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: null argument");
     if ((out16 != nullptr) != (slot16 != nullptr)) return fail(EBFI_ERR_ARG, "conv2d_packed_f16: out16 and slot16 come together");
     if (out16 && !out16_planar && (Cout % 16 != 0 || !aligned16(out16)))
@@ -3720,6 +3847,8 @@ extern "C" int ebfi_conv2d_packed_f16_c16(const void *input, int input_is_c16, c
     if ((int64_t)groups * (Cin_per_group + 64) * H * W * 4 >= (1LL << 31) - (1LL << 26) || (int64_t)(Cout + 64) * H * W * 4 >= (1LL << 31) - (1LL << 26))
         return fail(EBFI_ERR_ARG, "conv2d_packed_f16: one sample exceeds the 2 GiB reach of 32-bit buffer offsets");
     g.groups = groups;
+    if (int rc = check_out_layout("conv2d_packed_f16", out_layout, Cout, g.Ho, g.Wo, output, addend, out16)) return rc;
+    g.store = out_layout;
     const int K16 = (g.Cin + 15) / 16 * 16;
     const size_t need = (size_t)9 * g.Cout * K16 * 2;
     if (packed_bytes < need) return fail(EBFI_ERR_WORKSPACE, "conv2d_packed_f16: packed image %zu bytes < required %zu", packed_bytes, need);
@@ -3747,7 +3876,8 @@ extern "C" int ebfi_conv2d_packed_f16_c16(const void *input, int input_is_c16, c
     const double io_bytes = px * g.groups * g.Cin * (input_is_c16 ? 2.0 : 4.0) + px * g.Cout * ((output ? 4.0 : 0.0) + (out16 ? 2.0 : 0.0)) +
                             px * g.Cout * ((addend ? 4.0 : 0.0) + (mask_y ? (m16 ? 2.0 : 4.0) : 0.0)) + 2.0 * 9 * (double)g.Cout * g.Cin;
     // (label = kernel symbol / role: which operand storage the launch read and wrote)
-    ProfScope ps(input_is_c16 == 2 ? "conv_fwd_f16_ws/p16_f32" : out16_planar ? (input_is_c16 ? "conv_fwd_f16_ws/img_p16" : "conv_fwd_f16_ws/f32_p16") :
+    ProfScope ps(g.store ? (input_is_c16 ? "conv_fwd_f16_ws/img_shuffle" : "conv_fwd_f16_ws/f32_shuffle") :
+                 input_is_c16 == 2 ? "conv_fwd_f16_ws/p16_f32" : out16_planar ? (input_is_c16 ? "conv_fwd_f16_ws/img_p16" : "conv_fwd_f16_ws/f32_p16") :
                  input_is_c16 ? (out16 ? (output ? "conv_fwd_f16_ws/img_both" : "conv_fwd_f16_ws/img_img") : "conv_fwd_f16_ws/img_f32")
                               : (out16 ? "conv_fwd_f16_ws/f32_img" : "conv_fwd_f16_ws/f32_f32"), st, flops, io_bytes);
     const ScaleSlot isl{static_cast<float *>(in_slot)};
@@ -3761,10 +3891,20 @@ extern "C" int ebfi_conv2d_packed_f16_c16(const void *input, int input_is_c16, c
                            (int)tiles, isl, static_cast<const float *>(w_slot), FacEpi{nullptr, 0});                    \
     } while (0)
     if (input_is_c16 == 2) {
-        if (extra) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_f16: planar fp16 input with epilogue extras");
+        if (extra || g.store) return fail(EBFI_ERR_UNSUPPORTED, "conv2d_packed_f16: planar fp16 input with epilogue extras / a shuffled output");
         if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_f16_ws<false, false, true>), 160 * 1024)) return rc_;
         hipLaunchKernelGGL((conv_fwd_f16_ws<false, false, true>), grid, dim3(NTF16), lds, st, x, wp, bs, o, g, K16, act, slope, epi,
                            (int)tiles, isl, static_cast<const float *>(w_slot), FacEpi{nullptr, 0});
+    } else if (g.store != 0) {             // output through PixelShuffle(2) / its inverse: the EXTRA form built with the layouts
+#define EBFI_LAUNCH_F16ST(IN_)                                                                                           \
+    do {                                                                                                                 \
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_fwd_f16_ws<true, IN_, false, false, true>), 160 * 1024)) return rc_; \
+        hipLaunchKernelGGL((conv_fwd_f16_ws<true, IN_, false, false, true>), grid, dim3(NTF16), lds, st, x, wp, bs, o, g, K16, act, slope, epi, \
+                           (int)tiles, isl, static_cast<const float *>(w_slot), FacEpi{nullptr, 0});                    \
+    } while (0)
+        if (input_is_c16) EBFI_LAUNCH_F16ST(true);
+        else EBFI_LAUNCH_F16ST(false);
+#undef EBFI_LAUNCH_F16ST
     } else if (extra && input_is_c16) EBFI_LAUNCH_F16WS(true, true);
     else if (extra) EBFI_LAUNCH_F16WS(true, false);
     else if (input_is_c16) EBFI_LAUNCH_F16WS(false, true);
@@ -3772,6 +3912,7 @@ extern "C" int ebfi_conv2d_packed_f16_c16(const void *input, int input_is_c16, c
 #undef EBFI_LAUNCH_F16WS
     return check_launch("conv_fwd_f16_ws");
 }
+}  // namespace
 
 // weight / bias gradient of a (grouped) 3x3 convolution with fp16 operands: grad_output optionally times act'(saved_output)
 // (side output grad_preact_out as in ebfi_conv2d_backward_weight_ex); Cin_per_group a multiple of 64.

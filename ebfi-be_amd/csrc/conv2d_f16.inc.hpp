@@ -44,7 +44,8 @@ constexpr int NTF16 = 512;
 //           convolution that follows (weight rows in the "facrows" layout: one FAC channel per 32-row tile); the epilogue applies
 //           them to `fac.ev` and stores ONE value per pixel and channel (fac_epilogue_tile, conv2d.hip): the fused
 //           KernelConv -> FAC kernel of conv_fwd_bf16x3_ws<0, true> at one matrix-core product per tap instead of three
-template <bool EXTRA, bool IN16 = false, bool INP16 = false, bool FAC = false>
+//   ST (round 6, with EXTRA): the epilogue is built with the shuffled output layouts of ConvGeom::store (store_out_tile XM bit 3)
+template <bool EXTRA, bool IN16 = false, bool INP16 = false, bool FAC = false, bool ST = false>
 __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict__ x, const _Float16 *__restrict__ wp,
                                                          const float *__restrict__ bias, float *__restrict__ out, ConvGeom g, int K16,
                                                          int act, float slope, EpiExtra epi, int tiles_total, ScaleSlot in_slot,
@@ -163,8 +164,8 @@ __global__ __launch_bounds__(NTF16) void conv_fwd_f16_ws(const float *__restrict
                 fac_epilogue_tile<MT>(out, bias, acc[1], g, fac, cb_, co_base, cy0 + RW * wave + 1, cx0, lane, slope, oscale);
             } else {
                 if constexpr (EXTRA) saturate_fp16_conversions(true);      // (the epilogue's fp16 image stores; never across the MFMA loop)
-                store_out_tile<MT, EXTRA ? 3 : 0>(out, bias, acc[0], g, cb_, co_base, cy0 + RW * wave, cx0, lane, act, slope, epi, oscale, &amax16);
-                store_out_tile<MT, EXTRA ? 3 : 0>(out, bias, acc[1], g, cb_, co_base, cy0 + RW * wave + 1, cx0, lane, act, slope, epi, oscale, &amax16);
+                store_out_tile<MT, (EXTRA ? 3 : 0) | (ST ? 8 : 0)>(out, bias, acc[0], g, cb_, co_base, cy0 + RW * wave, cx0, lane, act, slope, epi, oscale, &amax16);
+                store_out_tile<MT, (EXTRA ? 3 : 0) | (ST ? 8 : 0)>(out, bias, acc[1], g, cb_, co_base, cy0 + RW * wave + 1, cx0, lane, act, slope, epi, oscale, &amax16);
                 if constexpr (EXTRA) saturate_fp16_conversions(false);
             }
 #pragma unroll

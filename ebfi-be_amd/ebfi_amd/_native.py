@@ -31,7 +31,7 @@ BUILD_SCRIPT = os.path.join(PKG_ROOT, "csrc", "build.sh")
 
 EBFI_F32, EBFI_F32_BF16MMA, EBFI_F32_BF16X3MMA = 0, 2, 3
 EBFI_ERR_UNSUPPORTED = -3   # include/ebfi_hip.h ebfi_status
-ABI_VERSION = 12         # include/ebfi_hip.h EBFI_ABI_VERSION
+ABI_VERSION = 13         # include/ebfi_hip.h EBFI_ABI_VERSION
 
 
 class EbfiNativeError(RuntimeError):
@@ -108,6 +108,8 @@ SIGNATURES = {
     "ebfi_se_gate_workspace": (_c.c_size_t, [_i, _i, _i64]),
     "ebfi_se_gate_forward": (_i, [_vp] * 8 + [_i, _i, _i64, _i, _c.c_float, _vp]),
     "ebfi_se_gate_backward": (_i, [_vp] * 11 + [_i, _i, _i64, _i, _c.c_float, _vp]),
+    "ebfi_conv2d_packed_x3_shuffled": (_i, [_vp, _vp, _c.c_size_t, _vp, _vp] + [_i] * 6 + [_c.c_float, _i, _vp]),
+    "ebfi_conv2d_packed_f16_shuffled": (_i, [_vp, _i, _vp, _c.c_size_t, _vp, _vp] + [_i] * 6 + [_c.c_float, _vp, _i, _c.c_float, _vp, _vp, _i, _vp]),
     "ebfi_se_gate_forward_ps": (_i, [_vp] * 7 + [_i, _i, _i, _i, _i, _c.c_float, _vp]),
     "ebfi_se_gate_backward_ps": (_i, [_vp] * 10 + [_i, _i, _i, _i, _i, _c.c_float, _vp]),
     "ebfi_groupnorm_workspace": (_sz, [_i, _i]),

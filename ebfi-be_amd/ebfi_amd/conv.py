@@ -264,80 +264,159 @@ class SiteConvBiasAct(Function):
     def backward(ctx, gout):
         x, y = ctx.saved_tensors
         site, (act, slope), geo = ctx.site, ctx.cfg, ctx.geo
-        gout = gout.contiguous()
-        lib = N.lib()
-        need_x = ctx.needs_input_grad[0]
-        need_p = any(ctx.needs_input_grad[6:])
-        gx, pgrads = None, [None] * (len(site.w_shapes) + len(site.b_shapes))
-        # fp16 single-product backward (ebfi_amd.f16scale, csrc/conv2d_f16.inc.hpp) where the kernels apply: 3x3 same-padded
-        # layers; weight gradient with 64-channel input blocks, data gradient with quad-aligned rows and >= 48 input channels
-        from . import f16scale
-        book = f16scale.active_book()
-        B, Cin, H, W, M, ks, _, pad = geo
-        f16 = book is not None and ks == 3 and pad == 1
-        # (partial 64-channel blocks -- the 32 / 48-channel layers of the detail branch -- go through the pixel-major kernel, which
-        # needs quad-aligned rows; below 32 channels the zero-filled half of the block would be most of the work)
-        # (the pixel-major kernel -- the only one for ragged Cin -- stages 16-byte quads: operands that are unaligned views
-        # take the split-precision kernel instead of failing with EBFI_ERR_UNSUPPORTED)
-        al16 = all(t is None or t.data_ptr() % 16 == 0 for t in (x, gout, y))
-        f16_w = f16 and (Cin % 64 == 0 or (Cin >= 32 and W % 4 == 0 and al16 and N.dev_env("EBFI_WGRAD_TR", "1") != "0"))
-        f16_x = f16 and W % 4 == 0 and Cin >= 48 and site.tr16_ptr() is not None
-        gpre = None
+        gx, pgrads = _site_backward(site, geo, act, slope, x, y, gout, ctx.needs_input_grad[0], any(ctx.needs_input_grad[6:]))
+        return (gx, None, None, None, None, None) + tuple(pgrads)
 
-        def weight_gradients(st_w):
-            """weight / bias gradient launches (+ slab reduction, + fold gathers) on stream `st_w`; returns (pgrads, gpre)."""
-            gw2 = torch.empty((site.M, site.K, site.ks, site.ks), dtype=x.dtype, device=x.device)
-            gb2 = torch.empty(site.M, dtype=x.dtype, device=x.device) if site.has_bias else None
-            need = int(lib.ebfi_conv2d_backward_weight_workspace(*geo, N.EBFI_F32))
-            ws = torch.empty(max(need, 4), dtype=torch.uint8, device=x.device)
-            # grad * act' for the data gradient: as the fp16 image that kernel stages (ebfi_amd.c16) when both gradients run on fp16
-            # operands and the pixel-major weight-gradient kernel applies -- half the bytes written and read again
-            gpre16 = need_x and act != ACT_NONE and f16_w and f16_x and al16 and W % 4 == 0 and M % 16 == 0 and site.groups == 1 and \
-                N.dev_env("EBFI_NO_GPRE16", "0") != "1" and N.dev_env("EBFI_WGRAD_TR", "1") != "0"
-            gp = None
-            if need_x and act != ACT_NONE:
-                if gpre16:
-                    from . import c16
-                    gp = c16.empty(B, M, H, W, x.device)
-                else:
-                    gp = torch.empty_like(gout)
-            if f16_w:
-                rc = lib.ebfi_conv2d_backward_weight_f16g_ex(N.ptr(x), N.ptr(gout), N.ptr(y), N.ptr(gw2), N.ptr(gb2), N.ptr(gp),
-                                                             1 if gpre16 else 0, B, Cin, H, W, M, ks, pad, 1, act, slope,
-                                                             book.operand((site.key, "x"), x), book.operand((site.key, "g"), gout),
-                                                             N.ptr(ws), need, st_w)
+
+def _site_backward(site, geo, act, slope, x, y, gout, need_x, need_p, unshuffle=None):
+    """Backward of one bank-site convolution (SiteConvBiasAct): returns (grad_x or None, [gradients of the site's source weights, then
+    of its source biases]).  unshuffle = (mask, mask_slope): the layer's input came out of PixelShuffle(2) + LeakyReLU(mask_slope)
+    behind another convolution (mask = that input, `x`): grad_x leaves as the PRE-activation gradient of that convolution, in its
+    layout [B, 4*Cin, H/2, W/2] -- the data-gradient kernel applies LeakyReLU'(mask) and stores through the inverse shuffle
+    (ebfi_conv2d_packed_f16_shuffled), so neither the pixel-unshuffle copy nor a mask pass over the saved activation runs."""
+    gout = gout.contiguous()
+    lib = N.lib()
+    gx, pgrads = None, [None] * (len(site.w_shapes) + len(site.b_shapes))
+    # fp16 single-product backward (ebfi_amd.f16scale, csrc/conv2d_f16.inc.hpp) where the kernels apply: 3x3 same-padded
+    # layers; weight gradient with 64-channel input blocks, data gradient with quad-aligned rows and >= 48 input channels
+    from . import f16scale
+    book = f16scale.active_book()
+    B, Cin, H, W, M, ks, _, pad = geo
+    f16 = book is not None and ks == 3 and pad == 1
+    # (partial 64-channel blocks -- the 32 / 48-channel layers of the detail branch -- go through the pixel-major kernel, which
+    # needs quad-aligned rows; below 32 channels the zero-filled half of the block would be most of the work)
+    # (the pixel-major kernel -- the only one for ragged Cin -- stages 16-byte quads: operands that are unaligned views
+    # take the split-precision kernel instead of failing with EBFI_ERR_UNSUPPORTED)
+    al16 = all(t is None or t.data_ptr() % 16 == 0 for t in (x, gout, y))
+    f16_w = f16 and (Cin % 64 == 0 or (Cin >= 32 and W % 4 == 0 and al16 and N.dev_env("EBFI_WGRAD_TR", "1") != "0"))
+    f16_x = f16 and W % 4 == 0 and Cin >= 48 and site.tr16_ptr() is not None
+    gpre = None
+
+    def weight_gradients(st_w):
+        """weight / bias gradient launches (+ slab reduction, + fold gathers) on stream `st_w`; returns (pgrads, gpre)."""
+        gw2 = torch.empty((site.M, site.K, site.ks, site.ks), dtype=x.dtype, device=x.device)
+        gb2 = torch.empty(site.M, dtype=x.dtype, device=x.device) if site.has_bias else None
+        need = int(lib.ebfi_conv2d_backward_weight_workspace(*geo, N.EBFI_F32))
+        ws = torch.empty(max(need, 4), dtype=torch.uint8, device=x.device)
+        # grad * act' for the data gradient: as the fp16 image that kernel stages (ebfi_amd.c16) when both gradients run on fp16
+        # operands and the pixel-major weight-gradient kernel applies -- half the bytes written and read again
+        gpre16 = need_x and act != ACT_NONE and f16_w and f16_x and al16 and W % 4 == 0 and M % 16 == 0 and site.groups == 1 and \
+            N.dev_env("EBFI_NO_GPRE16", "0") != "1" and N.dev_env("EBFI_WGRAD_TR", "1") != "0"
+        gp = None
+        if need_x and act != ACT_NONE:
+            if gpre16:
+                from . import c16
+                gp = c16.empty(B, M, H, W, x.device)
             else:
-                rc = lib.ebfi_conv2d_backward_weight_ex(N.ptr(x), N.ptr(gout), N.ptr(y), N.ptr(gw2), N.ptr(gb2), N.ptr(gp), *geo,
-                                                        act, slope, N.ptr(ws), need, N.EBFI_F32_BF16X3MMA, st_w)
-            N.check(rc, "ebfi_conv2d_backward_weight")
-            return _route_site_grads(site, gw2, gb2, st_w), gp
+                gp = torch.empty_like(gout)
+        if f16_w:
+            rc = lib.ebfi_conv2d_backward_weight_f16g_ex(N.ptr(x), N.ptr(gout), N.ptr(y), N.ptr(gw2), N.ptr(gb2), N.ptr(gp),
+                                                         1 if gpre16 else 0, B, Cin, H, W, M, ks, pad, 1, act, slope,
+                                                         book.operand((site.key, "x"), x), book.operand((site.key, "g"), gout),
+                                                         N.ptr(ws), need, st_w)
+        else:
+            rc = lib.ebfi_conv2d_backward_weight_ex(N.ptr(x), N.ptr(gout), N.ptr(y), N.ptr(gw2), N.ptr(gb2), N.ptr(gp), *geo,
+                                                    act, slope, N.ptr(ws), need, N.EBFI_F32_BF16X3MMA, st_w)
+        N.check(rc, "ebfi_conv2d_backward_weight")
+        return _route_site_grads(site, gw2, gb2, st_w), gp
 
+    with torch.cuda.device_of(x):
+        st = N.stream_ptr(x.device)
+        if need_p:
+            pgrads, gpre = weight_gradients(st)
+        if need_x:
+            src, sy, a = (gpre, None, ACT_NONE) if gpre is not None else (gout, y, act)
+            img = gpre is not None and gpre.dtype == torch.float16
+            # (the shuffled store is the fp16 data-gradient kernel's: ungrouped, even sizes, the mask 16-byte aligned like the rest)
+            native_unshuffle = unshuffle is not None and (img or (f16_x and a == ACT_NONE)) and site.groups == 1 and H % 2 == 0 and \
+                W % 4 == 0 and Cin > 32 and unshuffle[0].is_contiguous() and unshuffle[0].data_ptr() % 16 == 0 and \
+                N.dev_env("EBFI_NO_CONV_SHUFFLE", "0") != "1"
+            if native_unshuffle:
+                gx = torch.empty((B, 4 * Cin, H // 2, W // 2), dtype=x.dtype, device=x.device)
+                in_slot = book.ptr(book.slot((site.key, "g"))) if img else book.operand((site.key, "g"), src)
+                rc = lib.ebfi_conv2d_packed_f16_shuffled(N.ptr(src), 1 if img else 0, site.tr16_ptr(), site.tr16_bytes, N.ptr(None), N.ptr(gx),
+                                                         B, M, H, W, Cin, ACT_NONE, 0.0, N.ptr(unshuffle[0]), ACT_LEAKY, float(unshuffle[1]),
+                                                         in_slot, site.w_slot_ptr(), 2, st)
+                N.check(rc, "ebfi_conv2d_packed_f16_shuffled (data gradient through the inverse pixel shuffle)")
+                return gx, pgrads
+            gx = torch.empty_like(x)
+            if img:
+                # the image the weight gradient just wrote (scale: the slot it recorded into)
+                rc = lib.ebfi_conv2d_packed_f16_c16(N.ptr(gpre), 1, site.tr16_ptr(), site.tr16_bytes, N.ptr(None), N.ptr(gx), B,
+                                                    M // site.groups, H, W, Cin * site.groups, ks, pad, site.groups, ACT_NONE, 0.0,
+                                                    N.ptr(None), N.ptr(None), 0, 0.0, book.ptr(book.slot((site.key, "g"))),
+                                                    site.w_slot_ptr(), N.ptr(None), N.ptr(None), 0, 0, st)
+                N.check(rc, "ebfi_conv2d_packed_f16_c16 (data gradient from the image of grad * act')")
+            elif f16_x and a == ACT_NONE:
+                # the data gradient as a convolution of the pre-activation gradient with the transposed fp16 image
+                rc = lib.ebfi_conv2d_packed_f16(N.ptr(src), site.tr16_ptr(), site.tr16_bytes, N.ptr(None), N.ptr(gx), B,
+                                                M // site.groups, H, W, Cin * site.groups, ks, pad, site.groups, ACT_NONE, 0.0,
+                                                N.ptr(None), N.ptr(None), 0, 0.0, book.operand((site.key, "g"), src),
+                                                site.w_slot_ptr(), st)
+                N.check(rc, "ebfi_conv2d_packed_f16 (data gradient)")
+            else:
+                rc = lib.ebfi_conv2d_backward_data_bf16x3(N.ptr(src), N.ptr(sy), N.ptr(None), N.ptr(gx), *geo, a,
+                                                          slope if a != ACT_NONE else 0.0, site.tr_ptr(), site.tr_bytes, st)
+                N.check(rc, "ebfi_conv2d_backward_data_bf16x3 (packed)")
+            if unshuffle is not None:            # (kernels without the shuffled store: mask and inverse shuffle as torch ops)
+                m, ms = unshuffle
+                gx = torch.nn.functional.pixel_unshuffle(gx * torch.where(m > 0, 1.0, float(ms)), 2)
+    return gx, pgrads
+
+
+class SiteConvShufflePair(Function):
+    """conv A (3x3, bank site) -> PixelShuffle(2) -> LeakyReLU(slope_a) -> conv B (3x3, bank site, act_b): the reconstruction head
+    (models/Ours/model_singleframe.py:257-262) as ONE autograd node, so that no tensor crosses the shuffle twice: A's epilogue
+    applies the LeakyReLU and stores through the shuffle (ebfi_conv2d_packed_x3_shuffled); B's data gradient applies
+    LeakyReLU'(B's input) and stores through the inverse shuffle (_site_backward, unshuffle=), handing A its PRE-activation
+    gradient in A's own layout.  params = A's source weights and biases (`na` tensors), then B's."""
+
+    @staticmethod
+    def forward(ctx, x, site_a, slope_a, site_b, act_b, slope_b, na, *params):
+        x = x.contiguous()
+        B, Cin, H, W = (int(v) for v in x.shape)
+        if Cin != site_a.K or site_a.M != 4 * site_b.K:
+            raise RuntimeError("shuffled pair: %d -> %d channels, then %d -> %d" % (Cin, site_a.M, site_b.K, site_b.M))
+        geo_a = [B, Cin, H, W, site_a.M, 3, 1, 1]
+        geo_b = [B, site_b.K, 2 * H, 2 * W, site_b.M, 3, 1, 1]
+        y1 = torch.empty((B, site_b.K, 2 * H, 2 * W), dtype=x.dtype, device=x.device)
+        y2 = torch.empty((B, site_b.M, 2 * H, 2 * W), dtype=x.dtype, device=x.device)
         with torch.cuda.device_of(x):
             st = N.stream_ptr(x.device)
-            if need_p:
-                pgrads, gpre = weight_gradients(st)
-            if need_x:
-                gx = torch.empty_like(x)
-                src, sy, a = (gpre, None, ACT_NONE) if gpre is not None else (gout, y, act)
-                if gpre is not None and gpre.dtype == torch.float16:
-                    # the image the weight gradient just wrote (scale: the slot it recorded into)
-                    rc = lib.ebfi_conv2d_packed_f16_c16(N.ptr(gpre), 1, site.tr16_ptr(), site.tr16_bytes, N.ptr(None), N.ptr(gx), B,
-                                                        M // site.groups, H, W, Cin * site.groups, ks, pad, site.groups, ACT_NONE, 0.0,
-                                                        N.ptr(None), N.ptr(None), 0, 0.0, book.ptr(book.slot((site.key, "g"))),
-                                                        site.w_slot_ptr(), N.ptr(None), N.ptr(None), 0, 0, st)
-                    N.check(rc, "ebfi_conv2d_packed_f16_c16 (data gradient from the image of grad * act')")
-                elif f16_x and a == ACT_NONE:
-                    # the data gradient as a convolution of the pre-activation gradient with the transposed fp16 image
-                    rc = lib.ebfi_conv2d_packed_f16(N.ptr(src), site.tr16_ptr(), site.tr16_bytes, N.ptr(None), N.ptr(gx), B,
-                                                    M // site.groups, H, W, Cin * site.groups, ks, pad, site.groups, ACT_NONE, 0.0,
-                                                    N.ptr(None), N.ptr(None), 0, 0.0, book.operand((site.key, "g"), src),
-                                                    site.w_slot_ptr(), st)
-                    N.check(rc, "ebfi_conv2d_packed_f16 (data gradient)")
-                else:
-                    rc = lib.ebfi_conv2d_backward_data_bf16x3(N.ptr(src), N.ptr(sy), N.ptr(None), N.ptr(gx), *geo, a,
-                                                              slope if a != ACT_NONE else 0.0, site.tr_ptr(), site.tr_bytes, st)
-                    N.check(rc, "ebfi_conv2d_backward_data_bf16x3 (packed)")
-        return (gx, None, None, None, None, None) + tuple(pgrads)
+            rc = N.lib().ebfi_conv2d_packed_x3_shuffled(N.ptr(x), site_a.fwd_ptr(), site_a.fwd_bytes, N.ptr(site_a.bias()), N.ptr(y1), B, Cin,
+                                                        H, W, site_a.M, ACT_LEAKY, slope_a, 1, st)
+            N.check(rc, "ebfi_conv2d_packed_x3_shuffled")
+            rc = N.lib().ebfi_conv2d_forward_bf16x3(N.ptr(y1), N.ptr(None), N.ptr(site_b.bias()), N.ptr(y2), *geo_b, act_b, slope_b,
+                                                    site_b.fwd_ptr(), site_b.fwd_bytes, st)
+            N.check(rc, "ebfi_conv2d_forward_bf16x3 (packed)")
+        ctx.sites, ctx.cfg, ctx.geos, ctx.na = (site_a, site_b), (slope_a, act_b, slope_b), (geo_a, geo_b), na
+        ctx.save_for_backward(x, y1, y2 if act_b != ACT_NONE else None)
+        return y2
+
+    @staticmethod
+    def backward(ctx, g2):
+        x, y1, y2 = ctx.saved_tensors
+        (site_a, site_b), (slope_a, act_b, slope_b), (geo_a, geo_b), na = ctx.sites, ctx.cfg, ctx.geos, ctx.na
+        need = ctx.needs_input_grad
+        need_pa, need_pb = any(need[7:7 + na]), any(need[7 + na:])
+        need_a = need[0] or need_pa
+        ga, pg_b = _site_backward(site_b, geo_b, act_b, slope_b, y1, y2, g2, need_a, need_pb, unshuffle=(y1, slope_a))
+        gx, pg_a = (None, [None] * na)
+        if need_a:                               # (A's activation derivative is already in ga)
+            gx, pg_a = _site_backward(site_a, geo_a, ACT_NONE, 0.0, x, None, ga, need[0], need_pa)
+        return (gx, None, None, None, None, None, None) + tuple(pg_a) + tuple(pg_b)
+
+
+def shuffle_pair_usable(x, site_a, site_b):
+    """The shuffled store is the wave-specialised 3x3 kernel's: quad-aligned rows, more than 32 output channels (csrc/conv2d.hip)."""
+    return (site_usable(site_a, x) and site_b is not None and site_a.ks == 3 and site_b.ks == 3 and site_a.kind == "id" and
+            site_b.kind == "id" and site_a.groups == 1 and site_b.groups == 1 and site_a.M == 4 * site_b.K and site_a.M > 32 and
+            x.shape[3] % 4 == 0 and x.data_ptr() % 16 == 0 and not torch.is_autocast_enabled() and
+            N.dev_env("EBFI_NO_CONV_SHUFFLE", "0") != "1")
+
+
+def conv_shuffle_pair(x, site_a, slope_a, params_a, site_b, act_b, slope_b, params_b):
+    return SiteConvShufflePair.apply(x, site_a, float(slope_a), site_b, int(act_b), float(slope_b), len(params_a), *params_a, *params_b)
 
 
 def _route_site_grads(site, gw2, gb2, st):

@@ -508,6 +508,21 @@ class EVFIAutoEx(BaseModel):
         if isinstance(up, ConvLayer) and up.activation is None and isinstance(head[1], nn.PixelShuffle) and \
                 isinstance(head[2], nn.LeakyReLU) and up.native(x) is not None:
             c = up.conv2d
+            nxt = self.Reconstruction[1]
+            if isinstance(nxt, ConvLayer) and head[1].upscale_factor == 2 and nxt.norm not in ("BN", "IN"):
+                # round 6: the head's convolution stores THROUGH the shuffle and the next layer's data gradient stores through its
+                # inverse (conv.SiteConvShufflePair): the [B,64,H,W] map crosses no PixelShuffle copy in either direction
+                from . import weightbank
+                cb, fuse_b = nxt.conv2d, conv.activation_code(nxt.activation)
+                sa, sb = weightbank.lookup(c.weight, "id"), weightbank.lookup(cb.weight, "id")
+                plain = lambda m: m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.dilation == (1, 1) and m.groups == 1
+                if fuse_b is not None and fuse_b[0] in (conv.ACT_NONE, conv.ACT_LEAKY) and plain(c) and plain(cb) and \
+                        conv.shuffle_pair_usable(x, sa, sb) and len(sa.w_shapes) == 1 and len(sb.w_shapes) == 1 and \
+                        sa.has_bias == (c.bias is not None) and sb.has_bias == (cb.bias is not None):
+                    pa = [c.weight] + ([c.bias] if c.bias is not None else [])
+                    pb = [cb.weight] + ([cb.bias] if cb.bias is not None else [])
+                    y = conv.conv_shuffle_pair(x, sa, float(head[2].negative_slope), pa, sb, fuse_b[0], fuse_b[1], pb)
+                    return self.Reconstruction[2](y)
             y = conv.conv_bias_act(x, c.weight, c.bias, c.stride[0], c.padding[0], conv.ACT_LEAKY, float(head[2].negative_slope))
             y = F.pixel_shuffle(y, head[1].upscale_factor)
             return self.Reconstruction[2](self.Reconstruction[1](y))

@@ -67,8 +67,9 @@ extern "C" {
  *      [B,K,1,1] inputs in one launch each way); ebfi_kernelconv_fac_fused_f16 (the fused KernelConv -> FAC kernel of inference
  *      on fp16 operands)
  *  12  ebfi_se_gate_forward_ps / _backward_ps (the squeeze-excite gate of an up-convolution stage reading the transposed
- *      convolution's output through the pixel shuffle) */
-#define EBFI_ABI_VERSION 12
+ *      convolution's output through the pixel shuffle)
+ *  13  ebfi_conv2d_packed_x3_shuffled / ebfi_conv2d_packed_f16_shuffled (convolutions storing through PixelShuffle(2) / its inverse) */
+#define EBFI_ABI_VERSION 13
 
 typedef enum {
     EBFI_OK = 0,
@@ -338,6 +339,21 @@ int ebfi_conv2d_packed_f16_c16(const void *input, int input_is_c16, const void *
                                int pad, int groups, int act, float slope, const void *addend, const void *mask_y,
                                int mask_act, float mask_slope, void *in_slot, const void *w_slot, void *out16,
                                void *slot16, int out16_planar, int mask_is_c16, void *stream);
+/* Round 6 (ABI 13): the two packed convolutions with the fp32 output stored THROUGH PixelShuffle(2) (out_layout 1: `output` is
+ * [B, Cout/4, 2H, 2W], channel 4c + 2py + px of pixel (y, x) at (c, 2y + py, 2x + px); Cout % 4 == 0) or through its inverse
+ * (out_layout 2: [B, 4*Cout, H/2, W/2]; H, W even); 0 = the plain layout.  3x3 same-padded layers on the wave-specialised kernels
+ * (W % 4 == 0, Cout > 32, 16-byte aligned input), no groups, no addend, no fp16 side output.  Replaces the PixelShuffle copy of the
+ * reconstruction head (models/Ours/model_singleframe.py:257-260: conv 64 -> 256, nn.PixelShuffle(2), LeakyReLU) and its backward:
+ *   forward   ebfi_conv2d_packed_x3_shuffled(.., act = LeakyReLU, out_layout 1) writes what the next layer reads;
+ *   backward  ebfi_conv2d_packed_f16_shuffled on that next layer's TRANSPOSED fp16 image with mask_y = that layer's own input (the
+ *             shuffled activation, natural layout of this launch), out_layout 2: the pre-activation gradient of the 64 -> 256
+ *             convolution in ITS layout.  mask_y / mask_act / mask_slope as in ebfi_conv2d_packed_f16_c16 (fp32 mask tensor). */
+int ebfi_conv2d_packed_x3_shuffled(const void *input, const void *packed, size_t packed_bytes, const void *bias, void *output,
+                                   int B, int Cin, int H, int W, int Cout, int act, float slope, int out_layout, void *stream);
+int ebfi_conv2d_packed_f16_shuffled(const void *input, int input_is_c16, const void *packed16, size_t packed_bytes,
+                                    const void *bias, void *output, int B, int Cin, int H, int W, int Cout, int act, float slope,
+                                    const void *mask_y, int mask_act, float mask_slope, void *in_slot, const void *w_slot,
+                                    int out_layout, void *stream);
 int ebfi_conv2d_backward_weight_f16c(const void *input16, const void *grad16, int grad_is_planar, void *grad_weight,
                                      void *grad_bias, int B, int Cin_per_group, int H, int W, int Cout, int groups,
                                      const void *x_slot, const void *g_slot, void *workspace, size_t workspace_bytes,
