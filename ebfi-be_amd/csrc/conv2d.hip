@@ -2797,6 +2797,7 @@ __global__ __launch_bounds__(NTWS) void conv_fwd_bf16x3_ws(const float *__restri
 
 #include "conv2d_f16.inc.hpp"
 #include "conv2d_thin.inc.hpp"
+#include "conv2d_shift.inc.hpp"
 
 size_t bf16_pack_bytes(int M, int K, int ks) { return (size_t)ks * ks * M * (size_t)((K + 15) / 16 * 16) * 2; }
 
@@ -3451,6 +3452,8 @@ extern "C" size_t ebfi_conv2d_backward_weight_workspace(int B, int Cin, int H, i
     int slabs = wgrad_splits(g, ksize, stride);
     if (thin_wgrad_geometry(g, ksize, stride).kind != 0 && thin_wgrad_slabs(g) > slabs)
         slabs = thin_wgrad_slabs(g);            // (the thin-layer kernels write one slab per sample and row band: conv2d_thin.inc.hpp)
+    if (const ShiftPlan sp = shift_wgrad_geometry(g, ksize, stride); sp.kind != 0 && shift_wgrad_slabs(g, sp) > slabs)
+        slabs = shift_wgrad_slabs(g, sp);       // (one per sample, 16-row band and 64-column segment: conv2d_shift.inc.hpp)
     return (size_t)slabs * ((size_t)Cout * Cin * ksize * ksize + Cout) * sizeof(float);
 }
 
@@ -3497,6 +3500,12 @@ extern "C" int ebfi_conv2d_backward_weight_ex(const void *input, const void *gra
     float *slab = static_cast<float *>(workspace);
     // layers with <= 6 channels on one side: direct fp32 kernels that stream the thick tensor once (conv2d_thin.inc.hpp), whatever
     // operand format was asked for (they are exact)
+    // ... unless split precision was asked for: then the matrix cores with the taps on the row axis of the thin side (conv2d_shift.inc.hpp)
+    if (x3) {
+        if (const ShiftPlan sp = shift_wgrad_plan(g, ksize, stride, input, grad_output, saved_output, grad_preact_out); sp.kind != 0)
+            return launch_wgrad_shift(st, sp, x, go, yo, static_cast<float *>(grad_preact_out), slab, g, act, slope,
+                                      static_cast<float *>(grad_weight), static_cast<float *>(grad_bias));
+    }
     if (const ThinPlan tp = thin_wgrad_plan(g, ksize, stride, input, grad_output, saved_output, grad_preact_out); tp.kind != 0)
         return launch_wgrad_thin(st, tp, x, go, yo, static_cast<float *>(grad_preact_out), slab, g, ksize, act, slope,
                                  static_cast<float *>(grad_weight), static_cast<float *>(grad_bias));
@@ -3968,7 +3977,11 @@ extern "C" int ebfi_conv2d_backward_weight_f16g_ex(const void *input, const void
         return EBFI_OK;
     }
     float *slab = static_cast<float *>(workspace);
-    if (!gp16) {       // thin layers (64 -> 3, 64 -> 1): the direct fp32 kernel, no operand scaling involved
+    if (!gp16) {       // thin layers (64 -> 3, 64 -> 1): split precision on the matrix cores / the direct fp32 kernel, no operand scaling involved
+        if (const ShiftPlan sp = shift_wgrad_plan(g, 3, 1, input, grad_output, saved_output, grad_preact_out); sp.kind != 0)
+            return launch_wgrad_shift(st, sp, static_cast<const float *>(input), static_cast<const float *>(grad_output),
+                                      static_cast<const float *>(saved_output), static_cast<float *>(grad_preact_out), slab, g, act, slope,
+                                      static_cast<float *>(grad_weight), static_cast<float *>(grad_bias));
         if (const ThinPlan tp = thin_wgrad_plan(g, 3, 1, input, grad_output, saved_output, grad_preact_out); tp.kind != 0)
             return launch_wgrad_thin(st, tp, static_cast<const float *>(input), static_cast<const float *>(grad_output),
                                      static_cast<const float *>(saved_output), static_cast<float *>(grad_preact_out), slab, g, 3, act, slope,

@@ -82,15 +82,37 @@ THIN = [
     (1, 1, 256, 512, 16, 3, 1, 1, 0, False, "in"),       # Cin = 1, two workgroup rows per image row
     (4, 3, 256, 256, 64, 3, 2, 1, 1, True, "ins2"),      # FrameFeatExtract: 3x3 stride 2
     (6, 4, 200, 256, 16, 3, 2, 1, 0, True, "ins2"),      # ragged last band
+    # round 6 (conv2d_shift.inc.hpp): shapes only the matrix-core kernel with the taps on the thin side's row axis serves
+    (1, 16, 262, 262, 3, 7, 1, 0, 0, True, "out7"),      # the detail branch's output conv on the reflection-padded map (rows not quad-aligned)
+    (3, 16, 150, 230, 3, 7, 1, 0, 0, False, "out7"),     # ragged band and segment
+    (3, 64, 130, 172, 3, 3, 1, 1, 2, True, "out"),       # ragged band / segment
+    (2, 64, 150, 222, 1, 3, 1, 1, 0, True, "out"),       # one thin channel; rows that are not whole quads: dword loads
+    (2, 4, 136, 250, 64, 3, 1, 1, 1, True, "in"),        # rows that are not whole quads: dword loads / stores of the side tensor
 ]
+
+
+def _shift_role(Cin, Cout, k, s, p, role):
+    """the role label under which csrc/conv2d_shift.inc.hpp serves the layer in the split-precision mode, or None"""
+    if s != 1:
+        return None
+    if k == 7:
+        return "out7" if (p == 0 and Cout == 3 and Cin == 16) else None
+    if k == 3 and p == 1:
+        if Cout in (1, 3) and Cin == 64:
+            return "out"
+        if Cin == 4 and Cout == 64:
+            return "in"
+    return None
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("B,Cin,H,W,Cout,k,s,p,act,has_bias,role", THIN)
 def test_thin_layer_weight_gradients_vs_cpu(B, Cin, H, W, Cout, k, s, p, act, has_bias, role, mode):
     """csrc/conv2d_thin.inc.hpp: 3x3 layers with <= 4 channels on one side take direct fp32 weight-gradient kernels that stream
-    the thick tensor once.  Against torch's CPU autograd at the sizes that select them; the launch is checked to BE the thin kernel,
-    and the by-product grad * act'(out) feeds the data gradient as before."""
+    the thick tensor once; in the split-precision mode the shapes of the model (1 / 3 / 4 thin channels against 16..64, and the
+    7x7 16 -> 3 layer) take csrc/conv2d_shift.inc.hpp instead: the matrix cores with one row per (thin channel, tap).  Against
+    torch's CPU autograd at the sizes that select them; the launch is checked to BE the expected kernel, and the by-product
+    grad * act'(out) feeds the data gradient as before."""
     from ebfi_amd import conv
     from ebfi_amd import _native as N
     torch.manual_seed(Cin * 7 + Cout + k + s)
@@ -112,7 +134,13 @@ def test_thin_layer_weight_gradients_vs_cpu(B, Cin, H, W, Cout, k, s, p, act, ha
         prof = N.prof_collect()
     finally:
         conv.set_compute_dtype("fp32")
-    assert "conv_wgrad_thin/" + role in prof, sorted(prof)
+    shift = _shift_role(Cin, Cout, k, s, p, role) if mode == "bf16x3" else None
+    if shift is not None:          # split precision: the matrix cores with the taps on the thin side's row axis
+        assert "conv_wgrad_shift/" + shift in prof and not any(n.startswith("conv_wgrad_thin") for n in prof), sorted(prof)
+    elif k == 3 and W % 4 == 0 and 256 % (((W + 2 * p - k) // s + 1) // 4) == 0:      # (a thread = a column of quads: 256 threads are whole rows)
+        assert "conv_wgrad_thin/" + role in prof, sorted(prof)
+    else:                          # the exact mode outside the direct kernels' shapes: the fp32 matrix-core kernel
+        assert "conv_wgrad_f32" in prof, sorted(prof)
     # the forward of the thin-OUT layers (<= 3 output channels) in the split-precision mode: taps on the matrix row axis
     assert ("conv_thin_out_fwd" in prof) == (mode == "bf16x3" and role == "out" and Cout <= 3 and 16 <= Cin <= 64 and Cin % 16 == 0), sorted(prof)
     assert _rel(out.detach(), ref) < 2e-5

@@ -25,7 +25,11 @@ GEO = {"ebfi_conv2d_forward_bf16x3": slice(4, 12), "ebfi_conv2d_backward_data_bf
        "ebfi_conv2d_backward_weight_x3g": slice(4, 12), "ebfi_conv2d_forward": slice(4, 12), "ebfi_conv2d_backward_data": slice(4, 12),
        # fp16 backward of the generic (non-ResidualControl) layers: (x, gout, y, gw, gb, gpre, gpre_is_c16, B, Cin, H, W, M, ks, pad, ..)
        "ebfi_conv2d_backward_weight_f16g_ex": slice(7, 15), "ebfi_conv2d_packed_f16": slice(5, 13),
-       "ebfi_conv2d_packed_f16_c16": slice(6, 14), "ebfi_conv2d_thin_forward": slice(4, 12)}
+       "ebfi_conv2d_packed_f16_c16": slice(6, 14), "ebfi_conv2d_thin_forward": slice(4, 12),
+       # (B, Cin, H, W, Cout) only: printed with k = 3
+       "ebfi_conv2d_packed_x3_shuffled": slice(5, 10), "ebfi_conv2d_packed_f16_shuffled": slice(6, 11),
+       "ebfi_conv2d_packed_x3_c16": slice(5, 13), "ebfi_conv2d_packed_x3_rc": slice(5, 10),
+       "ebfi_conv2d_backward_weight_f16c": slice(5, 10)}
 
 
 def wrap(name):
@@ -53,6 +57,6 @@ for name, geo, e0, e1 in records:
 tot = sum(v[1] for v in agg.values())
 print("total %.1f us in %d launches" % (tot, len(records)))
 for (name, geo), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    B, C, H, W, Co, k = geo[:6]
+    B, C, H, W, Co, k = (tuple(geo) + (3,))[:6]
     fl = 2.0 * B * H * W * C * Co * k * k * n
     print("%-26s x%2d %8.1f us (%5.1f each) %5.1f TF/s  %s" % (name, n, us, us / n, fl / us / 1e6, geo))
