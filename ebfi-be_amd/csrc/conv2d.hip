@@ -3308,6 +3308,12 @@ int conv_backward_data_bf16_impl(const char *who, int x3, const void *grad_outpu
     ConvGeom f;
     if (int rc = make_geom(f, B, Cin, H, W, Cout, ksize, stride, pad)) return rc;
     if (B == 0) return EBFI_OK;
+    // the detail branch's output convolution (16 <- 3 channels on a full-resolution map): taps on the contraction axis of the thin
+    // gradient (conv2d_shift.inc.hpp) instead of 49 taps of a 29/32-empty tile
+    if (k7 && Cout == 3 && Cin == 16 && (int64_t)B * H * W >= 64 * 1024 && dev_getenv("EBFI_NO_SHIFT_WGRAD") == nullptr)
+        return launch_conv7_thin_dgrad(static_cast<hipStream_t>(stream), static_cast<const float *>(grad_output), nullptr,
+                                       static_cast<const float *>(weight), static_cast<float *>(grad_input), B, H, W, f.Ho, f.Wo, pad,
+                                       ACT_NONE, 0.f);
     if (k7)     // transposed, flipped filter on grad_output: [B, Cout, Ho, Wo] -> [B, Cin, H, W]
         return launch_conv7_x3(static_cast<hipStream_t>(stream), static_cast<const float *>(grad_output),
                                static_cast<const float *>(weight), nullptr, static_cast<float *>(grad_input), B, Cout, f.Ho, f.Wo,

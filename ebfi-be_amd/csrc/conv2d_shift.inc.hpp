@@ -465,3 +465,154 @@ int launch_wgrad_shift(hipStream_t st, const ShiftPlan &p, const float *x, const
     }
     return check_launch("conv_wgrad_reduce_f32");
 }
+
+// ====================================================================================================================
+// The DATA gradient of the 7x7 16 -> 3 layer (the detail branch's output convolution) with the same operand form:
+//
+//   gx[ci][y'][x'] = sum_{co, ky, kx} w[co][ci][ky][kx] * gp[co][y' + P - ky][x' + P - kx]
+//
+// conv7_x3 pads the three gradient channels to a 16-channel staging chunk and walks 49 taps of a 32-row tile: 108 us for 35 MB
+// of output.  Here the contraction index is k = (co, ky, j), j = 0..7 one 8-element run ALONG x of the thin tile (j = 7 - kx; j = 0
+// meets a zero weight): 21 runs = 168 -> 192 = six contraction steps of v_mfma_f32_16x16x32_bf16 per 16 output pixels, with
+//   A[ci][(co, ky, j)] = w[co][ci][ky][7 - j]         the whole weight: 6 x (hi, lo) fragments a lane keeps in registers,
+//   B[(co, ky, j)][x'] = gp[co][y' + P - ky][x' + P - 7 + j]   8 consecutive elements of the staged thin tile per lane -- from the
+//                                                      copy whose parity makes them dword-aligned (see conv_wgrad_shift),
+// and the 16 x 16 result tile is the 16 input channels of 16 pixels.  Workgroup = (sample, 16 rows, 64 columns) of grad_input;
+// the only global traffic is the thin tile (once) and the result.
+constexpr int D7_R = 16, D7_W = 64, D7_KS = 7, D7_NT = 3, D7_CI = 16;
+constexpr int D7_TH = D7_R + D7_KS - 1, D7_TW = D7_W + D7_KS, D7_TWP = 72;
+constexpr int D7_TSEL = D7_NT * D7_TH * D7_TWP;
+constexpr int D7_LDS = 4 * D7_TSEL * 2;
+
+struct D7Geom {
+    int B, H, W, Ho, Wo, P, act;
+    float slope;
+    int bands, segs;
+};
+
+__global__ __launch_bounds__(256) void conv7_thin_dgrad(const float *__restrict__ gout, const float *__restrict__ yact,
+                                                        const float *__restrict__ wgt, float *__restrict__ gx, D7Geom g) {
+    constexpr int KS = D7_KS, NT = D7_NT, TH = D7_TH, TW = D7_TW, TWP = D7_TWP, TSEL = D7_TSEL, KK = KS * KS;
+    __shared__ __attribute__((aligned(16))) __bf16 thin[4 * TSEL];       // [copy][hi | lo][NT][TH][TWP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int t_ = blockIdx.x;
+    const int seg = t_ % g.segs; t_ /= g.segs;
+    const int band = t_ % g.bands;
+    const int b = t_ / g.bands;
+    const int y0 = band * D7_R, x0 = seg * D7_W;
+    const int HWo = g.Ho * g.Wo, HW = g.H * g.W;
+    const float *gp_p = gout + (int64_t)b * NT * HWo;
+    const bool has_y = yact != nullptr && g.act != ACT_NONE;
+    const __amdgpu_buffer_rsrc_t rgp = make_rsrc(gp_p, (unsigned)NT * (unsigned)HWo * 4u);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(has_y ? yact + (int64_t)b * NT * HWo : gp_p, has_y ? (unsigned)NT * (unsigned)HWo * 4u : 0u);
+    const ThinAct da = thin_act(g.act, g.slope);
+    // thin tile: rows y0 + P - 6 .. y0 + 15 + P, columns x0 + P - 7 .. x0 + 63 + P; 0 outside the gradient
+    const int ty0 = y0 + g.P - (KS - 1), tx0 = x0 + g.P - KS;
+    {
+        constexpr int NEL = NT * TH * TW, NIT = (NEL + 255) / 256;
+        float tvv[NIT], tyv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 256;
+            const int t = idx / (TH * TW);
+            const int rem = idx - t * (TH * TW);
+            const int tr = rem / TW, tc = rem - tr * TW;
+            const int ty = ty0 + tr, tx = tx0 + tc;
+            const bool ok = idx < NEL && ty >= 0 && ty < g.Ho && tx >= 0 && tx < g.Wo;
+            const unsigned off = sel_off(ok, ((unsigned)t * (unsigned)HWo + (unsigned)(ty * g.Wo + tx)) * 4u);
+            tvv[it] = buf_ld(rgp, off);
+            tyv[it] = buf_ld(ry, off);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 256;
+            if (idx >= NEL) continue;
+            const int t = idx / (TH * TW);
+            const int rem = idx - t * (TH * TW);
+            const int tr = rem / TW, tc = rem - tr * TW;
+            const float v = thin_dact(tvv[it], tyv[it], da);
+            const __bf16 h = (__bf16)v;
+            const __bf16 l = (__bf16)(v - (float)h);
+            const int e = (t * TH + tr) * TWP + tc;
+            thin[0 * TSEL + e] = h;
+            thin[1 * TSEL + e] = l;
+            if (tc >= 1) {
+                thin[2 * TSEL + e - 1] = h;
+                thin[3 * TSEL + e - 1] = l;
+            }
+        }
+    }
+    // the weight as A fragments: lane (ci = lane & 15, kg = lane >> 4), step s: run q = 4 s + kg = (co, ky); element j -> kx = 7 - j
+    typedef float f32x4_d7 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4_d7 __attribute__((ext_vector_type(4)));
+    const int ci = lane & 15, kg = lane >> 4;
+    bf16x8 ah[6], al[6];
+    unsigned boff[6];                                            // LDS element offset of run q's row: (co * TH + (6 - ky)) * TWP
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int q = 4 * s + kg;
+        const bool live = q < NT * KS;
+        const int qq = live ? q : 0;
+        const int co = qq / KS, ky = qq - co * KS;
+        float wv[8];
+        wv[0] = 0.f;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) wv[j] = live ? wgt[((int64_t)co * D7_CI + ci) * KK + ky * KS + (7 - j)] : 0.f;
+        u32x4_d7 h4, l4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float h0 = (float)(__bf16)wv[2 * j], h1 = (float)(__bf16)wv[2 * j + 1];
+            h4[j] = sh_pack_bf16(h0, h1);
+            l4[j] = sh_pack_bf16(wv[2 * j] - h0, wv[2 * j + 1] - h1);
+        }
+        ah[s] = __builtin_bit_cast(bf16x8, h4);
+        al[s] = __builtin_bit_cast(bf16x8, l4);
+        boff[s] = (unsigned)((co * TH + (KS - 1 - ky)) * TWP);     // (padding runs: any live row -- their weights are zero)
+    }
+    __syncthreads();
+    // rows of this wave: r = wave, wave + 4, ...; per row four 16-pixel tiles
+    const int par = lane & 1;
+    const int nrows = min(D7_R, g.H - y0);
+    float *gxb = gx + (int64_t)b * D7_CI * HW;
+    for (int r = wave; r < nrows; r += 4) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            f32x4_d7 acc{0.f, 0.f, 0.f, 0.f};
+            const int xl = 16 * nt + (lane & 15);                // pixel within the segment; tile column of j = 0 is xl
+            const unsigned cbase = (unsigned)(2 * par) * TSEL + (unsigned)(r * TWP + xl - par);
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                const char *bp = reinterpret_cast<const char *>(thin) + (cbase + boff[s]) * 2u;
+                u32x4_d7 bh, bl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bh[j] = *reinterpret_cast<const unsigned *>(bp + 4 * j);
+                    bl[j] = *reinterpret_cast<const unsigned *>(bp + TSEL * 2 + 4 * j);
+                }
+                const bf16x8 b_h = __builtin_bit_cast(bf16x8, bh), b_l = __builtin_bit_cast(bf16x8, bl);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s], b_h, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], b_l, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], b_h, acc, 0, 0, 0);
+            }
+            // C[ci = 4 kg + j][pixel lane & 15]
+            const int y = y0 + r, xg = x0 + xl;
+            if (xg < g.W) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gxb[(int64_t)(4 * kg + j) * HW + (int64_t)y * g.W + xg] = acc[j];
+            }
+        }
+    }
+}
+
+// grad_input [B, 16, H, W] of a 7x7 stride-1 layer with 3 output channels from grad_output (times act'(saved_output) when given)
+int launch_conv7_thin_dgrad(hipStream_t st, const float *go, const float *y, const float *w, float *gx, int B, int H, int W, int Ho, int Wo,
+                            int pad, int act, float slope) {
+    D7Geom g{B, H, W, Ho, Wo, pad, act, slope, (int)ceil_div(H, D7_R), (int)ceil_div(W, D7_W)};
+    const int64_t wgs = (int64_t)B * g.bands * g.segs;
+    if (wgs > 2147483647LL) return fail(EBFI_ERR_ARG, "conv7_thin_dgrad: too many workgroups");
+    const double flops = 2.0 * B * Ho * Wo * 3.0 * 16.0 * 49.0;
+    const double bytes = 4.0 * ((double)B * 3 * Ho * Wo * (y ? 2 : 1) + (double)B * 16 * H * W);
+    ProfScope ps("conv7_thin_dgrad", st, flops, bytes);
+    hipLaunchKernelGGL(conv7_thin_dgrad, dim3((unsigned)wgs), dim3(256), 0, st, go, y, w, gx, g);
+    return check_launch("conv7_thin_dgrad");
+}

@@ -137,6 +137,7 @@ def test_thin_layer_weight_gradients_vs_cpu(B, Cin, H, W, Cout, k, s, p, act, ha
     shift = _shift_role(Cin, Cout, k, s, p, role) if mode == "bf16x3" else None
     if shift is not None:          # split precision: the matrix cores with the taps on the thin side's row axis
         assert "conv_wgrad_shift/" + shift in prof and not any(n.startswith("conv_wgrad_thin") for n in prof), sorted(prof)
+        assert ("conv7_thin_dgrad" in prof) == (shift == "out7"), sorted(prof)      # and the 7x7 layer's data gradient in the same form
     elif k == 3 and W % 4 == 0 and 256 % (((W + 2 * p - k) // s + 1) // 4) == 0:      # (a thread = a column of quads: 256 threads are whole rows)
         assert "conv_wgrad_thin/" + role in prof, sorted(prof)
     else:                          # the exact mode outside the direct kernels' shapes: the fp32 matrix-core kernel
