@@ -1,4 +1,6 @@
 // THIN 3x3 layers: weight gradients as direct fp32 kernels (included by conv2d.hip inside its anonymous namespace, round 5).
+// (Round 6: in the split-precision mode the model's shapes take conv2d_shift.inc.hpp -- matrix cores, taps on the thin side's row
+//  axis; these kernels remain the exact-fp32 form and serve the shapes that file does not build.)
 //
 // Four 3x3 layers of the model have <= 4 channels on one side at full resolution (B = 8, 256 x 256): the model's first and last
 // convolutions (3 -> 64 stride 2, 64 -> 3) and ExposureDecision's (4 -> 64, 64 -> 1).  On the matrix-core kernels the thin side
