@@ -211,6 +211,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_shift(const float *__restri
             const int u = ub + 16 * i;
             const unsigned base = ((unsigned)u * (unsigned)HWu + (unsigned)(y * g.Wu + cx)) * 4u;
             float gq[4], yq[4] = {0.f, 0.f, 0.f, 0.f};
+#if defined(EBFI_SHIFT_DIAG) && EBFI_SHIFT_DIAG == 2
+            gq[0] = gq[1] = gq[2] = gq[3] = (float)(base & 7u);  // (diagnostic build: no global loads of the thick tensor)
+            if (false)
+#endif
             if constexpr (ALIGNED) {                             // whole quads inside or outside the row
                 const unsigned off = sel_off(row_ok && cx < g.Wu, base);
                 const f32x4_sh t4 = __builtin_bit_cast(f32x4_sh, __builtin_amdgcn_raw_buffer_load_b128(rthick, off, 0, 0));
@@ -264,6 +268,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_shift(const float *__restri
         }
     };
     auto products = [&](int r) {                                 // the two 32-pixel contraction steps of thick row r (buffer r & 1)
+#if defined(EBFI_SHIFT_DIAG) && EBFI_SHIFT_DIAG == 1
+        return;                                                  // (diagnostic build: no LDS reads, no matrix products)
+#endif
         const char *tb = thick + ((r & 1) * 2) * SH_NUMAX * SH_UP * 2;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
