@@ -19,12 +19,16 @@
 // hi + lo pairs, three products per tile (hi.hi, hi.lo, lo.hi: the split-precision scheme of every other matrix-core kernel of this
 // file, ~1e-5 of fp32); the exact-fp32 mode keeps the direct kernels.
 //
+// Built for the model's shapes: 3x3 same-padded layers with 1 or 3 output channels from 64, or 64 from 4, and the 7x7 unpadded
+// 16 -> 3 layer (shift_wgrad_geometry); >= 64 K output pixels per launch -- below that the generic kernels' fixed costs are not the
+// problem.
+//
 // Workgroup = (sample, band of 16 thick rows, segment of 64 thick columns), 256 threads:
 //   * the thin tile the band can touch -- NT x (16 + KS - 1) x (64 + KS - 1) values, zero outside the thin tensor (= zero padding)
 //     -- is staged ONCE, split, as four LDS arrays: hi / lo x two copies, the second shifted by one element, so that the 8
 //     consecutive elements an A fragment needs (k = 8 consecutive pixels, from column `8 j + shift(kx)`) start on a dword in one of
 //     the copies whatever the parity of the shift: four aligned ds_read_b32 per fragment, no byte permutes;
-//   * per thick row: 16..64 channels x 64 pixels are loaded (next row's loads in flight during this row's products), multiplied
+//   * per thick row: 16 / 64 channels x 64 pixels are loaded (THREE rows of loads in flight: see the row loop), multiplied
 //     by act'(out) when the thick side is the gradient, split and written as [channel][72] bf16 rows (144-byte stride: the 16
 //     lanes of a B fragment hit 16 different bank quads) into one of two buffers; two 32-pixel contraction steps per row;
 //   * wave w owns the output tiles w, w + 4, ...; accumulators stay in registers for the whole band; the workgroup writes ONE slab
@@ -47,7 +51,6 @@ struct ShiftGeom {
     int act;
     float slope;
     int bands, segs;
-    int aligned;                       // thick rows are whole 16-byte quads on 16-byte aligned bases: 16-byte loads / stores
 };
 
 template <int KS, int NT>
@@ -447,7 +450,6 @@ int launch_wgrad_shift(hipStream_t st, const ShiftPlan &p, const float *x, const
         return fail(EBFI_ERR_ARG, "conv2d_backward_weight (shift): one sample exceeds the 2 GiB reach of 32-bit buffer offsets");
     const float *thickp = out ? x : go;
     const bool al = sg.Wu % 4 == 0 && aligned16(thickp) && (out || act == ACT_NONE || !y || aligned16(y)) && (out || !gp || aligned16(gp));
-    sg.aligned = al ? 1 : 0;
     const int kk = p.ks * p.ks;
     const double flops = 2.0 * g.B * g.Ho * g.Wo * (double)g.Cout * g.Cin * kk;
     const double bytes = conv_bytes_wgrad(g, kk, act != ACT_NONE, gp != nullptr);
