@@ -2284,6 +2284,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_f32(const float *__rest
                                                              int perm_cin, int perm_kk) {
     wgrad_reduce_body(slab, nslabs, n_weight, n_total, gw, gb, perm_cin, perm_kk);
 }
+// MANY slabs of a SMALL gradient (the thin layers of conv2d_shift.inc.hpp: 500-700 slabs of ~2000 values): 16 consecutive elements per
+// workgroup and sixteen thread rows, each summing every 16th slab with eight loads in flight -- a quarter of the dependent round
+// trips of the 64 x 4 form above, on four times as many workgroups (that form ran 10-12 us on 28-37 workgroups).  Fixed order.
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_tall(const float *__restrict__ slab, int nslabs, int64_t n_weight, int64_t n_total,
+                                                              float *__restrict__ gw, float *__restrict__ gb) {
+    __shared__ float part[16][16];
+    const int jj = threadIdx.x & 15, kq = threadIdx.x >> 4;
+    const int64_t j = (int64_t)blockIdx.x * 16 + jj;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (j < n_total) {
+        const float *p = slab + j;
+        int k = kq;
+        for (; k + 112 < nslabs; k += 128) {
+            float a[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = p[(int64_t)(k + 16 * i) * n_total];
+            s0 += a[0]; s1 += a[1]; s2 += a[2]; s3 += a[3];
+            s0 += a[4]; s1 += a[5]; s2 += a[6]; s3 += a[7];
+        }
+        for (; k < nslabs; k += 16) s0 += p[(int64_t)k * n_total];
+    }
+    part[kq][jj] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (kq == 0 && j < n_total) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += part[i][jj];
+        if (j < n_weight) gw[j] = s;
+        else if (gb) gb[j - n_weight] = s;
+    }
+}
 // the reductions of a batched weight-gradient launch (conv_wgrad_f16_tr_batch): blockIdx.y = layer
 struct ReduceItem {
     const float *slab;

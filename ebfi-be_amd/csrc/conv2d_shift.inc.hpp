@@ -468,11 +468,11 @@ int launch_wgrad_shift(hipStream_t st, const ShiftPlan &p, const float *x, const
     if (rc) return rc;
     const int64_t n_weight = (int64_t)g.Cout * g.Cin * kk, n_total = n_weight + g.Cout;
     {
-        ProfScope ps("conv_wgrad_reduce_f32", st);
-        hipLaunchKernelGGL(conv_wgrad_reduce_f32, dim3((unsigned)ceil_div(n_total, 64)), dim3(256), 0, st, slab, shift_wgrad_slabs(g, p), n_weight,
-                           n_total, gw, gb, 0, kk);
+        ProfScope ps("conv_wgrad_reduce_tall", st);
+        hipLaunchKernelGGL(conv_wgrad_reduce_tall, dim3((unsigned)ceil_div(n_total, 16)), dim3(256), 0, st, slab, shift_wgrad_slabs(g, p), n_weight,
+                           n_total, gw, gb);
     }
-    return check_launch("conv_wgrad_reduce_f32");
+    return check_launch("conv_wgrad_reduce_tall");
 }
 
 // ====================================================================================================================

@@ -30,4 +30,4 @@ for (B, Cin, H, W, Cout, k, p, act) in ((8, 64, 256, 256, 3, 3, 1, 2), (8, 64, 2
     torch.cuda.synchronize()
     N.prof_enable(False)
     prof = N.prof_collect()
-    print((B, Cin, H, W, Cout, k), {n: round(v[1] / v[0] * 1e3, 1) for n, v in prof.items() if "wgrad" in n and v[0]})
+    print((B, Cin, H, W, Cout, k), {n: round(v[1] / v[0] * 1e3, 1) for n, v in prof.items() if ("wgrad" in n or "conv7" in n) and v[0]})
