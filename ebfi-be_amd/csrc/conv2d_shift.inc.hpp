@@ -117,61 +117,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_shift(const float *__restri
     const __amdgpu_buffer_rsrc_t rythick = make_rsrc(ythick_p ? ythick_p : thick_p, ythick_p ? (unsigned)g.NU * (unsigned)HWu * 4u : 0u);
     const ThinAct da = thin_act(g.act, g.slope);
 
-    typedef float f32x4_sh __attribute__((ext_vector_type(4)));
-    typedef unsigned u32x4_sh __attribute__((ext_vector_type(4)));
-    typedef unsigned u32x2_sh __attribute__((ext_vector_type(2)));
-    // ---- thick rows: thread = (channel ub + 16 i, quad q of the 64 columns)
-    const int q4 = (tid & 15) * 4, ub = tid >> 4;
-    constexpr int NCH = NCHR;
-    constexpr int NLD = NCHR * (ALIGNED ? 1 : 4) * (THIN_OUT ? 1 : 2);      // loads per thread and thick row
-    // (THIN_IN: the saved output travels in registers beside the gradient and act' is applied when the row is written to LDS --
-    //  applied at load time it made every row wait for its own loads)
-    constexpr int NYC = THIN_OUT ? 1 : NCH;
-    auto load_row = [&](int r, float (&tv)[NCH][4], float (&ty)[NYC][4]) {
-        const int y = y0 + r;
-        const bool row_ok = y < g.Hu;
-        const int cx = x0 + q4;
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int u = ub + 16 * i;
-            const unsigned base = ((unsigned)u * (unsigned)HWu + (unsigned)(y * g.Wu + cx)) * 4u;
-            float gq[4], yq[4] = {0.f, 0.f, 0.f, 0.f};
-#if defined(EBFI_SHIFT_DIAG) && EBFI_SHIFT_DIAG == 2
-            gq[0] = gq[1] = gq[2] = gq[3] = (float)(base & 7u);  // (diagnostic build: no global loads of the thick tensor)
-            if (false)
-#endif
-            if constexpr (ALIGNED) {                             // whole quads inside or outside the row
-                const unsigned off = sel_off(row_ok && cx < g.Wu, base);
-                const f32x4_sh t4 = __builtin_bit_cast(f32x4_sh, __builtin_amdgcn_raw_buffer_load_b128(rthick, off, 0, 0));
-                gq[0] = t4.x; gq[1] = t4.y; gq[2] = t4.z; gq[3] = t4.w;
-                if constexpr (!THIN_OUT) {
-                    const f32x4_sh y4 = __builtin_bit_cast(f32x4_sh, __builtin_amdgcn_raw_buffer_load_b128(rythick, off, 0, 0));
-                    yq[0] = y4.x; yq[1] = y4.y; yq[2] = y4.z; yq[3] = y4.w;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const unsigned off = sel_off(row_ok && cx + j < g.Wu, base + 4u * (unsigned)j);
-                    gq[j] = buf_ld(rthick, off);
-                    if constexpr (!THIN_OUT) yq[j] = buf_ld(rythick, off);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                tv[i][j] = gq[j];
-                if constexpr (!THIN_OUT) ty[i][j] = yq[j];
-            }
-        }
-    };
-    // the first three thick rows are requested BEFORE the thin tile is staged: their round trip runs behind the tile's own loads,
-    // conversions and LDS writes (the first version staged the tile, then started the row pipeline from empty)
-    const int nrows = min(SH_R, g.Hu - y0);
-    float tv0[NCH][4], tv1[NCH][4], tv2[NCH][4], tv3[NCH][4];
-    float ty0_[NYC][4], ty1_[NYC][4], ty2_[NYC][4], ty3_[NYC][4];
-    load_row(0, tv0, ty0_);
-    if (1 < nrows) load_row(1, tv1, ty1_);
-    if (2 < nrows) load_row(2, tv2, ty2_);
-
     // ---- the thin tile, once: element (t, tr, tc) = T[t][ty0 + tr][tx0 + tc], 0 outside the tensor
     // A[(t, ky, kx)][thick (r, c)] = T[t][r + dy][c + dx]: THIN_OUT (dy, dx) = (P - ky, P - kx), THIN_IN (ky - P, kx - P)
     const int dmin = THIN_OUT ? g.P - (KS - 1) : -g.P;
@@ -246,10 +191,56 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_shift(const float *__restri
         okmask |= wrow ? (1u << i) : 0u;
         onemask |= (!THIN_OUT && tile < ntiles && m == MW) ? (1u << i) : 0u;
     }
+    typedef float f32x4_sh __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4_sh __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2_sh __attribute__((ext_vector_type(2)));
     f32x4_sh acc[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = f32x4_sh{0.f, 0.f, 0.f, 0.f};
 
+    // ---- thick rows: thread = (channel ub + 16 i, quad q of the 64 columns)
+    const int q4 = (tid & 15) * 4, ub = tid >> 4;
+    constexpr int NCH = NCHR;
+    constexpr int NLD = NCHR * (ALIGNED ? 1 : 4) * (THIN_OUT ? 1 : 2);      // loads per thread and thick row
+    // (THIN_IN: the saved output travels in registers beside the gradient and act' is applied when the row is written to LDS --
+    //  applied at load time it made every row wait for its own loads)
+    constexpr int NYC = THIN_OUT ? 1 : NCH;
+    auto load_row = [&](int r, float (&tv)[NCH][4], float (&ty)[NYC][4]) {
+        const int y = y0 + r;
+        const bool row_ok = y < g.Hu;
+        const int cx = x0 + q4;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int u = ub + 16 * i;
+            const unsigned base = ((unsigned)u * (unsigned)HWu + (unsigned)(y * g.Wu + cx)) * 4u;
+            float gq[4], yq[4] = {0.f, 0.f, 0.f, 0.f};
+#if defined(EBFI_SHIFT_DIAG) && EBFI_SHIFT_DIAG == 2
+            gq[0] = gq[1] = gq[2] = gq[3] = (float)(base & 7u);  // (diagnostic build: no global loads of the thick tensor)
+            if (false)
+#endif
+            if constexpr (ALIGNED) {                             // whole quads inside or outside the row
+                const unsigned off = sel_off(row_ok && cx < g.Wu, base);
+                const f32x4_sh t4 = __builtin_bit_cast(f32x4_sh, __builtin_amdgcn_raw_buffer_load_b128(rthick, off, 0, 0));
+                gq[0] = t4.x; gq[1] = t4.y; gq[2] = t4.z; gq[3] = t4.w;
+                if constexpr (!THIN_OUT) {
+                    const f32x4_sh y4 = __builtin_bit_cast(f32x4_sh, __builtin_amdgcn_raw_buffer_load_b128(rythick, off, 0, 0));
+                    yq[0] = y4.x; yq[1] = y4.y; yq[2] = y4.z; yq[3] = y4.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned off = sel_off(row_ok && cx + j < g.Wu, base + 4u * (unsigned)j);
+                    gq[j] = buf_ld(rthick, off);
+                    if constexpr (!THIN_OUT) yq[j] = buf_ld(rythick, off);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                tv[i][j] = gq[j];
+                if constexpr (!THIN_OUT) ty[i][j] = yq[j];
+            }
+        }
+    };
     auto store_row = [&](int r, int buf, float (&tv)[NCH][4], const float (&ty)[NYC][4]) {   // (act',) split, write [buf][hi | lo][u][q4 .. q4 + 3]; the side tensor
         const int y = y0 + r, cx = x0 + q4;
 #pragma unroll
@@ -323,7 +314,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_shift(const float *__restri
     // and the wait-count pass sees that row k + 1's NLD loads are complete once at most 2 NLD younger ones are outstanding (explicit
     // counts; with a branch around the younger loads it merged the two paths into "anything may be pending" and drained everything
     // before each LDS write).  With the side tensor's stores in flight loads and stores share the counter out of order: 0.
+    const int nrows = min(SH_R, g.Hu - y0);
+    float tv0[NCH][4], tv1[NCH][4], tv2[NCH][4], tv3[NCH][4];
+    float ty0_[NYC][4], ty1_[NYC][4], ty2_[NYC][4], ty3_[NYC][4];
     constexpr int WOLD = (!THIN_OUT && GPOUT) ? 0 : (2 * NLD < 60 ? 2 * NLD : 60);   // (a smaller count only waits longer; the counter has 6 bits)
+    load_row(0, tv0, ty0_);
+    if (1 < nrows) load_row(1, tv1, ty1_);
+    if (2 < nrows) load_row(2, tv2, ty2_);
     store_row(0, 0, tv0, ty0_);
     sh_lds_barrier();                                            // thin tile and thick row 0 are in LDS
 #define SH_STEP(K_, SA_, YA_, SB_, YB_)                                                                                  \
