@@ -55,10 +55,11 @@ def host_threads():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(model_args, budget_s=25.0):
+def cpu_baseline(model_args, budget_s=20.0):
     """Oracle fwd+bwd on the host cores, same architecture and input statistics as the GPU run, on a
-    bounded sample: B=1 at 256x256 when one iteration fits the budget, else B=1 at 128x128 (stated in
-    `sample`; the conv-dominated cost scales with the pixel count)."""
+    bounded sample of ~10-20 s of CPU work: as many B=1 iterations at 256x256 as fit the budget (at most 24; one
+    iteration is ~0.8 s on the GPU box's 16 threads), else B=1 at 128x128 (stated in `sample`; the conv-dominated cost
+    scales with the pixel count)."""
     from oracle import loss_ref, model_ref
     from ebfi_amd.engine import synthetic_batch
     from ebfi_amd.model import EVFIAutoEx
@@ -82,10 +83,10 @@ def cpu_baseline(model_args, budget_s=25.0):
     note("cpu baseline: B=1 128x128 fwd+bwd %.2f s on %d threads" % (t128, cores))
     if 4 * t128 * 2 <= budget_s:
         h = w = 256
-        iters = max(1, min(4, int(budget_s / (4 * t128)) - 1))
+        iters = max(1, min(24, int(budget_s / (4 * t128)) - 1))
     else:
         h = w = 128
-        iters = max(1, min(4, int(budget_s / max(t128, 1e-3)) - 1))
+        iters = max(1, min(24, int(budget_s / max(t128, 1e-3)) - 1))
     dt = run(h, w, iters)
     fps = iters / dt
     scale = (h * w) / float(H * W)
