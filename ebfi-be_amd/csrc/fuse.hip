@@ -190,6 +190,30 @@ __global__ __launch_bounds__(256) void to_c16_kernel(const float *__restrict__ s
     ScaleSlot{slot}.record(amax);
 }
 
+// The image of cat([src0, src1], 1) without the concatenated fp32 tensor (round 6; Modification: `cat([ev, FrameTensor])` has one
+// consumer in the training step, the 128 -> 1600 KernelConv, which reads only its image): channel group cg of the image comes from
+// src0 (C0 channels per sample) or src1 (C1); both multiples of 8, so a group never straddles.
+__global__ __launch_bounds__(256) void to_c16_cat2_kernel(const float *__restrict__ src0, int C0, const float *__restrict__ src1, int C1,
+                                                          _Float16 *__restrict__ dst, float *__restrict__ slot, int64_t HW4, int W4,
+                                                          int64_t total) {
+    saturate_fp16_conversions();
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float amax = 0.f;
+    if (i < total) {
+        const int C = C0 + C1;
+        const int64_t q = i % HW4, bg = i / HW4;                  // bg = b * (C / 8) + channel group
+        const int64_t G8 = C / 8, b = bg / G8, cg = bg - b * G8;
+        const int64_t c = cg * 8;
+        const f4 *p = c < C0 ? reinterpret_cast<const f4 *>(src0) + (b * C0 + c) * HW4 + q
+                             : reinterpret_cast<const f4 *>(src1) + (b * C1 + (c - C0)) * HW4 + q;
+        f4 v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = p[e * HW4];
+        c16_store_quad(dst, c16_piece(b, C / 16, cg / 2, HW4, q, W4, (int)(cg & 1)), v, slot[0], amax);
+    }
+    ScaleSlot{slot}.record(amax);
+}
+
 // src_fwd_kernel with the output additionally as a c16 image (the input of the weight gradient of the layer that follows)
 __global__ __launch_bounds__(256) void src_fwd_c16_kernel(const float *__restrict__ a0, const float *__restrict__ s0,
                                                           const float *__restrict__ a1, const float *__restrict__ s1,
@@ -481,6 +505,26 @@ extern "C" int ebfi_to_c16(const float *src, const float *mask_y, float mask_slo
                            static_cast<_Float16 *>(dst16), static_cast<float *>(slot), C, HW / 4, W / 4, total);
     }
     return check_launch("to_c16");
+}
+
+extern "C" int ebfi_to_c16_cat2(const float *src0, int C0, const float *src1, int C1, void *dst16, void *slot, int B, int H, int W,
+                                void *stream) {
+    const int64_t HW = (int64_t)H * W;
+    if (!src0 || !src1 || !dst16 || !slot) return fail(EBFI_ERR_ARG, "to_c16_cat2: null argument");
+    if (W % 4 != 0) return fail(EBFI_ERR_UNSUPPORTED, "to_c16_cat2: W %% 4 != 0 (W = %d)", W);
+    if (C0 < 8 || C1 < 8 || C0 % 8 != 0 || C1 % 8 != 0 || (C0 + C1) % 16 != 0)
+        return fail(EBFI_ERR_UNSUPPORTED, "to_c16_cat2: %d + %d channels (multiples of 8, a multiple of 16 together)", C0, C1);
+    if (int rc = check_planes("to_c16_cat2", B, C0 + C1, HW)) return rc;
+    if (!aligned16(src0) || !aligned16(src1) || !aligned16(dst16)) return fail(EBFI_ERR_ARG, "to_c16_cat2: 16-byte aligned tensors");
+    if (B == 0) return EBFI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)B * ((C0 + C1) / 8) * (HW / 4);
+    {
+        ProfScope ps("to_c16/cat2", st, 0.0, 6.0 * B * (C0 + C1) * (double)HW);
+        hipLaunchKernelGGL(to_c16_cat2_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, src0, C0, src1, C1,
+                           static_cast<_Float16 *>(dst16), static_cast<float *>(slot), HW / 4, W / 4, total);
+    }
+    return check_launch("to_c16/cat2");
 }
 
 extern "C" int ebfi_scale_residual_cat_forward_c16(const float *a0, const float *s0, const float *a1, const float *s1, const float *x,

@@ -31,7 +31,7 @@ BUILD_SCRIPT = os.path.join(PKG_ROOT, "csrc", "build.sh")
 
 EBFI_F32, EBFI_F32_BF16MMA, EBFI_F32_BF16X3MMA = 0, 2, 3
 EBFI_ERR_UNSUPPORTED = -3   # include/ebfi_hip.h ebfi_status
-ABI_VERSION = 13         # include/ebfi_hip.h EBFI_ABI_VERSION
+ABI_VERSION = 14         # include/ebfi_hip.h EBFI_ABI_VERSION
 
 
 class EbfiNativeError(RuntimeError):
@@ -74,6 +74,7 @@ SIGNATURES = {
     "ebfi_conv2d_backward_weight_f16g": (_i, [_vp] * 6 + [_i] * 8 + [_i, _c.c_float, _vp, _vp, _vp, _sz, _vp]),
     "ebfi_conv2d_backward_weight_f16g_ex": (_i, [_vp] * 6 + [_i] * 9 + [_i, _c.c_float, _vp, _vp, _vp, _sz, _vp]),
     "ebfi_to_c16": (_i, [_vp, _vp, _c.c_float, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ebfi_to_c16_cat2": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     "ebfi_conv2d_packed_x3_c16": (_i, [_vp, _vp, _sz, _vp, _vp] + [_i] * 8 + [_i, _c.c_float, _vp, _vp, _i, _c.c_float, _vp, _vp, _i, _vp]),
     "ebfi_conv2d_packed_f16_c16": (_i, [_vp, _i, _vp, _sz, _vp, _vp] + [_i] * 8 + [_i, _c.c_float, _vp, _vp, _i, _c.c_float,
                                         _vp, _vp, _vp, _vp, _i, _i, _vp]),

@@ -37,6 +37,24 @@ def to_c16(x, slot_ptr, mask_y=None, mask_slope=0.0, out=None):
     return out
 
 
+def to_c16_cat2(a, b, slot_ptr):
+    """The image of cat([a, b], 1) from its two fp32 parts (the concatenated tensor is never written); bit-identical to
+    to_c16(torch.cat([a, b], 1), slot_ptr)."""
+    N.require_gpu(a)
+    a, b = a.contiguous(), b.contiguous()
+    B, C0, H, W = (int(v) for v in a.shape)
+    C1 = int(b.shape[1])
+    if b.shape[0] != B or tuple(b.shape[2:]) != (H, W):
+        raise ValueError("to_c16_cat2: parts of %s and %s" % (tuple(a.shape), tuple(b.shape)))
+    out = empty(B, C0 + C1, H, W, a.device)
+    if out.numel() == 0:
+        return out
+    with torch.cuda.device_of(a):
+        rc = N.lib().ebfi_to_c16_cat2(N.ptr(a), C0, N.ptr(b), C1, N.ptr(out), slot_ptr, B, H, W, N.stream_ptr(a.device))
+    N.check(rc, "ebfi_to_c16_cat2")
+    return out
+
+
 def from_c16(img, scale=1.0):
     """Image -> fp32 [B,C,H,W] / scale (tests and diagnostics; plain torch)."""
     B, CB, H, _, W, _ = img.shape

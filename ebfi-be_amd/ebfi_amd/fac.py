@@ -164,11 +164,14 @@ class KernelConv2D(nn.Module):
 # 4.2 GB of fp32 traffic per step (B=8, 256x256) become 2.1 GB.  The forward sees filters rounded to 11 significant bits:
 # Sharp moves by 4e-5 and the packed gradient by 1.7e-3 of its norm (oracle experiment) -- inside the parity
 # bars (1e-3 / 5e-3), which tests/test_gpu_model.py::test_benchmarked_step_vs_oracle holds for the whole step.
-def kernelconv_fac_train_usable(site, book, cat, ev, ksize):
+def kernelconv_fac_train_usable(site, book, frame, ev, ksize):
+    """frame, ev: the two parts of the KernelConv's input cat([ev, frame], 1) (the concatenation itself need not exist)"""
     if site is None or book is None or N.dev_env("EBFI_NO_C16", "0") == "1" or N.dev_env("EBFI_NO_P16", "0") == "1":
         return False
-    B, Cin, H, W = cat.shape
-    if not (cat.is_cuda and cat.dtype == torch.float32 and ksize == 5 and W % 4 == 0 and Cin % 16 == 0 and site.ks == 3 and
+    B, Cf, H, W = frame.shape
+    Cin = Cf + ev.shape[1]
+    if not (frame.is_cuda and frame.dtype == torch.float32 and ev.dtype == torch.float32 and tuple(ev.shape[2:]) == (H, W) and
+            ev.shape[0] == B and ksize == 5 and W % 4 == 0 and Cin % 16 == 0 and Cin == site.K and site.ks == 3 and
             site.groups == 1 and site.has_bias and site.tr16_ptr() is not None and B * ev.shape[1] <= 65535 and
             site.M == ev.shape[1] * ksize * ksize):
         return False
@@ -176,23 +179,31 @@ def kernelconv_fac_train_usable(site, book, cat, ev, ksize):
 
 
 class KernelConvFacTrain(Function):
-    """apply(cat, ev, site, slope, ksize, weight, bias) -> FAC(ReplicationPad(ev), LeakyReLU(conv3x3(cat))).
-    weight / bias: the KernelConv parameters (inputs only so that autograd routes their gradients; values come from the bank)."""
+    """apply(frame, ev, site, slope, ksize, weight, bias) -> FAC(ReplicationPad(ev), LeakyReLU(conv3x3(cat([ev, frame], 1)))).
+    weight / bias: the KernelConv parameters (inputs only so that autograd routes their gradients; values come from the bank).
+    The concatenation is written only as the fp16 image both convolution passes read (ebfi_to_c16_cat2) when the forward runs on
+    fp16 operands; the gradient of `ev` returned here is the sum of its two paths (FAC input, first half of the concatenation)."""
 
     @staticmethod
-    def forward(ctx, cat, ev, site, slope, ksize, weight, bias):
+    def forward(ctx, frame, ev, site, slope, ksize, weight, bias):
         from . import c16, f16scale
         book = f16scale.active_book()
-        cat, ev = cat.contiguous(), ev.contiguous()
-        B, Cin, H, W = (int(v) for v in cat.shape)
-        C = int(ev.shape[1])
+        frame, ev = frame.contiguous(), ev.contiguous()
+        B, C, H, W = (int(v) for v in ev.shape)
+        Cin = C + int(frame.shape[1])
         lib = N.lib()
         sp = lambda role: book.ptr(book.slot((site.key, role)))
-        filt16 = torch.empty((B, site.M, H, W), dtype=torch.float16, device=cat.device)
-        with torch.cuda.device_of(cat):
-            st = N.stream_ptr(cat.device)
-            cat16 = c16.to_c16(cat, sp("x"))          # the weight gradient's input operand (cat itself is not needed again)
-            if f16scale.forward_level(book) >= 1 and site.fwd16_ptr() is not None:
+        filt16 = torch.empty((B, site.M, H, W), dtype=torch.float16, device=ev.device)
+        f16_fwd = f16scale.forward_level(book) >= 1 and site.fwd16_ptr() is not None
+        with torch.cuda.device_of(ev):
+            st = N.stream_ptr(ev.device)
+            cat = None
+            if f16_fwd and C % 8 == 0 and frame.shape[1] % 8 == 0 and N.dev_env("EBFI_NO_CAT16", "0") != "1":
+                cat16 = c16.to_c16_cat2(ev, frame, sp("x"))       # the image of the concatenation from its two parts
+            else:
+                cat = torch.cat([ev, frame], 1)
+                cat16 = c16.to_c16(cat, sp("x"))      # the weight gradient's input operand (cat itself is not needed again)
+            if f16_fwd:
                 # fp16-operand forward (Engine(forward_f16=...)): the convolution reads the image the weight gradient will read
                 # and the site's fp16 forward weight image -- one matrix-core product per tap instead of three
                 rc = lib.ebfi_conv2d_packed_f16_c16(N.ptr(cat16), 1, site.fwd16_ptr(), site.fwd16_bytes, N.ptr(site.bias()), N.ptr(None),
@@ -238,9 +249,13 @@ class KernelConvFacTrain(Function):
             N.check(lib.ebfi_conv2d_backward_weight_f16c(N.ptr(cat16), N.ptr(gk16), 1, N.ptr(gw), N.ptr(gb), B, Cin, H, W, site.M, 1, sp("x"),
                                                          sp("g"), N.ptr(ws), need, st), "ebfi_conv2d_backward_weight_f16c (planar)")
             gcat = None
-            if ctx.needs_input_grad[0]:
+            if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
                 gcat = torch.empty((B, Cin, H, W), dtype=torch.float32, device=dev)
                 N.check(lib.ebfi_conv2d_packed_f16_c16(N.ptr(gk16), 2, site.tr16_ptr(), site.tr16_bytes, N.ptr(None), N.ptr(gcat), B, site.M, H,
                                                        W, Cin, 3, 1, 1, 0, 0.0, N.ptr(None), N.ptr(None), 0, 0.0, sp("g"), site.w_slot_ptr(),
                                                        N.ptr(None), N.ptr(None), 0, 0, st), "ebfi_conv2d_packed_f16_c16 (planar)")
-        return gcat, gev, None, None, None, gw, gb
+        # inputs (frame, ev): the second half of the concatenation's gradient; the first half joins the FAC path's gradient of ev
+        gframe = gcat[:, C:] if gcat is not None and ctx.needs_input_grad[0] else None
+        if gcat is not None and gev is not None:
+            gev = gev + gcat[:, :C]
+        return gframe, gev, None, None, None, gw, gb

@@ -233,21 +233,25 @@ class Modification(BaseModel):
 
     def forward(self, FrameTensor, EventTensor):
         ev = self.Conv1(EventTensor)
+        from . import f16scale, fac as facmod, weightbank
+        book = f16scale.active_book()
+        c = self.KernelConv.conv2d
+        site = weightbank.lookup(c.weight, "id") if (book is not None and conv.get_compute_dtype() == "bf16x3") else None
+        if torch.is_grad_enabled() and site is not None and FrameTensor.shape[0] == ev.shape[0] and \
+                FrameTensor.shape[2:] == ev.shape[2:]:
+            # training step with the fp16 backward: the filters and their gradient exist only as fp16 planes (ebfi_amd.fac), and
+            # cat([ev, FrameTensor]) only as the fp16 image both passes of the 128 -> 1600 convolution read
+            fuse = self.KernelConv.native(FrameTensor)          # (the same predicate on a part: device, dtype, layer form)
+            if fuse is not None and fuse[0] == conv.ACT_LEAKY and \
+                    facmod.kernelconv_fac_train_usable(site, book, FrameTensor, ev, self.KPN.kernel_size):
+                ev1 = self.Conv3(facmod.KernelConvFacTrain.apply(FrameTensor, ev, site, fuse[1], self.KPN.kernel_size, c.weight, c.bias))
+                return FrameTensor * ev1 + self.Conv2(ev1)
         cat = torch.cat([ev, FrameTensor], dim=1)
         fused = self._fused_filters_apply(ev, cat)
         if fused is not None:
             ev1 = self.Conv3(fused)
             return FrameTensor * ev1 + self.Conv2(ev1)
         fuse = self.KernelConv.native(cat)
-        from . import f16scale, fac as facmod, weightbank
-        book = f16scale.active_book()
-        c = self.KernelConv.conv2d
-        site = weightbank.lookup(c.weight, "id") if (book is not None and conv.get_compute_dtype() == "bf16x3") else None
-        if fuse is not None and fuse[0] == conv.ACT_LEAKY and torch.is_grad_enabled() and \
-                facmod.kernelconv_fac_train_usable(site, book, cat, ev, self.KPN.kernel_size):
-            # training step with the fp16 backward: the filters and their gradient exist only as fp16 planes (ebfi_amd.fac)
-            ev1 = self.Conv3(facmod.KernelConvFacTrain.apply(cat, ev, site, fuse[1], self.KPN.kernel_size, c.weight, c.bias))
-            return FrameTensor * ev1 + self.Conv2(ev1)
         if fuse is not None and fuse[0] == conv.ACT_LEAKY and ev.is_cuda and N.dev_env("EBFI_NO_PREACT", "0") != "1":
             # the 1600-channel filter tensor has one consumer, the FAC op: its backward returns the gradient of the filters'
             # PRE-activation (kernel > 0 ? g : slope*g), so the 128 -> 1600 conv's weight / data gradient neither re-read the

@@ -68,8 +68,9 @@ extern "C" {
  *      on fp16 operands)
  *  12  ebfi_se_gate_forward_ps / _backward_ps (the squeeze-excite gate of an up-convolution stage reading the transposed
  *      convolution's output through the pixel shuffle)
- *  13  ebfi_conv2d_packed_x3_shuffled / ebfi_conv2d_packed_f16_shuffled (convolutions storing through PixelShuffle(2) / its inverse) */
-#define EBFI_ABI_VERSION 13
+ *  13  ebfi_conv2d_packed_x3_shuffled / ebfi_conv2d_packed_f16_shuffled (convolutions storing through PixelShuffle(2) / its inverse)
+ *  14  ebfi_to_c16_cat2 (the fp16 image of a two-part channel concatenation without the concatenated tensor) */
+#define EBFI_ABI_VERSION 14
 
 typedef enum {
     EBFI_OK = 0,
@@ -330,6 +331,11 @@ int ebfi_conv2d_backward_weight_f16g_ex(const void *input, const void *grad_outp
  *                                      scale gradients as per-slice partial sums [slices][B][C] (summed in order by the caller) */
 int ebfi_to_c16(const float *src, const float *mask_y, float mask_slope, void *dst16, void *slot, int B, int C, int H, int W,
                 void *stream);
+/* Round 6 (ABI 14): the image of cat([src0, src1], 1) -- [B, C0 + C1, H, W] -- written from its two parts: the concatenated fp32 tensor
+ * of Modification (`torch.cat([ev, FrameTensor], 1)`, model_singleframe.py:159-160) is never materialised when its only consumer, the
+ * 128 -> 1600 KernelConv of the training step, reads the image.  C0, C1 multiples of 8, C0 + C1 a multiple of 16; same bits as
+ * ebfi_to_c16 of the concatenation. */
+int ebfi_to_c16_cat2(const float *src0, int C0, const float *src1, int C1, void *dst16, void *slot, int B, int H, int W, void *stream);
 int ebfi_conv2d_packed_x3_c16(const void *input, const void *packed, size_t packed_bytes, const void *bias, void *output,
                               int B, int Cin_per_group, int H, int W, int Cout, int ksize, int pad, int groups, int act,
                               float slope, const void *addend, const void *mask_y, int mask_act, float mask_slope,

@@ -26,6 +26,21 @@ def _banked(cin, cout, groups=1):
     return w, b, bank, book, site
 
 
+@pytest.mark.parametrize("B,C0,C1,H,W", [(2, 64, 64, 16, 64), (1, 8, 24, 13, 36), (3, 40, 8, 8, 4)])
+def test_image_of_a_concatenation_from_its_two_parts(B, C0, C1, H, W):
+    """ebfi_to_c16_cat2 == ebfi_to_c16 of torch.cat, bit for bit, image and recorded |max|."""
+    from ebfi_amd import c16, f16scale
+    torch.manual_seed(C0 + C1)
+    a, b = torch.randn(B, C0, H, W).cuda(), torch.randn(B, C1, H, W).cuda() * 3.0
+    book = f16scale.ScaleBook("cuda")
+    i, j = book.slot("one"), book.slot("two")
+    book.calibrate(i, a, b)
+    book.calibrate(j, a, b)
+    ref = c16.to_c16(torch.cat([a, b], 1), book.ptr(i))
+    got = c16.to_c16_cat2(a, b, book.ptr(j))
+    assert torch.equal(got, ref) and book.amax(i) == book.amax(j) == max(a.abs().max().item(), b.abs().max().item())
+
+
 @pytest.mark.parametrize("B,C,H,W,masked", [(2, 64, 16, 64, False), (1, 128, 13, 36, True), (3, 16, 8, 4, False)])
 def test_to_c16_matches_torch(B, C, H, W, masked):
     from ebfi_amd import c16, f16scale

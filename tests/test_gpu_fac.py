@@ -310,54 +310,70 @@ def test_inference_bank_runs_modification_fused():
     assert _rel(y1.cpu(), ref) < 1e-3
 
 
-def test_kernelconv_fac_training_form_on_fp16_planes_vs_unfused_pair():
+@pytest.mark.parametrize("forward_f16", [None, "filters"])
+def test_kernelconv_fac_training_form_on_fp16_planes_vs_unfused_pair(forward_f16):
     """ebfi_amd.fac.KernelConvFacTrain (training half): the filters and their gradient exist only as planar fp16
-    tensors.  Against the unfused fp32 pair on the same weights and inputs: the output within the fp16 rounding of the filters
-    (a few 1e-4 of its scale), every gradient -- wrt the conv input, the feature map, the weight and the bias -- within 3e-3 of
-    its norm; the node saves the filters as fp16 planes, never an fp32 [B, C*25, h, w] tensor."""
+    tensors, and -- with the fp16-operand forward, the training step's default -- the convolution's input cat([ev, frame], 1) only
+    as the fp16 image written from its two parts (ebfi_to_c16_cat2).  Against the unfused fp32 pair on the same weights and inputs
+    (model_singleframe.py:159-163): the output within the fp16 rounding of the filters (a few 1e-4 of its scale; 2e-3 with fp16
+    operands), every gradient -- wrt the frame features, the event features (both of their paths), the weight and the bias --
+    within 3e-3 of its norm; the node saves the filters as fp16 planes, never an fp32 [B, C*25, h, w] tensor, and no fp32
+    concatenation."""
+    from ebfi_amd import _native as N
     from ebfi_amd import conv, f16scale, weightbank
     from ebfi_amd.fac import KernelConv2D, KernelConvFacTrain, kernelconv_fac_train_usable
     torch.manual_seed(7)
-    B, Cin, C, H, W, K = 2, 128, 64, 24, 64, 5
+    B, C, H, W, K = 2, 64, 24, 64, 5
+    Cin = 2 * C
     w = torch.nn.Parameter((torch.randn(C * K * K, Cin, 3, 3) * (1.0 / (Cin * 9) ** 0.5)).cuda())
     b = torch.nn.Parameter((torch.randn(C * K * K) * 0.1).cuda())
-    cat = torch.randn(B, Cin, H, W).cuda()
+    frame = torch.randn(B, C, H, W).cuda()
     ev = torch.randn(B, C, H, W).cuda()
     gout = torch.randn(B, C, H, W).cuda() * 1e-2
     bank = weightbank.WeightBank([w, b])
-    site = bank.register(w, b, "id")
+    site = bank.register(w, b, "id", fwd16=forward_f16 is not None)
     book = f16scale.ScaleBook("cuda")
+    book.forward_f16 = forward_f16
     bank.attach_scale_book(book)
     bank.refresh()
     conv.set_compute_dtype("bf16x3")
     try:
-        # reference: conv (split precision) + LeakyReLU -> fp32 filters -> FAC, autograd through both ops
+        # reference: conv (split precision) + LeakyReLU -> fp32 filters -> FAC, autograd through both ops and the concatenation
         with bank.active(), book.active():
-            c1, e1 = cat.clone().requires_grad_(), ev.clone().requires_grad_()
-            filt = conv.conv_bias_act(c1, w, b, 1, 1, conv.ACT_LEAKY, 0.01, grad_preact=True)
+            f1, e1 = frame.clone().requires_grad_(), ev.clone().requires_grad_()
+            filt = conv.conv_bias_act(torch.cat([e1, f1], 1), w, b, 1, 1, conv.ACT_LEAKY, 0.01, grad_preact=True)
             ref = KernelConv2D(K)(e1, filt, kernel_leaky_slope=0.01)
             book.operand((site.key, "f"), filt)            # (what the model's calibration pass does)
             ref.backward(gout)
             book.finish()
-        ref_g = (c1.grad.clone(), e1.grad.clone(), w.grad.clone(), b.grad.clone())
+        ref_g = (f1.grad.clone(), e1.grad.clone(), w.grad.clone(), b.grad.clone())
         w.grad = b.grad = None
-        assert kernelconv_fac_train_usable(site, book, cat, ev, K)
+        assert kernelconv_fac_train_usable(site, book, frame, ev, K)
         with bank.active(), book.active():
-            c2, e2 = cat.clone().requires_grad_(), ev.clone().requires_grad_()
-            out = KernelConvFacTrain.apply(c2, e2, site, 0.01, K, w, b)
+            f2, e2 = frame.clone().requires_grad_(), ev.clone().requires_grad_()
+            N.prof_reset()
+            N.prof_enable(True)
+            out = KernelConvFacTrain.apply(f2, e2, site, 0.01, K, w, b)
             saved = [(tuple(t.shape), t.dtype) for t in out.grad_fn.saved_tensors]
             out.backward(gout)
             book.finish()
         torch.cuda.synchronize()
+        N.prof_enable(False)
+        prof = N.prof_collect()
     finally:
         conv.set_compute_dtype("fp32")
     assert int(book.guard[0].item()) == 0
-    assert _rel(out.detach(), ref.detach()) < 1e-3
-    for got, want, name in zip((c2.grad, e2.grad, w.grad, b.grad), ref_g, ("cat", "ev", "weight", "bias")):
+    assert ("to_c16/cat2" in prof) == (forward_f16 is not None)
+    assert _rel(out.detach(), ref.detach()) < (2e-3 if forward_f16 else 1e-3)
+    for got, want, name in zip((f2.grad, e2.grad, w.grad, b.grad), ref_g, ("frame", "ev", "weight", "bias")):
         err = ((got - want).norm() / want.norm()).item()
-        assert err < 3e-3, (name, err)
+        # (fp16 operands move ~1e-3 of the filters across LeakyReLU's kink against the split-precision reference: each flips the slope
+        #  of its gradient, ~3 % of the gradient's norm at these random weights.  What the two-part image changes is pinned bit for bit
+        #  by test_gpu_c16.py::test_image_of_a_concatenation_from_its_two_parts; here the fp16-forward arm is a sanity bound.)
+        assert err < (5e-2 if forward_f16 else 3e-3), (name, err)
     # what the node keeps for its backward: the fp16 image of the conv input, the padded feature map, the fp16 filter planes
     assert ((B, C * K * K, H, W), torch.float16) in saved and not any(dt == torch.float32 and len(sh) == 4 and sh[1] == C * K * K for sh, dt in saved)
+    assert not any(dt == torch.float32 and len(sh) == 4 and sh[1] == Cin for sh, dt in saved)
 
 
 @pytest.mark.parametrize("mode,p", [("reflect", 3), ("replicate", 2), ("reflect", 1), ("replicate", 4)])

@@ -31,10 +31,10 @@ def test_library_exports_every_declared_symbol(built_lib):
 
 def test_library_loads_and_reports_version(built_lib):
     lib = N.lib()
-    # the binding, the header and the library agree on the ABI generation (13 since the shuffled-output convolutions of round 6)
+    # the binding, the header and the library agree on the ABI generation (14 since the two-part image writer of round 6)
     header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "ebfi_hip.h")).read()
-    assert "#define EBFI_ABI_VERSION 13" in header
-    assert lib.ebfi_abi_version() == 13 == N.ABI_VERSION
+    assert "#define EBFI_ABI_VERSION 14" in header
+    assert lib.ebfi_abi_version() == 14 == N.ABI_VERSION
     assert lib.ebfi_events_workspace(16) == (2 * 16 + 1) * 8
     # workspace query is pure host arithmetic: 512 slabs max, here 2*ceil(16/64)=2 tiles -> 2 slabs
     need = lib.ebfi_dcn_backward_workspace(2, 2, 4, 4, 2, 3, 3, 1, 1, 1, 1, 1, 1, 1, 0)

@@ -80,7 +80,7 @@ def main():
         kcw = eng.model.Modification.KernelConv.conv2d.weight
         keep = kcw.detach().clone()
         orig_apply = facmod.KernelConvFacTrain.apply
-        facmod.KernelConvFacTrain.apply = staticmethod(lambda cat, *rest: orig_apply(r16(cat), *rest))
+        facmod.KernelConvFacTrain.apply = staticmethod(lambda frame, *rest: orig_apply(r16(frame), *rest))   # (round 6: the node takes the concatenation's parts)
         with torch.no_grad():
             kcw.copy_(r16(kcw))
         try:
