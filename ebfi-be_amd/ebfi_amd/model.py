@@ -217,19 +217,21 @@ class Modification(BaseModel):
             bank.register(c.weight, c.bias, "facrows", fac.fac_rows_fold_weight, fac.fac_rows_fold_bias, need_tr=False,
                           fwd16=bank.book is not None)
 
-    def _fused_filters_apply(self, ev, cat):
-        """FAC(ev, LeakyReLU(KernelConv(cat))) as one kernel, or None when the fused form does not apply (training, other
-        precision modes, no inference bank, rows that do not split into 16-byte quads)."""
+    def _fused_filters_apply(self, ev, frame):
+        """FAC(ev, LeakyReLU(KernelConv(cat([ev, frame], 1)))) as one kernel, or None when the fused form does not apply (training,
+        other precision modes, no inference bank, rows that do not split into 16-byte quads).  The concatenation is left to the
+        kernel's host side: on fp16 operands it exists only as the fp16 image."""
         from . import fac, weightbank
-        if torch.is_grad_enabled() and (cat.requires_grad or any(p.requires_grad for p in self.KernelConv.parameters())):
+        if torch.is_grad_enabled() and (ev.requires_grad or frame.requires_grad or any(p.requires_grad for p in self.KernelConv.parameters())):
             return None
-        if conv.get_compute_dtype() != "bf16x3" or not cat.is_cuda or cat.dtype != torch.float32 or cat.shape[-1] % 4 != 0 or \
+        if conv.get_compute_dtype() != "bf16x3" or not frame.is_cuda or frame.dtype != torch.float32 or ev.dtype != torch.float32 or \
+                frame.shape[-1] % 4 != 0 or frame.shape[0] != ev.shape[0] or frame.shape[2:] != ev.shape[2:] or \
                 N.dev_env("EBFI_NO_FAC_FUSION", "0") == "1":
             return None
         site = weightbank.lookup(self.KernelConv.conv2d.weight, "facrows")
         if site is None:
             return None
-        return fac.kernelconv_fac_fused(cat, ev, site, self.KPN.kernel_size, float(self.KernelConv.activation.negative_slope))
+        return fac.kernelconv_fac_fused((ev, frame), ev, site, self.KPN.kernel_size, float(self.KernelConv.activation.negative_slope))
 
     def forward(self, FrameTensor, EventTensor):
         ev = self.Conv1(EventTensor)
@@ -246,11 +248,11 @@ class Modification(BaseModel):
                     facmod.kernelconv_fac_train_usable(site, book, FrameTensor, ev, self.KPN.kernel_size):
                 ev1 = self.Conv3(facmod.KernelConvFacTrain.apply(FrameTensor, ev, site, fuse[1], self.KPN.kernel_size, c.weight, c.bias))
                 return FrameTensor * ev1 + self.Conv2(ev1)
-        cat = torch.cat([ev, FrameTensor], dim=1)
-        fused = self._fused_filters_apply(ev, cat)
+        fused = self._fused_filters_apply(ev, FrameTensor)
         if fused is not None:
             ev1 = self.Conv3(fused)
             return FrameTensor * ev1 + self.Conv2(ev1)
+        cat = torch.cat([ev, FrameTensor], dim=1)
         fuse = self.KernelConv.native(cat)
         if fuse is not None and fuse[0] == conv.ACT_LEAKY and ev.is_cuda and N.dev_env("EBFI_NO_PREACT", "0") != "1":
             # the 1600-channel filter tensor has one consumer, the FAC op: its backward returns the gradient of the filters'

@@ -233,6 +233,18 @@ def test_fused_kernelconv_fac_on_fp16_operands(B, C, Cin, H, W, magnitude):
     assert _rel(outs["x3"], ref) < 1e-4
     assert _rel(outs["f16"], ref) < 1e-3, _rel(outs["f16"], ref)
     assert _rel(outs["f16"], outs["x3"]) < 1e-3
+    # the input handed over as the two parts of a channel concatenation (what Modification does): the same scale, the same image,
+    # the same bits -- and no concatenated tensor when the image form applies
+    if Cin % 16 == 0:
+        c0 = Cin // 2
+        N.prof_reset()
+        N.prof_enable(True)
+        with torch.no_grad():
+            two = kernelconv_fac_fused((cat[:, :c0].contiguous().cuda(), cat[:, c0:].contiguous().cuda()), feat.cuda(), site, K, slope).cpu()
+        torch.cuda.synchronize()
+        N.prof_enable(False)
+        assert torch.equal(two, outs["f16"])
+        assert (N.prof_collect().get("to_c16/cat2", (0,))[0] == 1) == (c0 % 8 == 0)
 
 
 def test_clip_interpolator_takes_the_fp16_fused_kernel():
